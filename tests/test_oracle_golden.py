@@ -1,0 +1,165 @@
+"""The oracle (oracle/gip_oracle.py) against outputs of the reference itself (tests/golden, made by
+tests/golden/make_golden.py in the build container).  CPU only."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import gip_oracle as O
+from tests.util import case_args, dump_pickle, parse_trec
+
+FN_CASES = ["F1_bm25_brute", "F1b_mix8_brute", "F3_hyb_brute_k100", "F3_hyb_brute_k1000", "F4_hyb128_brute",
+            "F5_hyb_lamda05", "F5_hyb_lamda03", "F6_hyb_theta03_rerank", "F6_hyb_theta03_norerank",
+            "F6_hyb_ip_rerank", "F6_hyb_ip_norerank", "F7_hyb_shard0of3", "F7_hyb_shard1of3", "F7_hyb_shard2of3"]
+
+
+def _prepared(golden, info):
+    d = golden.inputs(info["inputs"])
+    q, qi = O.prepare_queries(d["qv"], d["qi"], info.get("emb_dim", 768), info.get("lamda", 1.0))
+    lo, hi = info.get("row_lo", 0), info.get("row_hi", d["cv"].shape[0])
+    c = d["cv"][lo:hi].astype(np.float32)
+    ci = None if d["ci"] is None else d["ci"][lo:hi]
+    return d, q, qi, c, ci
+
+
+def _compare(ref_rows, ref_scores, rows, scores, exact_of):
+    """Reference vs oracle for one query: same score multiset (fp32 noise), same set of rows except
+    inside exact ties / the fp32-noise band at the boundary."""
+    assert len(rows) == len(ref_rows)
+    np.testing.assert_allclose(np.sort(scores), np.sort(ref_scores), rtol=2e-6, atol=2e-6)
+    if set(rows) != set(ref_rows):
+        ex = exact_of(np.array(sorted(set(rows) ^ set(ref_rows))))
+        kth = min(scores)
+        assert np.all(np.abs(ex - kth) <= 1e-5 * max(1.0, abs(kth))), "set differs outside the tie band"
+
+
+@pytest.mark.parametrize("case", FN_CASES)
+def test_gip_retrieval_matches_reference(golden, case):
+    info, ref_rows, ref_scores = golden.case(case)
+    d, q, qi, c, ci = _prepared(golden, info)
+    res, sc = O.GIP_retrieval(list(d["qids"]), q, qi, c, ci, case_args(info))
+    two_stage = info.get("theta", 0) > 0 and not info.get("brute_force", False)
+    for i, qid in enumerate(d["qids"]):
+        if two_stage:
+            # stage scores are approximations; only the reported score multiset/sets are compared
+            exact_of = lambda rows_, i=i: np.zeros(len(rows_)) + min(sc[qid])  # noqa: E731
+            if info.get("rerank"):
+                exact_of = lambda rows_, i=i: O.gip_scores_f64(q[i], qi[i], c[rows_], ci[rows_])  # noqa: E731
+        else:
+            exact_of = lambda rows_, i=i: O.gip_scores_f64(q[i], qi[i], c[rows_], ci[rows_])  # noqa: E731
+        _compare(ref_rows[i].tolist(), ref_scores[i], res[qid], np.array(sc[qid], np.float32), exact_of)
+        # the oracle's own fp32 scores agree with its exact f64 scores
+        if not two_stage:
+            ex = O.gip_scores_f64(q[i], qi[i], c, ci)
+            O.check_topk(res[qid], sc[qid], ex, info["topk"])
+            O.check_topk(ref_rows[i], ref_scores[i], ex, info["topk"])      # the reference passes its own contract
+
+
+def test_ip_retrieval_matches_reference(golden):
+    info, ref_rows, ref_scores = golden.case("F2_dense_ip")
+    d = golden.inputs("dense")
+    q, _ = O.prepare_queries(d["qv"], None, 768, 1.0)
+    c = d["cv"].astype(np.float32)
+    res, sc = O.IP_retrieval(list(d["qids"]), q, c, case_args(info))
+    for i, qid in enumerate(d["qids"]):
+        _compare(ref_rows[i].tolist(), ref_scores[i], res[qid], np.array(sc[qid], np.float32),
+                 lambda rows_, i=i: O.gip_scores_f64(q[i], None, c[rows_], None))
+        assert res[qid] == ref_rows[i].tolist()          # dense random scores: no ties, same order
+
+
+def test_k_larger_than_n(golden):
+    exc = golden.meta["exceptions"]["F8_gip_k_gt_n"]
+    assert exc[0] == "RuntimeError"
+    d = golden.inputs("hyb")
+    q, qi = O.prepare_queries(d["qv"], d["qi"], 768, 1.0)
+    info = dict(topk=100, brute_force=True)
+    with pytest.raises(RuntimeError, match="out of range"):
+        O.GIP_retrieval(list(d["qids"]), q, qi, d["cv"][:64].astype(np.float32), d["ci"][:64], case_args(info))
+    info, ref_rows, ref_scores = golden.case("F8_ip_k_gt_n")
+    dd = golden.inputs("dense")
+    qd, _ = O.prepare_queries(dd["qv"], None, 768, 1.0)
+    res, sc = O.IP_retrieval(list(dd["qids"]), qd, dd["cv"][:64].astype(np.float32), case_args(info))
+    assert ref_rows.shape[1] == 64
+    for i, qid in enumerate(dd["qids"]):
+        assert res[qid] == ref_rows[i].tolist()
+
+
+def _write_main_inputs(golden, tmp):
+    d = golden.inputs("hyb")
+    mq = golden.inputs("main_queries")
+    qp, ip_ = os.path.join(tmp, "q.pt"), os.path.join(tmp, "i.pt")
+    dump_pickle(qp, mq["qv"], mq["qi"], [str(x) for x in mq["qids"]])
+    dump_pickle(ip_, d["cv"], d["ci"], [str(x) for x in d["docids"]])
+    return qp, ip_
+
+
+def _same_trec(ref_text, got_text):
+    ref, got = parse_trec(ref_text), parse_trec(got_text)
+    assert list(ref) == list(got)                                 # query order
+    for qid in ref:
+        r, g = ref[qid], got[qid]
+        assert len(r) == len(g)
+        assert [x[1] for x in r] == [x[1] for x in g]             # rank numbers incl. the self-match gap
+        np.testing.assert_allclose([x[2] for x in r], [x[2] for x in g], rtol=2e-6, atol=2e-6)
+        assert len(set(x[0] for x in r) ^ set(x[0] for x in g)) <= 2
+
+
+@pytest.mark.parametrize("fname,kw", [
+    ("golden_main_hyb_brute.trec", dict(brute_force=True, topk=100)),
+    ("golden_main_hyb_lamda05.trec", dict(brute_force=True, topk=100, lamda=0.5, run_name="dhr")),
+    ("golden_main_hyb_theta_rerank.trec", dict(theta=0.3, rerank=True, agip_topk=512, topk=100)),
+    ("golden_main_hyb_shard0.trec", dict(brute_force=True, topk=100, total_shrad=3, shrad=0)),
+    ("golden_main_hyb_shard1.trec", dict(brute_force=True, topk=100, total_shrad=3, shrad=1)),
+    ("golden_main_hyb_shard2.trec", dict(brute_force=True, topk=100, total_shrad=3, shrad=2)),
+])
+def test_main_trec_bytes(golden, fname, kw):
+    with tempfile.TemporaryDirectory() as tmp:
+        qp, ip_ = _write_main_inputs(golden, tmp)
+        text = O.run_main(qp, ip_, **kw)
+    ref = golden.trec(fname)
+    _same_trec(ref, text)
+    # self-match filter: query 0 carries the id of doc 5 and retrieves it first -> ranks start at 2
+    first = ref.splitlines()[0].split(" ")
+    if kw.get("shrad", 0) == 0:
+        assert first[3] == "2"
+    # fp32 summation order differs between torch and numpy (last-bit differences), so lines are
+    # byte-identical only where the fp32 score is; every score token is the repr of an fp32 value
+    # widened to double, exactly like the reference's (e.g. 69.52739715576172)
+    same = sum(1 for a, b in zip(ref.splitlines(), text.splitlines()) if a == b)
+    assert same > 0
+    for line in text.splitlines()[:200]:
+        tok = line.split(" ")[4]
+        assert float(np.float32(float(tok))) == float(tok) and repr(float(tok)) == tok
+
+
+def test_index_merge_and_dense_main(golden):
+    dd = golden.inputs("dense")
+    m = golden.meta["index_merge"]
+    with tempfile.TemporaryDirectory() as tmp:
+        b = m["bounds"]
+        for i in range(3):
+            dump_pickle(os.path.join(tmp, f"msmarco-passage.split{i:02d}.pt"), dd["cv"][b[i]:b[i + 1]], None,
+                        [str(x) for x in dd["docids"][b[i]:b[i + 1]]])
+        emb, idx, ids = O.merge_index(tmp, "msmarco-passage", order=m["glob_order"])
+        assert idx == 0 and m["idx_value"] == 0               # dense merge stores the int 0 (index.py:40-43)
+        assert ids == [str(x) for x in golden.calls["F11_merge_dense.ids"]]
+        assert float(emb.astype(np.float64).sum()) == float(golden.calls["F11_merge_dense.checksum"][0])
+        ip_ = os.path.join(tmp, "merged.pt")
+        dump_pickle(ip_, emb, idx, ids)
+        qp = os.path.join(tmp, "q.pt")
+        dump_pickle(qp, dd["qv"], None, [str(x) for x in dd["qids"]])
+        text = O.run_main(qp, ip_, topk=100)
+    _same_trec(golden.trec("golden_main_dense_merged.trec"), text)
+
+
+def test_merge_results_equals_unsharded(golden):
+    """merge.result.py semantics: merging the three reference shard runs reproduces the reference's
+    unsharded run (same docids per query, re-numbered ranks)."""
+    shards = [golden.trec(f"golden_main_hyb_shard{i}.trec") for i in range(3)]
+    merged = parse_trec(O.merge_results(shards, topk=100, run_name="h2oloo"))
+    full = parse_trec(golden.trec("golden_main_hyb_brute.trec"))
+    for qid in full:
+        f_docs = [x[0] for x in full[qid]]
+        m_docs = [x[0] for x in merged[qid]][: len(f_docs)]
+        assert len(set(f_docs) ^ set(m_docs)) <= 2
