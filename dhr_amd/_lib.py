@@ -1,0 +1,140 @@
+"""ctypes binding of libdhr_hip.so (include/dhr_hip.h).  There is no CPU fallback: if the library
+is missing or a call fails this raises -- the product path is the HIP path or nothing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+DHR_OK = 0
+IDX_NONE, IDX_U8, IDX_I8, IDX_I16 = 0, 1, 2, 3
+VAL_F16, VAL_F32 = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+PARAM_CAND_CAP, PARAM_FIRST_ROWS, PARAM_PROFILE, PARAM_MAX_GROWTH = 1, 2, 3, 4
+
+EXPORTS = ["dhr_version", "dhr_last_error", "dhr_index_create", "dhr_index_destroy", "dhr_index_set_param",
+           "dhr_index_device_bytes", "dhr_search", "dhr_score_rows", "dhr_merge_topk", "dhr_merge_topk_host",
+           "dhr_get_stats", "dhr_debug_bound_scores"]
+
+
+class DhrError(RuntimeError):
+    pass
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [("device", C.c_int32), ("mem_kind", C.c_int32), ("n_rows", C.c_int64), ("d_dlr", C.c_int32),
+                ("d_cls", C.c_int32), ("value", C.c_void_p), ("ld_value", C.c_int64), ("index", C.c_void_p),
+                ("index_dtype", C.c_int32), ("reserved0", C.c_int32), ("ld_index", C.c_int64),
+                ("row_offset", C.c_int64)]
+
+
+class QueryBatch(C.Structure):
+    _fields_ = [("n_queries", C.c_int32), ("mem_kind", C.c_int32), ("value", C.c_void_p), ("value_dtype", C.c_int32),
+                ("index_dtype", C.c_int32), ("ld_value", C.c_int64), ("index", C.c_void_p), ("ld_index", C.c_int64)]
+
+
+class SearchStats(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_queries", C.c_int64), ("k", C.c_int64), ("phases", C.c_int32),
+                ("overflow_retries", C.c_int32), ("candidates_bound", C.c_int64), ("candidates_exact", C.c_int64),
+                ("gemm_rows", C.c_int64), ("gemm_ms", C.c_double), ("refine_ms", C.c_double),
+                ("rescore_ms", C.c_double), ("select_ms", C.c_double), ("prep_ms", C.c_double),
+                ("total_ms", C.c_double), ("gemm_flops", C.c_double)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load():
+    """Load (building first if the sources are newer and hipcc is available)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        try:
+            _build.build()
+        except Exception as e:  # noqa: BLE001
+            raise DhrError(f"libdhr_hip.so is not built and hipcc failed: {e}") from e
+    lib = C.CDLL(path)
+    lib.dhr_version.restype = C.c_int
+    lib.dhr_last_error.restype = C.c_char_p
+    lib.dhr_index_create.argtypes = [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]
+    lib.dhr_index_destroy.argtypes = [C.c_void_p]
+    lib.dhr_index_destroy.restype = None
+    lib.dhr_index_set_param.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
+    lib.dhr_index_device_bytes.argtypes = [C.c_void_p]
+    lib.dhr_index_device_bytes.restype = C.c_int64
+    lib.dhr_search.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.dhr_score_rows.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.dhr_merge_topk.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]
+    lib.dhr_merge_topk_host.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.dhr_get_stats.argtypes = [C.c_void_p, C.POINTER(SearchStats)]
+    lib.dhr_debug_bound_scores.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != DHR_OK:
+        raise DhrError(f"{what} failed ({rc}): {load().dhr_last_error().decode()}")
+
+
+_NP_IDX = {np.dtype(np.uint8): IDX_U8, np.dtype(np.int8): IDX_I8, np.dtype(np.int16): IDX_I16}
+
+
+def idx_code(dtype) -> int:
+    """numpy/torch integer dtype of an index array -> dhr_idx_dtype."""
+    name = str(dtype).replace("torch.", "")
+    try:
+        return _NP_IDX[np.dtype(name)]
+    except (KeyError, TypeError):
+        raise DhrError(f"unsupported index dtype {dtype} (uint8 / int8 / int16)") from None
+
+
+def _ptr_ld(a):
+    """(pointer, leading dimension in elements, mem_kind) of a 2-D numpy array or torch tensor."""
+    if isinstance(a, np.ndarray):
+        if a.ndim != 2 or a.strides[1] != a.itemsize or a.strides[0] % a.itemsize:
+            raise DhrError("arrays must be 2-D with a contiguous last dimension")
+        return a.ctypes.data, a.strides[0] // a.itemsize, MEM_HOST
+    if a.dim() != 2 or a.stride(1) != 1:
+        raise DhrError("tensors must be 2-D with a contiguous last dimension")
+    return a.data_ptr(), a.stride(0), (MEM_DEVICE if a.is_cuda else MEM_HOST)
+
+
+def _val_code(a) -> int:
+    name = str(a.dtype).replace("torch.", "")
+    if name == "float16":
+        return VAL_F16
+    if name == "float32":
+        return VAL_F32
+    raise DhrError(f"unsupported value dtype {a.dtype} (float16 / float32)")
+
+
+def make_query_batch(value, index):
+    """-> (QueryBatch, keepalive).  value [Q,K] fp16|fp32, index [Q,D] or None; numpy (host) or
+    torch (host/device) -- both must live in the same memory kind."""
+    qb = QueryBatch()
+    p, ld, kind = _ptr_ld(value)
+    qb.n_queries = int(value.shape[0])
+    qb.mem_kind = kind
+    qb.value, qb.ld_value, qb.value_dtype = p, ld, _val_code(value)
+    if index is not None:
+        pi, ldi, kind_i = _ptr_ld(index)
+        if kind_i != kind:
+            raise DhrError("query value and index must live in the same memory kind")
+        qb.index, qb.ld_index, qb.index_dtype = pi, ldi, idx_code(index.dtype)
+    else:
+        qb.index, qb.ld_index, qb.index_dtype = None, 0, IDX_NONE
+    return qb, (value, index)

@@ -1,0 +1,543 @@
+// Host controller + C ABI of libdhr_hip.so (include/dhr_hip.h).
+//
+// Search = phases over growing corpus chunks:
+//   phase 0   : the first rows are scored exhaustively (exact) to seed every query's top-k / tau
+//   phase p>0 : bound GEMM over the next chunk with the fused filter  U >= tau - margin  -> candidate
+//               lists; exact rescoring of the candidates; per-query top-k merge -> new tau.
+// tau (exact k-th best so far) never exceeds the final k-th best and U >= exact score, so no row of
+// the true top-k is ever dropped; chunk sizes adapt to the observed candidate counts, and a phase
+// whose candidate list overflowed is re-run in halves (a chunk of <= cap rows cannot overflow).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dhr_internal.h"
+
+using namespace dhr;
+
+static thread_local std::string g_last_error;
+static int set_error(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                                          \
+  do {                                                                                                         \
+    hipError_t _e = (expr);                                                                                    \
+    if (_e != hipSuccess)                                                                                      \
+      return set_error(DHR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" +    \
+                                        std::to_string(__LINE__) + ")");                                       \
+  } while (0)
+
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+static inline int idx_esize(int dt) { return dt == DHR_IDX_I16 ? 2 : 1; }
+
+struct Workspace {
+  int q_pad = 0, kp = 0;
+  int64_t cap = 0, keys_ld = 0, k_pad = 0, d_dlr = 0;
+  __half* q_tiles = nullptr;
+  float* q32 = nullptr;
+  int16_t* q_idx = nullptr;
+  float *margin = nullptr, *tau = nullptr, *thr = nullptr;
+  uint32_t* cnt = nullptr;
+  uint2* cand = nullptr;
+  uint64_t *rs_keys = nullptr, *topk_keys = nullptr;
+  uint32_t* d_max = nullptr;             // {max, pad} + u64 sum live in one 16-byte device block
+  void* h_pinned = nullptr;              // 16 bytes pinned mirror
+  void* q_stage = nullptr;  size_t q_stage_bytes = 0;
+  void* qi_stage = nullptr; size_t qi_stage_bytes = 0;
+  void* out_stage = nullptr; size_t out_stage_bytes = 0;
+  int64_t bytes = 0;
+};
+
+struct dhr_index {
+  int device = 0;
+  int64_t n_rows = 0, n_tiles = 0, row_offset = 0;
+  int d_dlr = 0, d_cls = 0, k = 0, k_pad = 0, ksteps = 0, idx_dtype = DHR_IDX_NONE;
+  __half* tiles = nullptr;
+  void* c_idx = nullptr;
+  __half* dlr_signed = nullptr;
+  bool abs_mode = false;
+  float dmax = 0.f;
+  int64_t index_bytes = 0;
+  // params
+  int64_t cand_cap = 16384, first_rows = 0;
+  int profile = 0, max_growth16 = 32;
+  Workspace ws;
+  dhr_search_stats stats{};
+};
+
+static void free_ws(Workspace& w) {
+  hipFree(w.q_tiles); hipFree(w.q32); hipFree(w.q_idx); hipFree(w.margin); hipFree(w.tau); hipFree(w.thr);
+  hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max);
+  if (w.h_pinned) hipHostFree(w.h_pinned);
+  hipFree(w.q_stage); hipFree(w.qi_stage); hipFree(w.out_stage);
+  w = Workspace();
+}
+
+extern "C" int dhr_version(void) { return DHR_VERSION; }
+extern "C" const char* dhr_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" void dhr_index_destroy(dhr_index* ix) {
+  if (!ix) return;
+  hipSetDevice(ix->device);
+  free_ws(ix->ws);
+  hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->dlr_signed);
+  delete ix;
+}
+
+extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) {
+  if (!ix) return set_error(DHR_ERR_INVALID, "null index");
+  switch (param) {
+    case DHR_PARAM_CAND_CAP:
+      if (value < 1024 || value > (1 << 22)) return set_error(DHR_ERR_INVALID, "cand_cap must be in [1024, 4194304]");
+      ix->cand_cap = value; return DHR_OK;
+    case DHR_PARAM_FIRST_ROWS:
+      if (value < 0) return set_error(DHR_ERR_INVALID, "first_rows must be >= 0");
+      ix->first_rows = value; return DHR_OK;
+    case DHR_PARAM_PROFILE: ix->profile = value != 0; return DHR_OK;
+    case DHR_PARAM_MAX_GROWTH:
+      if (value < 1 || value > 1024) return set_error(DHR_ERR_INVALID, "max_growth must be in [1,1024] sixteenths");
+      ix->max_growth16 = (int)value; return DHR_OK;
+  }
+  return set_error(DHR_ERR_INVALID, "unknown parameter");
+}
+
+extern "C" int64_t dhr_index_device_bytes(const dhr_index* ix) { return ix ? ix->index_bytes + ix->ws.bytes : 0; }
+extern "C" int dhr_get_stats(const dhr_index* ix, dhr_search_stats* out) {
+  if (!ix || !out) return set_error(DHR_ERR_INVALID, "null argument");
+  *out = ix->stats;
+  return DHR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ index build
+static int ingest(dhr_index* ix, const dhr_index_desc* d, bool abs_mode, uint32_t* d_flags /* {max_sq, neg} */,
+                  void* stage, int64_t block_rows, hipStream_t s) {
+  const int64_t n = ix->n_rows;
+  for (int64_t lo = 0; lo < n; lo += block_rows) {
+    const int64_t rows = std::min(block_rows, n - lo);
+    const __half* src;
+    int64_t ld;
+    if (d->mem_kind == DHR_MEM_HOST) {
+      HIP_TRY(hipMemcpy2DAsync(stage, (size_t)ix->k * 2, (const char*)d->value + lo * d->ld_value * 2,
+                               (size_t)d->ld_value * 2, (size_t)ix->k * 2, (size_t)rows, hipMemcpyHostToDevice, s));
+      src = (const __half*)stage;
+      ld = ix->k;
+    } else {
+      src = (const __half*)d->value + lo * d->ld_value;
+      ld = d->ld_value;
+    }
+    if (!abs_mode) HIP_TRY(launch_scan_rows(src, ld, rows, ix->d_dlr, ix->k, d_flags, d_flags + 1, s));
+    const int64_t fill = (lo + rows == n) ? round_up(lo + rows, TILE_ROWS) - lo : rows;   // zero the tail of the last tile
+    HIP_TRY(launch_tile_rows(src, ld, lo, rows, fill, ix->k, ix->k_pad, ix->d_dlr, abs_mode, ix->tiles, ix->dlr_signed, s));
+    if (d->mem_kind == DHR_MEM_HOST) HIP_TRY(hipStreamSynchronize(s));   // the staging buffer is reused
+  }
+  return DHR_OK;
+}
+
+extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
+  if (!d || !out) return set_error(DHR_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (d->n_rows <= 0 || d->n_rows >= (int64_t)0xFFFFFF00ll) return set_error(DHR_ERR_INVALID, "n_rows must be in [1, 2^32-256)");
+  if (d->d_dlr < 0 || d->d_cls < 0 || d->d_dlr + d->d_cls <= 0) return set_error(DHR_ERR_INVALID, "bad d_dlr/d_cls");
+  if (!d->value || d->ld_value < d->d_dlr + d->d_cls) return set_error(DHR_ERR_INVALID, "bad value pointer / ld_value");
+  const bool has_idx = d->index != nullptr && d->index_dtype != DHR_IDX_NONE;
+  if (has_idx != (d->d_dlr > 0))
+    return set_error(DHR_ERR_INVALID, "an index array is required iff d_dlr > 0 (dense-only: index=NULL, d_dlr=0)");
+  if (has_idx && (d->index_dtype < DHR_IDX_U8 || d->index_dtype > DHR_IDX_I16)) return set_error(DHR_ERR_INVALID, "bad index_dtype");
+  if (has_idx && d->ld_index < d->d_dlr) return set_error(DHR_ERR_INVALID, "bad ld_index");
+  if (d->d_dlr % 8) return set_error(DHR_ERR_UNSUPPORTED, "d_dlr (--emb_dim) must be a multiple of 8");
+  if (d->d_dlr + d->d_cls > 8192) return set_error(DHR_ERR_UNSUPPORTED, "more than 8192 columns");
+  if (d->mem_kind != DHR_MEM_HOST && d->mem_kind != DHR_MEM_DEVICE) return set_error(DHR_ERR_INVALID, "bad mem_kind");
+  HIP_TRY(hipSetDevice(d->device));
+
+  dhr_index* ix = new dhr_index();
+  ix->device = d->device;
+  ix->n_rows = d->n_rows;
+  ix->row_offset = d->row_offset;
+  ix->d_dlr = d->d_dlr;
+  ix->d_cls = d->d_cls;
+  ix->k = d->d_dlr + d->d_cls;
+  ix->k_pad = (int)round_up(ix->k, TILE_K);
+  ix->ksteps = ix->k_pad / TILE_K;
+  ix->idx_dtype = has_idx ? d->index_dtype : DHR_IDX_NONE;
+  ix->n_tiles = (d->n_rows + TILE_ROWS - 1) / TILE_ROWS;
+  hipStream_t s = nullptr;
+  void* stage = nullptr;
+  uint32_t* d_flags = nullptr;
+  int rc = DHR_OK;
+  auto fail = [&](int code) { hipFree(stage); hipFree(d_flags); dhr_index_destroy(ix); return code; };
+
+  const size_t tile_bytes = (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2;
+  if (hipMalloc((void**)&ix->tiles, tile_bytes) != hipSuccess)
+    return fail(set_error(DHR_ERR_HIP, "hipMalloc of " + std::to_string(tile_bytes) + " bytes for the corpus tiles failed"));
+  ix->index_bytes = (int64_t)tile_bytes;
+  if (hipMalloc((void**)&d_flags, 16) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMalloc failed"));
+  if (hipMemsetAsync(d_flags, 0, 16, s) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMemsetAsync failed"));
+  const int64_t block_rows = 65536;
+  if (d->mem_kind == DHR_MEM_HOST &&
+      hipMalloc(&stage, (size_t)std::min<int64_t>(block_rows, d->n_rows) * ix->k * 2) != hipSuccess)
+    return fail(set_error(DHR_ERR_HIP, "hipMalloc of the staging buffer failed"));
+  if ((rc = ingest(ix, d, false, d_flags, stage, block_rows, s)) != DHR_OK) return fail(rc);
+  uint32_t flags[2] = {0, 0};
+  if (hipMemcpy(flags, d_flags, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMemcpy failed"));
+  float max_sq;
+  memcpy(&max_sq, &flags[0], 4);
+  ix->dmax = std::sqrt(max_sq) * 1.0005f + 1e-30f;
+  if (flags[1]) {
+    // negative gated values: the bound needs |q|.|d| on the DLR half; keep the signed values aside
+    ix->abs_mode = true;
+    const size_t sb = (size_t)ix->n_tiles * TILE_ROWS * ix->d_dlr * 2;
+    if (hipMalloc((void**)&ix->dlr_signed, sb) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMalloc (signed DLR copy) failed"));
+    ix->index_bytes += (int64_t)sb;
+    if ((rc = ingest(ix, d, true, d_flags, stage, block_rows, s)) != DHR_OK) return fail(rc);
+  }
+  if (has_idx) {
+    const int es = idx_esize(d->index_dtype);
+    const size_t ib = (size_t)d->n_rows * d->d_dlr * es;
+    if (hipMalloc(&ix->c_idx, ib) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMalloc of the index array failed"));
+    ix->index_bytes += (int64_t)ib;
+    if (hipMemcpy2DAsync(ix->c_idx, (size_t)d->d_dlr * es, d->index, (size_t)d->ld_index * es, (size_t)d->d_dlr * es,
+                         (size_t)d->n_rows, d->mem_kind == DHR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                         s) != hipSuccess)
+      return fail(set_error(DHR_ERR_HIP, "copy of the index array failed"));
+  }
+  if (hipStreamSynchronize(s) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "index build failed on the device"));
+  hipFree(stage);
+  hipFree(d_flags);
+  *out = ix;
+  return DHR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ workspace
+template <typename T>
+static hipError_t re_malloc(T*& p, size_t bytes, int64_t& total) {
+  if (p) hipFree(p);
+  p = nullptr;
+  total += (int64_t)bytes;
+  return hipMalloc((void**)&p, bytes ? bytes : 16);
+}
+
+static int ensure_ws(dhr_index* ix, int n_queries, int k, int64_t keys_ld_min) {
+  Workspace& w = ix->ws;
+  const int q_pad = (int)round_up(n_queries, TILE_ROWS);
+  int kp = 1;
+  while (kp < k) kp <<= 1;
+  if (kp < 64) kp = 64;
+  const int64_t cap = ix->cand_cap;
+  const int64_t keys_ld = std::max<int64_t>(cap, keys_ld_min);
+  if (w.q_pad == q_pad && w.kp == kp && w.cap == cap && w.keys_ld >= keys_ld && w.k_pad == ix->k_pad) return DHR_OK;
+  free_ws(w);
+  int64_t tot = 0;
+  HIP_TRY(re_malloc(w.q_tiles, (size_t)q_pad * ix->k_pad * 2, tot));
+  HIP_TRY(re_malloc(w.q32, (size_t)q_pad * ix->k_pad * 4, tot));
+  HIP_TRY(re_malloc(w.q_idx, (size_t)q_pad * std::max(ix->d_dlr, 8) * 2, tot));
+  HIP_TRY(re_malloc(w.margin, (size_t)q_pad * 4, tot));
+  HIP_TRY(re_malloc(w.tau, (size_t)q_pad * 4, tot));
+  HIP_TRY(re_malloc(w.thr, (size_t)q_pad * 4, tot));
+  HIP_TRY(re_malloc(w.cnt, (size_t)q_pad * 4, tot));
+  HIP_TRY(re_malloc(w.cand, (size_t)q_pad * cap * 8, tot));
+  HIP_TRY(re_malloc(w.rs_keys, (size_t)q_pad * keys_ld * 8, tot));
+  HIP_TRY(re_malloc(w.topk_keys, (size_t)q_pad * kp * 8, tot));
+  HIP_TRY(re_malloc(w.d_max, 16, tot));
+  HIP_TRY(hipHostMalloc(&w.h_pinned, 16, hipHostMallocDefault));
+  w.q_pad = q_pad; w.kp = kp; w.cap = cap; w.keys_ld = keys_ld; w.k_pad = ix->k_pad; w.d_dlr = ix->d_dlr;
+  w.bytes = tot;
+  return DHR_OK;
+}
+
+static int check_queries(const dhr_index* ix, const dhr_query_batch* qb) {
+  if (!ix || !qb) return set_error(DHR_ERR_INVALID, "null argument");
+  if (qb->n_queries <= 0) return set_error(DHR_ERR_INVALID, "n_queries must be > 0");
+  if (!qb->value || qb->ld_value < ix->k) return set_error(DHR_ERR_INVALID, "bad query value pointer / ld_value");
+  if (qb->value_dtype != DHR_VAL_F16 && qb->value_dtype != DHR_VAL_F32) return set_error(DHR_ERR_INVALID, "bad value_dtype");
+  const bool has_idx = qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE;
+  if (has_idx && ix->d_dlr == 0)
+    return set_error(DHR_ERR_INVALID, "the query batch has an index array but the corpus index was built without one");
+  if (has_idx && (qb->index_dtype < DHR_IDX_U8 || qb->index_dtype > DHR_IDX_I16)) return set_error(DHR_ERR_INVALID, "bad index_dtype");
+  if (has_idx && qb->ld_index < ix->d_dlr) return set_error(DHR_ERR_INVALID, "bad query ld_index");
+  if (qb->mem_kind != DHR_MEM_HOST && qb->mem_kind != DHR_MEM_DEVICE) return set_error(DHR_ERR_INVALID, "bad mem_kind");
+  return DHR_OK;
+}
+
+static int grow(void*& p, size_t& have, size_t need, int64_t& total) {
+  if (have >= need) return DHR_OK;
+  if (p) hipFree(p);
+  p = nullptr;
+  HIP_TRY(hipMalloc(&p, need));
+  total += (int64_t)(need - have);
+  have = need;
+  return DHR_OK;
+}
+
+// queries -> device operand tiles / fp32 copy / idx / margins (all inside the workspace)
+static int prep_queries(dhr_index* ix, const dhr_query_batch* qb, hipStream_t s) {
+  Workspace& w = ix->ws;
+  const void* v = qb->value;
+  const void* qi = qb->index;
+  int64_t ldv = qb->ld_value, ldi = qb->ld_index;
+  const int es = qb->value_dtype == DHR_VAL_F32 ? 4 : 2;
+  if (qb->mem_kind == DHR_MEM_HOST) {
+    int rc = grow(w.q_stage, w.q_stage_bytes, (size_t)qb->n_queries * ix->k * es, w.bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync(w.q_stage, (size_t)ix->k * es, qb->value, (size_t)qb->ld_value * es, (size_t)ix->k * es,
+                             (size_t)qb->n_queries, hipMemcpyHostToDevice, s));
+    v = w.q_stage; ldv = ix->k;
+    if (ix->d_dlr > 0 && qb->index && qb->index_dtype != DHR_IDX_NONE) {
+      const int ies = idx_esize(qb->index_dtype);
+      rc = grow(w.qi_stage, w.qi_stage_bytes, (size_t)qb->n_queries * ix->d_dlr * ies, w.bytes);
+      if (rc) return rc;
+      HIP_TRY(hipMemcpy2DAsync(w.qi_stage, (size_t)ix->d_dlr * ies, qb->index, (size_t)qb->ld_index * ies,
+                               (size_t)ix->d_dlr * ies, (size_t)qb->n_queries, hipMemcpyHostToDevice, s));
+      qi = w.qi_stage; ldi = ix->d_dlr;
+    }
+  }
+  HIP_TRY(launch_query_prep(v, qb->value_dtype == DHR_VAL_F32, ldv, (ix->d_dlr > 0 && qb->index) ? qi : nullptr, qb->index_dtype, ldi,
+                            qb->n_queries, w.q_pad, ix->k, ix->k_pad, ix->d_dlr, ix->abs_mode, ix->dmax, w.q_tiles, w.q32,
+                            w.q_idx, w.margin, w.tau, w.thr, s));
+  return DHR_OK;
+}
+
+struct Timer {
+  bool on; hipStream_t s; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; std::vector<int> kind;
+  void begin(int k) { if (!on) return; hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); ev.push_back({a, b}); kind.push_back(k); }
+  void end() { if (!on) return; hipEventRecord(ev.back().second, s); }
+  void collect(double* ms /*[5]*/) {
+    for (size_t i = 0; i < ev.size(); ++i) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, ev[i].first, ev[i].second) == hipSuccess) ms[kind[i]] += t;
+      hipEventDestroy(ev[i].first); hipEventDestroy(ev[i].second);
+    }
+    ev.clear(); kind.clear();
+  }
+};
+enum { T_GEMM = 0, T_REFINE = 1, T_RESCORE = 2, T_SELECT = 3, T_PREP = 4 };
+
+static RescoreArgs base_rescore_args(const dhr_index* ix, int n_queries, bool gate) {
+  const Workspace& w = ix->ws;
+  RescoreArgs r{};
+  r.a_tiles = ix->tiles; r.dlr_signed = ix->dlr_signed; r.c_idx = ix->c_idx; r.c_idx_dtype = ix->idx_dtype;
+  r.q32 = w.q32; r.q_idx = w.q_idx; r.ksteps = ix->ksteps; r.d_dlr = ix->d_dlr; r.k_pad = ix->k_pad;
+  r.n_rows = ix->n_rows; r.n_queries = n_queries; r.gate = gate ? 1 : 0;
+  return r;
+}
+
+extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_scores, int64_t* out_rows,
+                          int32_t out_mem_kind, void* stream) {
+  int rc = check_queries(ix, qb);
+  if (rc) return rc;
+  if (k <= 0) return set_error(DHR_ERR_INVALID, "k must be > 0");
+  if (k > 4096) return set_error(DHR_ERR_UNSUPPORTED, "k > 4096 is not supported by the LDS top-k merge yet");
+  if (!out_scores || !out_rows) return set_error(DHR_ERR_INVALID, "null output pointer");
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int Q = qb->n_queries;
+  const bool gate = ix->d_dlr > 0 && qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE;   // else plain IP
+  const int64_t n = ix->n_rows;
+  const int64_t group_rows = (int64_t)DOC_GROUP * TILE_ROWS;
+
+  // rows scored exhaustively in phase 0 (>= k so that tau exists afterwards), whole tile groups
+  int64_t first = std::max<int64_t>(ix->first_rows, std::max<int64_t>(2048, 2 * (int64_t)k));
+  first = std::min(round_up(first, group_rows), round_up(n, group_rows));
+  const int64_t first_valid = std::min(first, n);
+  if ((rc = ensure_ws(ix, Q, k, first_valid)) != DHR_OK) return rc;
+  Workspace& w = ix->ws;
+
+  hipEvent_t ev0, ev1;
+  HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
+  HIP_TRY(hipEventRecord(ev0, s));
+  Timer tm{ix->profile != 0, s, {}, {}};
+  dhr_search_stats st{};
+  st.n_rows = n; st.n_queries = Q; st.k = k;
+
+  tm.begin(T_PREP);
+  if ((rc = prep_queries(ix, qb, s)) != DHR_OK) return rc;
+  HIP_TRY(hipMemsetAsync(w.topk_keys, 0, (size_t)w.q_pad * w.kp * 8, s));
+  tm.end();
+
+  SelectArgs sel{};
+  sel.topk_keys = w.topk_keys; sel.in_keys = w.rs_keys; sel.ld_keys = w.keys_ld; sel.cap = (uint32_t)w.cap;
+  sel.k = k; sel.kp = w.kp; sel.sort_n = 4 * w.kp; sel.margin = w.margin; sel.tau = w.tau; sel.thr = w.thr;
+  sel.n_queries = Q;
+
+  // ---- phase 0: exhaustive exact scoring of rows [0, first_valid)
+  {
+    RescoreArgs r = base_rescore_args(ix, Q, gate);
+    r.row0 = 0; r.count_all = (uint32_t)first_valid; r.max_count = (uint32_t)first_valid;
+    r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
+    tm.begin(T_RESCORE); HIP_TRY(launch_rescore(r, s)); tm.end();
+    sel.cnt = nullptr; sel.count_all = (uint32_t)first_valid;
+    tm.begin(T_SELECT); HIP_TRY(launch_select(sel, s)); tm.end();
+    st.candidates_exact += (int64_t)first_valid * Q;
+  }
+
+  // ---- phases p>0: bound GEMM + filter over growing chunks
+  int64_t pos = first / TILE_ROWS;                  // next corpus tile
+  int64_t seen = first_valid;
+  int64_t chunk_tiles = std::max<int64_t>(DOC_GROUP, round_up(first, group_rows) / TILE_ROWS);
+  uint32_t* h = (uint32_t*)w.h_pinned;
+  while (pos < ix->n_tiles) {
+    chunk_tiles = std::min(chunk_tiles, round_up(ix->n_tiles - pos, DOC_GROUP));
+    GemmArgs g{};
+    g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K;
+    g.tile_lo = pos; g.tile_hi = std::min(pos + chunk_tiles, ix->n_tiles); g.n_qtiles = w.q_pad / TILE_ROWS;
+    g.n_rows = n; g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = Q;
+    HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));
+    HIP_TRY(hipMemsetAsync(w.d_max, 0, 16, s));
+    tm.begin(T_GEMM); HIP_TRY(launch_gemm_filter(g, s)); tm.end();
+    HIP_TRY(launch_max_u32(w.cnt, Q, w.d_max, (unsigned long long*)(w.d_max + 2), s));
+    HIP_TRY(hipMemcpyAsync(h, w.d_max, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t maxc = h[0];
+    unsigned long long sumc;
+    memcpy(&sumc, h + 2, 8);
+    const int64_t chunk_rows = (g.tile_hi - g.tile_lo) * TILE_ROWS;
+    st.phases++;
+    st.gemm_rows += chunk_rows;
+    st.gemm_flops += 2.0 * (double)w.q_pad * (double)chunk_rows * (double)ix->k_pad;
+    if (maxc > w.cap && chunk_tiles > DOC_GROUP) {          // overflow: redo this chunk in halves
+      st.overflow_retries++;
+      chunk_tiles = std::max<int64_t>(DOC_GROUP, round_up(chunk_tiles / 2, DOC_GROUP));
+      continue;
+    }
+    st.candidates_bound += (int64_t)sumc;
+    const uint32_t maxr = std::min<uint32_t>(maxc, (uint32_t)w.cap);
+    if (maxr > 0) {
+      RescoreArgs r = base_rescore_args(ix, Q, gate);
+      r.cand = w.cand; r.cnt = w.cnt; r.cap = (uint32_t)w.cap; r.max_count = maxr;
+      r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
+      tm.begin(T_RESCORE); HIP_TRY(launch_rescore(r, s)); tm.end();
+      sel.cnt = w.cnt; sel.count_all = 0;
+      tm.begin(T_SELECT); HIP_TRY(launch_select(sel, s)); tm.end();
+      st.candidates_exact += (int64_t)sumc;
+    }
+    pos = g.tile_hi;
+    seen += chunk_rows;
+    // next chunk: aim at cap/4 candidates for the fullest query, never more than growth * rows seen
+    const double target = (double)w.cap / 4.0;
+    double next_rows = (maxc == 0) ? (double)chunk_rows * 4.0 : (double)chunk_rows * target / (double)maxc;
+    next_rows = std::min(next_rows, (double)seen * ix->max_growth16 / 16.0);
+    chunk_tiles = std::max<int64_t>(DOC_GROUP, (int64_t)(next_rows / group_rows) * DOC_GROUP);
+  }
+
+  // ---- results
+  float* d_scores = out_scores;
+  int64_t* d_rows = out_rows;
+  if (out_mem_kind == DHR_MEM_HOST) {
+    const size_t need = (size_t)Q * k * 12;
+    if ((rc = grow(w.out_stage, w.out_stage_bytes, need, w.bytes)) != DHR_OK) return rc;
+    d_rows = (int64_t*)w.out_stage;
+    d_scores = (float*)((char*)w.out_stage + (size_t)Q * k * 8);
+  }
+  HIP_TRY(launch_emit(w.topk_keys, w.kp, Q, k, ix->row_offset, d_scores, d_rows, s));
+  if (out_mem_kind == DHR_MEM_HOST) {
+    HIP_TRY(hipMemcpyAsync(out_rows, d_rows, (size_t)Q * k * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_scores, d_scores, (size_t)Q * k * 4, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipEventRecord(ev1, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  float total = 0.f;
+  hipEventElapsedTime(&total, ev0, ev1);
+  hipEventDestroy(ev0); hipEventDestroy(ev1);
+  st.total_ms = total;
+  double ms[5] = {0, 0, 0, 0, 0};
+  tm.collect(ms);
+  st.gemm_ms = ms[T_GEMM]; st.refine_ms = ms[T_REFINE]; st.rescore_ms = ms[T_RESCORE]; st.select_ms = ms[T_SELECT];
+  st.prep_ms = ms[T_PREP];
+  ix->stats = st;
+  return DHR_OK;
+}
+
+extern "C" int dhr_score_rows(dhr_index* ix, const dhr_query_batch* qb, int32_t m, const int64_t* rows, float* out_scores,
+                              int32_t mem_kind, void* stream) {
+  int rc = check_queries(ix, qb);
+  if (rc) return rc;
+  if (m <= 0 || !rows || !out_scores) return set_error(DHR_ERR_INVALID, "bad m / null pointer");
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int Q = qb->n_queries;
+  const bool gate = ix->d_dlr > 0 && qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE;
+  if ((rc = ensure_ws(ix, Q, 1, 0)) != DHR_OK) return rc;
+  Workspace& w = ix->ws;
+  if ((rc = prep_queries(ix, qb, s)) != DHR_OK) return rc;
+  const size_t n = (size_t)Q * m;
+  void* tmp = nullptr;                     // [rows64 (host input only)] [rows32] [scores]
+  HIP_TRY(hipMalloc(&tmp, n * 16));
+  int64_t* d_rows64 = (int64_t*)tmp;
+  uint32_t* d_rows32 = (uint32_t*)((char*)tmp + n * 8);
+  float* d_sc = (float*)((char*)tmp + n * 12);
+  const int64_t* src_rows = rows;
+  auto done = [&](int code) { hipFree(tmp); return code; };
+  if (mem_kind == DHR_MEM_HOST) {
+    if (hipMemcpyAsync(d_rows64, rows, n * 8, hipMemcpyHostToDevice, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "H2D failed"));
+    src_rows = d_rows64;
+  }
+  if (launch_rows_to_local(src_rows, (int64_t)n, ix->row_offset, ix->n_rows, d_rows32, s) != hipSuccess)
+    return done(set_error(DHR_ERR_HIP, "rows_to_local launch failed"));
+  RescoreArgs r = base_rescore_args(ix, Q, gate);
+  r.rows32 = d_rows32; r.ld_rows = m; r.count_all = (uint32_t)m; r.max_count = (uint32_t)m;
+  r.out_scores = (mem_kind == DHR_MEM_HOST) ? d_sc : out_scores; r.ld_scores = m;
+  if (launch_rescore(r, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "rescore launch failed"));
+  if (mem_kind == DHR_MEM_HOST && hipMemcpyAsync(out_scores, d_sc, n * 4, hipMemcpyDeviceToHost, s) != hipSuccess)
+    return done(set_error(DHR_ERR_HIP, "D2H failed"));
+  if (hipStreamSynchronize(s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "score_rows failed on the device"));
+  return done(DHR_OK);
+}
+
+extern "C" int dhr_debug_bound_scores(dhr_index* ix, const dhr_query_batch* qb, int64_t row_lo, int64_t row_hi,
+                                      float* out_dev, void* stream) {
+  int rc = check_queries(ix, qb);
+  if (rc) return rc;
+  if (row_lo < 0 || row_hi > ix->n_rows || row_lo >= row_hi || !out_dev) return set_error(DHR_ERR_INVALID, "bad row range");
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = ensure_ws(ix, qb->n_queries, 1, 0)) != DHR_OK) return rc;
+  Workspace& w = ix->ws;
+  if ((rc = prep_queries(ix, qb, s)) != DHR_OK) return rc;
+  GemmArgs g{};
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.tile_lo = row_lo / TILE_ROWS;
+  g.tile_hi = (row_hi + TILE_ROWS - 1) / TILE_ROWS; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
+  g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
+  g.dump = out_dev; g.dump_ld = row_hi - row_lo; g.dump_row0 = row_lo;
+  HIP_TRY(launch_gemm_filter(g, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return DHR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ shard reduce
+extern "C" int dhr_merge_topk(int32_t device, int32_t n_queries, int32_t n_in, const float* in_scores,
+                              const int64_t* in_rows, int32_t k_out, float* out_scores, int64_t* out_rows, void* stream) {
+  if (n_queries <= 0 || n_in <= 0 || k_out <= 0 || !in_scores || !in_rows || !out_scores || !out_rows)
+    return set_error(DHR_ERR_INVALID, "bad argument");
+  if (n_in > 16384) return set_error(DHR_ERR_UNSUPPORTED, "more than 16384 entries per query in the device reduce");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(launch_merge_topk(n_queries, n_in, in_scores, in_rows, k_out, out_scores, out_rows, (hipStream_t)stream));
+  return DHR_OK;
+}
+
+extern "C" int dhr_merge_topk_host(int32_t n_queries, int32_t n_in, const float* in_scores, const int64_t* in_rows,
+                                   int32_t k_out, float* out_scores, int64_t* out_rows) {
+  if (n_queries <= 0 || n_in <= 0 || k_out <= 0 || !in_scores || !in_rows || !out_scores || !out_rows)
+    return set_error(DHR_ERR_INVALID, "bad argument");
+  std::vector<int> order;
+  for (int q = 0; q < n_queries; ++q) {
+    const float* s = in_scores + (size_t)q * n_in;
+    const int64_t* r = in_rows + (size_t)q * n_in;
+    order.clear();
+    for (int j = 0; j < n_in; ++j)
+      if (r[j] >= 0) order.push_back(j);
+    const int take = std::min<int>(k_out, (int)order.size());
+    std::partial_sort(order.begin(), order.begin() + take, order.end(), [&](int a, int b) {
+      const uint32_t ka = f32_ordered(s[a]), kb = f32_ordered(s[b]);
+      if (ka != kb) return ka > kb;
+      return r[a] < r[b];
+    });
+    for (int j = 0; j < k_out; ++j) {
+      out_scores[(size_t)q * k_out + j] = j < take ? s[order[j]] : -INFINITY;
+      out_rows[(size_t)q * k_out + j] = j < take ? r[order[j]] : -1;
+    }
+  }
+  return DHR_OK;
+}

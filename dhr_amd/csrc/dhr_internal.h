@@ -1,0 +1,126 @@
+// Internal declarations shared by the kernels (kernels.hip) and the host controller (api.hip).
+// gfx950 only: 64-wide wavefronts, v_mfma_f32_32x32x16_f16, global_load_lds (16 B), 160 KiB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/dhr_hip.h"
+
+namespace dhr {
+
+// ---------------------------------------------------------------------------------------------
+// Operand tiles.  Corpus rows and query rows are both stored as the *LDS image* the bound GEMM
+// stages: [tile][kstep][256 rows][8 chunks][8 fp16], chunk position XOR-swizzled by (row>>1)&7 so
+// that the four 16-lane groups of a ds_read_b128 fragment read hit 16 distinct 16-B slots
+// (cdna_hip_programming.md T2).  A K-step tile is one contiguous 32 KiB block in HBM, so the
+// global->LDS DMA is perfectly linear on both sides.
+// ---------------------------------------------------------------------------------------------
+constexpr int TILE_ROWS = 256;
+constexpr int TILE_K = 64;
+constexpr int CHUNK = 8;                                   // fp16 per 16-byte chunk
+constexpr int TILE_HALVES = TILE_ROWS * TILE_K;            // 16384 fp16 = 32 KiB
+constexpr int DOC_GROUP = 4;                               // doc tiles that share one XCD sweep
+
+__host__ __device__ inline int64_t tiled_chunk_offset(int64_t row, int chunk, int ksteps) {
+  const int64_t tile = row >> 8;
+  const int rl = (int)(row & 255);
+  const int ks = chunk >> 3, cc = chunk & 7;
+  const int phys = cc ^ ((rl >> 1) & 7);
+  return ((tile * ksteps + ks) * TILE_ROWS + rl) * (int64_t)TILE_K + phys * CHUNK;   // in fp16 elements
+}
+
+// Candidate keys: (order-preserving bits of the fp32 score) << 32 | (0xFFFFFFFF - local row), so a
+// plain descending u64 sort is "score desc, row asc".  0 = empty slot.
+__host__ __device__ inline uint32_t f32_ordered(float f) {
+  union { float f; uint32_t u; } v; v.f = f;
+  return (v.u & 0x80000000u) ? ~v.u : (v.u | 0x80000000u);
+}
+__host__ __device__ inline float ordered_f32(uint32_t o) {
+  union { float f; uint32_t u; } v;
+  v.u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+  return v.f;
+}
+__host__ __device__ inline uint64_t make_key(float score, uint32_t row) {
+  return ((uint64_t)f32_ordered(score) << 32) | (uint64_t)(0xFFFFFFFFu - row);
+}
+
+struct GemmArgs {
+  const __half* a_tiles;      // corpus operand tiles
+  const __half* b_tiles;      // query operand tiles
+  int ksteps;                 // K_pad / 64
+  int k_split;                // K-steps [0,k_split) are the gated (DLR) half; informational
+  int64_t tile_lo, tile_hi;   // corpus tile range of this launch
+  int n_qtiles;               // Q_pad / 256
+  int64_t n_rows;             // valid corpus rows (rows >= n_rows are zero padding)
+  const float* thr;           // [Q_pad] tau - margin (+inf for padded queries)
+  uint2* cand;                // [Q_pad][cap] (local row, bound score bits)
+  uint32_t* cnt;              // [Q_pad]
+  uint32_t cap;
+  float* dump;                // debug: [n_queries][dump_ld] bound scores, or nullptr
+  int64_t dump_ld;
+  int64_t dump_row0;
+  int n_queries;
+};
+
+struct RescoreArgs {
+  const __half* a_tiles;      // corpus tiles (values)
+  const __half* dlr_signed;   // abs mode: signed DLR values row-major [n_rows_pad][d_dlr], else null
+  const void* c_idx;          // [n_rows_pad][d_dlr] (1 or 2 bytes per entry) or null
+  int c_idx_dtype;            // dhr_idx_dtype
+  const float* q32;           // [Q_pad][K_pad]
+  const int16_t* q_idx;       // [Q_pad][d_dlr]
+  int ksteps, d_dlr, k_pad;
+  int gate;                   // 0: ungated inner product over all columns (--IP stage 1)
+  int64_t n_rows;
+  // candidate source: explicit list (cand != null) or the implicit range [row0, row0+count_all)
+  const uint2* cand; const uint32_t* cnt; uint32_t cap;
+  const uint32_t* rows32;     // alternative explicit list [n_queries][ld_rows] of local rows (score_rows)
+  int64_t ld_rows;
+  int64_t row0; uint32_t count_all;
+  const float* thr_exact;     // optional [Q_pad]: candidates whose refined bound < thr are dropped (unused v1)
+  uint64_t* out_keys;         // [Q_pad][ld_keys] or null
+  int64_t ld_keys;
+  float* out_scores;          // [n_queries][ld_scores] or null
+  int64_t ld_scores;
+  int n_queries;
+  uint32_t max_count;         // grid.x * CANDS_PER_WG covers this many
+};
+
+struct SelectArgs {
+  uint64_t* topk_keys;        // [Q_pad][kp] sorted descending, 0 = empty
+  const uint64_t* in_keys;    // [Q_pad][ld_keys]
+  int64_t ld_keys;
+  const uint32_t* cnt;        // per query count (null -> count_all)
+  uint32_t count_all, cap;
+  int k, kp, sort_n;
+  const float* margin;        // [Q_pad]
+  float* tau;                 // [Q_pad] exact k-th best so far (-inf until k results exist)
+  float* thr;                 // [Q_pad] tau - margin
+  int n_queries;
+};
+
+// launchers (kernels.hip)
+hipError_t launch_scan_rows(const __half* src, int64_t ld, int64_t n_rows, int d_dlr, int k, uint32_t* max_sq_bits,
+                            uint32_t* neg_flag, hipStream_t s);
+hipError_t launch_tile_rows(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
+                            int k, int k_pad, int d_dlr, bool abs_dlr, __half* tiles, __half* dlr_signed, hipStream_t s);
+hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const void* idx, int idx_dtype, int64_t ld_idx,
+                             int n_queries, int q_pad, int k, int k_pad, int d_dlr, bool abs_dlr, float dmax,
+                             __half* q_tiles, float* q32, int16_t* q_idx, float* margin, float* tau, float* thr,
+                             hipStream_t s);
+hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s);
+hipError_t launch_rescore(const RescoreArgs& a, hipStream_t s);
+hipError_t launch_select(const SelectArgs& a, hipStream_t s);
+hipError_t launch_emit(const uint64_t* topk_keys, int kp, int n_queries, int k, int64_t row_offset, float* out_scores,
+                       int64_t* out_rows, hipStream_t s);
+hipError_t launch_max_u32(const uint32_t* v, int n, uint32_t* out_max, unsigned long long* out_sum, hipStream_t s);
+hipError_t launch_rows_to_local(const int64_t* rows, int64_t n, int64_t row_offset, int64_t n_rows, uint32_t* out,
+                                hipStream_t s);
+hipError_t launch_merge_topk(int n_queries, int n_in, const float* in_scores, const int64_t* in_rows, int k_out,
+                             float* out_scores, int64_t* out_rows, hipStream_t s);
+
+constexpr int RESCORE_CANDS_PER_WG = 32;
+constexpr int SELECT_THREADS = 1024;
+
+}  // namespace dhr

@@ -1,0 +1,622 @@
+// HIP kernels of the MI355X dense-hybrid retrieval path (gfx950 only).
+//
+//   scan_rows / tile_rows   corpus upload: norms + sign scan, row-major fp16 -> MFMA operand tiles
+//   query_prep              queries -> operand tiles (fp16), exact fp32 copy, int16 idx, filter margins
+//   gemm_filter             bound GEMM  U = Q x D^T  (v_mfma_f32_32x32x16_f16, LDS-DMA staged tiles)
+//                           fused with the per-query threshold filter: scores never reach HBM
+//   rescore                 exact gated inner product of the surviving (query,row) pairs (fp64 sum)
+//   select                  per-query running top-k (bitonic in LDS) and threshold update
+//   emit / merge_topk       result formatting; k-way reduce of per-shard lists
+//
+// Reference semantics: /root/reference/retrieval/gip_retrieval.py:119-125 (gated IP + topk),
+// :74-75 (plain IP + argsort), retrieval/merge.result.py:22-42 (shard reduce).
+#include "dhr_internal.h"
+
+namespace dhr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef short short8 __attribute__((ext_vector_type(8)));
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------ scan_rows
+// One wave per corpus row: max_d ||d||^2 (for the rounding margin of the bound filter) and "any
+// negative DLR value" (switches the bound to |q|.|d| on the gated half).
+__global__ void __launch_bounds__(256) scan_rows_kernel(const __half* __restrict__ src, int64_t ld, int64_t n_rows,
+                                                        int d_dlr, int k, uint32_t* max_sq_bits, uint32_t* neg_flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const bool vec = ((k & 7) == 0) && ((ld & 7) == 0) && ((((uintptr_t)src) & 15) == 0);
+  float best = 0.f;
+  bool neg = false;
+  for (int64_t row = wave0; row < n_rows; row += nwaves) {
+    const __half* r = src + row * ld;
+    float s = 0.f;
+    if (vec) {
+      for (int c = lane; c * 8 < k; c += 64) {
+        const half8 v = *(const half8*)(r + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = (float)v[e];
+          s += f * f;
+          neg |= (c * 8 + e < d_dlr) && (f < 0.f);
+        }
+      }
+    } else {
+      for (int j = lane; j < k; j += 64) {
+        const float f = __half2float(r[j]);
+        s += f * f;
+        neg |= (j < d_dlr) && (f < 0.f);
+      }
+    }
+    s = wave_sum(s);
+    best = fmaxf(best, s);
+  }
+  if (lane == 0 && best > 0.f) atomicMax(max_sq_bits, __float_as_uint(best));
+  if (__any(neg) && lane == 0) atomicOr(neg_flag, 1u);
+}
+
+hipError_t launch_scan_rows(const __half* src, int64_t ld, int64_t n_rows, int d_dlr, int k, uint32_t* max_sq_bits,
+                            uint32_t* neg_flag, hipStream_t s) {
+  if (n_rows <= 0) return hipSuccess;
+  const int64_t blocks = (n_rows + 3) / 4;
+  hipLaunchKernelGGL(scan_rows_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, src, ld,
+                     n_rows, d_dlr, k, max_sq_bits, neg_flag);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ tile_rows
+// Thread per 16-byte chunk: rows [row_lo, row_lo+n_rows_fill) of the tiled image; rows beyond
+// n_rows_src and columns beyond k are zero.  abs_dlr: |v| on the gated half of the tile image and the
+// signed values go to dlr_signed (row-major) for the exact rescoring.
+__global__ void __launch_bounds__(256) tile_rows_kernel(const __half* __restrict__ src, int64_t ld, int64_t row_lo,
+                                                        int64_t n_rows_src, int64_t n_rows_fill, int k, int k_pad,
+                                                        int d_dlr, int abs_dlr, __half* __restrict__ tiles,
+                                                        __half* __restrict__ dlr_signed) {
+  const int cpr = k_pad >> 3;
+  const int ksteps = k_pad >> 6;
+  const int64_t total = n_rows_fill * cpr;
+  const bool vec = ((k & 7) == 0) && ((ld & 7) == 0) && ((((uintptr_t)src) & 15) == 0);
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t rl = g / cpr;
+    const int c = (int)(g - rl * cpr);
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
+    if (rl < n_rows_src && c * 8 < k) {
+      const __half* r = src + rl * ld + c * 8;
+      if (vec) {
+        v = *(const half8*)r;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (c * 8 + e < k) v[e] = (_Float16)__half2float(r[e]);
+      }
+    }
+    const int64_t row = row_lo + rl;
+    if (abs_dlr && c * 8 < d_dlr) {
+      *(half8*)(dlr_signed + row * d_dlr + c * 8) = v;          // d_dlr % 8 == 0 is enforced by the API
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] < (_Float16)0.f ? -v[e] : v[e];
+    }
+    *(half8*)(tiles + tiled_chunk_offset(row, c, ksteps)) = v;
+  }
+}
+
+hipError_t launch_tile_rows(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
+                            int k, int k_pad, int d_dlr, bool abs_dlr, __half* tiles, __half* dlr_signed,
+                            hipStream_t s) {
+  if (n_rows_fill <= 0) return hipSuccess;
+  const int64_t total = n_rows_fill * (k_pad >> 3);
+  const int64_t blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, src, ld,
+                     row_lo, n_rows_src, n_rows_fill, k, k_pad, d_dlr, abs_dlr ? 1 : 0, tiles, dlr_signed);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ query_prep
+// One wave per (padded) query row.  Produces the fp16 operand tile image (|.| on the gated half in
+// abs mode), the exact fp32 query used by the rescoring, the int16 index row, and the filter margin
+//   margin = 1.05*K_pad*2^-24*||q16||*dmax   (fp32 accumulation error of the MFMA chain, products exact)
+//          + ||q32 - q16||*dmax              (fp16 rounding of a query that is not fp16-representable)
+// so that  U_computed >= S_exact - margin  for every row (Cauchy-Schwarz on sum |q_j d_j|).
+__global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict__ src, int src_is_f32, int64_t ld,
+                                                         const void* __restrict__ idx, int idx_dtype, int64_t ld_idx,
+                                                         int n_queries, int q_pad, int k, int k_pad, int d_dlr,
+                                                         int abs_dlr, float dmax, __half* __restrict__ q_tiles,
+                                                         float* __restrict__ q32, int16_t* __restrict__ q_idx,
+                                                         float* __restrict__ margin, float* __restrict__ tau,
+                                                         float* __restrict__ thr) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= q_pad) return;
+  const int ksteps = k_pad >> 6;
+  const bool real = q < n_queries;
+  float s16 = 0.f, sr = 0.f;
+  for (int c = lane; c * 8 < k_pad; c += 64) {
+    half8 h;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = c * 8 + e;
+      float v = 0.f;
+      if (real && j < k)
+        v = src_is_f32 ? ((const float*)src)[(int64_t)q * ld + j] : __half2float(((const __half*)src)[(int64_t)q * ld + j]);
+      f[e] = v;
+      _Float16 hv = (_Float16)v;                       // round to nearest even
+      const float back = (float)hv;
+      s16 += back * back;
+      sr += (v - back) * (v - back);
+      if (abs_dlr && j < d_dlr && hv < (_Float16)0.f) hv = -hv;
+      h[e] = hv;
+    }
+    *(half8*)(q_tiles + tiled_chunk_offset(q, c, ksteps)) = h;
+    float4* o = (float4*)(q32 + (int64_t)q * k_pad + c * 8);
+    o[0] = make_float4(f[0], f[1], f[2], f[3]);
+    o[1] = make_float4(f[4], f[5], f[6], f[7]);
+  }
+  for (int j = lane; j < d_dlr; j += 64) {
+    int v = 0;
+    if (real && idx) {
+      if (idx_dtype == DHR_IDX_U8) v = ((const uint8_t*)idx)[(int64_t)q * ld_idx + j];
+      else if (idx_dtype == DHR_IDX_I8) v = ((const int8_t*)idx)[(int64_t)q * ld_idx + j];
+      else v = ((const int16_t*)idx)[(int64_t)q * ld_idx + j];
+    }
+    q_idx[(int64_t)q * d_dlr + j] = (int16_t)v;
+  }
+  s16 = wave_sum(s16);
+  sr = wave_sum(sr);
+  if (lane == 0) {
+    const float m = 1.05f * (float)k_pad * 5.9604645e-8f * sqrtf(s16) * dmax + 1.0001f * sqrtf(sr) * dmax;
+    margin[q] = m;
+    tau[q] = -INFINITY;
+    thr[q] = real ? -INFINITY : INFINITY;              // padded queries never pass the filter
+  }
+}
+
+hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const void* idx, int idx_dtype, int64_t ld_idx,
+                             int n_queries, int q_pad, int k, int k_pad, int d_dlr, bool abs_dlr, float dmax,
+                             __half* q_tiles, float* q32, int16_t* q_idx, float* margin, float* tau, float* thr,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(query_prep_kernel, dim3((q_pad + 3) / 4), dim3(256), 0, s, src, src_is_f32, ld, idx, idx_dtype,
+                     ld_idx, n_queries, q_pad, k, k_pad, d_dlr, abs_dlr ? 1 : 0, dmax, q_tiles, q32, q_idx, margin, tau,
+                     thr);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ gemm_filter
+// Output tile: 256 corpus rows x 256 queries, K-step 64, 8 waves (2 along rows x 4 along queries),
+// each wave 128 rows x 64 queries = 4x2 blocks of v_mfma_f32_32x32x16_f16 (128 fp32 accumulators).
+// A (corpus) and B (queries) K-step tiles are contiguous 32 KiB LDS images in HBM; each wave DMAs
+// 4+4 KiB per K-step with global_load_lds_dwordx4 into a double-buffered 2 x 64 KiB LDS ring.
+// MFMA D layout: column (lane&31) = query, rows over registers = corpus rows, so one threshold
+// register per 32-query block covers all 16 accumulators of a block.
+//
+// Workgroup -> tile map (XCD aware): workgroup b runs on XCD b%8 (observed placement, speed only).
+// Each XCD sweeps DOC_GROUP corpus tiles against every query tile, consecutive workgroups sharing
+// operands, so a K-step slice of the group is fetched once into that XCD's L2 and reused.
+constexpr int GEMM_THREADS = 512;
+constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_HALVES * 2;   // 2 stages x (A + B) x 32 KiB = 128 KiB
+
+template <bool DUMP>
+__global__ void __launch_bounds__(GEMM_THREADS) gemm_filter_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // ---- tile assignment
+  const int64_t b = blockIdx.x;
+  const int xcd = (int)(b & 7);
+  const int64_t i = b >> 3;
+  const int per_group = DOC_GROUP * p.n_qtiles;
+  const int64_t g_local = i / per_group;
+  const int r = (int)(i - g_local * per_group);
+  const int qt = r / DOC_GROUP;
+  const int dl = r - qt * DOC_GROUP;
+  const int64_t dt = p.tile_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
+  if (dt >= p.tile_hi) return;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2;            // 0..1 : 128-row half
+  const int wn = wave & 3;             // 0..3 : 64-query quarter
+  const int ksteps = p.ksteps;
+
+  const char* a_src = (const char*)(p.a_tiles + dt * (int64_t)ksteps * TILE_HALVES);
+  const char* b_src = (const char*)(p.b_tiles + (int64_t)qt * ksteps * TILE_HALVES);
+  // this wave's 4 x 1 KiB pieces of each 32 KiB tile
+  const int piece0 = wave * 4;
+
+  auto stage = [&](int buf, int ks) {
+    char* la = smem + buf * (2 * TILE_HALVES * 2);
+    char* lb = la + TILE_HALVES * 2;
+    const char* ga = a_src + (int64_t)ks * (TILE_HALVES * 2);
+    const char* gb = b_src + (int64_t)ks * (TILE_HALVES * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int off = (piece0 + j) * 1024;
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga + off + lane * 16), LDS_PTR(la + off), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gb + off + lane * 16), LDS_PTR(lb + off), 16, 0, 0);
+    }
+  };
+
+  floatx16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  // fragment read offsets (bytes) inside a 32 KiB tile image: row*128 + ((chunk ^ ((row>>1)&7)) * 16)
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+  const int swz = (frow >> 1) & 7;      // row bases are multiples of 32, so only lane bits matter
+  int a_off[4], b_off[2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) a_off[mi] = (wm * 128 + mi * 32 + frow) * 128;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) b_off[ni] = (wn * 64 + ni * 32 + frow) * 128;
+
+  stage(0, 0);
+  __syncthreads();
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < ksteps) stage(buf ^ 1, ks + 1);
+    const char* la = smem + buf * (2 * TILE_HALVES * 2);
+    const char* lb = la + TILE_HALVES * 2;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int coff = ((kk * 2 + fhalf) ^ swz) * 16;
+      half8 af[4], bf[2];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) af[mi] = *(const half8*)(la + a_off[mi] + coff);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) bf[ni] = *(const half8*)(lb + b_off[ni] + coff);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();    // drains the DMA of the next stage (vmcnt(0)) and fences the reads of this one
+  }
+
+  // ---- epilogue: threshold filter (or dump)
+  const int64_t row_base = dt * TILE_ROWS + wm * 128;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
+    if (DUMP) {
+      if (q < p.n_queries) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int64_t row = row_base + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+            if (row < p.n_rows && row >= p.dump_row0 && row - p.dump_row0 < p.dump_ld)
+              p.dump[(int64_t)q * p.dump_ld + (row - p.dump_row0)] = acc[mi][ni][e];
+          }
+      }
+    } else {
+      const float t = p.thr[q];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc[mi][ni][e];
+          if (v >= t) {
+            const int64_t row = row_base + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+            if (row < p.n_rows) {
+              const uint32_t slot = atomicAdd(p.cnt + q, 1u);
+              if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)row, __float_as_uint(v));
+            }
+          }
+        }
+    }
+  }
+}
+
+hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
+  const int64_t n_tiles = a.tile_hi - a.tile_lo;
+  if (n_tiles <= 0) return hipSuccess;
+  const int64_t groups = (n_tiles + DOC_GROUP - 1) / DOC_GROUP;
+  const int64_t groups_per_xcd = (groups + 7) / 8;
+  const int64_t blocks = groups_per_xcd * 8 * DOC_GROUP * a.n_qtiles;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_filter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       GEMM_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)gemm_filter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            GEMM_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (a.dump)
+    hipLaunchKernelGGL(gemm_filter_kernel<true>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+  else
+    hipLaunchKernelGGL(gemm_filter_kernel<false>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ rescore
+// Exact score of (query, row) pairs.  One wave per pair; lane l owns the 16-byte chunks l, l+64, ...
+// of the row (read straight from the operand tiles: a row is ksteps pieces of 128 contiguous bytes).
+// Products of the stored fp16 values with the fp32 query are exact in fp64; the sum is accumulated
+// in fp64 and rounded once to fp32, so the result does not depend on tiling, chunking or sharding.
+__global__ void __launch_bounds__(256) rescore_kernel(RescoreArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int q = blockIdx.y;
+  uint32_t count;
+  if (p.cand) { count = p.cnt[q]; if (count > p.cap) count = p.cap; }
+  else if (p.rows32) count = p.count_all;
+  else count = p.count_all;
+  const uint32_t base = blockIdx.x * RESCORE_CANDS_PER_WG;
+  if (base >= count) return;
+  const float* q32 = p.q32 + (int64_t)q * p.k_pad;
+  const int16_t* qi = p.q_idx + (int64_t)q * p.d_dlr;
+  const int nchunks = p.k_pad >> 3;
+  const int dlr_chunks = p.d_dlr >> 3;
+  for (uint32_t i = base + wave; i < base + RESCORE_CANDS_PER_WG && i < count; i += 4) {
+    uint32_t row;
+    if (p.cand) row = p.cand[(int64_t)q * p.cap + i].x;
+    else if (p.rows32) row = p.rows32[(int64_t)q * p.ld_rows + i];
+    else row = (uint32_t)(p.row0 + i);
+    const bool valid = (int64_t)row < p.n_rows;
+    double acc = 0.0;
+    if (valid) {
+      for (int c = lane; c < nchunks; c += 64) {
+        half8 dv = *(const half8*)(p.a_tiles + tiled_chunk_offset(row, c, p.ksteps));
+        const float4 qa = *(const float4*)(q32 + c * 8);
+        const float4 qb = *(const float4*)(q32 + c * 8 + 4);
+        const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        if (c < dlr_chunks && p.dlr_signed) dv = *(const half8*)(p.dlr_signed + (int64_t)row * p.d_dlr + c * 8);
+        if (c < dlr_chunks && p.gate) {
+          int ci[8];
+          if (p.c_idx_dtype == DHR_IDX_I16) {
+            const short8 v = *(const short8*)((const int16_t*)p.c_idx + (int64_t)row * p.d_dlr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ci[e] = v[e];
+          } else {
+            const uint2 v = *(const uint2*)((const uint8_t*)p.c_idx + (int64_t)row * p.d_dlr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const uint32_t w = (e < 4) ? v.x : v.y;
+              const uint32_t byte = (w >> (8 * (e & 3))) & 0xFFu;
+              ci[e] = (p.c_idx_dtype == DHR_IDX_I8) ? (int)(int8_t)byte : (int)byte;
+            }
+          }
+          const short8 qiv = *(const short8*)(qi + c * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const double d = (ci[e] == (int)qiv[e]) ? (double)(float)dv[e] : 0.0;
+            acc = fma(d, (double)qv[e], acc);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc = fma((double)(float)dv[e], (double)qv[e], acc);
+        }
+      }
+      acc = wave_sum_f64(acc);
+    }
+    if (lane == 0) {
+      const float sc = valid ? (float)acc : -INFINITY;
+      if (p.out_keys) p.out_keys[(int64_t)q * p.ld_keys + i] = valid ? make_key(sc, row) : 0ull;
+      if (p.out_scores && q < p.n_queries) p.out_scores[(int64_t)q * p.ld_scores + i] = sc;
+    }
+  }
+}
+
+hipError_t launch_rescore(const RescoreArgs& a, hipStream_t s) {
+  if (a.max_count == 0 || a.n_queries <= 0) return hipSuccess;
+  const unsigned gx = (a.max_count + RESCORE_CANDS_PER_WG - 1) / RESCORE_CANDS_PER_WG;
+  hipLaunchKernelGGL(rescore_kernel, dim3(gx, (unsigned)a.n_queries), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ select
+// One workgroup per query.  LDS holds sort_n u64 keys: the running top-k (kp slots) plus up to
+// sort_n-kp new keys that beat the current k-th key; a descending bitonic sort over the live prefix
+// merges them.  Writes the new top-k, tau (exact k-th best so far) and thr = tau - margin.
+__device__ __forceinline__ void bitonic_desc(uint64_t* keys, int n, int tid, int nthreads) {
+  for (int size = 2; size <= n; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (n >> 1); t += nthreads) {
+        const int pos = 2 * t - (t & (stride - 1));
+        const uint64_t a = keys[pos], b = keys[pos + stride];
+        const bool desc = (pos & size) == 0;
+        if ((a < b) == desc) { keys[pos] = b; keys[pos + stride] = a; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void __launch_bounds__(SELECT_THREADS) select_kernel(SelectArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* keys = (uint64_t*)smem;
+  int& fill = *(int*)(smem + (size_t)p.sort_n * 8);   // all LDS in the dynamic region (keeps it 16-B aligned)
+  const int q = blockIdx.x;
+  const int tid = threadIdx.x;
+  uint32_t count = p.cnt ? p.cnt[q] : p.count_all;
+  if (p.cnt && count > p.cap) count = p.cap;
+  uint64_t* topk = p.topk_keys + (int64_t)q * p.kp;
+  const uint64_t* in = p.in_keys + (int64_t)q * p.ld_keys;
+  for (int j = tid; j < p.kp; j += SELECT_THREADS) keys[j] = topk[j];
+  if (tid == 0) fill = p.kp;
+  __syncthreads();
+  const uint32_t room = p.sort_n - p.kp;
+  for (uint32_t base = 0; base < count; base += room) {
+    const uint64_t kth = keys[p.k - 1];
+    __syncthreads();
+    const uint32_t end = (base + room < count) ? base + room : count;
+    for (uint32_t j = base + tid; j < end; j += SELECT_THREADS) {
+      const uint64_t key = in[j];
+      if (key > kth) keys[atomicAdd(&fill, 1)] = key;
+    }
+    __syncthreads();
+    const int live = fill;
+    int n = p.kp;
+    while (n < live) n <<= 1;
+    for (int j = live + tid; j < n; j += SELECT_THREADS) keys[j] = 0ull;
+    __syncthreads();
+    if (live > p.kp) bitonic_desc(keys, n, tid, SELECT_THREADS);
+    if (tid == 0) fill = p.kp;
+    __syncthreads();
+  }
+  for (int j = tid; j < p.kp; j += SELECT_THREADS) topk[j] = (j < p.k) ? keys[j] : 0ull;
+  if (tid == 0) {
+    const uint64_t kth = keys[p.k - 1];
+    const float t = kth ? ordered_f32((uint32_t)(kth >> 32)) : -INFINITY;
+    p.tau[q] = t;
+    p.thr[q] = (q < p.n_queries) ? t - p.margin[q] : INFINITY;
+  }
+}
+
+hipError_t launch_select(const SelectArgs& a, hipStream_t s) {
+  static int attr_bytes = 0;
+  const int bytes = a.sort_n * 8 + 16;
+  if (bytes > attr_bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    attr_bytes = bytes;
+  }
+  hipLaunchKernelGGL(select_kernel, dim3((unsigned)a.n_queries), dim3(SELECT_THREADS), bytes, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ emit / helpers
+__global__ void emit_kernel(const uint64_t* __restrict__ topk_keys, int kp, int n_queries, int k, int64_t row_offset,
+                            float* __restrict__ out_scores, int64_t* __restrict__ out_rows) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (int64_t)n_queries * k) return;
+  const int q = (int)(g / k), j = (int)(g - (int64_t)q * k);
+  const uint64_t key = topk_keys[(int64_t)q * kp + j];
+  if (key) {
+    out_scores[g] = ordered_f32((uint32_t)(key >> 32));
+    out_rows[g] = row_offset + (int64_t)(0xFFFFFFFFu - (uint32_t)key);
+  } else {
+    out_scores[g] = -INFINITY;
+    out_rows[g] = -1;
+  }
+}
+hipError_t launch_emit(const uint64_t* topk_keys, int kp, int n_queries, int k, int64_t row_offset, float* out_scores,
+                       int64_t* out_rows, hipStream_t s) {
+  const int64_t total = (int64_t)n_queries * k;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, topk_keys, kp, n_queries, k,
+                     row_offset, out_scores, out_rows);
+  return hipGetLastError();
+}
+
+__global__ void max_u32_kernel(const uint32_t* __restrict__ v, int n, uint32_t* out_max, unsigned long long* out_sum) {
+  uint32_t m = 0;
+  unsigned long long s = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t x = v[i];
+    m = x > m ? x : m;
+    s += x;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t om = __shfl_xor(m, o, 64);
+    m = om > m ? om : m;
+    s += __shfl_xor(s, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(out_max, m);
+    atomicAdd(out_sum, s);
+  }
+}
+hipError_t launch_max_u32(const uint32_t* v, int n, uint32_t* out_max, unsigned long long* out_sum, hipStream_t s) {
+  hipLaunchKernelGGL(max_u32_kernel, dim3(32), dim3(256), 0, s, v, n, out_max, out_sum);
+  return hipGetLastError();
+}
+
+__global__ void rows_to_local_kernel(const int64_t* __restrict__ rows, int64_t n, int64_t row_offset, int64_t n_rows,
+                                     uint32_t* __restrict__ out) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const int64_t r = rows[g] - row_offset;
+  out[g] = (rows[g] >= 0 && r >= 0 && r < n_rows) ? (uint32_t)r : 0xFFFFFFFFu;
+}
+hipError_t launch_rows_to_local(const int64_t* rows, int64_t n, int64_t row_offset, int64_t n_rows, uint32_t* out,
+                                hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rows_to_local_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, n, row_offset,
+                     n_rows, out);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ merge_topk
+// Per query: k_out best of n_in (score,row) pairs, order (score desc, row asc); row < 0 = padding.
+// LDS: ordered score (u32) + position (u32) per entry; ties are resolved on the int64 rows in HBM.
+__global__ void __launch_bounds__(1024) merge_topk_kernel(int n_in, int n_pad, const float* __restrict__ in_scores,
+                                                          const int64_t* __restrict__ in_rows, int k_out,
+                                                          float* __restrict__ out_scores, int64_t* __restrict__ out_rows) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* sk = (uint32_t*)smem;
+  uint32_t* pos = sk + n_pad;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const float* s = in_scores + (int64_t)q * n_in;
+  const int64_t* r = in_rows + (int64_t)q * n_in;
+  for (int j = tid; j < n_pad; j += 1024) {
+    const bool ok = j < n_in && r[j] >= 0;
+    sk[j] = ok ? f32_ordered(s[j]) : 0u;
+    pos[j] = ok ? (uint32_t)j : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  auto before = [&](uint32_t ka, uint32_t pa, uint32_t kb, uint32_t pb) -> bool {   // a sorts before b
+    if (pa == 0xFFFFFFFFu) return false;
+    if (pb == 0xFFFFFFFFu) return true;
+    if (ka != kb) return ka > kb;
+    return r[pa] < r[pb];
+  };
+  for (int size = 2; size <= n_pad; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (n_pad >> 1); t += 1024) {
+        const int p0 = 2 * t - (t & (stride - 1)), p1 = p0 + stride;
+        const uint32_t ka = sk[p0], pa = pos[p0], kb = sk[p1], pb = pos[p1];
+        const bool desc = (p0 & size) == 0;
+        const bool swap = desc ? before(kb, pb, ka, pa) : before(ka, pa, kb, pb);
+        if (swap) { sk[p0] = kb; pos[p0] = pb; sk[p1] = ka; pos[p1] = pa; }
+      }
+      __syncthreads();
+    }
+  for (int j = tid; j < k_out; j += 1024) {
+    const uint32_t pj = (j < n_pad) ? pos[j] : 0xFFFFFFFFu;
+    out_scores[(int64_t)q * k_out + j] = (pj != 0xFFFFFFFFu) ? s[pj] : -INFINITY;
+    out_rows[(int64_t)q * k_out + j] = (pj != 0xFFFFFFFFu) ? r[pj] : -1;
+  }
+}
+hipError_t launch_merge_topk(int n_queries, int n_in, const float* in_scores, const int64_t* in_rows, int k_out,
+                             float* out_scores, int64_t* out_rows, hipStream_t s) {
+  if (n_queries <= 0) return hipSuccess;
+  int n_pad = 2;
+  while (n_pad < n_in) n_pad <<= 1;
+  const int bytes = n_pad * 8;
+  if (bytes > 160 * 1024) return hipErrorInvalidValue;
+  static int attr_bytes = 0;
+  if (bytes > attr_bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)merge_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    attr_bytes = bytes;
+  }
+  hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)n_queries), dim3(1024), bytes, s, n_in, n_pad, in_scores, in_rows,
+                     k_out, out_scores, out_rows);
+  return hipGetLastError();
+}
+
+}  // namespace dhr

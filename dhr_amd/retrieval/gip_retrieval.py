@@ -1,0 +1,313 @@
+"""MI355X drop-in for castorini/dhr's retrieval/gip_retrieval.py (brute-force dense-hybrid search).
+
+Same CLI flags (incl. the typos --shrad/--total_shrad/--lamda), same pickle inputs
+([value fp16, index u8|i8|i16|None|0, ids]), same `result.trec` output and the same function
+signatures as the reference (/root/reference/retrieval/gip_retrieval.py:60-165, 233-344) -- but the
+per-query torch loop (mask * corpus -> einsum -> topk, :115-126) is replaced by ONE call into
+libdhr_hip.so per query batch: a bound GEMM on the matrix cores with a fused threshold filter, exact
+fp64 rescoring of the survivors and a per-query top-k merge, all on the GPU (dhr_amd/csrc).
+
+There is no CPU path here.  If the HIP library or a GPU is missing every entry point raises.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import pickle
+import time
+
+import numpy as np
+
+from .. import _lib
+
+
+# ----------------------------------------------------------------------------------------------- index handle
+class GipIndex:
+    """One corpus shard resident on one GPU (dhr_index_create).  value: fp16 [N, K] numpy array or
+    torch tensor (host or device); index: [N, D_dlr] uint8/int8/int16 or None (dense-only)."""
+
+    def __init__(self, value, index=None, *, emb_dim=None, device: int = 0, row_offset: int = 0):
+        lib = _lib.load()
+        value = _as_f16(value)
+        n, k = int(value.shape[0]), int(value.shape[1])
+        if index is not None and np.isscalar(index):          # merged dense index stores the int 0 (index.py:40-43)
+            index = None
+        d_dlr = 0 if index is None else int(index.shape[1])
+        if index is not None and emb_dim is not None and emb_dim != d_dlr:
+            raise ValueError(f"--emb_dim {emb_dim} does not match the index array width {d_dlr}")
+        desc = _lib.IndexDesc()
+        desc.device = device
+        desc.n_rows = n
+        desc.d_dlr, desc.d_cls = d_dlr, k - d_dlr
+        desc.value, desc.ld_value, desc.mem_kind = _lib._ptr_ld(value)
+        if index is not None:
+            p, ld, kind = _lib._ptr_ld(index)
+            if kind != desc.mem_kind:
+                raise ValueError("corpus value and index must live in the same memory kind")
+            desc.index, desc.ld_index, desc.index_dtype = p, ld, _lib.idx_code(index.dtype)
+        else:
+            desc.index, desc.ld_index, desc.index_dtype = None, 0, _lib.IDX_NONE
+        desc.row_offset = row_offset
+        h = C.c_void_p()
+        _lib.check(lib.dhr_index_create(C.byref(desc), C.byref(h)), "dhr_index_create")
+        self._h, self._lib = h, lib
+        self.n_rows, self.k, self.d_dlr, self.device, self.row_offset = n, k, d_dlr, device, row_offset
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dhr_index_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_param(self, param: int, value: int):
+        _lib.check(self._lib.dhr_index_set_param(self._h, param, int(value)), "dhr_index_set_param")
+
+    def device_bytes(self) -> int:
+        return int(self._lib.dhr_index_device_bytes(self._h))
+
+    def stats(self) -> dict:
+        st = _lib.SearchStats()
+        _lib.check(self._lib.dhr_get_stats(self._h, C.byref(st)), "dhr_get_stats")
+        return st.as_dict()
+
+    def search(self, q_value, q_index, k: int, *, out_device: bool = False, stream: int = 0):
+        """-> (scores fp32 [Q,k], rows int64 [Q,k]); rows are global (row_offset added), best first,
+        (-inf, -1) padding when k > n_rows.  numpy outputs unless out_device (then torch cuda tensors)."""
+        qb, keep = _lib.make_query_batch(q_value, q_index)
+        nq = qb.n_queries
+        if out_device:
+            import torch
+            dev = torch.device("cuda", self.device)
+            scores = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            rows = torch.empty((nq, k), dtype=torch.int64, device=dev)
+            ps, pr, kind = scores.data_ptr(), rows.data_ptr(), _lib.MEM_DEVICE
+        else:
+            scores = np.empty((nq, k), np.float32)
+            rows = np.empty((nq, k), np.int64)
+            ps, pr, kind = scores.ctypes.data, rows.ctypes.data, _lib.MEM_HOST
+        _lib.check(self._lib.dhr_search(self._h, C.byref(qb), int(k), ps, pr, kind, stream), "dhr_search")
+        del keep
+        return scores, rows
+
+    def score_rows(self, q_value, q_index, rows):
+        """Exact gated inner product of each query against its own list of (global) rows [Q, m]."""
+        qb, keep = _lib.make_query_batch(q_value, q_index)
+        rows = np.ascontiguousarray(rows, np.int64)
+        out = np.empty(rows.shape, np.float32)
+        _lib.check(self._lib.dhr_score_rows(self._h, C.byref(qb), int(rows.shape[1]), rows.ctypes.data, out.ctypes.data,
+                                            _lib.MEM_HOST, 0), "dhr_score_rows")
+        del keep
+        return out
+
+
+def _as_f16(a):
+    """Corpus values are fp16 on disk; the reference widens them to fp32 on its CPU path
+    (gip_retrieval.py:313).  Accept either and hand fp16 to the library (the widening is exact, so
+    narrowing an fp32 array that came from the file is too; anything else is rejected)."""
+    name = str(a.dtype).replace("torch.", "")
+    if name == "float16":
+        return a
+    if name != "float32":
+        raise TypeError(f"corpus values must be float16 (or float32 widened from float16), got {a.dtype}")
+    if isinstance(a, np.ndarray):
+        h = a.astype(np.float16)
+        if not np.array_equal(h.astype(np.float32), a):
+            raise ValueError("fp32 corpus values are not fp16-representable")
+        return h
+    h = a.half()
+    if not bool((h.float() == a).all()):
+        raise ValueError("fp32 corpus values are not fp16-representable")
+    return h
+
+
+def _np(a):
+    return a if isinstance(a, np.ndarray) else a.detach().cpu().numpy()
+
+
+def _to_dicts(qids, rows, scores, offset=0):
+    all_results, all_scores = {}, {}
+    for i, qid in enumerate(qids):
+        r = rows[i]
+        keep = r >= 0
+        all_results[qid] = (r[keep] - offset).tolist()
+        all_scores[qid] = scores[i][keep].tolist()
+    return all_results, all_scores
+
+
+def _corpus_index(corpus_embs, corpus_arg_idxs, args):
+    if isinstance(corpus_embs, GipIndex):
+        return corpus_embs, False
+    return GipIndex(corpus_embs, corpus_arg_idxs, device=getattr(args, "device", 0)), True
+
+
+# ----------------------------------------------------------------------------------------------- reference API
+def IP_retrieval(qids, query_embs, corpus_embs, args):
+    """gip_retrieval.py:60-85: plain inner product, k best rows (local indices), best first.
+    corpus_embs: array/tensor [N,K] or a prebuilt GipIndex (dense-only)."""
+    index, owned = _corpus_index(corpus_embs, None, args)
+    start_time = time.time()
+    scores, rows = index.search(query_embs, None, args.topk)
+    res = _to_dicts(qids, rows, scores, index.row_offset)
+    time_per_query = (time.time() - start_time) / len(qids)
+    print('Retrieving {} queries ({:0.3f} s/query), average number of index use {}'.format(len(qids), time_per_query, 0.0))
+    if owned:
+        index.close()
+    return res
+
+
+def GIP_retrieval(qids, query_embs, query_arg_idxs, corpus_embs, corpus_arg_idxs, args):
+    """gip_retrieval.py:88-165.  brute force / theta==0: exact gated inner product over all rows.
+    theta>0: stage 1 keeps only the query columns with value > theta (:130-136) or uses the plain
+    inner product (--IP, :139); --rerank rescans the agip_topk stage-1 rows with the exact GIP
+    (:141-153).  Row indices are local to the corpus slice, as in the reference."""
+    index, owned = _corpus_index(corpus_embs, corpus_arg_idxs, args)
+    theta = 0 if args.brute_force else args.theta
+    n = index.n_rows
+    start_time = time.time()
+    total_num_idx = 0
+    try:
+        if theta == 0:
+            if args.topk > n and not getattr(args, "allow_short", False):
+                raise RuntimeError("selected index k out of range")          # torch.topk, :123
+            total_num_idx = args.emb_dim * len(qids)
+            scores, rows = index.search(query_embs, query_arg_idxs, args.topk)
+        else:
+            q = _np(query_embs).astype(np.float32)
+            qi = _np(query_arg_idxs)
+            k1 = args.agip_topk if args.rerank else args.topk
+            if k1 > n and not getattr(args, "allow_short", False):
+                raise RuntimeError("selected index k out of range")
+            if not args.IP:
+                q1 = np.where(q > theta, q, np.float32(0))                    # restrict to the important columns
+                s1, r1 = index.search(q1, qi, k1)
+            else:
+                s1, r1 = index.search(q, None, k1)                            # ungated inner product
+            if args.rerank:
+                s2 = index.score_rows(q, qi, r1)
+                order = np.lexsort((r1, -s2.astype(np.float64)), axis=1)[:, : args.topk]
+                rows = np.take_along_axis(r1, order, axis=1)
+                scores = np.take_along_axis(s2, order, axis=1)
+            else:
+                scores, rows = s1, r1
+        res = _to_dicts(qids, rows, scores, index.row_offset)
+    finally:
+        if owned:
+            index.close()
+    average_num_idx = total_num_idx / len(qids)
+    time_per_query = (time.time() - start_time) / len(qids)
+    print('Retrieving {} queries ({:0.3f} s/query), average number of index use {}'.format(len(qids), time_per_query, average_num_idx))
+    return res
+
+
+def PQ_IP_retrieval(*_a, **_k):
+    raise NotImplementedError("--PQIP needs the faiss product-quantised first stage (gip_retrieval.py:167-231); "
+                              "not built yet (SURVEY.md section 8f row 3)")
+
+
+# ----------------------------------------------------------------------------------------------- main()
+def build_parser():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--query_emb_path", type=str, required=True)
+    parser.add_argument("--index_path", type=str, required=True)
+    parser.add_argument("--faiss_pq_index_path", type=str, default=None)
+    parser.add_argument("--emb_dim", type=int, default=768, help='DLR dimension')
+    parser.add_argument("--theta", type=float, default=0.1)
+    parser.add_argument("--topk", type=int, default=1000)
+    parser.add_argument("--agip_topk", type=int, default=10000)
+    parser.add_argument("--combine_cls", action='store_true')
+    parser.add_argument("--IP", action='store_true')
+    parser.add_argument("--PQIP", action='store_true')
+    parser.add_argument("--batch", type=int, default=1)
+    parser.add_argument("--brute_force", action='store_true')
+    parser.add_argument("--use_gpu", action='store_true')
+    parser.add_argument("--rerank", action='store_true')
+    parser.add_argument("--lamda", type=float, default=1, help='weight for [CSL] for concatenation')
+    parser.add_argument("--total_shrad", type=int, default=1)
+    parser.add_argument("--shrad", type=int, default=0)
+    parser.add_argument("--run_name", type=str, default='h2oloo')
+    # not in the reference: which GPU holds the shard (the reference hard-wires cuda:0, :261)
+    parser.add_argument("--device", type=int, default=0)
+    parser.add_argument("--output", type=str, default=None, help="override the result file name")
+    return parser
+
+
+def load_queries(path, emb_dim, lamda):
+    """gip_retrieval.py:263-283: [value fp16, index|None, qids]; fp32; CLS tail *= lamda in fp32."""
+    with open(path, 'rb') as f:
+        query_embs, query_arg_idxs, qids = pickle.load(f)
+    query_embs = np.asarray(query_embs).astype(np.float32)
+    if query_arg_idxs is None or np.isscalar(query_arg_idxs):
+        query_arg_idxs = None
+    else:
+        query_arg_idxs = np.asarray(query_arg_idxs)
+    cls_dim = query_embs.shape[1] - emb_dim
+    if cls_dim > 0:
+        query_embs[:, -cls_dim:] = np.float32(lamda) * query_embs[:, -cls_dim:]
+    return query_embs, query_arg_idxs, qids
+
+
+def shard_bounds(n_docs, total_shrad, shrad):
+    """gip_retrieval.py:292-306: per = len(docids)//total_shrad; the last shard takes the remainder."""
+    per = n_docs // total_shrad
+    lo = per * shrad
+    hi = n_docs if shrad == total_shrad - 1 else per * (shrad + 1)
+    return lo, hi
+
+
+def load_corpus_shard(path, total_shrad=1, shrad=0):
+    """gip_retrieval.py:287-306.  No fp32 copy is made; the fp16 slice goes straight to the GPU."""
+    with open(path, 'rb') as f:
+        corpus_embs, corpus_arg_idxs, docids = pickle.load(f)
+    lo, hi = shard_bounds(len(docids), total_shrad, shrad)
+    corpus_embs = np.asarray(corpus_embs)[lo:hi]
+    if corpus_arg_idxs is None or np.isscalar(corpus_arg_idxs):
+        corpus_arg_idxs = None                                                # dense index (None or merged 0)
+    else:
+        corpus_arg_idxs = np.asarray(corpus_arg_idxs)[lo:hi]
+    return corpus_embs, corpus_arg_idxs, docids[lo:hi], lo
+
+
+def write_trec(fout, results, scores, docids, run_name):
+    """gip_retrieval.py:333-342 (self-matches skipped, rank numbers keep their gaps)."""
+    for query_id in results:
+        result = results[query_id]
+        score = scores[query_id]
+        for rank, docidx in enumerate(result):
+            docid = docids[docidx]
+            if docid != query_id:
+                fout.write('{} Q0 {} {} {} {}\n'.format(query_id, docid, rank + 1, score[rank], run_name))
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    _lib.load()                                      # fail before touching the data if the HIP library is missing
+    print('Load query embeddings ...')
+    query_embs, query_arg_idxs, qids = load_queries(args.query_emb_path, args.emb_dim, args.lamda)
+    print('Load index ...')
+    corpus_embs, corpus_arg_idxs, docids, _lo = load_corpus_shard(args.index_path, args.total_shrad, args.shrad)
+    if query_arg_idxs is not None and corpus_arg_idxs is None:
+        raise ValueError("the query file has an index array but the corpus index has none")
+    if query_arg_idxs is not None:
+        index = GipIndex(corpus_embs, corpus_arg_idxs, emb_dim=args.emb_dim, device=args.device)
+        if not args.PQIP:
+            results, scores = GIP_retrieval(qids, query_embs, query_arg_idxs, index, None, args)
+        else:
+            results, scores = PQ_IP_retrieval(qids, query_embs, query_arg_idxs, index, None, args)
+    else:
+        index = GipIndex(corpus_embs, None, device=args.device)
+        results, scores = IP_retrieval(qids, query_embs, index, args)
+    index.close()
+    if args.output:
+        name = args.output
+    elif args.total_shrad == 1:
+        name = 'result.trec'
+    else:
+        name = 'result{}.trec'.format(args.shrad)
+    with open(name, 'w') as fout:
+        write_trec(fout, results, scores, docids, args.run_name)
+    print('finish')
+
+
+if __name__ == "__main__":
+    main()

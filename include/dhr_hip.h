@@ -1,0 +1,145 @@
+/*
+ * dhr_hip.h -- C ABI of libdhr_hip.so: MI355X (gfx950) brute-force dense-hybrid retrieval.
+ *
+ * The reference (castorini/dhr, /root/reference) has NO native/FFI interface for this path: the
+ * hot path is Python calling torch ops (retrieval/gip_retrieval.py:60-165).  This header is the
+ * boundary a maintainer would bind instead of those torch calls (ctypes stub: INTEGRATION.md).
+ * Each entry point names the reference code it replaces.  Plain pointers and sizes only; no C++
+ * exceptions, no exit() cross this boundary; every function returns 0 or a negative dhr_status.
+ *
+ * Threading: one handle is used by one host thread at a time; distinct handles (e.g. one per
+ * device / per rank) may be used concurrently.  dhr_search synchronizes the stream it is given
+ * before returning (the phase controller reads candidate counts back between launches).
+ */
+#ifndef DHR_HIP_H
+#define DHR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DHR_VERSION 100 /* 0.1.0 */
+
+typedef enum dhr_status {
+  DHR_OK = 0,
+  DHR_ERR_INVALID = -1,     /* bad argument (NULL, negative size, unsupported dtype ...) */
+  DHR_ERR_UNSUPPORTED = -2, /* legal input the kernels do not cover (see dhr_last_error) */
+  DHR_ERR_HIP = -3,         /* a HIP runtime call failed (no device, OOM, launch failure) */
+  DHR_ERR_INTERNAL = -4
+} dhr_status;
+
+typedef enum dhr_idx_dtype { DHR_IDX_NONE = 0, DHR_IDX_U8 = 1, DHR_IDX_I8 = 2, DHR_IDX_I16 = 3 } dhr_idx_dtype;
+typedef enum dhr_val_dtype { DHR_VAL_F16 = 0, DHR_VAL_F32 = 1 } dhr_val_dtype;
+typedef enum dhr_mem_kind { DHR_MEM_HOST = 0, DHR_MEM_DEVICE = 1 } dhr_mem_kind;
+
+typedef struct dhr_index dhr_index; /* opaque */
+
+/* One corpus shard in the reference's record layout (3-list pickle [value, index, ids]:
+ * tevatron/driver/encode.py:165-170,203-204; merged by retrieval/index.py:26-47):
+ *   value  fp16 [n_rows, d_dlr + d_cls] row-major, first d_dlr columns = densified lexical (gated),
+ *          the rest = dense [CLS] (ungated);
+ *   index  uint8 / int8 / int16 [n_rows, d_dlr], or NULL for dense-only models (then d_dlr = 0).
+ * The library copies and re-lays the data into its own device layout (MFMA-fragment tiles); the
+ * caller keeps ownership of the inputs and may free them after dhr_index_create returns. */
+typedef struct dhr_index_desc {
+  int32_t device;      /* HIP device ordinal */
+  int32_t mem_kind;    /* dhr_mem_kind of value/index */
+  int64_t n_rows;      /* rows of THIS shard (gip_retrieval.py:292-306 slice) */
+  int32_t d_dlr;       /* gated columns == --emb_dim when index != NULL, else 0 */
+  int32_t d_cls;       /* ungated columns */
+  const void* value;   /* fp16 */
+  int64_t ld_value;    /* elements between consecutive rows (>= d_dlr + d_cls) */
+  const void* index;   /* or NULL */
+  int32_t index_dtype; /* dhr_idx_dtype */
+  int32_t reserved0;
+  int64_t ld_index;    /* elements between consecutive rows (>= d_dlr) */
+  int64_t row_offset;  /* global row id of local row 0; added to every returned row */
+} dhr_index_desc;
+
+/* A batch of queries, same record layout as the corpus (value may also be fp32: the reference's
+ * CPU path converts queries to fp32 and scales the CLS tail by --lamda in fp32,
+ * gip_retrieval.py:275-283 -- hand that fp32 array over unchanged). */
+typedef struct dhr_query_batch {
+  int32_t n_queries;
+  int32_t mem_kind;
+  const void* value;   /* [n_queries, d_dlr + d_cls] */
+  int32_t value_dtype; /* dhr_val_dtype */
+  int32_t index_dtype; /* dhr_idx_dtype; NONE iff the index was built without an index array */
+  int64_t ld_value;
+  const void* index;   /* [n_queries, d_dlr] or NULL */
+  int64_t ld_index;
+} dhr_query_batch;
+
+/* Counters of the last dhr_search on a handle (what the phase controller did and how long the
+ * kernels ran, measured with hipEvents on the search stream). */
+typedef struct dhr_search_stats {
+  int64_t n_rows, n_queries, k;
+  int32_t phases;            /* bound-GEMM launches */
+  int32_t overflow_retries;  /* phases re-run in halves because a candidate list filled */
+  int64_t candidates_bound;  /* pairs that passed the bound filter (sum over queries) */
+  int64_t candidates_exact;  /* pairs rescored exactly (incl. the dense first phase) */
+  int64_t gemm_rows;         /* corpus rows pushed through the bound GEMM */
+  double gemm_ms, refine_ms, rescore_ms, select_ms, prep_ms, total_ms;
+  double gemm_flops;         /* 2 * Q_pad * rows * K_pad actually issued by the bound GEMM */
+} dhr_search_stats;
+
+/* Tunables (dhr_index_set_param). */
+typedef enum dhr_param {
+  DHR_PARAM_CAND_CAP = 1,     /* per-query candidate list capacity (entries) */
+  DHR_PARAM_FIRST_ROWS = 2,   /* rows scored exhaustively to seed the thresholds (>= k enforced) */
+  DHR_PARAM_PROFILE = 3,      /* 1: record per-kernel hipEvent timings into dhr_search_stats */
+  DHR_PARAM_MAX_GROWTH = 4    /* max (next chunk rows) / (rows seen), in 1/16ths (default 32 = 2x) */
+} dhr_param;
+
+int dhr_version(void);
+/* Message of the last failure on the calling thread ("" if none). */
+const char* dhr_last_error(void);
+
+/* Replaces the corpus half of main() (gip_retrieval.py:289-315: slice, astype, .cuda). */
+int dhr_index_create(const dhr_index_desc* desc, dhr_index** out);
+void dhr_index_destroy(dhr_index* index);
+int dhr_index_set_param(dhr_index* index, int32_t param, int64_t value);
+/* Device bytes held by the handle (index + workspaces). */
+int64_t dhr_index_device_bytes(const dhr_index* index);
+
+/* Replaces the query loop of GIP_retrieval (brute force, gip_retrieval.py:115-126) and of
+ * IP_retrieval (:70-79) for ALL queries of the batch at once:
+ *   score[q][n] = sum_{j<d_dlr} [c_idx[n][j]==q_idx[j]] * c_val[n][j]*q_val[j] + sum_{c} c_val*q_val
+ * and returns per query the k best rows, best first (score desc, row asc on exact ties).
+ *   out_scores [n_queries, k] fp32, out_rows [n_queries, k] int64 GLOBAL rows (row_offset added);
+ *   if k > n_rows the tail is (-inf, -1)   (the reference raises / truncates: SURVEY appendix).
+ * Scores are the exactly-rounded value of the gated inner product (fp64 accumulation of exact
+ * products), i.e. within fp32 summation noise of the reference's einsum.
+ * out_mem_kind says where out_scores/out_rows live.  stream is a hipStream_t (NULL = default). */
+int dhr_search(dhr_index* index, const dhr_query_batch* queries, int32_t k, float* out_scores,
+               int64_t* out_rows, int32_t out_mem_kind, void* stream);
+
+/* Exact gated inner product of each query against m given rows (stage 2 of --rerank,
+ * gip_retrieval.py:144-146 / :207-208).  rows [n_queries, m] int64 GLOBAL rows (row < 0 -> -inf).
+ * out_scores [n_queries, m].  Pointers live in mem_kind memory. */
+int dhr_score_rows(dhr_index* index, const dhr_query_batch* queries, int32_t m, const int64_t* rows,
+                   float* out_scores, int32_t mem_kind, void* stream);
+
+/* The multi-shard reduce (retrieval/merge.result.py:22-42 without the text round trip): per query,
+ * the k_out best of n_lists*k_in (score, row) pairs, best first (score desc, row asc); entries with
+ * row < 0 are padding.  in_scores/in_rows are [n_queries, n_lists*k_in] (each query's lists
+ * concatenated).  All four pointers are DEVICE pointers on `device`. */
+int dhr_merge_topk(int32_t device, int32_t n_queries, int32_t n_in, const float* in_scores,
+                   const int64_t* in_rows, int32_t k_out, float* out_scores, int64_t* out_rows, void* stream);
+/* Same reduce on HOST pointers (no GPU needed; used by the CPU/gloo tests of the sharded path). */
+int dhr_merge_topk_host(int32_t n_queries, int32_t n_in, const float* in_scores, const int64_t* in_rows,
+                        int32_t k_out, float* out_scores, int64_t* out_rows);
+
+int dhr_get_stats(const dhr_index* index, dhr_search_stats* out);
+
+/* Debug/test hook: the bound-GEMM scores U[q][row] for rows [row_lo,row_hi) of the shard, written
+ * to a DEVICE buffer [n_queries, row_hi-row_lo] fp32 (U >= exact score; equal for dense-only). */
+int dhr_debug_bound_scores(dhr_index* index, const dhr_query_batch* queries, int64_t row_lo, int64_t row_hi,
+                           float* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DHR_HIP_H */

@@ -1,0 +1,299 @@
+"""GPU parity tests: the HIP path (through the C ABI / ctypes) against the oracle and against the
+golden vectors produced by the reference.  Run on the MI355X box with `pytest -m gpu`."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import gip_oracle as O
+from tests.util import case_args, dump_pickle, parse_trec
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    from dhr_amd.retrieval import gip_retrieval as G_
+    from dhr_amd import _lib
+    _lib.load()
+    return G_
+
+
+def _search_check(G, cv, ci, qv32, qi, k, *, params=(), emb_dim=None, queries=None, row_offset=0):
+    from dhr_amd import _lib
+    ix = G.GipIndex(cv, ci, row_offset=row_offset)
+    for p, v in params:
+        ix.set_param(p, v)
+    ix.set_param(_lib.PARAM_PROFILE, 1)
+    scores, rows = ix.search(qv32, qi, k)
+    st = ix.stats()
+    ix.close()
+    n = cv.shape[0]
+    c32 = cv.astype(np.float32)
+    for i in (queries if queries is not None else range(qv32.shape[0])):
+        ex = O.gip_scores_f64(qv32[i], None if qi is None else qi[i], c32, ci)
+        kk = min(k, n)
+        assert np.all(rows[i, kk:] == -1) and np.all(np.isneginf(scores[i, kk:]))
+        O.check_topk(rows[i, :kk] - row_offset, scores[i, :kk], ex, k)
+        # exactly rounded scores: fp32(round(exact f64))
+        np.testing.assert_allclose(scores[i, :kk], ex[rows[i, :kk] - row_offset].astype(np.float32), rtol=0, atol=1e-6 * max(1.0, np.abs(ex).max()))
+    return scores, rows, st
+
+
+def test_bound_gemm_layout(G, golden):
+    """The MFMA bound GEMM (tile layout, swizzle, fragment mapping) == plain Q x D^T."""
+    import ctypes as C
+    import torch
+    from dhr_amd import _lib
+    d = golden.inputs("hyb")
+    cv = d["cv"][:1000]                      # ragged: not a multiple of 256
+    ix = G.GipIndex(cv, d["ci"][:1000])
+    qv = d["qv"].astype(np.float32)
+    qb, keep = _lib.make_query_batch(qv, d["qi"])
+    out = torch.zeros((qv.shape[0], 1000), dtype=torch.float32, device="cuda")
+    _lib.check(ix._lib.dhr_debug_bound_scores(ix._h, C.byref(qb), 0, 1000, out.data_ptr(), 0), "debug_bound")
+    u = out.cpu().numpy()
+    ref = qv.astype(np.float64) @ cv.astype(np.float64).T
+    np.testing.assert_allclose(u, ref, rtol=1e-5, atol=1e-4)
+    ix.close()
+
+
+FN_BRUTE = ["F1_bm25_brute", "F1b_mix8_brute", "F3_hyb_brute_k100", "F3_hyb_brute_k1000", "F4_hyb128_brute",
+            "F5_hyb_lamda05", "F5_hyb_lamda03", "F7_hyb_shard0of3", "F7_hyb_shard1of3", "F7_hyb_shard2of3"]
+
+
+@pytest.mark.parametrize("case", FN_BRUTE)
+def test_gip_retrieval_golden(G, golden, case):
+    """GIP_retrieval (HIP) vs the reference's recorded rows/scores and vs the exact oracle."""
+    info, ref_rows, ref_scores = golden.case(case)
+    d = golden.inputs(info["inputs"])
+    q, qi = O.prepare_queries(d["qv"], d["qi"], 768, info.get("lamda", 1.0))
+    lo, hi = info.get("row_lo", 0), info.get("row_hi", d["cv"].shape[0])
+    cv, ci = d["cv"][lo:hi], d["ci"][lo:hi]
+    res, sc = G.GIP_retrieval(list(d["qids"]), q, qi, cv, ci, case_args(info))
+    c32 = cv.astype(np.float32)
+    for i, qid in enumerate(d["qids"]):
+        ex = O.gip_scores_f64(q[i], qi[i], c32, ci)
+        O.check_topk(res[qid], sc[qid], ex, info["topk"], ref_scores=ref_scores[i])
+        diff = set(res[qid]) ^ set(ref_rows[i].tolist())
+        if diff:       # only ties / fp32-noise at the boundary may differ from the reference
+            kth = min(sc[qid])
+            assert np.all(np.abs(ex[sorted(diff)] - kth) <= 1e-5 * max(1.0, abs(kth)))
+
+
+def test_ip_retrieval_golden(G, golden):
+    info, ref_rows, ref_scores = golden.case("F2_dense_ip")
+    d = golden.inputs("dense")
+    q, _ = O.prepare_queries(d["qv"], None, 768, 1.0)
+    res, sc = G.IP_retrieval(list(d["qids"]), q, d["cv"], case_args(info))
+    for i, qid in enumerate(d["qids"]):
+        assert res[qid] == ref_rows[i].tolist()
+        np.testing.assert_allclose(sc[qid], ref_scores[i], rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", ["F6_hyb_theta03_rerank", "F6_hyb_theta03_norerank", "F6_hyb_ip_rerank",
+                                  "F6_hyb_ip_norerank"])
+def test_theta_modes_golden(G, golden, case):
+    info, ref_rows, ref_scores = golden.case(case)
+    d = golden.inputs("hyb")
+    q, qi = O.prepare_queries(d["qv"], d["qi"], 768, 1.0)
+    res, sc = G.GIP_retrieval(list(d["qids"]), q, qi, d["cv"], d["ci"], case_args(info))
+    for i, qid in enumerate(d["qids"]):
+        np.testing.assert_allclose(np.sort(sc[qid]), np.sort(ref_scores[i]), rtol=3e-6, atol=3e-6)
+        assert len(set(res[qid]) ^ set(ref_rows[i].tolist())) <= 2
+
+
+def test_k_larger_than_n(G, golden):
+    d = golden.inputs("hyb")
+    q, qi = O.prepare_queries(d["qv"], d["qi"], 768, 1.0)
+    args = case_args(dict(topk=100, brute_force=True))
+    with pytest.raises(RuntimeError, match="out of range"):
+        G.GIP_retrieval(list(d["qids"]), q, qi, d["cv"][:64], d["ci"][:64], args)
+    args.allow_short = True
+    res, sc = G.GIP_retrieval(list(d["qids"]), q, qi, d["cv"][:64], d["ci"][:64], args)
+    for i, qid in enumerate(d["qids"]):
+        ex = O.gip_scores_f64(q[i], qi[i], d["cv"][:64].astype(np.float32), d["ci"][:64])
+        assert len(res[qid]) == 64
+        O.check_topk(res[qid], sc[qid], ex, 100)
+    # IP_retrieval silently returns N rows, like the reference (F8)
+    info, ref_rows, _ = golden.case("F8_ip_k_gt_n")
+    dd = golden.inputs("dense")
+    qd, _ = O.prepare_queries(dd["qv"], None, 768, 1.0)
+    res, sc = G.IP_retrieval(list(dd["qids"]), qd, dd["cv"][:64], case_args(info))
+    for i, qid in enumerate(dd["qids"]):
+        assert res[qid] == ref_rows[i].tolist()
+
+
+@pytest.mark.parametrize("cap,first", [(1024, 0), (4096, 2048), (16384, 0)])
+def test_multi_phase_and_overflow(G, cap, first):
+    """Small candidate capacity forces many bound-GEMM phases and overflow retries; results must not
+    change.  N is ragged, K = 768+128."""
+    from dhr_amd import _lib, synth
+    cv, ci, qv, qi = synth.make_pair(7, 21000, 40, 768, 128)
+    q32 = qv.astype(np.float32)
+    _, _, st = _search_check(G, cv, ci, q32, qi, 100, params=[(_lib.PARAM_CAND_CAP, cap), (_lib.PARAM_FIRST_ROWS, first)],
+                             queries=range(0, 40, 5))
+    assert st["phases"] >= 2
+    print(cap, first, st)
+
+
+def test_negative_dlr_values_abs_mode(G):
+    from dhr_amd import synth
+    cv, ci, qv, qi = synth.make_pair(8, 6000, 16, 768, 64)
+    rng = np.random.default_rng(0)
+    cv = cv.copy(); qv = qv.copy()
+    cv[:, :768] *= rng.choice([-1, 1], size=(6000, 768)).astype(np.float16)
+    qv[:, :768] *= rng.choice([-1, 1], size=(16, 768)).astype(np.float16)
+    _search_check(G, cv, ci, qv.astype(np.float32), qi, 50)
+
+
+def test_fp32_queries_not_fp16_representable(G):
+    from dhr_amd import synth
+    cv, ci, qv, qi = synth.make_pair(9, 5000, 8, 768, 768)
+    q32 = qv.astype(np.float32)
+    q32[:, 768:] *= np.float32(0.3)         # --lamda 0.3: not representable in fp16
+    _search_check(G, cv, ci, q32, qi, 100)
+
+
+def test_dense_only_and_bm25_int16(G):
+    from dhr_amd import synth
+    cv, _, qv, _ = synth.make_pair(10, 9000, 8, 0, 768, kind="dense")
+    _search_check(G, cv, None, qv.astype(np.float32), None, 100)
+    cv, ci, qv, qi = synth.make_pair(11, 9000, 8, 768, 0, kind="bm25")
+    assert ci.dtype == np.int16
+    _search_check(G, cv, ci, qv.astype(np.float32), qi, 100)
+    _search_check(G, cv, ci, qv, qi, 100)   # fp16 queries straight from the file
+
+
+def test_row_offset_and_score_rows(G):
+    from dhr_amd import synth
+    cv, ci, qv, qi = synth.make_pair(12, 3000, 8, 768, 128)
+    q32 = qv.astype(np.float32)
+    scores, rows, _ = _search_check(G, cv, ci, q32, qi, 64, row_offset=1_000_000)
+    ix = G.GipIndex(cv, ci, row_offset=1_000_000)
+    s2 = ix.score_rows(q32, qi, rows)
+    np.testing.assert_array_equal(s2, scores)
+    bad = rows.copy(); bad[:, 0] = -1; bad[:, 1] = 5      # outside the shard -> -inf
+    s3 = ix.score_rows(q32, qi, bad)
+    assert np.all(np.isneginf(s3[:, :2]))
+    ix.close()
+
+
+def test_device_inputs_and_outputs(G):
+    import torch
+    from dhr_amd import synth
+    cv, ci, qv, qi = synth.make_pair(13, 4000, 8, 768, 128)
+    ix_h = G.GipIndex(cv, ci)
+    s_h, r_h = ix_h.search(qv.astype(np.float32), qi, 50)
+    ix_h.close()
+    ix_d = G.GipIndex(torch.from_numpy(cv).cuda(), torch.from_numpy(ci).cuda())
+    s_d, r_d = ix_d.search(torch.from_numpy(qv).cuda(), torch.from_numpy(qi).cuda(), 50, out_device=True)
+    ix_d.close()
+    np.testing.assert_array_equal(s_d.cpu().numpy(), s_h)
+    np.testing.assert_array_equal(r_d.cpu().numpy(), r_h)
+
+
+def test_merge_topk_device_matches_host_and_oracle(G):
+    import ctypes as C
+    import torch
+    from dhr_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    q, lists, k = 37, 4, 100
+    s = np.round(rng.standard_normal((q, lists * k)).astype(np.float32), 1)      # many exact ties
+    r = rng.permutation(10_000_000)[: q * lists * k].reshape(q, lists * k).astype(np.int64)
+    r[:, -7:] = -1
+    es, er = O.merge_topk([s], [r], k)
+    hs, hr = np.empty((q, k), np.float32), np.empty((q, k), np.int64)
+    _lib.check(lib.dhr_merge_topk_host(q, lists * k, s.ctypes.data, r.ctypes.data, k, hs.ctypes.data, hr.ctypes.data), "host merge")
+    np.testing.assert_array_equal(hs, es); np.testing.assert_array_equal(hr, er)
+    ds, dr = torch.from_numpy(s).cuda(), torch.from_numpy(r).cuda()
+    os_, or_ = torch.empty((q, k), dtype=torch.float32, device="cuda"), torch.empty((q, k), dtype=torch.int64, device="cuda")
+    _lib.check(lib.dhr_merge_topk(0, q, lists * k, ds.data_ptr(), dr.data_ptr(), k, os_.data_ptr(), or_.data_ptr(), 0), "dev merge")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(os_.cpu().numpy(), es); np.testing.assert_array_equal(or_.cpu().numpy(), er)
+
+
+def test_sharded_equals_unsharded(G):
+    """Row shards (gip_retrieval.py:292-306 arithmetic) + the shard reduce == one index."""
+    from dhr_amd import synth, _lib
+    cv, ci, qv, qi = synth.make_pair(14, 10007, 16, 768, 128)
+    q32 = qv.astype(np.float32)
+    full_s, full_r, _ = _search_check(G, cv, ci, q32, qi, 100, queries=[0, 5])
+    parts_s, parts_r = [], []
+    for sh in range(3):
+        lo, hi = G.shard_bounds(10007, 3, sh)
+        ix = G.GipIndex(cv[lo:hi], ci[lo:hi], row_offset=lo)
+        s, r = ix.search(q32, qi, 100)
+        ix.close()
+        parts_s.append(s); parts_r.append(r)
+    ms, mr = O.merge_topk(parts_s, parts_r, 100)
+    np.testing.assert_array_equal(mr, full_r)
+    np.testing.assert_array_equal(ms, full_s)
+
+
+@pytest.mark.parametrize("fname,argv", [
+    ("golden_main_hyb_brute.trec", ["--brute_force", "--combine_cls", "--topk", "100"]),
+    ("golden_main_hyb_lamda05.trec", ["--brute_force", "--topk", "100", "--lamda", "0.5", "--run_name", "dhr"]),
+    ("golden_main_hyb_theta_rerank.trec", ["--theta", "0.3", "--rerank", "--agip_topk", "512", "--topk", "100"]),
+    ("golden_main_hyb_shard1.trec", ["--brute_force", "--topk", "100", "--total_shrad", "3", "--shrad", "1"]),
+    ("golden_main_hyb_shard2.trec", ["--brute_force", "--topk", "100", "--total_shrad", "3", "--shrad", "2"]),
+])
+def test_cli_main_trec(G, golden, fname, argv):
+    d = golden.inputs("hyb")
+    mq = golden.inputs("main_queries")
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        qp, ip_ = os.path.join(tmp, "q.pt"), os.path.join(tmp, "i.pt")
+        dump_pickle(qp, mq["qv"], mq["qi"], [str(x) for x in mq["qids"]])
+        dump_pickle(ip_, d["cv"], d["ci"], [str(x) for x in d["docids"]])
+        os.chdir(tmp)
+        try:
+            G.main(["--query_emb_path", qp, "--index_path", ip_] + argv)
+            name = "result.trec" if "--total_shrad" not in argv else "result{}.trec".format(argv[-1])
+            got = open(os.path.join(tmp, name)).read()
+        finally:
+            os.chdir(cwd)
+    ref = parse_trec(golden.trec(fname))
+    out = parse_trec(got)
+    assert list(ref) == list(out)
+    for qid in ref:
+        assert [x[1] for x in ref[qid]] == [x[1] for x in out[qid]]
+        np.testing.assert_allclose([x[2] for x in ref[qid]], [x[2] for x in out[qid]], rtol=3e-6, atol=3e-6)
+        assert len(set(x[0] for x in ref[qid]) ^ set(x[0] for x in out[qid])) <= 2
+
+
+def test_cli_dense_merged_index(G, golden):
+    """index.py merge (dense: index array -> 0) then gip main() on it -> IP_retrieval path."""
+    from dhr_amd.retrieval import index as I
+    dd = golden.inputs("dense")
+    b = golden.meta["index_merge"]["bounds"]
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        for i in range(3):
+            dump_pickle(os.path.join(tmp, f"msmarco-passage.split{i:02d}.pt"), dd["cv"][b[i]:b[i + 1]], None,
+                        [str(x) for x in dd["docids"][b[i]:b[i + 1]]])
+        I.main(["--index_path", tmp])
+        qp = os.path.join(tmp, "q.pt")
+        dump_pickle(qp, dd["qv"], None, [str(x) for x in dd["qids"]])
+        os.chdir(tmp)
+        try:
+            G.main(["--query_emb_path", qp, "--index_path", os.path.join(tmp, "msmarco-passage.index.pt"), "--topk", "100"])
+            got = open(os.path.join(tmp, "result.trec")).read()
+        finally:
+            os.chdir(cwd)
+    ref = parse_trec(golden.trec("golden_main_dense_merged.trec"))
+    out = parse_trec(got)
+    for qid in ref:      # row order differs (sorted merge) but docids/scores are the same
+        assert [x[0] for x in ref[qid]] == [x[0] for x in out[qid]]
+        np.testing.assert_allclose([x[2] for x in ref[qid]], [x[2] for x in out[qid]], rtol=3e-6, atol=3e-6)
+
+
+def test_larger_random_hybrid(G):
+    """N = 200k x 1536, 300 queries (two query tiles), k = 1000; a sample of queries is checked
+    against the exact oracle."""
+    from dhr_amd import synth
+    cv, ci, qv, qi = synth.make_pair(15, 200_000, 300, 768, 768)
+    _, _, st = _search_check(G, cv, ci, qv.astype(np.float32), qi, 1000, queries=[0, 1, 150, 299])
+    print(st)
