@@ -59,6 +59,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one process do not
+    # share the device.  Import torch FIRST so that the loader resolves our NEEDED libamdhip64.so.7
+    # to the copy that is already mapped (same SONAME) and torch tensors and our kernels share it.
+    import torch  # noqa: F401
     path = _build.LIB
     if not os.path.exists(path):
         try:
