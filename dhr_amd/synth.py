@@ -98,11 +98,12 @@ def torch_make_dlr(gen, n: int, d_dlr: int, lmin: int, lmax: int, device, *, uni
     if uniform_idx:
         idx = torch.randint(0, n_idx, (n, d_dlr), generator=gen, device=device, dtype=torch.int64)
     else:
-        p = torch.tensor(bg_categorical(n_idx), device=device, dtype=torch.float32)
-        idx = torch.multinomial(p, n * d_dlr, replacement=True, generator=gen).view(n, d_dlr)
+        cdf = torch.tensor(np.cumsum(bg_categorical(n_idx)), device=device, dtype=torch.float32)
+        u = torch.rand((n, d_dlr), generator=gen, device=device)
+        idx = torch.bucketize(u, cdf).clamp_(max=n_idx - 1)
     perm = torch.from_numpy(np.random.Generator(np.random.PCG64(977)).permutation(vocab)).to(device)
-    pz = torch.tensor(_zipf_p(vocab), device=device, dtype=torch.float32)
-    t = perm[torch.multinomial(pz, n * lmax, replacement=True, generator=gen)].view(n, lmax)
+    cz = torch.tensor(np.cumsum(_zipf_p(vocab)), device=device, dtype=torch.float32)
+    t = perm[torch.bucketize(torch.rand((n, lmax), generator=gen, device=device), cz).clamp_(max=vocab - 1)]
     w = torch.rand((n, lmax), generator=gen, device=device) * 2.9 + 0.1
     length = torch.randint(lmin, lmax + 1, (n, 1), generator=gen, device=device)
     w = torch.where(torch.arange(lmax, device=device)[None, :] < length, w, torch.zeros_like(w))

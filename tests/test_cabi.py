@@ -1,0 +1,83 @@
+"""CPU-only checks of the C-ABI boundary: the library builds/loads, exports every symbol that
+include/dhr_hip.h declares, fails loudly without a GPU, and its host-side reduce matches the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "dhr_hip.h")).read()
+    return sorted(set(re.findall(r"\b(dhr_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dhr_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/dhr_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == names
+    assert lib.dhr_version() == 100
+
+
+def test_struct_layouts_match_header():
+    from dhr_amd import _lib
+    assert C.sizeof(_lib.IndexDesc) == 72
+    assert C.sizeof(_lib.QueryBatch) == 48
+    assert C.sizeof(_lib.SearchStats) == 112
+
+
+def test_invalid_arguments_return_codes_not_crashes():
+    from dhr_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    d = _lib.IndexDesc()
+    assert lib.dhr_index_create(None, C.byref(h)) == -1
+    d.n_rows = 0
+    assert lib.dhr_index_create(C.byref(d), C.byref(h)) == -1
+    assert b"n_rows" in lib.dhr_last_error()
+    v = np.zeros((4, 20), np.float16)
+    d.n_rows, d.d_dlr, d.d_cls, d.value, d.ld_value = 4, 12, 8, v.ctypes.data, 20
+    i = np.zeros((4, 12), np.uint8)
+    d.index, d.index_dtype, d.ld_index = i.ctypes.data, _lib.IDX_U8, 12
+    assert lib.dhr_index_create(C.byref(d), C.byref(h)) == -2          # d_dlr % 8
+    assert lib.dhr_merge_topk_host(0, 1, None, None, 1, None, None) == -1
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from dhr_amd import _lib
+    from dhr_amd.retrieval.gip_retrieval import GipIndex
+    with pytest.raises(_lib.DhrError, match="dhr_index_create failed"):
+        GipIndex(np.zeros((16, 64), np.float16))
+
+
+def test_host_merge_matches_oracle():
+    from dhr_amd import _lib
+    from oracle import gip_oracle as O
+    lib = _lib.load()
+    rng = np.random.default_rng(1)
+    q, n_in, k = 11, 257, 40
+    s = np.round(rng.standard_normal((q, n_in)).astype(np.float32), 1)
+    r = rng.permutation(100000)[: q * n_in].reshape(q, n_in).astype(np.int64)
+    r[:, ::17] = -1
+    s[0, :] = -np.inf                                  # all -inf scores still rank by row
+    es, er = O.merge_topk([s], [r], k)
+    hs, hr = np.empty((q, k), np.float32), np.empty((q, k), np.int64)
+    assert lib.dhr_merge_topk_host(q, n_in, s.ctypes.data, r.ctypes.data, k, hs.ctypes.data, hr.ctypes.data) == 0
+    np.testing.assert_array_equal(hs, es)
+    np.testing.assert_array_equal(hr, er)
+    # k_out larger than the valid entries -> (-inf, -1) padding
+    hs2, hr2 = np.empty((q, 300), np.float32), np.empty((q, 300), np.int64)
+    assert lib.dhr_merge_topk_host(q, n_in, s.ctypes.data, r.ctypes.data, 300, hs2.ctypes.data, hr2.ctypes.data) == 0
+    valid = (r >= 0).sum(1)
+    for i in range(q):
+        assert np.all(hr2[i, valid[i]:] == -1) and np.all(np.isneginf(hs2[i, valid[i]:]))
