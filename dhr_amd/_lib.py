@@ -13,7 +13,7 @@ DHR_OK = 0
 IDX_NONE, IDX_U8, IDX_I8, IDX_I16 = 0, 1, 2, 3
 VAL_F16, VAL_F32 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
-PARAM_CAND_CAP, PARAM_FIRST_ROWS, PARAM_PROFILE, PARAM_MAX_GROWTH = 1, 2, 3, 4
+PARAM_CAND_CAP, PARAM_FIRST_ROWS, PARAM_PROFILE, PARAM_MAX_GROWTH, PARAM_SAMPLE_PERIOD = 1, 2, 3, 4, 5
 
 EXPORTS = ["dhr_version", "dhr_last_error", "dhr_index_create", "dhr_index_destroy", "dhr_index_set_param",
            "dhr_index_device_bytes", "dhr_search", "dhr_score_rows", "dhr_merge_topk", "dhr_merge_topk_host",
@@ -39,7 +39,7 @@ class QueryBatch(C.Structure):
 class SearchStats(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("n_queries", C.c_int64), ("k", C.c_int64), ("phases", C.c_int32),
                 ("overflow_retries", C.c_int32), ("candidates_bound", C.c_int64), ("candidates_exact", C.c_int64),
-                ("gemm_rows", C.c_int64), ("gemm_ms", C.c_double), ("refine_ms", C.c_double),
+                ("gemm_rows", C.c_int64), ("sample_fallback_queries", C.c_int64), ("gemm_ms", C.c_double), ("refine_ms", C.c_double),
                 ("rescore_ms", C.c_double), ("select_ms", C.c_double), ("prep_ms", C.c_double),
                 ("total_ms", C.c_double), ("gemm_flops", C.c_double)]
 

@@ -45,6 +45,8 @@ struct Workspace {
   uint2* cand = nullptr;
   uint64_t *rs_keys = nullptr, *topk_keys = nullptr;
   uint32_t* d_max = nullptr;             // {max, pad} + u64 sum live in one 16-byte device block
+  float* tau_hat = nullptr;
+  uint32_t* fail_flags = nullptr;
   void* h_pinned = nullptr;              // 16 bytes pinned mirror
   void* q_stage = nullptr;  size_t q_stage_bytes = 0;
   void* qi_stage = nullptr; size_t qi_stage_bytes = 0;
@@ -63,15 +65,16 @@ struct dhr_index {
   float dmax = 0.f;
   int64_t index_bytes = 0;
   // params
-  int64_t cand_cap = 16384, first_rows = 0;
+  int64_t cand_cap = 32768, first_rows = 0;
   int profile = 0, max_growth16 = 32;
-  Workspace ws;
+  int sample_period = 16;
+  Workspace ws, ws_fb;
   dhr_search_stats stats{};
 };
 
 static void free_ws(Workspace& w) {
   hipFree(w.q_tiles); hipFree(w.q32); hipFree(w.q_idx); hipFree(w.margin); hipFree(w.tau); hipFree(w.thr);
-  hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max);
+  hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags);
   if (w.h_pinned) hipHostFree(w.h_pinned);
   hipFree(w.q_stage); hipFree(w.qi_stage); hipFree(w.out_stage);
   w = Workspace();
@@ -84,6 +87,7 @@ extern "C" void dhr_index_destroy(dhr_index* ix) {
   if (!ix) return;
   hipSetDevice(ix->device);
   free_ws(ix->ws);
+  free_ws(ix->ws_fb);
   hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->dlr_signed);
   delete ix;
 }
@@ -98,6 +102,9 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
       if (value < 0) return set_error(DHR_ERR_INVALID, "first_rows must be >= 0");
       ix->first_rows = value; return DHR_OK;
     case DHR_PARAM_PROFILE: ix->profile = value != 0; return DHR_OK;
+    case DHR_PARAM_SAMPLE_PERIOD:
+      if (value < 0 || value > 256) return set_error(DHR_ERR_INVALID, "sample_period must be in [0,256] (0/1 = off)");
+      ix->sample_period = (int)value; return DHR_OK;
     case DHR_PARAM_MAX_GROWTH:
       if (value < 1 || value > 1024) return set_error(DHR_ERR_INVALID, "max_growth must be in [1,1024] sixteenths");
       ix->max_growth16 = (int)value; return DHR_OK;
@@ -105,7 +112,7 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
   return set_error(DHR_ERR_INVALID, "unknown parameter");
 }
 
-extern "C" int64_t dhr_index_device_bytes(const dhr_index* ix) { return ix ? ix->index_bytes + ix->ws.bytes : 0; }
+extern "C" int64_t dhr_index_device_bytes(const dhr_index* ix) { return ix ? ix->index_bytes + ix->ws.bytes + ix->ws_fb.bytes : 0; }
 extern "C" int dhr_get_stats(const dhr_index* ix, dhr_search_stats* out) {
   if (!ix || !out) return set_error(DHR_ERR_INVALID, "null argument");
   *out = ix->stats;
@@ -220,8 +227,7 @@ static hipError_t re_malloc(T*& p, size_t bytes, int64_t& total) {
   return hipMalloc((void**)&p, bytes ? bytes : 16);
 }
 
-static int ensure_ws(dhr_index* ix, int n_queries, int k, int64_t keys_ld_min) {
-  Workspace& w = ix->ws;
+static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t keys_ld_min) {
   const int q_pad = (int)round_up(n_queries, TILE_ROWS);
   int kp = 1;
   while (kp < k) kp <<= 1;
@@ -242,6 +248,8 @@ static int ensure_ws(dhr_index* ix, int n_queries, int k, int64_t keys_ld_min) {
   HIP_TRY(re_malloc(w.rs_keys, (size_t)q_pad * keys_ld * 8, tot));
   HIP_TRY(re_malloc(w.topk_keys, (size_t)q_pad * kp * 8, tot));
   HIP_TRY(re_malloc(w.d_max, 16, tot));
+  HIP_TRY(re_malloc(w.tau_hat, (size_t)q_pad * 4, tot));
+  HIP_TRY(re_malloc(w.fail_flags, (size_t)q_pad * 4, tot));
   HIP_TRY(hipHostMalloc(&w.h_pinned, 16, hipHostMallocDefault));
   w.q_pad = q_pad; w.kp = kp; w.cap = cap; w.keys_ld = keys_ld; w.k_pad = ix->k_pad; w.d_dlr = ix->d_dlr;
   w.bytes = tot;
@@ -273,8 +281,7 @@ static int grow(void*& p, size_t& have, size_t need, int64_t& total) {
 }
 
 // queries -> device operand tiles / fp32 copy / idx / margins (all inside the workspace)
-static int prep_queries(dhr_index* ix, const dhr_query_batch* qb, hipStream_t s) {
-  Workspace& w = ix->ws;
+static int prep_queries(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, hipStream_t s) {
   const void* v = qb->value;
   const void* qi = qb->index;
   int64_t ldv = qb->ld_value, ldi = qb->ld_index;
@@ -315,13 +322,186 @@ struct Timer {
 };
 enum { T_GEMM = 0, T_REFINE = 1, T_RESCORE = 2, T_SELECT = 3, T_PREP = 4 };
 
-static RescoreArgs base_rescore_args(const dhr_index* ix, int n_queries, bool gate) {
-  const Workspace& w = ix->ws;
+static RescoreArgs base_rescore_args(const dhr_index* ix, const Workspace& w, int n_queries, bool gate) {
   RescoreArgs r{};
   r.a_tiles = ix->tiles; r.dlr_signed = ix->dlr_signed; r.c_idx = ix->c_idx; r.c_idx_dtype = ix->idx_dtype;
   r.q32 = w.q32; r.q_idx = w.q_idx; r.ksteps = ix->ksteps; r.d_dlr = ix->d_dlr; r.k_pad = ix->k_pad;
   r.n_rows = ix->n_rows; r.n_queries = n_queries; r.gate = gate ? 1 : 0;
   return r;
+}
+
+// One bound-GEMM launch over sequence positions [lo,hi) + candidate statistics read back.
+static int gemm_phase(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi, int map_mode, int period, int64_t head,
+                      Timer& tm, dhr_search_stats& st, hipStream_t s, uint32_t* maxc, unsigned long long* sumc) {
+  GemmArgs g{};
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K;
+  g.seq_lo = lo; g.seq_hi = hi; g.map_mode = map_mode; g.period = period; g.head = head; g.n_tiles = ix->n_tiles;
+  g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt;
+  g.cap = (uint32_t)w.cap; g.n_queries = Q;
+  HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));
+  HIP_TRY(hipMemsetAsync(w.d_max, 0, 16, s));
+  tm.begin(T_GEMM); HIP_TRY(launch_gemm_filter(g, s)); tm.end();
+  HIP_TRY(launch_max_u32(w.cnt, Q, w.d_max, (unsigned long long*)(w.d_max + 2), s));
+  HIP_TRY(hipMemcpyAsync(w.h_pinned, w.d_max, 16, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *maxc = ((uint32_t*)w.h_pinned)[0];
+  memcpy(sumc, (uint32_t*)w.h_pinned + 2, 8);
+  const double rows = (double)(hi - lo) * TILE_ROWS;
+  st.phases++;
+  st.gemm_rows += (int64_t)rows;
+  st.gemm_flops += 2.0 * (double)w.q_pad * rows * (double)ix->k_pad;
+  return DHR_OK;
+}
+
+static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, uint32_t maxc, Timer& tm,
+                          hipStream_t s) {
+  const uint32_t maxr = std::min<uint32_t>(maxc, (uint32_t)w.cap);
+  if (maxr == 0) return DHR_OK;
+  RescoreArgs r = base_rescore_args(ix, w, Q, gate);
+  r.cand = w.cand; r.cnt = w.cnt; r.cap = (uint32_t)w.cap; r.max_count = maxr;
+  r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
+  tm.begin(T_RESCORE); HIP_TRY(launch_rescore(r, s)); tm.end();
+  sel.cnt = w.cnt; sel.count_all = 0;
+  tm.begin(T_SELECT); HIP_TRY(launch_select(sel, s)); tm.end();
+  return DHR_OK;
+}
+
+// Streaming phases over a tile sequence with growing chunks (exact for any input: tau only ever
+// comes from exact scores already seen, overflowing chunks are re-run in halves).
+static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, int64_t n_seq, int map_mode,
+                         int period, int64_t head, int64_t first_chunk, int64_t seen_rows, Timer& tm, dhr_search_stats& st,
+                         hipStream_t s) {
+  int64_t pos = 0;
+  int64_t chunk = std::max<int64_t>(DOC_GROUP, first_chunk);
+  while (pos < n_seq) {
+    chunk = std::min(chunk, round_up(n_seq - pos, DOC_GROUP));
+    const int64_t hi = std::min(pos + chunk, n_seq);
+    uint32_t maxc; unsigned long long sumc;
+    int rc = gemm_phase(ix, w, Q, pos, hi, map_mode, period, head, tm, st, s, &maxc, &sumc);
+    if (rc) return rc;
+    const int64_t chunk_rows = (hi - pos) * TILE_ROWS;
+    if (maxc > w.cap && chunk > DOC_GROUP) {               // overflow: redo this chunk in halves
+      st.overflow_retries++;
+      chunk = std::max<int64_t>(DOC_GROUP, round_up(chunk / 2, DOC_GROUP));
+      continue;
+    }
+    st.candidates_bound += (int64_t)sumc;
+    st.candidates_exact += (int64_t)sumc;
+    if ((rc = rescore_select(ix, w, Q, gate, sel, maxc, tm, s)) != DHR_OK) return rc;
+    pos = hi;
+    seen_rows += chunk_rows;
+    // next chunk: aim at cap/4 candidates for the fullest query, never more than growth * rows seen
+    const double target = (double)w.cap / 4.0;
+    double next_rows = (maxc == 0) ? (double)chunk_rows * 4.0 : (double)chunk_rows * target / (double)maxc;
+    next_rows = std::min(next_rows, (double)seen_rows * ix->max_growth16 / 16.0);
+    chunk = std::max<int64_t>(DOC_GROUP, (int64_t)(next_rows / (DOC_GROUP * TILE_ROWS)) * DOC_GROUP);
+  }
+  return DHR_OK;
+}
+
+// Leaves the sorted top-k keys of every query in w.topk_keys.  qb must already be validated.
+static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, int k, bool allow_sampling, Timer& tm,
+                       dhr_search_stats& st, hipStream_t s) {
+  int rc;
+  const int Q = qb->n_queries;
+  const bool gate = ix->d_dlr > 0 && qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE;   // else plain IP
+  const int64_t n = ix->n_rows;
+  const int64_t group_rows = (int64_t)DOC_GROUP * TILE_ROWS;
+  // rows scored exhaustively in phase 0 (>= k so that tau exists afterwards), whole tile groups
+  int64_t first = std::max<int64_t>(ix->first_rows, std::max<int64_t>(2048, 2 * (int64_t)k));
+  first = std::min(round_up(first, group_rows), round_up(n, group_rows));
+  const int64_t first_valid = std::min(first, n);
+  if ((rc = ensure_ws(ix, w, Q, k, first_valid)) != DHR_OK) return rc;
+
+  tm.begin(T_PREP);
+  if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
+  HIP_TRY(hipMemsetAsync(w.topk_keys, 0, (size_t)w.q_pad * w.kp * 8, s));
+  tm.end();
+
+  // sampled threshold: period S, conservative rank r (SURVEY hard part 3 / DESIGN.md "controller")
+  const int64_t head = first / TILE_ROWS;                       // tiles scored exhaustively
+  const int64_t rest = ix->n_tiles - head;
+  int S = allow_sampling ? ix->sample_period : 0;
+  int r_eff = k;
+  if (S >= 2) {
+    const double mean = (double)k / S;
+    r_eff = (int)std::ceil(mean + 4.0 * std::sqrt(mean) + 4.0);
+    if (r_eff >= k || rest < 32 * (int64_t)S || (rest / S) * TILE_ROWS < 16 * (int64_t)r_eff) S = 0;
+  }
+  if (S < 2) r_eff = k;
+
+  SelectArgs sel{};
+  sel.topk_keys = w.topk_keys; sel.in_keys = w.rs_keys; sel.ld_keys = w.keys_ld; sel.cap = (uint32_t)w.cap;
+  sel.k = r_eff; sel.kp = w.kp; sel.sort_n = 4 * w.kp; sel.margin = w.margin; sel.tau = w.tau; sel.thr = w.thr;
+  sel.n_queries = Q;
+
+  // ---- phase 0: exhaustive exact scoring of rows [0, first_valid)
+  {
+    RescoreArgs r = base_rescore_args(ix, w, Q, gate);
+    r.row0 = 0; r.count_all = (uint32_t)first_valid; r.max_count = (uint32_t)first_valid;
+    r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
+    tm.begin(T_RESCORE); HIP_TRY(launch_rescore(r, s)); tm.end();
+    sel.cnt = nullptr; sel.count_all = (uint32_t)first_valid;
+    tm.begin(T_SELECT); HIP_TRY(launch_select(sel, s)); tm.end();
+    st.candidates_exact += (int64_t)first_valid * Q;
+  }
+  if (rest <= 0) return DHR_OK;
+
+  if (S < 2) {
+    // plain streaming over all remaining tiles
+    return stream_phases(ix, w, Q, gate, sel, rest, 1, 1, head, head, first_valid, tm, st, s);
+  }
+
+  // ---- sampled run: top-r_eff of {head rows} + {every S-th tile}  ->  tau_hat
+  const int64_t n_sample = (rest + S - 1) / S;
+  if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, head, first_valid, tm, st, s)) != DHR_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(w.tau_hat, w.tau, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
+
+  // ---- main pass: all other tiles with the fixed threshold tau_hat - margin
+  sel.k = k;
+  const int64_t n_main = rest - n_sample;
+  {
+    uint32_t maxc; unsigned long long sumc;
+    if ((rc = gemm_phase(ix, w, Q, 0, n_main, 2, S, head, tm, st, s, &maxc, &sumc)) != DHR_OK) return rc;
+    st.candidates_bound += (int64_t)sumc;
+    st.candidates_exact += (int64_t)sumc;
+    if ((rc = rescore_select(ix, w, Q, gate, sel, maxc, tm, s)) != DHR_OK) return rc;
+  }
+  // ---- verify; queries whose list overflowed or that found < k rows above tau_hat are redone exactly
+  HIP_TRY(hipMemsetAsync(w.d_max, 0, 16, s));
+  HIP_TRY(launch_verify(w.topk_keys, w.kp, k, w.cnt, (uint32_t)w.cap, w.tau_hat, Q, w.fail_flags, w.d_max, s));
+  HIP_TRY(hipMemcpyAsync(w.h_pinned, w.d_max, 16, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const uint32_t n_fail = ((uint32_t*)w.h_pinned)[0];
+  st.sample_fallback_queries += n_fail;
+  if (n_fail == 0) return DHR_OK;
+
+  std::vector<uint32_t> flags(Q);
+  HIP_TRY(hipMemcpy(flags.data(), w.fail_flags, (size_t)Q * 4, hipMemcpyDeviceToHost));
+  std::vector<int32_t> ids;
+  for (int q = 0; q < Q; ++q)
+    if (flags[q]) ids.push_back(q);
+  const int nf = (int)ids.size();
+  void* tmp = nullptr;
+  const size_t b32 = (size_t)nf * ix->k_pad * 4, bidx = (size_t)nf * std::max(ix->d_dlr, 8) * 2, bids = (size_t)nf * 4;
+  HIP_TRY(hipMalloc(&tmp, b32 + bidx + bids + 64));
+  float* f32 = (float*)tmp;
+  int16_t* fidx = (int16_t*)((char*)tmp + b32);
+  int32_t* d_ids = (int32_t*)((char*)tmp + b32 + bidx);
+  auto done = [&](int code) { hipFree(tmp); return code; };
+  if (hipMemcpyAsync(d_ids, ids.data(), bids, hipMemcpyHostToDevice, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "H2D failed"));
+  if (launch_gather_queries(w.q32, w.q_idx, ix->k_pad, ix->d_dlr, d_ids, nf, f32, fidx, s) != hipSuccess)
+    return done(set_error(DHR_ERR_HIP, "gather_queries launch failed"));
+  dhr_query_batch sub{};
+  sub.n_queries = nf; sub.mem_kind = DHR_MEM_DEVICE; sub.value = f32; sub.value_dtype = DHR_VAL_F32; sub.ld_value = ix->k_pad;
+  sub.index = gate ? fidx : nullptr; sub.index_dtype = gate ? DHR_IDX_I16 : DHR_IDX_NONE; sub.ld_index = ix->d_dlr;
+  Workspace& w2 = ix->ws_fb;
+  if ((rc = search_core(ix, w2, &sub, k, false, tm, st, s)) != DHR_OK) return done(rc);
+  if (w2.kp != w.kp) return done(set_error(DHR_ERR_INTERNAL, "fallback workspace mismatch"));
+  if (launch_scatter_keys(w2.topk_keys, w.topk_keys, w.kp, d_ids, nf, s) != hipSuccess)
+    return done(set_error(DHR_ERR_HIP, "scatter_keys launch failed"));
+  if (hipStreamSynchronize(s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "fallback search failed on the device"));
+  return done(DHR_OK);
 }
 
 extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_scores, int64_t* out_rows,
@@ -334,93 +514,14 @@ extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, f
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = (hipStream_t)stream;
   const int Q = qb->n_queries;
-  const bool gate = ix->d_dlr > 0 && qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE;   // else plain IP
-  const int64_t n = ix->n_rows;
-  const int64_t group_rows = (int64_t)DOC_GROUP * TILE_ROWS;
-
-  // rows scored exhaustively in phase 0 (>= k so that tau exists afterwards), whole tile groups
-  int64_t first = std::max<int64_t>(ix->first_rows, std::max<int64_t>(2048, 2 * (int64_t)k));
-  first = std::min(round_up(first, group_rows), round_up(n, group_rows));
-  const int64_t first_valid = std::min(first, n);
-  if ((rc = ensure_ws(ix, Q, k, first_valid)) != DHR_OK) return rc;
-  Workspace& w = ix->ws;
-
   hipEvent_t ev0, ev1;
   HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
   HIP_TRY(hipEventRecord(ev0, s));
   Timer tm{ix->profile != 0, s, {}, {}};
   dhr_search_stats st{};
-  st.n_rows = n; st.n_queries = Q; st.k = k;
-
-  tm.begin(T_PREP);
-  if ((rc = prep_queries(ix, qb, s)) != DHR_OK) return rc;
-  HIP_TRY(hipMemsetAsync(w.topk_keys, 0, (size_t)w.q_pad * w.kp * 8, s));
-  tm.end();
-
-  SelectArgs sel{};
-  sel.topk_keys = w.topk_keys; sel.in_keys = w.rs_keys; sel.ld_keys = w.keys_ld; sel.cap = (uint32_t)w.cap;
-  sel.k = k; sel.kp = w.kp; sel.sort_n = 4 * w.kp; sel.margin = w.margin; sel.tau = w.tau; sel.thr = w.thr;
-  sel.n_queries = Q;
-
-  // ---- phase 0: exhaustive exact scoring of rows [0, first_valid)
-  {
-    RescoreArgs r = base_rescore_args(ix, Q, gate);
-    r.row0 = 0; r.count_all = (uint32_t)first_valid; r.max_count = (uint32_t)first_valid;
-    r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
-    tm.begin(T_RESCORE); HIP_TRY(launch_rescore(r, s)); tm.end();
-    sel.cnt = nullptr; sel.count_all = (uint32_t)first_valid;
-    tm.begin(T_SELECT); HIP_TRY(launch_select(sel, s)); tm.end();
-    st.candidates_exact += (int64_t)first_valid * Q;
-  }
-
-  // ---- phases p>0: bound GEMM + filter over growing chunks
-  int64_t pos = first / TILE_ROWS;                  // next corpus tile
-  int64_t seen = first_valid;
-  int64_t chunk_tiles = std::max<int64_t>(DOC_GROUP, round_up(first, group_rows) / TILE_ROWS);
-  uint32_t* h = (uint32_t*)w.h_pinned;
-  while (pos < ix->n_tiles) {
-    chunk_tiles = std::min(chunk_tiles, round_up(ix->n_tiles - pos, DOC_GROUP));
-    GemmArgs g{};
-    g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K;
-    g.tile_lo = pos; g.tile_hi = std::min(pos + chunk_tiles, ix->n_tiles); g.n_qtiles = w.q_pad / TILE_ROWS;
-    g.n_rows = n; g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = Q;
-    HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));
-    HIP_TRY(hipMemsetAsync(w.d_max, 0, 16, s));
-    tm.begin(T_GEMM); HIP_TRY(launch_gemm_filter(g, s)); tm.end();
-    HIP_TRY(launch_max_u32(w.cnt, Q, w.d_max, (unsigned long long*)(w.d_max + 2), s));
-    HIP_TRY(hipMemcpyAsync(h, w.d_max, 16, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const uint32_t maxc = h[0];
-    unsigned long long sumc;
-    memcpy(&sumc, h + 2, 8);
-    const int64_t chunk_rows = (g.tile_hi - g.tile_lo) * TILE_ROWS;
-    st.phases++;
-    st.gemm_rows += chunk_rows;
-    st.gemm_flops += 2.0 * (double)w.q_pad * (double)chunk_rows * (double)ix->k_pad;
-    if (maxc > w.cap && chunk_tiles > DOC_GROUP) {          // overflow: redo this chunk in halves
-      st.overflow_retries++;
-      chunk_tiles = std::max<int64_t>(DOC_GROUP, round_up(chunk_tiles / 2, DOC_GROUP));
-      continue;
-    }
-    st.candidates_bound += (int64_t)sumc;
-    const uint32_t maxr = std::min<uint32_t>(maxc, (uint32_t)w.cap);
-    if (maxr > 0) {
-      RescoreArgs r = base_rescore_args(ix, Q, gate);
-      r.cand = w.cand; r.cnt = w.cnt; r.cap = (uint32_t)w.cap; r.max_count = maxr;
-      r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
-      tm.begin(T_RESCORE); HIP_TRY(launch_rescore(r, s)); tm.end();
-      sel.cnt = w.cnt; sel.count_all = 0;
-      tm.begin(T_SELECT); HIP_TRY(launch_select(sel, s)); tm.end();
-      st.candidates_exact += (int64_t)sumc;
-    }
-    pos = g.tile_hi;
-    seen += chunk_rows;
-    // next chunk: aim at cap/4 candidates for the fullest query, never more than growth * rows seen
-    const double target = (double)w.cap / 4.0;
-    double next_rows = (maxc == 0) ? (double)chunk_rows * 4.0 : (double)chunk_rows * target / (double)maxc;
-    next_rows = std::min(next_rows, (double)seen * ix->max_growth16 / 16.0);
-    chunk_tiles = std::max<int64_t>(DOC_GROUP, (int64_t)(next_rows / group_rows) * DOC_GROUP);
-  }
+  st.n_rows = ix->n_rows; st.n_queries = Q; st.k = k;
+  Workspace& w = ix->ws;
+  if ((rc = search_core(ix, w, qb, k, true, tm, st, s)) != DHR_OK) return rc;
 
   // ---- results
   float* d_scores = out_scores;
@@ -459,9 +560,9 @@ extern "C" int dhr_score_rows(dhr_index* ix, const dhr_query_batch* qb, int32_t 
   hipStream_t s = (hipStream_t)stream;
   const int Q = qb->n_queries;
   const bool gate = ix->d_dlr > 0 && qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE;
-  if ((rc = ensure_ws(ix, Q, 1, 0)) != DHR_OK) return rc;
   Workspace& w = ix->ws;
-  if ((rc = prep_queries(ix, qb, s)) != DHR_OK) return rc;
+  if ((rc = ensure_ws(ix, w, Q, 1, 0)) != DHR_OK) return rc;
+  if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
   const size_t n = (size_t)Q * m;
   void* tmp = nullptr;                     // [rows64 (host input only)] [rows32] [scores]
   HIP_TRY(hipMalloc(&tmp, n * 16));
@@ -476,7 +577,7 @@ extern "C" int dhr_score_rows(dhr_index* ix, const dhr_query_batch* qb, int32_t 
   }
   if (launch_rows_to_local(src_rows, (int64_t)n, ix->row_offset, ix->n_rows, d_rows32, s) != hipSuccess)
     return done(set_error(DHR_ERR_HIP, "rows_to_local launch failed"));
-  RescoreArgs r = base_rescore_args(ix, Q, gate);
+  RescoreArgs r = base_rescore_args(ix, w, Q, gate);
   r.rows32 = d_rows32; r.ld_rows = m; r.count_all = (uint32_t)m; r.max_count = (uint32_t)m;
   r.out_scores = (mem_kind == DHR_MEM_HOST) ? d_sc : out_scores; r.ld_scores = m;
   if (launch_rescore(r, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "rescore launch failed"));
@@ -493,12 +594,12 @@ extern "C" int dhr_debug_bound_scores(dhr_index* ix, const dhr_query_batch* qb, 
   if (row_lo < 0 || row_hi > ix->n_rows || row_lo >= row_hi || !out_dev) return set_error(DHR_ERR_INVALID, "bad row range");
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = ensure_ws(ix, qb->n_queries, 1, 0)) != DHR_OK) return rc;
   Workspace& w = ix->ws;
-  if ((rc = prep_queries(ix, qb, s)) != DHR_OK) return rc;
+  if ((rc = ensure_ws(ix, w, qb->n_queries, 1, 0)) != DHR_OK) return rc;
+  if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.tile_lo = row_lo / TILE_ROWS;
-  g.tile_hi = (row_hi + TILE_ROWS - 1) / TILE_ROWS; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.seq_lo = row_lo / TILE_ROWS;
+  g.seq_hi = (row_hi + TILE_ROWS - 1) / TILE_ROWS; g.map_mode = 0; g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
   g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
   g.dump = out_dev; g.dump_ld = row_hi - row_lo; g.dump_row0 = row_lo;
   HIP_TRY(launch_gemm_filter(g, s));

@@ -41,6 +41,11 @@ __host__ __device__ inline float ordered_f32(uint32_t o) {
   v.u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
   return v.f;
 }
+__host__ __device__ inline int64_t seq_to_tile(int64_t i, int map_mode, int period, int64_t head) {
+  if (map_mode == 0) return i;
+  if (map_mode == 1) return head + i * period;
+  return head + (i / (period - 1)) * period + i % (period - 1) + 1;
+}
 __host__ __device__ inline uint64_t make_key(float score, uint32_t row) {
   return ((uint64_t)f32_ordered(score) << 32) | (uint64_t)(0xFFFFFFFFu - row);
 }
@@ -50,7 +55,13 @@ struct GemmArgs {
   const __half* b_tiles;      // query operand tiles
   int ksteps;                 // K_pad / 64
   int k_split;                // K-steps [0,k_split) are the gated (DLR) half; informational
-  int64_t tile_lo, tile_hi;   // corpus tile range of this launch
+  // corpus tiles of this launch: sequence positions [seq_lo, seq_hi) mapped to tile ids by
+  //   map_mode 0: tile = i                 (contiguous)
+  //   map_mode 1: tile = head + i*period   (the strided sample)
+  //   map_mode 2: tile = head + (i/(period-1))*period + i%(period-1) + 1   (everything but the sample)
+  int64_t seq_lo, seq_hi;
+  int map_mode, period;
+  int64_t head, n_tiles;
   int n_qtiles;               // Q_pad / 256
   int64_t n_rows;             // valid corpus rows (rows >= n_rows are zero padding)
   const float* thr;           // [Q_pad] tau - margin (+inf for padded queries)
@@ -117,6 +128,11 @@ hipError_t launch_emit(const uint64_t* topk_keys, int kp, int n_queries, int k, 
 hipError_t launch_max_u32(const uint32_t* v, int n, uint32_t* out_max, unsigned long long* out_sum, hipStream_t s);
 hipError_t launch_rows_to_local(const int64_t* rows, int64_t n, int64_t row_offset, int64_t n_rows, uint32_t* out,
                                 hipStream_t s);
+hipError_t launch_verify(const uint64_t* topk_keys, int kp, int k, const uint32_t* cnt, uint32_t cap, const float* tau_hat,
+                         int n_queries, uint32_t* fail_flags, uint32_t* n_fail, hipStream_t s);
+hipError_t launch_gather_queries(const float* q32, const int16_t* q_idx, int k_pad, int d_dlr, const int32_t* ids, int n,
+                                 float* out32, int16_t* out_idx, hipStream_t s);
+hipError_t launch_scatter_keys(const uint64_t* src, uint64_t* dst, int kp, const int32_t* ids, int n, hipStream_t s);
 hipError_t launch_merge_topk(int n_queries, int n_in, const float* in_scores, const int64_t* in_rows, int k_out,
                              float* out_scores, int64_t* out_rows, hipStream_t s);
 

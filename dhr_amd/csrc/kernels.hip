@@ -223,8 +223,10 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_filter_kernel(GemmArgs p) {
   const int r = (int)(i - g_local * per_group);
   const int qt = r / DOC_GROUP;
   const int dl = r - qt * DOC_GROUP;
-  const int64_t dt = p.tile_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
-  if (dt >= p.tile_hi) return;
+  const int64_t seq = p.seq_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
+  if (seq >= p.seq_hi) return;
+  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head);
+  if (dt >= p.n_tiles) return;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -328,7 +330,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_filter_kernel(GemmArgs p) {
 }
 
 hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
-  const int64_t n_tiles = a.tile_hi - a.tile_lo;
+  const int64_t n_tiles = a.seq_hi - a.seq_lo;
   if (n_tiles <= 0) return hipSuccess;
   const int64_t groups = (n_tiles + DOC_GROUP - 1) / DOC_GROUP;
   const int64_t groups_per_xcd = (groups + 7) / 8;
@@ -557,6 +559,54 @@ hipError_t launch_rows_to_local(const int64_t* rows, int64_t n, int64_t row_offs
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(rows_to_local_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, rows, n, row_offset,
                      n_rows, out);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ sampled-threshold helpers
+// A query's result is complete iff its candidate list did not overflow and its k-th best exact score
+// reached the sampled threshold tau_hat (then every row with score >= tau_hat was collected).
+__global__ void verify_kernel(const uint64_t* __restrict__ topk_keys, int kp, int k, const uint32_t* __restrict__ cnt,
+                              uint32_t cap, const float* __restrict__ tau_hat, int n_queries, uint32_t* fail_flags,
+                              uint32_t* n_fail) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_queries) return;
+  const uint64_t kth = topk_keys[(int64_t)q * kp + (k - 1)];
+  const bool ok = cnt[q] <= cap && kth != 0ull && ordered_f32((uint32_t)(kth >> 32)) >= tau_hat[q];
+  fail_flags[q] = ok ? 0u : 1u;
+  if (!ok) atomicAdd(n_fail, 1u);
+}
+hipError_t launch_verify(const uint64_t* topk_keys, int kp, int k, const uint32_t* cnt, uint32_t cap, const float* tau_hat,
+                         int n_queries, uint32_t* fail_flags, uint32_t* n_fail, hipStream_t s) {
+  hipLaunchKernelGGL(verify_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, topk_keys, kp, k, cnt, cap, tau_hat,
+                     n_queries, fail_flags, n_fail);
+  return hipGetLastError();
+}
+
+__global__ void gather_queries_kernel(const float* __restrict__ q32, const int16_t* __restrict__ q_idx, int k_pad,
+                                      int d_dlr, const int32_t* __restrict__ ids, int n, float* __restrict__ out32,
+                                      int16_t* __restrict__ out_idx) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const int64_t src = ids[i];
+  for (int j = threadIdx.x; j < k_pad; j += blockDim.x) out32[(int64_t)i * k_pad + j] = q32[src * k_pad + j];
+  for (int j = threadIdx.x; j < d_dlr; j += blockDim.x) out_idx[(int64_t)i * d_dlr + j] = q_idx[src * d_dlr + j];
+}
+hipError_t launch_gather_queries(const float* q32, const int16_t* q_idx, int k_pad, int d_dlr, const int32_t* ids, int n,
+                                 float* out32, int16_t* out_idx, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_queries_kernel, dim3(n), dim3(256), 0, s, q32, q_idx, k_pad, d_dlr, ids, n, out32, out_idx);
+  return hipGetLastError();
+}
+
+__global__ void scatter_keys_kernel(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int kp,
+                                    const int32_t* __restrict__ ids, int n) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  for (int j = threadIdx.x; j < kp; j += blockDim.x) dst[(int64_t)ids[i] * kp + j] = src[(int64_t)i * kp + j];
+}
+hipError_t launch_scatter_keys(const uint64_t* src, uint64_t* dst, int kp, const int32_t* ids, int n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(scatter_keys_kernel, dim3(n), dim3(256), 0, s, src, dst, kp, ids, n);
   return hipGetLastError();
 }
 

@@ -81,6 +81,7 @@ typedef struct dhr_search_stats {
   int64_t candidates_bound;  /* pairs that passed the bound filter (sum over queries) */
   int64_t candidates_exact;  /* pairs rescored exactly (incl. the dense first phase) */
   int64_t gemm_rows;         /* corpus rows pushed through the bound GEMM */
+  int64_t sample_fallback_queries; /* queries redone exactly because the sampled threshold was too high */
   double gemm_ms, refine_ms, rescore_ms, select_ms, prep_ms, total_ms;
   double gemm_flops;         /* 2 * Q_pad * rows * K_pad actually issued by the bound GEMM */
 } dhr_search_stats;
@@ -90,7 +91,8 @@ typedef enum dhr_param {
   DHR_PARAM_CAND_CAP = 1,     /* per-query candidate list capacity (entries) */
   DHR_PARAM_FIRST_ROWS = 2,   /* rows scored exhaustively to seed the thresholds (>= k enforced) */
   DHR_PARAM_PROFILE = 3,      /* 1: record per-kernel hipEvent timings into dhr_search_stats */
-  DHR_PARAM_MAX_GROWTH = 4    /* max (next chunk rows) / (rows seen), in 1/16ths (default 32 = 2x) */
+  DHR_PARAM_MAX_GROWTH = 4,   /* max (next chunk rows) / (rows seen), in 1/16ths (default 32 = 2x) */
+  DHR_PARAM_SAMPLE_PERIOD = 5 /* every S-th corpus tile seeds the thresholds (default 16; 0 = plain streaming) */
 } dhr_param;
 
 int dhr_version(void);

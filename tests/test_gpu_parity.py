@@ -297,3 +297,52 @@ def test_larger_random_hybrid(G):
     cv, ci, qv, qi = synth.make_pair(15, 200_000, 300, 768, 768)
     _, _, st = _search_check(G, cv, ci, qv.astype(np.float32), qi, 1000, queries=[0, 1, 150, 299])
     print(st)
+
+
+def _structured_corpus(n, boosted_mod, period=16, head_tiles=8):
+    """Dense-only corpus whose best rows all sit in tiles with (tile - head) % period == boosted_mod."""
+    rng = np.random.default_rng(5)
+    cv = (rng.standard_normal((n, 64)) * 0.05).astype(np.float16)
+    tile = np.arange(n) // 256
+    boosted = (tile >= head_tiles) & (((tile - head_tiles) % period) == boosted_mod)
+    cv[boosted, 0] += np.float16(2.0)
+    qv = np.zeros((5, 64), np.float16)
+    qv[:, 0] = 1.0
+    qv[:, 1:] = (rng.standard_normal((5, 63)) * 0.05).astype(np.float16)
+    return cv, qv
+
+
+@pytest.mark.parametrize("boosted_mod", [0, 3])
+def test_sampled_threshold_fallbacks(G, boosted_mod):
+    """Adversarial row order for the sampled threshold: (0) every high-scoring row sits in a SAMPLE tile,
+    so tau_hat is far too high and fewer than k rows reach it -> the queries must be redone exactly;
+    (3) every high-scoring row sits in one non-sample residue -> tau_hat is low, lists overflow.
+    Either way the result must equal the exact top-k."""
+    from dhr_amd import _lib
+    n = 300_000
+    cv, qv = _structured_corpus(n, boosted_mod)
+    _, _, st = _search_check(G, cv, None, qv.astype(np.float32), None, 1000,
+                             params=[(_lib.PARAM_CAND_CAP, 4096)])
+    print(boosted_mod, st)
+    if boosted_mod == 0:
+        assert st["sample_fallback_queries"] == 5
+    _, _, st2 = _search_check(G, cv, None, qv.astype(np.float32), None, 1000,
+                              params=[(_lib.PARAM_SAMPLE_PERIOD, 0)])
+    assert st2["sample_fallback_queries"] == 0
+
+
+def test_sampling_on_off_same_result(G):
+    from dhr_amd import _lib, synth
+    cv, ci, qv, qi = synth.make_pair(16, 150_000, 20, 768, 128)
+    q32 = qv.astype(np.float32)
+    out = []
+    for period in (0, 8, 16):
+        ix = G.GipIndex(cv, ci)
+        ix.set_param(_lib.PARAM_SAMPLE_PERIOD, period)
+        s, r = ix.search(q32, qi, 500)
+        out.append((s, r, ix.stats()))
+        ix.close()
+    for s, r, st in out[1:]:
+        np.testing.assert_array_equal(r, out[0][1])
+        np.testing.assert_array_equal(s, out[0][0])
+    print([o[2]["candidates_exact"] for o in out], [o[2]["phases"] for o in out])
