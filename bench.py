@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--topk", type=int, default=1000)
     ap.add_argument("--uniform-idx", action="store_true", help="adversarial variant: uniform slice indices")
     ap.add_argument("--cand-cap", type=int, default=0)
+    ap.add_argument("--idx-buckets", type=int, default=0)
+    ap.add_argument("--sample-period", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=200_000)
     ap.add_argument("--cpu-queries", type=int, default=12)
@@ -115,12 +117,14 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
     t_build = time.perf_counter()
-    index = GipIndex(cv, ci, device=local_rank, row_offset=lo)
+    index = GipIndex(cv, ci, device=local_rank, row_offset=lo, idx_buckets=args.idx_buckets)
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
     index.set_param(_lib.PARAM_PROFILE, 1)
     if args.cand_cap:
         index.set_param(_lib.PARAM_CAND_CAP, args.cand_cap)
+    if args.sample_period >= 0:
+        index.set_param(_lib.PARAM_SAMPLE_PERIOD, args.sample_period)
 
     # host sample for the CPU baseline + an in-bench parity check (rank 0, N=1 only)
     sample = None
@@ -155,9 +159,9 @@ def main():
         st = index.stats()
         gemm_ms += st["gemm_ms"]
         launches += st["phases"]
-        gemm_flops_alg += 2.0 * nq * st["gemm_rows"] * K        # algorithmic: real Q and K, rows pushed through the GEMM
+        gemm_flops_alg += st["gemm_flops_alg"]                  # algorithmic: real Q and K of every launch
         for key in ("rescore_ms", "select_ms", "prep_ms", "total_ms", "candidates_bound", "candidates_exact",
-                    "overflow_retries", "gemm_rows"):
+                    "overflow_retries", "gemm_rows", "sample_fallback_queries"):
             stats_acc[key] = stats_acc.get(key, 0) + st[key]
     barrier()
     elapsed = time.perf_counter() - t0

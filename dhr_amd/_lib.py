@@ -27,7 +27,7 @@ class DhrError(RuntimeError):
 class IndexDesc(C.Structure):
     _fields_ = [("device", C.c_int32), ("mem_kind", C.c_int32), ("n_rows", C.c_int64), ("d_dlr", C.c_int32),
                 ("d_cls", C.c_int32), ("value", C.c_void_p), ("ld_value", C.c_int64), ("index", C.c_void_p),
-                ("index_dtype", C.c_int32), ("reserved0", C.c_int32), ("ld_index", C.c_int64),
+                ("index_dtype", C.c_int32), ("idx_buckets", C.c_int32), ("ld_index", C.c_int64),
                 ("row_offset", C.c_int64)]
 
 
@@ -41,7 +41,7 @@ class SearchStats(C.Structure):
                 ("overflow_retries", C.c_int32), ("candidates_bound", C.c_int64), ("candidates_exact", C.c_int64),
                 ("gemm_rows", C.c_int64), ("sample_fallback_queries", C.c_int64), ("gemm_ms", C.c_double), ("refine_ms", C.c_double),
                 ("rescore_ms", C.c_double), ("select_ms", C.c_double), ("prep_ms", C.c_double),
-                ("total_ms", C.c_double), ("gemm_flops", C.c_double)]
+                ("total_ms", C.c_double), ("gemm_flops", C.c_double), ("gemm_flops_alg", C.c_double)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

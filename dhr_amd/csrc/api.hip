@@ -36,7 +36,7 @@ static inline int idx_esize(int dt) { return dt == DHR_IDX_I16 ? 2 : 1; }
 
 struct Workspace {
   int q_pad = 0, kp = 0;
-  int64_t cap = 0, keys_ld = 0, k_pad = 0, d_dlr = 0;
+  int64_t cap = 0, keys_ld = 0, kt = 0, d_dlr = 0;
   __half* q_tiles = nullptr;
   float* q32 = nullptr;
   int16_t* q_idx = nullptr;
@@ -57,10 +57,15 @@ struct Workspace {
 struct dhr_index {
   int device = 0;
   int64_t n_rows = 0, n_tiles = 0, row_offset = 0;
-  int d_dlr = 0, d_cls = 0, k = 0, k_pad = 0, ksteps = 0, idx_dtype = DHR_IDX_NONE;
+  int d_dlr = 0, d_cls = 0, k = 0, idx_dtype = DHR_IDX_NONE;
+  int k_rm = 0;        // row-major padded width (k rounded up to 64): q32 rows, vals_rm rows
+  int n_buckets = 1;   // index buckets per gated slice in the bound operands
+  int kt = 0;          // operand-tile columns = n_buckets*d_dlr + d_cls rounded up to 64
+  int ksteps = 0;      // kt / 64
   __half* tiles = nullptr;
+  __half* vals_rm = nullptr;
   void* c_idx = nullptr;
-  __half* dlr_signed = nullptr;
+  uint8_t* bucket_map = nullptr;   // [d_dlr][256] for 8-bit index dtypes, else null (value % n_buckets)
   bool abs_mode = false;
   float dmax = 0.f;
   int64_t index_bytes = 0;
@@ -88,7 +93,7 @@ extern "C" void dhr_index_destroy(dhr_index* ix) {
   hipSetDevice(ix->device);
   free_ws(ix->ws);
   free_ws(ix->ws_fb);
-  hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->dlr_signed);
+  hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map);
   delete ix;
 }
 
@@ -120,7 +125,7 @@ extern "C" int dhr_get_stats(const dhr_index* ix, dhr_search_stats* out) {
 }
 
 // ------------------------------------------------------------------------------------------ index build
-static int ingest(dhr_index* ix, const dhr_index_desc* d, bool abs_mode, uint32_t* d_flags /* {max_sq, neg} */,
+static int ingest(dhr_index* ix, const dhr_index_desc* d, bool first_pass, uint32_t* d_flags /* {max_sq, neg} */,
                   void* stage, int64_t block_rows, hipStream_t s) {
   const int64_t n = ix->n_rows;
   for (int64_t lo = 0; lo < n; lo += block_rows) {
@@ -136,12 +141,40 @@ static int ingest(dhr_index* ix, const dhr_index_desc* d, bool abs_mode, uint32_
       src = (const __half*)d->value + lo * d->ld_value;
       ld = d->ld_value;
     }
-    if (!abs_mode) HIP_TRY(launch_scan_rows(src, ld, rows, ix->d_dlr, ix->k, d_flags, d_flags + 1, s));
+    if (first_pass) {
+      HIP_TRY(launch_scan_rows(src, ld, rows, ix->d_dlr, ix->k, d_flags, d_flags + 1, s));
+      HIP_TRY(launch_copy_rows(src, ld, rows, ix->k, ix->k_rm, ix->vals_rm + lo * ix->k_rm, s));
+    }
     const int64_t fill = (lo + rows == n) ? round_up(lo + rows, TILE_ROWS) - lo : rows;   // zero the tail of the last tile
-    HIP_TRY(launch_tile_rows(src, ld, lo, rows, fill, ix->k, ix->k_pad, ix->d_dlr, abs_mode, ix->tiles, ix->dlr_signed, s));
+    HIP_TRY(launch_tile_rows(src, ld, lo, rows, fill, ix->d_dlr, ix->d_cls, ix->n_buckets, ix->kt, ix->c_idx, ix->idx_dtype,
+                             ix->bucket_map, ix->abs_mode, ix->tiles, s));
     if (d->mem_kind == DHR_MEM_HOST) HIP_TRY(hipStreamSynchronize(s));   // the staging buffer is reused
   }
   return DHR_OK;
+}
+
+// Per-slice index-value -> bucket table, balanced by corpus frequency (greedy: most frequent value first
+// into the lightest bucket), so that two different values of one slice rarely share a bucket.
+static void build_bucket_map(const std::vector<uint32_t>& hist, int d_dlr, int nb, std::vector<uint8_t>& map) {
+  map.assign((size_t)d_dlr * 256, 0);
+  std::vector<int> order(256);
+  std::vector<uint64_t> load(nb);
+  for (int j = 0; j < d_dlr; ++j) {
+    const uint32_t* h = &hist[(size_t)j * 256];
+    for (int v = 0; v < 256; ++v) order[v] = v;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h[a] > h[b]; });
+    std::fill(load.begin(), load.end(), 0);
+    int rr = 0;
+    for (int v : order) {
+      int best = 0;
+      if (h[v] == 0) best = rr++ % nb;                   // unseen values: round robin
+      else
+        for (int b = 1; b < nb; ++b)
+          if (load[b] < load[best]) best = b;
+      map[(size_t)j * 256 + v] = (uint8_t)best;
+      load[best] += h[v];
+    }
+  }
 }
 
 extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
@@ -157,6 +190,7 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
   if (has_idx && d->ld_index < d->d_dlr) return set_error(DHR_ERR_INVALID, "bad ld_index");
   if (d->d_dlr % 8) return set_error(DHR_ERR_UNSUPPORTED, "d_dlr (--emb_dim) must be a multiple of 8");
   if (d->d_dlr + d->d_cls > 8192) return set_error(DHR_ERR_UNSUPPORTED, "more than 8192 columns");
+  if (d->idx_buckets < 0 || d->idx_buckets > 16) return set_error(DHR_ERR_INVALID, "idx_buckets must be in [0,16] (0 = default)");
   if (d->mem_kind != DHR_MEM_HOST && d->mem_kind != DHR_MEM_DEVICE) return set_error(DHR_ERR_INVALID, "bad mem_kind");
   HIP_TRY(hipSetDevice(d->device));
 
@@ -167,40 +201,29 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
   ix->d_dlr = d->d_dlr;
   ix->d_cls = d->d_cls;
   ix->k = d->d_dlr + d->d_cls;
-  ix->k_pad = (int)round_up(ix->k, TILE_K);
-  ix->ksteps = ix->k_pad / TILE_K;
+  ix->k_rm = (int)round_up(ix->k, TILE_K);
+  ix->n_buckets = has_idx ? (d->idx_buckets > 0 ? d->idx_buckets : 2) : 1;
+  ix->kt = (int)round_up((int64_t)ix->n_buckets * ix->d_dlr + ix->d_cls, TILE_K);
+  ix->ksteps = ix->kt / TILE_K;
   ix->idx_dtype = has_idx ? d->index_dtype : DHR_IDX_NONE;
   ix->n_tiles = (d->n_rows + TILE_ROWS - 1) / TILE_ROWS;
   hipStream_t s = nullptr;
   void* stage = nullptr;
   uint32_t* d_flags = nullptr;
+  uint32_t* d_hist = nullptr;
   int rc = DHR_OK;
-  auto fail = [&](int code) { hipFree(stage); hipFree(d_flags); dhr_index_destroy(ix); return code; };
+  auto fail = [&](int code) { hipFree(stage); hipFree(d_flags); hipFree(d_hist); dhr_index_destroy(ix); return code; };
 
   const size_t tile_bytes = (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2;
   if (hipMalloc((void**)&ix->tiles, tile_bytes) != hipSuccess)
     return fail(set_error(DHR_ERR_HIP, "hipMalloc of " + std::to_string(tile_bytes) + " bytes for the corpus tiles failed"));
-  ix->index_bytes = (int64_t)tile_bytes;
+  const size_t rm_bytes = (size_t)ix->n_rows * ix->k_rm * 2;
+  if (hipMalloc((void**)&ix->vals_rm, rm_bytes) != hipSuccess)
+    return fail(set_error(DHR_ERR_HIP, "hipMalloc of " + std::to_string(rm_bytes) + " bytes for the row-major corpus copy failed"));
+  ix->index_bytes = (int64_t)(tile_bytes + rm_bytes);
   if (hipMalloc((void**)&d_flags, 16) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMalloc failed"));
   if (hipMemsetAsync(d_flags, 0, 16, s) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMemsetAsync failed"));
-  const int64_t block_rows = 65536;
-  if (d->mem_kind == DHR_MEM_HOST &&
-      hipMalloc(&stage, (size_t)std::min<int64_t>(block_rows, d->n_rows) * ix->k * 2) != hipSuccess)
-    return fail(set_error(DHR_ERR_HIP, "hipMalloc of the staging buffer failed"));
-  if ((rc = ingest(ix, d, false, d_flags, stage, block_rows, s)) != DHR_OK) return fail(rc);
-  uint32_t flags[2] = {0, 0};
-  if (hipMemcpy(flags, d_flags, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMemcpy failed"));
-  float max_sq;
-  memcpy(&max_sq, &flags[0], 4);
-  ix->dmax = std::sqrt(max_sq) * 1.0005f + 1e-30f;
-  if (flags[1]) {
-    // negative gated values: the bound needs |q|.|d| on the DLR half; keep the signed values aside
-    ix->abs_mode = true;
-    const size_t sb = (size_t)ix->n_tiles * TILE_ROWS * ix->d_dlr * 2;
-    if (hipMalloc((void**)&ix->dlr_signed, sb) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMalloc (signed DLR copy) failed"));
-    ix->index_bytes += (int64_t)sb;
-    if ((rc = ingest(ix, d, true, d_flags, stage, block_rows, s)) != DHR_OK) return fail(rc);
-  }
+  // the index array first: the tile builder needs it for the bucket split
   if (has_idx) {
     const int es = idx_esize(d->index_dtype);
     const size_t ib = (size_t)d->n_rows * d->d_dlr * es;
@@ -210,10 +233,40 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
                          (size_t)d->n_rows, d->mem_kind == DHR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
                          s) != hipSuccess)
       return fail(set_error(DHR_ERR_HIP, "copy of the index array failed"));
+    if (ix->n_buckets > 1 && es == 1) {
+      const size_t hb = (size_t)d->d_dlr * 256 * 4;
+      if (hipMalloc((void**)&d_hist, hb) != hipSuccess || hipMemsetAsync(d_hist, 0, hb, s) != hipSuccess)
+        return fail(set_error(DHR_ERR_HIP, "hipMalloc (index histogram) failed"));
+      if (launch_idx_hist((const uint8_t*)ix->c_idx, d->n_rows, d->d_dlr, d_hist, s) != hipSuccess)
+        return fail(set_error(DHR_ERR_HIP, "idx_hist launch failed"));
+      std::vector<uint32_t> hist((size_t)d->d_dlr * 256);
+      if (hipMemcpy(hist.data(), d_hist, hb, hipMemcpyDeviceToHost) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMemcpy failed"));
+      std::vector<uint8_t> map;
+      build_bucket_map(hist, d->d_dlr, ix->n_buckets, map);
+      if (hipMalloc((void**)&ix->bucket_map, map.size()) != hipSuccess ||
+          hipMemcpy(ix->bucket_map, map.data(), map.size(), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(set_error(DHR_ERR_HIP, "bucket map upload failed"));
+    }
+  }
+  const int64_t block_rows = 65536;
+  if (d->mem_kind == DHR_MEM_HOST &&
+      hipMalloc(&stage, (size_t)std::min<int64_t>(block_rows, d->n_rows) * ix->k * 2) != hipSuccess)
+    return fail(set_error(DHR_ERR_HIP, "hipMalloc of the staging buffer failed"));
+  if ((rc = ingest(ix, d, true, d_flags, stage, block_rows, s)) != DHR_OK) return fail(rc);
+  uint32_t flags[2] = {0, 0};
+  if (hipMemcpy(flags, d_flags, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMemcpy failed"));
+  float max_sq;
+  memcpy(&max_sq, &flags[0], 4);
+  ix->dmax = std::sqrt(max_sq) * 1.0005f + 1e-30f;
+  if (flags[1]) {
+    // negative gated values: the bound needs |q|.|d| on the gated half -> rebuild the tile image with |.|
+    ix->abs_mode = true;
+    if ((rc = ingest(ix, d, false, d_flags, stage, block_rows, s)) != DHR_OK) return fail(rc);
   }
   if (hipStreamSynchronize(s) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "index build failed on the device"));
   hipFree(stage);
   hipFree(d_flags);
+  hipFree(d_hist);
   *out = ix;
   return DHR_OK;
 }
@@ -234,11 +287,11 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   if (kp < 64) kp = 64;
   const int64_t cap = ix->cand_cap;
   const int64_t keys_ld = std::max<int64_t>(cap, keys_ld_min);
-  if (w.q_pad == q_pad && w.kp == kp && w.cap == cap && w.keys_ld >= keys_ld && w.k_pad == ix->k_pad) return DHR_OK;
+  if (w.q_pad == q_pad && w.kp == kp && w.cap == cap && w.keys_ld >= keys_ld && w.kt == ix->kt) return DHR_OK;
   free_ws(w);
   int64_t tot = 0;
-  HIP_TRY(re_malloc(w.q_tiles, (size_t)q_pad * ix->k_pad * 2, tot));
-  HIP_TRY(re_malloc(w.q32, (size_t)q_pad * ix->k_pad * 4, tot));
+  HIP_TRY(re_malloc(w.q_tiles, (size_t)q_pad * ix->kt * 2, tot));
+  HIP_TRY(re_malloc(w.q32, (size_t)q_pad * ix->k_rm * 4, tot));
   HIP_TRY(re_malloc(w.q_idx, (size_t)q_pad * std::max(ix->d_dlr, 8) * 2, tot));
   HIP_TRY(re_malloc(w.margin, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.tau, (size_t)q_pad * 4, tot));
@@ -251,7 +304,7 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.tau_hat, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.fail_flags, (size_t)q_pad * 4, tot));
   HIP_TRY(hipHostMalloc(&w.h_pinned, 16, hipHostMallocDefault));
-  w.q_pad = q_pad; w.kp = kp; w.cap = cap; w.keys_ld = keys_ld; w.k_pad = ix->k_pad; w.d_dlr = ix->d_dlr;
+  w.q_pad = q_pad; w.kp = kp; w.cap = cap; w.keys_ld = keys_ld; w.kt = ix->kt; w.d_dlr = ix->d_dlr;
   w.bytes = tot;
   return DHR_OK;
 }
@@ -302,7 +355,8 @@ static int prep_queries(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, 
     }
   }
   HIP_TRY(launch_query_prep(v, qb->value_dtype == DHR_VAL_F32, ldv, (ix->d_dlr > 0 && qb->index) ? qi : nullptr, qb->index_dtype, ldi,
-                            qb->n_queries, w.q_pad, ix->k, ix->k_pad, ix->d_dlr, ix->abs_mode, ix->dmax, w.q_tiles, w.q32,
+                            qb->n_queries, w.q_pad, ix->d_dlr, ix->d_cls, ix->k_rm, ix->n_buckets, ix->kt, ix->bucket_map,
+                            ix->abs_mode, ix->dmax, w.q_tiles, w.q32,
                             w.q_idx, w.margin, w.tau, w.thr, s));
   return DHR_OK;
 }
@@ -324,8 +378,8 @@ enum { T_GEMM = 0, T_REFINE = 1, T_RESCORE = 2, T_SELECT = 3, T_PREP = 4 };
 
 static RescoreArgs base_rescore_args(const dhr_index* ix, const Workspace& w, int n_queries, bool gate) {
   RescoreArgs r{};
-  r.a_tiles = ix->tiles; r.dlr_signed = ix->dlr_signed; r.c_idx = ix->c_idx; r.c_idx_dtype = ix->idx_dtype;
-  r.q32 = w.q32; r.q_idx = w.q_idx; r.ksteps = ix->ksteps; r.d_dlr = ix->d_dlr; r.k_pad = ix->k_pad;
+  r.vals_rm = ix->vals_rm; r.c_idx = ix->c_idx; r.c_idx_dtype = ix->idx_dtype;
+  r.q32 = w.q32; r.q_idx = w.q_idx; r.d_dlr = ix->d_dlr; r.k_rm = ix->k_rm;
   r.n_rows = ix->n_rows; r.n_queries = n_queries; r.gate = gate ? 1 : 0;
   return r;
 }
@@ -349,7 +403,8 @@ static int gemm_phase(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi
   const double rows = (double)(hi - lo) * TILE_ROWS;
   st.phases++;
   st.gemm_rows += (int64_t)rows;
-  st.gemm_flops += 2.0 * (double)w.q_pad * rows * (double)ix->k_pad;
+  st.gemm_flops += 2.0 * (double)w.q_pad * rows * (double)ix->kt;
+  st.gemm_flops_alg += 2.0 * (double)Q * rows * (double)ix->k;
   return DHR_OK;
 }
 
@@ -483,17 +538,17 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     if (flags[q]) ids.push_back(q);
   const int nf = (int)ids.size();
   void* tmp = nullptr;
-  const size_t b32 = (size_t)nf * ix->k_pad * 4, bidx = (size_t)nf * std::max(ix->d_dlr, 8) * 2, bids = (size_t)nf * 4;
+  const size_t b32 = (size_t)nf * ix->k_rm * 4, bidx = (size_t)nf * std::max(ix->d_dlr, 8) * 2, bids = (size_t)nf * 4;
   HIP_TRY(hipMalloc(&tmp, b32 + bidx + bids + 64));
   float* f32 = (float*)tmp;
   int16_t* fidx = (int16_t*)((char*)tmp + b32);
   int32_t* d_ids = (int32_t*)((char*)tmp + b32 + bidx);
   auto done = [&](int code) { hipFree(tmp); return code; };
   if (hipMemcpyAsync(d_ids, ids.data(), bids, hipMemcpyHostToDevice, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "H2D failed"));
-  if (launch_gather_queries(w.q32, w.q_idx, ix->k_pad, ix->d_dlr, d_ids, nf, f32, fidx, s) != hipSuccess)
+  if (launch_gather_queries(w.q32, w.q_idx, ix->k_rm, ix->d_dlr, d_ids, nf, f32, fidx, s) != hipSuccess)
     return done(set_error(DHR_ERR_HIP, "gather_queries launch failed"));
   dhr_query_batch sub{};
-  sub.n_queries = nf; sub.mem_kind = DHR_MEM_DEVICE; sub.value = f32; sub.value_dtype = DHR_VAL_F32; sub.ld_value = ix->k_pad;
+  sub.n_queries = nf; sub.mem_kind = DHR_MEM_DEVICE; sub.value = f32; sub.value_dtype = DHR_VAL_F32; sub.ld_value = ix->k_rm;
   sub.index = gate ? fidx : nullptr; sub.index_dtype = gate ? DHR_IDX_I16 : DHR_IDX_NONE; sub.ld_index = ix->d_dlr;
   Workspace& w2 = ix->ws_fb;
   if ((rc = search_core(ix, w2, &sub, k, false, tm, st, s)) != DHR_OK) return done(rc);

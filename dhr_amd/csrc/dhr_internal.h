@@ -75,13 +75,12 @@ struct GemmArgs {
 };
 
 struct RescoreArgs {
-  const __half* a_tiles;      // corpus tiles (values)
-  const __half* dlr_signed;   // abs mode: signed DLR values row-major [n_rows_pad][d_dlr], else null
+  const __half* vals_rm;      // corpus values, row-major fp16 [n_rows][k_rm]
   const void* c_idx;          // [n_rows_pad][d_dlr] (1 or 2 bytes per entry) or null
   int c_idx_dtype;            // dhr_idx_dtype
   const float* q32;           // [Q_pad][K_pad]
   const int16_t* q_idx;       // [Q_pad][d_dlr]
-  int ksteps, d_dlr, k_pad;
+  int d_dlr, k_rm;
   int gate;                   // 0: ungated inner product over all columns (--IP stage 1)
   int64_t n_rows;
   // candidate source: explicit list (cand != null) or the implicit range [row0, row0+count_all)
@@ -115,11 +114,14 @@ struct SelectArgs {
 hipError_t launch_scan_rows(const __half* src, int64_t ld, int64_t n_rows, int d_dlr, int k, uint32_t* max_sq_bits,
                             uint32_t* neg_flag, hipStream_t s);
 hipError_t launch_tile_rows(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
-                            int k, int k_pad, int d_dlr, bool abs_dlr, __half* tiles, __half* dlr_signed, hipStream_t s);
+                            int d_dlr, int d_cls, int n_buckets, int kt, const void* idx, int idx_dtype,
+                            const uint8_t* map, bool abs_dlr, __half* tiles, hipStream_t s);
+hipError_t launch_copy_rows(const __half* src, int64_t ld, int64_t n_rows, int k, int k_rm, __half* dst, hipStream_t s);
+hipError_t launch_idx_hist(const uint8_t* idx, int64_t n_rows, int d_dlr, uint32_t* hist, hipStream_t s);
 hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const void* idx, int idx_dtype, int64_t ld_idx,
-                             int n_queries, int q_pad, int k, int k_pad, int d_dlr, bool abs_dlr, float dmax,
-                             __half* q_tiles, float* q32, int16_t* q_idx, float* margin, float* tau, float* thr,
-                             hipStream_t s);
+                             int n_queries, int q_pad, int d_dlr, int d_cls, int k_rm, int n_buckets, int kt,
+                             const uint8_t* map, bool abs_dlr, float dmax, __half* q_tiles, float* q32, int16_t* q_idx,
+                             float* margin, float* tau, float* thr, hipStream_t s);
 hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s);
 hipError_t launch_rescore(const RescoreArgs& a, hipStream_t s);
 hipError_t launch_select(const SelectArgs& a, hipStream_t s);
@@ -130,7 +132,7 @@ hipError_t launch_rows_to_local(const int64_t* rows, int64_t n, int64_t row_offs
                                 hipStream_t s);
 hipError_t launch_verify(const uint64_t* topk_keys, int kp, int k, const uint32_t* cnt, uint32_t cap, const float* tau_hat,
                          int n_queries, uint32_t* fail_flags, uint32_t* n_fail, hipStream_t s);
-hipError_t launch_gather_queries(const float* q32, const int16_t* q_idx, int k_pad, int d_dlr, const int32_t* ids, int n,
+hipError_t launch_gather_queries(const float* q32, const int16_t* q_idx, int k_rm, int d_dlr, const int32_t* ids, int n,
                                  float* out32, int16_t* out_idx, hipStream_t s);
 hipError_t launch_scatter_keys(const uint64_t* src, uint64_t* dst, int kp, const int32_t* ids, int n, hipStream_t s);
 hipError_t launch_merge_topk(int n_queries, int n_in, const float* in_scores, const int64_t* in_rows, int k_out,

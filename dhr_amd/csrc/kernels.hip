@@ -10,6 +10,8 @@
 //
 // Reference semantics: /root/reference/retrieval/gip_retrieval.py:119-125 (gated IP + topk),
 // :74-75 (plain IP + argsort), retrieval/merge.result.py:22-42 (shard reduce).
+#include <algorithm>
+
 #include "dhr_internal.h"
 
 namespace dhr {
@@ -79,51 +81,121 @@ hipError_t launch_scan_rows(const __half* src, int64_t ld, int64_t n_rows, int d
 }
 
 // ------------------------------------------------------------------------------------------ tile_rows
-// Thread per 16-byte chunk: rows [row_lo, row_lo+n_rows_fill) of the tiled image; rows beyond
-// n_rows_src and columns beyond k are zero.  abs_dlr: |v| on the gated half of the tile image and the
-// signed values go to dlr_signed (row-major) for the exact rescoring.
+// Bucket of a slice index value: per-slice 256-entry table (8-bit index dtypes, balanced by corpus
+// frequency at build time) or value % n_buckets (int16 indices, whole-word BM25 vocabularies).
+__device__ __forceinline__ int bucket_of(int idx_value, int j, const uint8_t* __restrict__ map, int n_buckets) {
+  if (map) return map[j * 256 + (idx_value & 255)];
+  return (int)((uint32_t)(idx_value & 0xFFFF) % (uint32_t)n_buckets);
+}
+__device__ __forceinline__ int load_idx(const void* __restrict__ idx, int dtype, int64_t off) {
+  if (dtype == DHR_IDX_I16) return ((const int16_t*)idx)[off];
+  if (dtype == DHR_IDX_I8) return ((const int8_t*)idx)[off];
+  return ((const uint8_t*)idx)[off];
+}
+
+// Thread per 16-byte chunk of the OPERAND-TILE image, rows [row_lo, row_lo+n_rows_fill).  Tile columns:
+//   [ bucket 0 : d_dlr ][ bucket 1 : d_dlr ] ... [ bucket B-1 : d_dlr ][ dense : d_cls ][ zero pad ]
+// the gated value of slice j sits in segment bucket(idx[j]) and is 0 in the other segments, so the
+// plain inner product of two such rows is  sum_j q_j d_j [bucket(qi_j)==bucket(di_j)]  >=  the gated sum
+// (values made non-negative with |.| when abs_dlr) -- an upper bound B-times tighter than the ungated one.
+// Rows beyond n_rows_src and columns beyond the data are zero.
 __global__ void __launch_bounds__(256) tile_rows_kernel(const __half* __restrict__ src, int64_t ld, int64_t row_lo,
-                                                        int64_t n_rows_src, int64_t n_rows_fill, int k, int k_pad,
-                                                        int d_dlr, int abs_dlr, __half* __restrict__ tiles,
-                                                        __half* __restrict__ dlr_signed) {
-  const int cpr = k_pad >> 3;
-  const int ksteps = k_pad >> 6;
+                                                        int64_t n_rows_src, int64_t n_rows_fill, int d_dlr, int d_cls,
+                                                        int n_buckets, int kt, const void* __restrict__ idx, int idx_dtype,
+                                                        const uint8_t* __restrict__ map, int abs_dlr,
+                                                        __half* __restrict__ tiles) {
+  const int cpr = kt >> 3;
+  const int ksteps = kt >> 6;
+  const int k = d_dlr + d_cls;
+  const int dlr_cols = n_buckets * d_dlr;
   const int64_t total = n_rows_fill * cpr;
-  const bool vec = ((k & 7) == 0) && ((ld & 7) == 0) && ((((uintptr_t)src) & 15) == 0);
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
     const int64_t rl = g / cpr;
     const int c = (int)(g - rl * cpr);
+    const int64_t row = row_lo + rl;
     half8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
-    if (rl < n_rows_src && c * 8 < k) {
-      const __half* r = src + rl * ld + c * 8;
-      if (vec) {
-        v = *(const half8*)r;
+    if (rl < n_rows_src) {
+      const int col0 = c * 8;
+      if (col0 < dlr_cols) {
+        const int b = col0 / d_dlr, j0 = col0 - b * d_dlr;          // d_dlr % 8 == 0: a chunk never straddles
+        const __half* r = src + rl * ld + j0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          _Float16 x = (_Float16)__half2float(r[e]);
+          if (n_buckets > 1 && bucket_of(load_idx(idx, idx_dtype, row * d_dlr + j0 + e), j0 + e, map, n_buckets) != b)
+            x = (_Float16)0.f;
+          if (abs_dlr && x < (_Float16)0.f) x = -x;
+          v[e] = x;
+        }
       } else {
+        const int j0 = d_dlr + (col0 - dlr_cols);
+        const __half* r = src + rl * ld + j0;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (c * 8 + e < k) v[e] = (_Float16)__half2float(r[e]);
+          if (j0 + e < k) v[e] = (_Float16)__half2float(r[e]);
       }
-    }
-    const int64_t row = row_lo + rl;
-    if (abs_dlr && c * 8 < d_dlr) {
-      *(half8*)(dlr_signed + row * d_dlr + c * 8) = v;          // d_dlr % 8 == 0 is enforced by the API
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] < (_Float16)0.f ? -v[e] : v[e];
     }
     *(half8*)(tiles + tiled_chunk_offset(row, c, ksteps)) = v;
   }
 }
 
 hipError_t launch_tile_rows(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
-                            int k, int k_pad, int d_dlr, bool abs_dlr, __half* tiles, __half* dlr_signed,
-                            hipStream_t s) {
+                            int d_dlr, int d_cls, int n_buckets, int kt, const void* idx, int idx_dtype,
+                            const uint8_t* map, bool abs_dlr, __half* tiles, hipStream_t s) {
   if (n_rows_fill <= 0) return hipSuccess;
-  const int64_t total = n_rows_fill * (k_pad >> 3);
+  const int64_t total = n_rows_fill * (kt >> 3);
   const int64_t blocks = (total + 255) / 256;
   hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, src, ld,
-                     row_lo, n_rows_src, n_rows_fill, k, k_pad, d_dlr, abs_dlr ? 1 : 0, tiles, dlr_signed);
+                     row_lo, n_rows_src, n_rows_fill, d_dlr, d_cls, n_buckets, kt, idx, idx_dtype, map,
+                     abs_dlr ? 1 : 0, tiles);
+  return hipGetLastError();
+}
+
+// Row-major fp16 copy [n][k_rm] (zero padded) that the exact rescoring reads: one contiguous row per pair.
+__global__ void __launch_bounds__(256) copy_rows_kernel(const __half* __restrict__ src, int64_t ld, int64_t n_rows, int k,
+                                                        int k_rm, __half* __restrict__ dst) {
+  const int cpr = k_rm >> 3;
+  const int64_t total = n_rows * cpr;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t rl = g / cpr;
+    const int c = (int)(g - rl * cpr);
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (c * 8 + e < k) ? (_Float16)__half2float(src[rl * ld + c * 8 + e]) : (_Float16)0.f;
+    *(half8*)(dst + rl * k_rm + c * 8) = v;
+  }
+}
+hipError_t launch_copy_rows(const __half* src, int64_t ld, int64_t n_rows, int k, int k_rm, __half* dst, hipStream_t s) {
+  if (n_rows <= 0) return hipSuccess;
+  const int64_t blocks = (n_rows * (k_rm >> 3) + 255) / 256;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, src, ld, n_rows,
+                     k, k_rm, dst);
+  return hipGetLastError();
+}
+
+// Histogram of the 8-bit slice-index values per slice: hist[j][v] (u32), for the bucket maps.
+__global__ void __launch_bounds__(256) idx_hist_kernel(const uint8_t* __restrict__ idx, int64_t n_rows, int d_dlr,
+                                                       uint32_t* __restrict__ hist) {
+  // block = (slice group of 64 slices) x (row stripe); LDS histogram 64 x 256
+  __shared__ uint32_t h[64 * 256];
+  for (int i = threadIdx.x; i < 64 * 256; i += 256) h[i] = 0;
+  __syncthreads();
+  const int j0 = blockIdx.x * 64;
+  const int lane_j = threadIdx.x & 63;
+  const int sub = threadIdx.x >> 6;
+  if (j0 + lane_j < d_dlr)
+    for (int64_t r = (int64_t)blockIdx.y * 4 + sub; r < n_rows; r += (int64_t)gridDim.y * 4)
+      atomicAdd(&h[lane_j * 256 + idx[r * d_dlr + j0 + lane_j]], 1u);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 256; i += 256)
+    if (h[i] && j0 + (i >> 8) < d_dlr) atomicAdd(&hist[(int64_t)(j0 + (i >> 8)) * 256 + (i & 255)], h[i]);
+}
+hipError_t launch_idx_hist(const uint8_t* idx, int64_t n_rows, int d_dlr, uint32_t* hist, hipStream_t s) {
+  const int64_t stripes = std::min<int64_t>(256, (n_rows + 1023) / 1024);
+  hipLaunchKernelGGL(idx_hist_kernel, dim3((d_dlr + 63) / 64, (unsigned)(stripes < 1 ? 1 : stripes)), dim3(256), 0, s, idx,
+                     n_rows, d_dlr, hist);
   return hipGetLastError();
 }
 
@@ -135,7 +207,8 @@ hipError_t launch_tile_rows(const __half* src, int64_t ld, int64_t row_lo, int64
 // so that  U_computed >= S_exact - margin  for every row (Cauchy-Schwarz on sum |q_j d_j|).
 __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict__ src, int src_is_f32, int64_t ld,
                                                          const void* __restrict__ idx, int idx_dtype, int64_t ld_idx,
-                                                         int n_queries, int q_pad, int k, int k_pad, int d_dlr,
+                                                         int n_queries, int q_pad, int d_dlr, int d_cls, int k_rm,
+                                                         int n_buckets, int kt, const uint8_t* __restrict__ map,
                                                          int abs_dlr, float dmax, __half* __restrict__ q_tiles,
                                                          float* __restrict__ q32, int16_t* __restrict__ q_idx,
                                                          float* __restrict__ margin, float* __restrict__ tau,
@@ -143,44 +216,49 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= q_pad) return;
-  const int ksteps = k_pad >> 6;
+  const int k = d_dlr + d_cls;
+  const int ksteps = kt >> 6;
+  const int dlr_cols = n_buckets * d_dlr;
   const bool real = q < n_queries;
+  auto qval = [&](int j) -> float {
+    if (!real || j >= k) return 0.f;
+    return src_is_f32 ? ((const float*)src)[(int64_t)q * ld + j] : __half2float(((const __half*)src)[(int64_t)q * ld + j]);
+  };
+  auto qidx = [&](int j) -> int { return (real && idx) ? load_idx(idx, idx_dtype, (int64_t)q * ld_idx + j) : 0; };
+  // exact fp32 copy (row-major, what the rescoring multiplies with) + norms of q16 and of the fp16 residual
   float s16 = 0.f, sr = 0.f;
-  for (int c = lane; c * 8 < k_pad; c += 64) {
+  for (int j = lane; j < k_rm; j += 64) {
+    const float v = qval(j);
+    q32[(int64_t)q * k_rm + j] = v;
+    const float back = (float)(_Float16)v;
+    s16 += back * back;
+    sr += (v - back) * (v - back);
+  }
+  for (int j = lane; j < d_dlr; j += 64) q_idx[(int64_t)q * d_dlr + j] = (int16_t)qidx(j);
+  // operand tile image: gated value in the segment of its bucket (all segments when the batch is
+  // ungated: then every bucket pair "matches" and the product is the plain inner product)
+  for (int c = lane; c * 8 < kt; c += 64) {
     half8 h;
-    float f[8];
+    const int col0 = c * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int j = c * 8 + e;
       float v = 0.f;
-      if (real && j < k)
-        v = src_is_f32 ? ((const float*)src)[(int64_t)q * ld + j] : __half2float(((const __half*)src)[(int64_t)q * ld + j]);
-      f[e] = v;
-      _Float16 hv = (_Float16)v;                       // round to nearest even
-      const float back = (float)hv;
-      s16 += back * back;
-      sr += (v - back) * (v - back);
-      if (abs_dlr && j < d_dlr && hv < (_Float16)0.f) hv = -hv;
-      h[e] = hv;
+      if (col0 < dlr_cols) {
+        const int b = col0 / d_dlr, j = col0 - b * d_dlr + e;
+        v = qval(j);
+        if (n_buckets > 1 && idx && bucket_of(qidx(j), j, map, n_buckets) != b) v = 0.f;
+        if (abs_dlr) v = fabsf(v);
+      } else {
+        v = qval(d_dlr + (col0 - dlr_cols) + e);
+      }
+      h[e] = (_Float16)v;                                  // round to nearest even
     }
     *(half8*)(q_tiles + tiled_chunk_offset(q, c, ksteps)) = h;
-    float4* o = (float4*)(q32 + (int64_t)q * k_pad + c * 8);
-    o[0] = make_float4(f[0], f[1], f[2], f[3]);
-    o[1] = make_float4(f[4], f[5], f[6], f[7]);
-  }
-  for (int j = lane; j < d_dlr; j += 64) {
-    int v = 0;
-    if (real && idx) {
-      if (idx_dtype == DHR_IDX_U8) v = ((const uint8_t*)idx)[(int64_t)q * ld_idx + j];
-      else if (idx_dtype == DHR_IDX_I8) v = ((const int8_t*)idx)[(int64_t)q * ld_idx + j];
-      else v = ((const int16_t*)idx)[(int64_t)q * ld_idx + j];
-    }
-    q_idx[(int64_t)q * d_dlr + j] = (int16_t)v;
   }
   s16 = wave_sum(s16);
   sr = wave_sum(sr);
   if (lane == 0) {
-    const float m = 1.05f * (float)k_pad * 5.9604645e-8f * sqrtf(s16) * dmax + 1.0001f * sqrtf(sr) * dmax;
+    const float m = 1.05f * (float)(kt + 256) * 5.9604645e-8f * sqrtf(s16) * dmax + 1.0001f * sqrtf(sr) * dmax;
     margin[q] = m;
     tau[q] = -INFINITY;
     thr[q] = real ? -INFINITY : INFINITY;              // padded queries never pass the filter
@@ -188,12 +266,12 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
 }
 
 hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const void* idx, int idx_dtype, int64_t ld_idx,
-                             int n_queries, int q_pad, int k, int k_pad, int d_dlr, bool abs_dlr, float dmax,
-                             __half* q_tiles, float* q32, int16_t* q_idx, float* margin, float* tau, float* thr,
-                             hipStream_t s) {
+                             int n_queries, int q_pad, int d_dlr, int d_cls, int k_rm, int n_buckets, int kt,
+                             const uint8_t* map, bool abs_dlr, float dmax, __half* q_tiles, float* q32, int16_t* q_idx,
+                             float* margin, float* tau, float* thr, hipStream_t s) {
   hipLaunchKernelGGL(query_prep_kernel, dim3((q_pad + 3) / 4), dim3(256), 0, s, src, src_is_f32, ld, idx, idx_dtype,
-                     ld_idx, n_queries, q_pad, k, k_pad, d_dlr, abs_dlr ? 1 : 0, dmax, q_tiles, q32, q_idx, margin, tau,
-                     thr);
+                     ld_idx, n_queries, q_pad, d_dlr, d_cls, k_rm, n_buckets, kt, map, abs_dlr ? 1 : 0, dmax, q_tiles, q32,
+                     q_idx, margin, tau, thr);
   return hipGetLastError();
 }
 
@@ -354,7 +432,7 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------ rescore
 // Exact score of (query, row) pairs.  One wave per pair; lane l owns the 16-byte chunks l, l+64, ...
-// of the row (read straight from the operand tiles: a row is ksteps pieces of 128 contiguous bytes).
+// of the row (read from the row-major fp16 copy of the corpus: one contiguous row per pair).
 // Products of the stored fp16 values with the fp32 query are exact in fp64; the sum is accumulated
 // in fp64 and rounded once to fp32, so the result does not depend on tiling, chunking or sharding.
 __global__ void __launch_bounds__(256) rescore_kernel(RescoreArgs p) {
@@ -367,9 +445,9 @@ __global__ void __launch_bounds__(256) rescore_kernel(RescoreArgs p) {
   else count = p.count_all;
   const uint32_t base = blockIdx.x * RESCORE_CANDS_PER_WG;
   if (base >= count) return;
-  const float* q32 = p.q32 + (int64_t)q * p.k_pad;
+  const float* q32 = p.q32 + (int64_t)q * p.k_rm;
   const int16_t* qi = p.q_idx + (int64_t)q * p.d_dlr;
-  const int nchunks = p.k_pad >> 3;
+  const int nchunks = p.k_rm >> 3;
   const int dlr_chunks = p.d_dlr >> 3;
   for (uint32_t i = base + wave; i < base + RESCORE_CANDS_PER_WG && i < count; i += 4) {
     uint32_t row;
@@ -380,11 +458,10 @@ __global__ void __launch_bounds__(256) rescore_kernel(RescoreArgs p) {
     double acc = 0.0;
     if (valid) {
       for (int c = lane; c < nchunks; c += 64) {
-        half8 dv = *(const half8*)(p.a_tiles + tiled_chunk_offset(row, c, p.ksteps));
+        const half8 dv = *(const half8*)(p.vals_rm + (int64_t)row * p.k_rm + c * 8);
         const float4 qa = *(const float4*)(q32 + c * 8);
         const float4 qb = *(const float4*)(q32 + c * 8 + 4);
         const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-        if (c < dlr_chunks && p.dlr_signed) dv = *(const half8*)(p.dlr_signed + (int64_t)row * p.d_dlr + c * 8);
         if (c < dlr_chunks && p.gate) {
           int ci[8];
           if (p.c_idx_dtype == DHR_IDX_I16) {

@@ -26,7 +26,7 @@ class GipIndex:
     """One corpus shard resident on one GPU (dhr_index_create).  value: fp16 [N, K] numpy array or
     torch tensor (host or device); index: [N, D_dlr] uint8/int8/int16 or None (dense-only)."""
 
-    def __init__(self, value, index=None, *, emb_dim=None, device: int = 0, row_offset: int = 0):
+    def __init__(self, value, index=None, *, emb_dim=None, device: int = 0, row_offset: int = 0, idx_buckets: int = 0):
         lib = _lib.load()
         value = _as_f16(value)
         n, k = int(value.shape[0]), int(value.shape[1])
@@ -48,6 +48,7 @@ class GipIndex:
         else:
             desc.index, desc.ld_index, desc.index_dtype = None, 0, _lib.IDX_NONE
         desc.row_offset = row_offset
+        desc.idx_buckets = idx_buckets
         h = C.c_void_p()
         _lib.check(lib.dhr_index_create(C.byref(desc), C.byref(h)), "dhr_index_create")
         self._h, self._lib = h, lib

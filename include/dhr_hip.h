@@ -53,7 +53,7 @@ typedef struct dhr_index_desc {
   int64_t ld_value;    /* elements between consecutive rows (>= d_dlr + d_cls) */
   const void* index;   /* or NULL */
   int32_t index_dtype; /* dhr_idx_dtype */
-  int32_t reserved0;
+  int32_t idx_buckets; /* index buckets per gated slice in the bound GEMM operands (0 = default 2; 1 = ungated bound) */
   int64_t ld_index;    /* elements between consecutive rows (>= d_dlr) */
   int64_t row_offset;  /* global row id of local row 0; added to every returned row */
 } dhr_index_desc;
@@ -83,7 +83,8 @@ typedef struct dhr_search_stats {
   int64_t gemm_rows;         /* corpus rows pushed through the bound GEMM */
   int64_t sample_fallback_queries; /* queries redone exactly because the sampled threshold was too high */
   double gemm_ms, refine_ms, rescore_ms, select_ms, prep_ms, total_ms;
-  double gemm_flops;         /* 2 * Q_pad * rows * K_pad actually issued by the bound GEMM */
+  double gemm_flops;         /* 2 * Q_pad * rows * K_tile actually issued by the bound GEMM (padding, bucket split) */
+  double gemm_flops_alg;     /* algorithmic: 2 * Q * rows * (d_dlr + d_cls), summed over the launches */
 } dhr_search_stats;
 
 /* Tunables (dhr_index_set_param). */

@@ -30,7 +30,7 @@ def test_struct_layouts_match_header():
     from dhr_amd import _lib
     assert C.sizeof(_lib.IndexDesc) == 72
     assert C.sizeof(_lib.QueryBatch) == 48
-    assert C.sizeof(_lib.SearchStats) == 120
+    assert C.sizeof(_lib.SearchStats) == 128
 
 
 def test_invalid_arguments_return_codes_not_crashes():

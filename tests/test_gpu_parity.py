@@ -20,9 +20,9 @@ def G():
     return G_
 
 
-def _search_check(G, cv, ci, qv32, qi, k, *, params=(), emb_dim=None, queries=None, row_offset=0):
+def _search_check(G, cv, ci, qv32, qi, k, *, params=(), emb_dim=None, queries=None, row_offset=0, idx_buckets=0):
     from dhr_amd import _lib
-    ix = G.GipIndex(cv, ci, row_offset=row_offset)
+    ix = G.GipIndex(cv, ci, row_offset=row_offset, idx_buckets=idx_buckets)
     for p, v in params:
         ix.set_param(p, v)
     ix.set_param(_lib.PARAM_PROFILE, 1)
@@ -48,7 +48,7 @@ def test_bound_gemm_layout(G, golden):
     from dhr_amd import _lib
     d = golden.inputs("hyb")
     cv = d["cv"][:1000]                      # ragged: not a multiple of 256
-    ix = G.GipIndex(cv, d["ci"][:1000])
+    ix = G.GipIndex(cv, d["ci"][:1000], idx_buckets=1)
     qv = d["qv"].astype(np.float32)
     qb, keep = _lib.make_query_batch(qv, d["qi"])
     out = torch.zeros((qv.shape[0], 1000), dtype=torch.float32, device="cuda")
@@ -56,6 +56,23 @@ def test_bound_gemm_layout(G, golden):
     u = out.cpu().numpy()
     ref = qv.astype(np.float64) @ cv.astype(np.float64).T
     np.testing.assert_allclose(u, ref, rtol=1e-5, atol=1e-4)
+    ix.close()
+    # bucket-split operands: still an upper bound of the gated score, and tighter with more buckets
+    exact = np.stack([O.gip_scores_f64(qv[i], d["qi"][i], cv.astype(np.float32), d["ci"][:1000]) for i in range(qv.shape[0])])
+    slack = []
+    for nb in (2, 4, 8):
+        ix = G.GipIndex(cv, d["ci"][:1000], idx_buckets=nb)
+        _lib.check(ix._lib.dhr_debug_bound_scores(ix._h, C.byref(qb), 0, 1000, out.data_ptr(), 0), "debug_bound")
+        ub = out.cpu().numpy().astype(np.float64)
+        assert np.all(ub >= exact - 1e-3) and np.all(ub <= ref + 1e-3)
+        slack.append(float((ub - exact).mean()))
+        ix.close()
+    assert slack[0] > slack[1] > slack[2] and slack[0] < float((ref - exact).mean())
+    # ungated query batch (--IP stage 1) on a bucketed index: the bound is the plain inner product again
+    ix = G.GipIndex(cv, d["ci"][:1000], idx_buckets=4)
+    qb2, keep2 = _lib.make_query_batch(qv, None)
+    _lib.check(ix._lib.dhr_debug_bound_scores(ix._h, C.byref(qb2), 0, 1000, out.data_ptr(), 0), "debug_bound")
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-4)
     ix.close()
 
 
@@ -125,15 +142,15 @@ def test_k_larger_than_n(G, golden):
         assert res[qid] == ref_rows[i].tolist()
 
 
-@pytest.mark.parametrize("cap,first", [(1024, 0), (4096, 2048), (16384, 0)])
-def test_multi_phase_and_overflow(G, cap, first):
+@pytest.mark.parametrize("cap,first,nb", [(1024, 0, 1), (4096, 2048, 2), (16384, 0, 4), (1024, 0, 3)])
+def test_multi_phase_and_overflow(G, cap, first, nb):
     """Small candidate capacity forces many bound-GEMM phases and overflow retries; results must not
     change.  N is ragged, K = 768+128."""
     from dhr_amd import _lib, synth
     cv, ci, qv, qi = synth.make_pair(7, 21000, 40, 768, 128)
     q32 = qv.astype(np.float32)
     _, _, st = _search_check(G, cv, ci, q32, qi, 100, params=[(_lib.PARAM_CAND_CAP, cap), (_lib.PARAM_FIRST_ROWS, first)],
-                             queries=range(0, 40, 5))
+                             queries=range(0, 40, 5), idx_buckets=nb)
     assert st["phases"] >= 2
     print(cap, first, st)
 
@@ -146,6 +163,7 @@ def test_negative_dlr_values_abs_mode(G):
     cv[:, :768] *= rng.choice([-1, 1], size=(6000, 768)).astype(np.float16)
     qv[:, :768] *= rng.choice([-1, 1], size=(16, 768)).astype(np.float16)
     _search_check(G, cv, ci, qv.astype(np.float32), qi, 50)
+    _search_check(G, cv, ci, qv.astype(np.float32), qi, 50, idx_buckets=4)
 
 
 def test_fp32_queries_not_fp16_representable(G):
