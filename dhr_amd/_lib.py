@@ -13,11 +13,11 @@ DHR_OK = 0
 IDX_NONE, IDX_U8, IDX_I8, IDX_I16 = 0, 1, 2, 3
 VAL_F16, VAL_F32 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
-PARAM_CAND_CAP, PARAM_FIRST_ROWS, PARAM_PROFILE, PARAM_MAX_GROWTH, PARAM_SAMPLE_PERIOD = 1, 2, 3, 4, 5
+PARAM_CAND_CAP, PARAM_FIRST_ROWS, PARAM_PROFILE, PARAM_MAX_GROWTH, PARAM_SAMPLE_PERIOD, PARAM_GEMM_VARIANT = 1, 2, 3, 4, 5, 6
 
 EXPORTS = ["dhr_version", "dhr_last_error", "dhr_index_create", "dhr_index_destroy", "dhr_index_set_param",
            "dhr_index_device_bytes", "dhr_search", "dhr_score_rows", "dhr_merge_topk", "dhr_merge_topk_host",
-           "dhr_get_stats", "dhr_debug_bound_scores"]
+           "dhr_get_stats", "dhr_debug_bound_scores", "dhr_debug_gemm_time"]
 
 
 class DhrError(RuntimeError):
@@ -85,6 +85,8 @@ def load():
     lib.dhr_merge_topk_host.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.dhr_get_stats.argtypes = [C.c_void_p, C.POINTER(SearchStats)]
     lib.dhr_debug_bound_scores.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.dhr_debug_gemm_time.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_int32, C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double), C.c_void_p]
     _lib = lib
     return lib
 

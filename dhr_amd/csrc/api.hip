@@ -110,6 +110,9 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
     case DHR_PARAM_SAMPLE_PERIOD:
       if (value < 0 || value > 256) return set_error(DHR_ERR_INVALID, "sample_period must be in [0,256] (0/1 = off)");
       ix->sample_period = (int)value; return DHR_OK;
+    case DHR_PARAM_GEMM_VARIANT:
+      if (value < 0 || value > 2) return set_error(DHR_ERR_INVALID, "gemm_variant must be 0, 1 or 2");
+      dhr::g_gemm_variant = (int)value; return DHR_OK;
     case DHR_PARAM_MAX_GROWTH:
       if (value < 1 || value > 1024) return set_error(DHR_ERR_INVALID, "max_growth must be in [1,1024] sixteenths");
       ix->max_growth16 = (int)value; return DHR_OK;
@@ -202,7 +205,7 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
   ix->d_cls = d->d_cls;
   ix->k = d->d_dlr + d->d_cls;
   ix->k_rm = (int)round_up(ix->k, TILE_K);
-  ix->n_buckets = has_idx ? (d->idx_buckets > 0 ? d->idx_buckets : 2) : 1;
+  ix->n_buckets = has_idx ? (d->idx_buckets > 0 ? d->idx_buckets : 3) : 1;
   ix->kt = (int)round_up((int64_t)ix->n_buckets * ix->d_dlr + ix->d_cls, TILE_K);
   ix->ksteps = ix->kt / TILE_K;
   ix->idx_dtype = has_idx ? d->index_dtype : DHR_IDX_NONE;
@@ -659,6 +662,39 @@ extern "C" int dhr_debug_bound_scores(dhr_index* ix, const dhr_query_batch* qb, 
   g.dump = out_dev; g.dump_ld = row_hi - row_lo; g.dump_row0 = row_lo;
   HIP_TRY(launch_gemm_filter(g, s));
   HIP_TRY(hipStreamSynchronize(s));
+  return DHR_OK;
+}
+
+// Kernel-tuning hook: the bound GEMM alone over the whole shard with the filter closed (thr = +inf),
+// `iters` launches, average milliseconds per launch (hipEvents on the stream).
+extern "C" int dhr_debug_gemm_time(dhr_index* ix, const dhr_query_batch* qb, int32_t iters, double* ms_out, double* flops_out,
+                                   void* stream) {
+  int rc = check_queries(ix, qb);
+  if (rc) return rc;
+  if (iters <= 0 || !ms_out) return set_error(DHR_ERR_INVALID, "bad iters / null pointer");
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = (hipStream_t)stream;
+  Workspace& w = ix->ws;
+  if ((rc = ensure_ws(ix, w, qb->n_queries, 1, 0)) != DHR_OK) return rc;
+  if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
+  std::vector<float> inf((size_t)w.q_pad, INFINITY);
+  HIP_TRY(hipMemcpyAsync(w.thr, inf.data(), (size_t)w.q_pad * 4, hipMemcpyHostToDevice, s));
+  GemmArgs g{};
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.seq_lo = 0; g.seq_hi = ix->n_tiles; g.map_mode = 0;
+  g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
+  g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
+  HIP_TRY(launch_gemm_filter(g, s));                      // warm-up
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) HIP_TRY(launch_gemm_filter(g, s));
+  HIP_TRY(hipEventRecord(e1, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  *ms_out = ms / iters;
+  if (flops_out) *flops_out = 2.0 * (double)w.q_pad * (double)ix->n_tiles * TILE_ROWS * (double)ix->kt;
   return DHR_OK;
 }
 

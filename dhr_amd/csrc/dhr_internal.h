@@ -138,6 +138,7 @@ hipError_t launch_scatter_keys(const uint64_t* src, uint64_t* dst, int kp, const
 hipError_t launch_merge_topk(int n_queries, int n_in, const float* in_scores, const int64_t* in_rows, int k_out,
                              float* out_scores, int64_t* out_rows, hipStream_t s);
 
+extern int g_gemm_variant;
 constexpr int RESCORE_CANDS_PER_WG = 32;
 constexpr int SELECT_THREADS = 1024;
 

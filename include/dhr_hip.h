@@ -53,7 +53,7 @@ typedef struct dhr_index_desc {
   int64_t ld_value;    /* elements between consecutive rows (>= d_dlr + d_cls) */
   const void* index;   /* or NULL */
   int32_t index_dtype; /* dhr_idx_dtype */
-  int32_t idx_buckets; /* index buckets per gated slice in the bound GEMM operands (0 = default 2; 1 = ungated bound) */
+  int32_t idx_buckets; /* index buckets per gated slice in the bound GEMM operands (0 = default 3; 1 = ungated bound) */
   int64_t ld_index;    /* elements between consecutive rows (>= d_dlr) */
   int64_t row_offset;  /* global row id of local row 0; added to every returned row */
 } dhr_index_desc;
@@ -93,6 +93,7 @@ typedef enum dhr_param {
   DHR_PARAM_FIRST_ROWS = 2,   /* rows scored exhaustively to seed the thresholds (>= k enforced) */
   DHR_PARAM_PROFILE = 3,      /* 1: record per-kernel hipEvent timings into dhr_search_stats */
   DHR_PARAM_MAX_GROWTH = 4,   /* max (next chunk rows) / (rows seen), in 1/16ths (default 32 = 2x) */
+  DHR_PARAM_GEMM_VARIANT = 6, /* process-wide: 0 = single-phase bound GEMM, 1 = ping-pong wave groups (default) */
   DHR_PARAM_SAMPLE_PERIOD = 5 /* every S-th corpus tile seeds the thresholds (default 16; 0 = plain streaming) */
 } dhr_param;
 
@@ -141,6 +142,11 @@ int dhr_get_stats(const dhr_index* index, dhr_search_stats* out);
  * to a DEVICE buffer [n_queries, row_hi-row_lo] fp32 (U >= exact score; equal for dense-only). */
 int dhr_debug_bound_scores(dhr_index* index, const dhr_query_batch* queries, int64_t row_lo, int64_t row_hi,
                            float* out_dev, void* stream);
+
+/* Kernel-tuning hook: the bound GEMM alone over the whole shard with the filter closed; average
+ * milliseconds per launch over `iters` launches and the flops one launch issues (padded sizes). */
+int dhr_debug_gemm_time(dhr_index* index, const dhr_query_batch* queries, int32_t iters, double* ms_out,
+                        double* flops_out, void* stream);
 
 #ifdef __cplusplus
 }
