@@ -46,8 +46,13 @@ struct Workspace {
   uint64_t *rs_keys = nullptr, *topk_keys = nullptr;
   uint32_t* d_max = nullptr;             // {max, pad} + u64 sum live in one 16-byte device block
   float* tau_hat = nullptr;
+  float* thr_hat = nullptr;              // frozen main-pass threshold (tau_hat - margin)
   uint32_t* fail_flags = nullptr;
+  uint2* cand2 = nullptr;                // second candidate list set: chunk i+1's GEMM overlaps chunk i's rescoring
+  uint32_t* cnt2 = nullptr;
   void* h_pinned = nullptr;              // 16 bytes pinned mirror
+  char* h_pinned2 = nullptr;             // 2 x 16 bytes pinned (main-pass chunk statistics)
+  uint32_t* d_max2 = nullptr;            // 2 x 16 bytes device
   void* q_stage = nullptr;  size_t q_stage_bytes = 0;
   void* qi_stage = nullptr; size_t qi_stage_bytes = 0;
   void* out_stage = nullptr; size_t out_stage_bytes = 0;
@@ -70,17 +75,21 @@ struct dhr_index {
   float dmax = 0.f;
   int64_t index_bytes = 0;
   // params
-  int64_t cand_cap = 32768, first_rows = 0;
+  int64_t cand_cap = 65536, first_rows = 0;
   int profile = 0, max_growth16 = 32;
   int sample_period = 16;
+  int main_chunks = 4;
+  hipStream_t s_aux = nullptr;          // non-blocking stream for rescoring/select overlapped with the main-pass GEMM
   Workspace ws, ws_fb;
   dhr_search_stats stats{};
 };
 
 static void free_ws(Workspace& w) {
   hipFree(w.q_tiles); hipFree(w.q32); hipFree(w.q_idx); hipFree(w.margin); hipFree(w.tau); hipFree(w.thr);
-  hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags);
+  hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2);
   if (w.h_pinned) hipHostFree(w.h_pinned);
+  if (w.h_pinned2) hipHostFree(w.h_pinned2);
+  hipFree(w.d_max2);
   hipFree(w.q_stage); hipFree(w.qi_stage); hipFree(w.out_stage);
   w = Workspace();
 }
@@ -93,6 +102,7 @@ extern "C" void dhr_index_destroy(dhr_index* ix) {
   hipSetDevice(ix->device);
   free_ws(ix->ws);
   free_ws(ix->ws_fb);
+  if (ix->s_aux) hipStreamDestroy(ix->s_aux);
   hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map);
   delete ix;
 }
@@ -110,6 +120,9 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
     case DHR_PARAM_SAMPLE_PERIOD:
       if (value < 0 || value > 256) return set_error(DHR_ERR_INVALID, "sample_period must be in [0,256] (0/1 = off)");
       ix->sample_period = (int)value; return DHR_OK;
+    case DHR_PARAM_MAIN_CHUNKS:
+      if (value < 1 || value > 64) return set_error(DHR_ERR_INVALID, "main_chunks must be in [1,64]");
+      ix->main_chunks = (int)value; return DHR_OK;
     case DHR_PARAM_GEMM_VARIANT:
       if (value < 0 || value > 2) return set_error(DHR_ERR_INVALID, "gemm_variant must be 0, 1 or 2");
       dhr::g_gemm_variant = (int)value; return DHR_OK;
@@ -306,7 +319,10 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.d_max, 16, tot));
   HIP_TRY(re_malloc(w.tau_hat, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.fail_flags, (size_t)q_pad * 4, tot));
+  HIP_TRY(re_malloc(w.thr_hat, (size_t)q_pad * 4, tot));
   HIP_TRY(hipHostMalloc(&w.h_pinned, 16, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&w.h_pinned2, 32, hipHostMallocDefault));
+  HIP_TRY(re_malloc(w.d_max2, 32, tot));
   w.q_pad = q_pad; w.kp = kp; w.cap = cap; w.keys_ld = keys_ld; w.kt = ix->kt; w.d_dlr = ix->d_dlr;
   w.bytes = tot;
   return DHR_OK;
@@ -366,8 +382,10 @@ static int prep_queries(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, 
 
 struct Timer {
   bool on; hipStream_t s; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; std::vector<int> kind;
-  void begin(int k) { if (!on) return; hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); ev.push_back({a, b}); kind.push_back(k); }
-  void end() { if (!on) return; hipEventRecord(ev.back().second, s); }
+  void begin(int k) { begin_on(k, s); }
+  void end() { end_on(s); }
+  void begin_on(int k, hipStream_t st) { if (!on) return; hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); ev.push_back({a, b}); kind.push_back(k); }
+  void end_on(hipStream_t st) { if (!on) return; hipEventRecord(ev.back().second, st); }
   void collect(double* ms /*[5]*/) {
     for (size_t i = 0; i < ev.size(); ++i) {
       float t = 0.f;
@@ -515,19 +533,82 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, head, first_valid, tm, st, s)) != DHR_OK) return rc;
   HIP_TRY(hipMemcpyAsync(w.tau_hat, w.tau, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
 
-  // ---- main pass: all other tiles with the fixed threshold tau_hat - margin
+  // ---- main pass: all other tiles with the FROZEN threshold tau_hat - margin, in a few chunks; the
+  // bound GEMM of chunk i+1 (stream s) overlaps the exact rescoring + top-k merge of chunk i (aux stream)
   sel.k = k;
   const int64_t n_main = rest - n_sample;
   {
-    uint32_t maxc; unsigned long long sumc;
-    if ((rc = gemm_phase(ix, w, Q, 0, n_main, 2, S, head, tm, st, s, &maxc, &sumc)) != DHR_OK) return rc;
-    st.candidates_bound += (int64_t)sumc;
-    st.candidates_exact += (int64_t)sumc;
-    if ((rc = rescore_select(ix, w, Q, gate, sel, maxc, tm, s)) != DHR_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(w.thr_hat, w.thr, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(w.fail_flags, 0, (size_t)w.q_pad * 4, s));
+    if (!w.cand2) {
+      int64_t tot = 0;
+      HIP_TRY(re_malloc(w.cand2, (size_t)w.q_pad * w.cap * 8, tot));
+      HIP_TRY(re_malloc(w.cnt2, (size_t)w.q_pad * 4, tot));
+      w.bytes += tot;
+    }
+    if (!ix->s_aux) HIP_TRY(hipStreamCreateWithFlags(&ix->s_aux, hipStreamNonBlocking));
+    hipStream_t sb = ix->s_aux;
+    const int M = (int)std::max<int64_t>(1, std::min<int64_t>(ix->main_chunks, n_main / (64 * DOC_GROUP)));
+    const int64_t per = round_up((n_main + M - 1) / M, DOC_GROUP);
+    std::vector<hipEvent_t> ev_gemm(M), ev_done(M);
+    for (int i = 0; i < M; ++i) {
+      HIP_TRY(hipEventCreateWithFlags(&ev_gemm[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming));
+    }
+    uint32_t* h = (uint32_t*)w.h_pinned;          // 16 bytes per set: {max, pad, sum64}; two sets live in 32 bytes
+    auto enqueue_gemm = [&](int i) -> int {
+      uint2* cand = (i & 1) ? w.cand2 : w.cand;
+      uint32_t* cnt = (i & 1) ? w.cnt2 : w.cnt;
+      const int64_t lo = (int64_t)i * per, hi = std::min<int64_t>(n_main, lo + per);
+      if (i >= 2) HIP_TRY(hipStreamWaitEvent(s, ev_done[i - 2], 0));      // list set is free again
+      GemmArgs g{};
+      g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K;
+      g.seq_lo = lo; g.seq_hi = hi; g.map_mode = 2; g.period = S; g.head = head; g.n_tiles = ix->n_tiles;
+      g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr_hat; g.cand = cand; g.cnt = cnt;
+      g.cap = (uint32_t)w.cap; g.n_queries = Q;
+      HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)w.q_pad * 4, s));
+      HIP_TRY(hipMemsetAsync(w.d_max2 + 4 * (i & 1), 0, 16, s));
+      tm.begin(T_GEMM); HIP_TRY(launch_gemm_filter(g, s)); tm.end();
+      HIP_TRY(launch_max_u32(cnt, Q, w.d_max2 + 4 * (i & 1), (unsigned long long*)(w.d_max2 + 4 * (i & 1) + 2), s));
+      HIP_TRY(hipMemcpyAsync(w.h_pinned2 + 16 * (i & 1), w.d_max2 + 4 * (i & 1), 16, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipEventRecord(ev_gemm[i], s));
+      const double rows = (double)(hi - lo) * TILE_ROWS;
+      st.phases++;
+      st.gemm_rows += (int64_t)rows;
+      st.gemm_flops += 2.0 * (double)w.q_pad * rows * (double)ix->kt;
+      st.gemm_flops_alg += 2.0 * (double)Q * rows * (double)ix->k;
+      return DHR_OK;
+    };
+    (void)h;
+    if ((rc = enqueue_gemm(0)) != DHR_OK) return rc;
+    for (int i = 0; i < M; ++i) {
+      if (i + 1 < M && (rc = enqueue_gemm(i + 1)) != DHR_OK) return rc;
+      HIP_TRY(hipEventSynchronize(ev_gemm[i]));
+      const uint32_t maxc = *(const uint32_t*)(w.h_pinned2 + 16 * (i & 1));
+      unsigned long long sumc;
+      memcpy(&sumc, w.h_pinned2 + 16 * (i & 1) + 8, 8);
+      st.candidates_bound += (int64_t)sumc;
+      st.candidates_exact += (int64_t)sumc;
+      uint2* cand = (i & 1) ? w.cand2 : w.cand;
+      uint32_t* cnt = (i & 1) ? w.cnt2 : w.cnt;
+      HIP_TRY(launch_mark_overflow(cnt, (uint32_t)w.cap, Q, w.fail_flags, sb));
+      const uint32_t maxr = std::min<uint32_t>(maxc, (uint32_t)w.cap);
+      if (maxr > 0) {
+        RescoreArgs r = base_rescore_args(ix, w, Q, gate);
+        r.cand = cand; r.cnt = cnt; r.cap = (uint32_t)w.cap; r.max_count = maxr;
+        r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
+        tm.begin_on(T_RESCORE, sb); HIP_TRY(launch_rescore(r, sb)); tm.end_on(sb);
+        sel.cnt = cnt; sel.count_all = 0;
+        tm.begin_on(T_SELECT, sb); HIP_TRY(launch_select(sel, sb)); tm.end_on(sb);
+      }
+      HIP_TRY(hipEventRecord(ev_done[i], sb));
+    }
+    HIP_TRY(hipStreamWaitEvent(s, ev_done[M - 1], 0));
+    for (int i = 0; i < M; ++i) { hipEventDestroy(ev_gemm[i]); hipEventDestroy(ev_done[i]); }
   }
   // ---- verify; queries whose list overflowed or that found < k rows above tau_hat are redone exactly
   HIP_TRY(hipMemsetAsync(w.d_max, 0, 16, s));
-  HIP_TRY(launch_verify(w.topk_keys, w.kp, k, w.cnt, (uint32_t)w.cap, w.tau_hat, Q, w.fail_flags, w.d_max, s));
+  HIP_TRY(launch_verify(w.topk_keys, w.kp, k, w.tau_hat, Q, w.fail_flags, w.d_max, s));
   HIP_TRY(hipMemcpyAsync(w.h_pinned, w.d_max, 16, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   const uint32_t n_fail = ((uint32_t*)w.h_pinned)[0];

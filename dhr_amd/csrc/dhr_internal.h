@@ -130,8 +130,9 @@ hipError_t launch_emit(const uint64_t* topk_keys, int kp, int n_queries, int k, 
 hipError_t launch_max_u32(const uint32_t* v, int n, uint32_t* out_max, unsigned long long* out_sum, hipStream_t s);
 hipError_t launch_rows_to_local(const int64_t* rows, int64_t n, int64_t row_offset, int64_t n_rows, uint32_t* out,
                                 hipStream_t s);
-hipError_t launch_verify(const uint64_t* topk_keys, int kp, int k, const uint32_t* cnt, uint32_t cap, const float* tau_hat,
-                         int n_queries, uint32_t* fail_flags, uint32_t* n_fail, hipStream_t s);
+hipError_t launch_mark_overflow(const uint32_t* cnt, uint32_t cap, int n_queries, uint32_t* fail_flags, hipStream_t s);
+hipError_t launch_verify(const uint64_t* topk_keys, int kp, int k, const float* tau_hat, int n_queries, uint32_t* fail_flags,
+                         uint32_t* n_fail, hipStream_t s);
 hipError_t launch_gather_queries(const float* q32, const int16_t* q_idx, int k_rm, int d_dlr, const int32_t* ids, int n,
                                  float* out32, int16_t* out_idx, hipStream_t s);
 hipError_t launch_scatter_keys(const uint64_t* src, uint64_t* dst, int kp, const int32_t* ids, int n, hipStream_t s);

@@ -705,12 +705,13 @@ __global__ void __launch_bounds__(GEMM_W4_THREADS, 1) gemm_filter_w4_kernel(Gemm
 }
 
 int g_gemm_ablate = 0;    // tuning only (DHR_GEMM_ABLATE environment variable)
-int g_gemm_variant = 2;   // 0: single-phase kernel, 1: ping-pong wave groups, 2: one wave per SIMD (128x128 per wave)
+int g_gemm_variant = 0;   // 0: single-phase kernel, 1: ping-pong wave groups, 2: one wave per SIMD (128x128 per wave)
 
 hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
   static bool env_read = false;
   if (!env_read) {
     if (const char* e = getenv("DHR_GEMM_ABLATE")) g_gemm_ablate = atoi(e);
+    if (const char* e = getenv("DHR_GEMM_VARIANT")) g_gemm_variant = atoi(e);
     env_read = true;
   }
   const int64_t n_tiles = a.seq_hi - a.seq_lo;
@@ -978,20 +979,27 @@ hipError_t launch_rows_to_local(const int64_t* rows, int64_t n, int64_t row_offs
 // ------------------------------------------------------------------------------------------ sampled-threshold helpers
 // A query's result is complete iff its candidate list did not overflow and its k-th best exact score
 // reached the sampled threshold tau_hat (then every row with score >= tau_hat was collected).
-__global__ void verify_kernel(const uint64_t* __restrict__ topk_keys, int kp, int k, const uint32_t* __restrict__ cnt,
-                              uint32_t cap, const float* __restrict__ tau_hat, int n_queries, uint32_t* fail_flags,
-                              uint32_t* n_fail) {
+__global__ void mark_overflow_kernel(const uint32_t* __restrict__ cnt, uint32_t cap, int n_queries, uint32_t* fail_flags) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n_queries && cnt[q] > cap) fail_flags[q] = 1u;
+}
+hipError_t launch_mark_overflow(const uint32_t* cnt, uint32_t cap, int n_queries, uint32_t* fail_flags, hipStream_t s) {
+  hipLaunchKernelGGL(mark_overflow_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, cnt, cap, n_queries, fail_flags);
+  return hipGetLastError();
+}
+__global__ void verify_kernel(const uint64_t* __restrict__ topk_keys, int kp, int k, const float* __restrict__ tau_hat,
+                              int n_queries, uint32_t* fail_flags, uint32_t* n_fail) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n_queries) return;
   const uint64_t kth = topk_keys[(int64_t)q * kp + (k - 1)];
-  const bool ok = cnt[q] <= cap && kth != 0ull && ordered_f32((uint32_t)(kth >> 32)) >= tau_hat[q];
+  const bool ok = fail_flags[q] == 0u && kth != 0ull && ordered_f32((uint32_t)(kth >> 32)) >= tau_hat[q];
   fail_flags[q] = ok ? 0u : 1u;
   if (!ok) atomicAdd(n_fail, 1u);
 }
-hipError_t launch_verify(const uint64_t* topk_keys, int kp, int k, const uint32_t* cnt, uint32_t cap, const float* tau_hat,
-                         int n_queries, uint32_t* fail_flags, uint32_t* n_fail, hipStream_t s) {
-  hipLaunchKernelGGL(verify_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, topk_keys, kp, k, cnt, cap, tau_hat,
-                     n_queries, fail_flags, n_fail);
+hipError_t launch_verify(const uint64_t* topk_keys, int kp, int k, const float* tau_hat, int n_queries, uint32_t* fail_flags,
+                         uint32_t* n_fail, hipStream_t s) {
+  hipLaunchKernelGGL(verify_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, topk_keys, kp, k, tau_hat, n_queries,
+                     fail_flags, n_fail);
   return hipGetLastError();
 }
 

@@ -93,6 +93,7 @@ typedef enum dhr_param {
   DHR_PARAM_FIRST_ROWS = 2,   /* rows scored exhaustively to seed the thresholds (>= k enforced) */
   DHR_PARAM_PROFILE = 3,      /* 1: record per-kernel hipEvent timings into dhr_search_stats */
   DHR_PARAM_MAX_GROWTH = 4,   /* max (next chunk rows) / (rows seen), in 1/16ths (default 32 = 2x) */
+  DHR_PARAM_MAIN_CHUNKS = 7,  /* main-pass chunks whose rescoring overlaps the next chunk's GEMM (default 4) */
   DHR_PARAM_GEMM_VARIANT = 6, /* process-wide: 0 = single-phase bound GEMM, 1 = ping-pong wave groups (default) */
   DHR_PARAM_SAMPLE_PERIOD = 5 /* every S-th corpus tile seeds the thresholds (default 16; 0 = plain streaming) */
 } dhr_param;
