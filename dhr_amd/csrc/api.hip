@@ -78,9 +78,9 @@ struct dhr_index {
   int64_t cand_cap = 65536, first_rows = 0;
   int profile = 0, max_growth16 = 32;
   int sample_period = 16;
-  int main_chunks = 4;
+  int main_chunks = 8;
   hipStream_t s_aux = nullptr;          // non-blocking stream for rescoring/select overlapped with the main-pass GEMM
-  Workspace ws, ws_fb;
+  Workspace ws, ws_fb[2];              // ws_fb[d]: workspace of fallback depth d+1 (16x candidate capacity)
   dhr_search_stats stats{};
 };
 
@@ -101,7 +101,8 @@ extern "C" void dhr_index_destroy(dhr_index* ix) {
   if (!ix) return;
   hipSetDevice(ix->device);
   free_ws(ix->ws);
-  free_ws(ix->ws_fb);
+  free_ws(ix->ws_fb[0]);
+  free_ws(ix->ws_fb[1]);
   if (ix->s_aux) hipStreamDestroy(ix->s_aux);
   hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map);
   delete ix;
@@ -133,7 +134,7 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
   return set_error(DHR_ERR_INVALID, "unknown parameter");
 }
 
-extern "C" int64_t dhr_index_device_bytes(const dhr_index* ix) { return ix ? ix->index_bytes + ix->ws.bytes + ix->ws_fb.bytes : 0; }
+extern "C" int64_t dhr_index_device_bytes(const dhr_index* ix) { return ix ? ix->index_bytes + ix->ws.bytes + ix->ws_fb[0].bytes + ix->ws_fb[1].bytes : 0; }
 extern "C" int dhr_get_stats(const dhr_index* ix, dhr_search_stats* out) {
   if (!ix || !out) return set_error(DHR_ERR_INVALID, "null argument");
   *out = ix->stats;
@@ -296,12 +297,12 @@ static hipError_t re_malloc(T*& p, size_t bytes, int64_t& total) {
   return hipMalloc((void**)&p, bytes ? bytes : 16);
 }
 
-static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t keys_ld_min) {
+static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t keys_ld_min, int64_t cap_mult = 1) {
   const int q_pad = (int)round_up(n_queries, TILE_ROWS);
   int kp = 1;
   while (kp < k) kp <<= 1;
   if (kp < 64) kp = 64;
-  const int64_t cap = ix->cand_cap;
+  const int64_t cap = std::min<int64_t>(ix->cand_cap * cap_mult, (int64_t)1 << 22);
   const int64_t keys_ld = std::max<int64_t>(cap, keys_ld_min);
   if (w.q_pad == q_pad && w.kp == kp && w.cap == cap && w.keys_ld >= keys_ld && w.kt == ix->kt) return DHR_OK;
   free_ws(w);
@@ -476,7 +477,7 @@ static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectAr
 }
 
 // Leaves the sorted top-k keys of every query in w.topk_keys.  qb must already be validated.
-static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, int k, bool allow_sampling, Timer& tm,
+static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, int k, int depth, Timer& tm,
                        dhr_search_stats& st, hipStream_t s) {
   int rc;
   const int Q = qb->n_queries;
@@ -487,7 +488,10 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   int64_t first = std::max<int64_t>(ix->first_rows, std::max<int64_t>(2048, 2 * (int64_t)k));
   first = std::min(round_up(first, group_rows), round_up(n, group_rows));
   const int64_t first_valid = std::min(first, n);
-  if ((rc = ensure_ws(ix, w, Q, k, first_valid)) != DHR_OK) return rc;
+  // depth 0: sampled thresholds; depth 1 (queries that failed at depth 0): the same with 16x list capacity;
+  // depth 2: plain streaming, exact for any input
+  const bool allow_sampling = depth < 2;
+  if ((rc = ensure_ws(ix, w, Q, k, first_valid, depth == 0 ? 1 : 16)) != DHR_OK) return rc;
 
   tm.begin(T_PREP);
   if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
@@ -634,8 +638,8 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   dhr_query_batch sub{};
   sub.n_queries = nf; sub.mem_kind = DHR_MEM_DEVICE; sub.value = f32; sub.value_dtype = DHR_VAL_F32; sub.ld_value = ix->k_rm;
   sub.index = gate ? fidx : nullptr; sub.index_dtype = gate ? DHR_IDX_I16 : DHR_IDX_NONE; sub.ld_index = ix->d_dlr;
-  Workspace& w2 = ix->ws_fb;
-  if ((rc = search_core(ix, w2, &sub, k, false, tm, st, s)) != DHR_OK) return done(rc);
+  Workspace& w2 = ix->ws_fb[depth];
+  if ((rc = search_core(ix, w2, &sub, k, depth + 1, tm, st, s)) != DHR_OK) return done(rc);
   if (w2.kp != w.kp) return done(set_error(DHR_ERR_INTERNAL, "fallback workspace mismatch"));
   if (launch_scatter_keys(w2.topk_keys, w.topk_keys, w.kp, d_ids, nf, s) != hipSuccess)
     return done(set_error(DHR_ERR_HIP, "scatter_keys launch failed"));
@@ -660,7 +664,7 @@ extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, f
   dhr_search_stats st{};
   st.n_rows = ix->n_rows; st.n_queries = Q; st.k = k;
   Workspace& w = ix->ws;
-  if ((rc = search_core(ix, w, qb, k, true, tm, st, s)) != DHR_OK) return rc;
+  if ((rc = search_core(ix, w, qb, k, 0, tm, st, s)) != DHR_OK) return rc;
 
   // ---- results
   float* d_scores = out_scores;
