@@ -125,7 +125,7 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
       if (value < 1 || value > 64) return set_error(DHR_ERR_INVALID, "main_chunks must be in [1,64]");
       ix->main_chunks = (int)value; return DHR_OK;
     case DHR_PARAM_GEMM_VARIANT:
-      if (value < 0 || value > 2) return set_error(DHR_ERR_INVALID, "gemm_variant must be 0, 1 or 2");
+      if (value != 0 && value != 2 && value != 3) return set_error(DHR_ERR_INVALID, "gemm_variant must be 0, 2 or 3");
       dhr::g_gemm_variant = (int)value; return DHR_OK;
     case DHR_PARAM_MAX_GROWTH:
       if (value < 1 || value > 1024) return set_error(DHR_ERR_INVALID, "max_growth must be in [1,1024] sixteenths");
@@ -652,7 +652,7 @@ extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, f
   int rc = check_queries(ix, qb);
   if (rc) return rc;
   if (k <= 0) return set_error(DHR_ERR_INVALID, "k must be > 0");
-  if (k > 4096) return set_error(DHR_ERR_UNSUPPORTED, "k > 4096 is not supported by the LDS top-k merge yet");
+  if (k > 16384) return set_error(DHR_ERR_UNSUPPORTED, "k > 16384 is not supported by the LDS top-k merge");
   if (!out_scores || !out_rows) return set_error(DHR_ERR_INVALID, "null output pointer");
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = (hipStream_t)stream;

@@ -415,13 +415,14 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_filter_kernel(GemmArgs p) {
   gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane);
 }
 
-// Ping-pong variant: the 8 waves form two groups (one wave of each group per SIMD).  While group A
-// issues the 32 MFMAs of a K-step from fragments it holds in registers, group B reads its 24 fragments
-// of the same K-step from LDS (and both groups issue the LDS-DMA of the next K-step); then they swap.
-// The matrix pipe of every SIMD always has one wave in its MFMA phase, and the only waits on the
-// DMA are one counted drain per K-step placed two half-steps after the issue.
+// Variant 3: same tiling as gemm_filter_kernel (8 waves, 128 x 64 per wave) with three changes aimed at
+// the matrix pipe's idle time: (1) the two wave groups (one wave of each per SIMD) issue their LDS-DMA
+// at DIFFERENT points of the K-step (group 0 at the start, group 1 in the middle), so one wave of every
+// SIMD is always in its MFMA stream while the other pays the DMA issue cost; (2) fragments are
+// software-pipelined one 16-deep k-slice ahead (two register sets); (3) the single hand-over barrier of a
+// K-step sits BEFORE the last k-slice's MFMAs, and the first fragments of the next K-step are read under them.
 template <bool DUMP>
-__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_pp_kernel(GemmArgs p) {
+__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_v3_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int64_t b = blockIdx.x;
   const int xcd = (int)(b & 7);
@@ -438,7 +439,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_pp_kernel(GemmArg
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2;            // group: 0 = A (rows 0..127), 1 = B (rows 128..255)
+  const int wm = wave >> 2;            // wave group / 128-row half
   const int wn = wave & 3;
   const int ksteps = p.ksteps;
   const char* a_src = (const char*)(p.a_tiles + dt * (int64_t)ksteps * TILE_HALVES);
@@ -475,53 +476,46 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_pp_kernel(GemmArg
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) b_off[ni] = (wn * 64 + ni * 32 + frow) * 128;
 
-  half8 af[4][4], bf[4][2];
-  auto read_frags = [&](int buf) {
-    const char* la = smem + buf * (2 * TILE_HALVES * 2);
-    const char* lb = la + TILE_HALVES * 2;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int coff = ((kk * 2 + fhalf) ^ swz) * 16;
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) af[kk][mi] = *(const half8*)(la + a_off[mi] + coff);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) bf[kk][ni] = *(const half8*)(lb + b_off[ni] + coff);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads are done before it passes the barrier
-  };
-  auto mfma_all = [&]() {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk][mi], bf[kk][ni], acc[mi][ni], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
+  half8 a0[4], b0[2], a1[4], b1[2];
+#define V3_READ(AF, BF, BUF, KK)                                                               \
+  {                                                                                            \
+    const char* la_ = smem + (BUF) * (2 * TILE_HALVES * 2);                                    \
+    const char* lb_ = la_ + TILE_HALVES * 2;                                                   \
+    const int coff_ = ((((KK) * 2) + fhalf) ^ swz) * 16;                                       \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) AF[mi] = *(const half8*)(la_ + a_off[mi] + coff_); \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) BF[ni] = *(const half8*)(lb_ + b_off[ni] + coff_); \
+  }
+#define V3_MFMA8(AF, BF)                                                                       \
+  {                                                                                            \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                           \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                           \
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[mi], BF[ni], acc[mi][ni], 0, 0, 0); \
+  }
 
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  V3_READ(a0, b0, 0, 0);
+  const int last = ksteps - 1;
   for (int t = 0; t < ksteps; ++t) {
-    // ---- first half-step: A reads K-step t, B multiplies K-step t-1; everyone prefetches K-step t+1
-    if (t + 1 < ksteps) stage((t + 1) & 1, t + 1);
-    if (wm == 0) read_frags(t & 1);
-    else if (t > 0) mfma_all();
-    __builtin_amdgcn_sched_barrier(0);
+    const int buf = t & 1;
+    const int ks1 = t + 1 < last ? t + 1 : last;     // past the end: re-stage the last K-step into the dead buffer
+    if (wm == 0) stage(buf ^ 1, ks1);
+    V3_READ(a1, b1, buf, 1);
+    V3_MFMA8(a0, b0);
+    V3_READ(a0, b0, buf, 2);
+    V3_MFMA8(a1, b1);
+    if (wm == 1) stage(buf ^ 1, ks1);
+    V3_READ(a1, b1, buf, 3);
+    V3_MFMA8(a0, b0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- second half-step: A multiplies K-step t, B reads it
-    if (wm == 0) mfma_all();
-    else read_frags(t & 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // K-step t+1 has landed (issued one half-step ago)
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
+    V3_READ(a0, b0, buf ^ 1, 0);
+    V3_MFMA8(a1, b1);
   }
-  if (wm == 1) mfma_all();
-  __syncthreads();
+#undef V3_READ
+#undef V3_MFMA8
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane);
 }
 
@@ -705,7 +699,7 @@ __global__ void __launch_bounds__(GEMM_W4_THREADS, 1) gemm_filter_w4_kernel(Gemm
 }
 
 int g_gemm_ablate = 0;    // tuning only (DHR_GEMM_ABLATE environment variable)
-int g_gemm_variant = 0;   // 0: single-phase kernel, 1: ping-pong wave groups, 2: one wave per SIMD (128x128 per wave)
+int g_gemm_variant = 0;   // 0 single-phase, 2 one wave per SIMD, 3 staggered DMA + pipelined fragments
 
 hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
   static bool env_read = false;
@@ -727,10 +721,10 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
     e = hipFuncSetAttribute((const void*)gemm_filter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)gemm_filter_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)gemm_filter_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_set = true;
@@ -755,11 +749,11 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
       hipLaunchKernelGGL((gemm_filter_w4_kernel<false, 2>), dim3((unsigned)blocks), dim3(GEMM_W4_THREADS), GEMM_LDS_BYTES, s, a);
     } else
       hipLaunchKernelGGL(gemm_filter_w4_kernel<false>, dim3((unsigned)blocks), dim3(GEMM_W4_THREADS), GEMM_LDS_BYTES, s, a);
-  } else if (g_gemm_variant == 1) {
+  } else if (g_gemm_variant == 3) {
     if (a.dump)
-      hipLaunchKernelGGL(gemm_filter_pp_kernel<true>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+      hipLaunchKernelGGL(gemm_filter_v3_kernel<true>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
     else
-      hipLaunchKernelGGL(gemm_filter_pp_kernel<false>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+      hipLaunchKernelGGL(gemm_filter_v3_kernel<false>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
   } else if (a.dump)
     hipLaunchKernelGGL(gemm_filter_kernel<true>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
   else
@@ -901,7 +895,92 @@ __global__ void __launch_bounds__(SELECT_THREADS) select_kernel(SelectArgs p) {
   }
 }
 
+// Large k (4096 < k <= 16384, e.g. the documented --agip_topk 10000): the running top-k alone fills LDS
+// (kp keys), so new keys come in sorted batches of SELECT_BIG_BATCH and are merged IN PLACE: every old
+// and new key computes its final position (own index + number of keys of the other sequence that beat
+// it, by binary search), then all keys are written at once.
+constexpr int SELECT_BIG_BATCH = 2048;
+__device__ __forceinline__ int count_greater(const uint64_t* arr, int n, uint64_t key) {   // arr sorted descending
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (arr[mid] > key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__global__ void __launch_bounds__(SELECT_THREADS) select_big_kernel(SelectArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* A = (uint64_t*)smem;
+  uint64_t* B = A + p.kp;
+  int& fill = *(int*)(smem + (size_t)(p.kp + SELECT_BIG_BATCH) * 8);
+  const int q = blockIdx.x, tid = threadIdx.x;
+  uint32_t count = p.cnt ? p.cnt[q] : p.count_all;
+  if (p.cnt && count > p.cap) count = p.cap;
+  uint64_t* topk = p.topk_keys + (int64_t)q * p.kp;
+  const uint64_t* in = p.in_keys + (int64_t)q * p.ld_keys;
+  for (int j = tid; j < p.kp; j += SELECT_THREADS) A[j] = topk[j];
+  if (tid == 0) fill = 0;
+  __syncthreads();
+  const int per_thread = p.kp / SELECT_THREADS;                     // 8 or 16
+  for (uint32_t base = 0; base < count; base += SELECT_BIG_BATCH) {
+    const uint64_t kth = A[p.k - 1];
+    __syncthreads();
+    const uint32_t end = (base + SELECT_BIG_BATCH < count) ? base + SELECT_BIG_BATCH : count;
+    for (uint32_t j = base + tid; j < end; j += SELECT_THREADS) {
+      const uint64_t key = in[j];
+      if (key > kth) B[atomicAdd(&fill, 1)] = key;
+    }
+    __syncthreads();
+    const int m = fill;
+    if (m > 0) {
+      for (int j = m + tid; j < SELECT_BIG_BATCH; j += SELECT_THREADS) B[j] = 0ull;
+      __syncthreads();
+      bitonic_desc(B, SELECT_BIG_BATCH, tid, SELECT_THREADS);
+      uint64_t ka[16]; int da[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = tid + e * SELECT_THREADS;
+        if (e < per_thread) { ka[e] = A[i]; da[e] = i + count_greater(B, m, ka[e]); }
+      }
+      uint64_t kb[2]; int db[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int j = tid + e * SELECT_THREADS;
+        kb[e] = (j < m) ? B[j] : 0ull;
+        db[e] = (j < m) ? j + count_greater(A, p.kp, kb[e]) : p.kp;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (e < per_thread && da[e] < p.kp) A[da[e]] = ka[e];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        if (db[e] < p.kp) A[db[e]] = kb[e];
+    }
+    if (tid == 0) fill = 0;
+    __syncthreads();
+  }
+  for (int j = tid; j < p.kp; j += SELECT_THREADS) topk[j] = (j < p.k) ? A[j] : 0ull;
+  if (tid == 0) {
+    const uint64_t kth = A[p.k - 1];
+    const float t = kth ? ordered_f32((uint32_t)(kth >> 32)) : -INFINITY;
+    p.tau[q] = t;
+    p.thr[q] = (q < p.n_queries) ? t - p.margin[q] : INFINITY;
+  }
+}
+
 hipError_t launch_select(const SelectArgs& a, hipStream_t s) {
+  if (a.kp > 4096) {
+    const int bytes = (a.kp + SELECT_BIG_BATCH) * 8 + 16;
+    static int big_bytes = 0;
+    if (bytes > big_bytes) {
+      hipError_t e = hipFuncSetAttribute((const void*)select_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (e != hipSuccess) return e;
+      big_bytes = bytes;
+    }
+    hipLaunchKernelGGL(select_big_kernel, dim3((unsigned)a.n_queries), dim3(SELECT_THREADS), bytes, s, a);
+    return hipGetLastError();
+  }
   static int attr_bytes = 0;
   const int bytes = a.sort_n * 8 + 16;
   if (bytes > attr_bytes) {

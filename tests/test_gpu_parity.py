@@ -364,3 +364,33 @@ def test_sampling_on_off_same_result(G):
         np.testing.assert_array_equal(r, out[0][1])
         np.testing.assert_array_equal(s, out[0][0])
     print([o[2]["candidates_exact"] for o in out], [o[2]["phases"] for o in out])
+
+
+@pytest.mark.parametrize("k", [4097, 10000, 16384])
+def test_large_k(G, k):
+    """k beyond the single-pass LDS merge (the documented --agip_topk default is 10000)."""
+    from dhr_amd import synth
+    cv, ci, qv, qi = synth.make_pair(17, 40_000, 6, 768, 64)
+    _search_check(G, cv, ci, qv.astype(np.float32), qi, k, queries=[0, 5])
+
+
+def test_two_stage_default_agip_topk(G):
+    """--theta 0.3 --rerank with the reference's default --agip_topk 10000 against the oracle."""
+    from dhr_amd import synth
+    cv, ci, qv, qi = synth.make_pair(18, 30_000, 4, 768, 128)
+    q32 = qv.astype(np.float32)
+    args = case_args(dict(topk=1000, theta=0.3, rerank=True, agip_topk=10000))
+    qids = [str(i) for i in range(4)]
+    res, sc = G.GIP_retrieval(qids, q32, qi, cv, ci, args)
+    eres, esc = O.GIP_retrieval(qids, q32, qi, cv.astype(np.float32), ci, args)
+    for qid in qids:
+        np.testing.assert_allclose(np.sort(sc[qid]), np.sort(esc[qid]), rtol=3e-6, atol=3e-6)
+        assert len(set(res[qid]) ^ set(eres[qid])) <= 4
+
+
+def test_config1_bm25_100k(G):
+    """BASELINE config 1 shape: DLR-only BM25-like vectors, int16 slice index, 100k passages."""
+    from dhr_amd import synth
+    cv, ci, qv, qi = synth.make_pair(19, 100_000, 48, 768, 0, kind="bm25")
+    _, _, st = _search_check(G, cv, ci, qv.astype(np.float32), qi, 1000, queries=[0, 13, 47])
+    print(st)
