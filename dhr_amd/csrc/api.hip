@@ -67,6 +67,7 @@ struct dhr_index {
   int n_buckets = 1;   // index buckets per gated slice in the bound operands
   int kt = 0;          // operand-tile columns = n_buckets*d_dlr + d_cls rounded up to 64
   int ksteps = 0;      // kt / 64
+  int ts = 0, td = 0;  // 2:4 sparse layout (two buckets): ts 32-slice stages + td dense stages; ts == 0 -> dense layouts
   __half* tiles = nullptr;
   __half* vals_rm = nullptr;
   void* c_idx = nullptr;
@@ -125,7 +126,7 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
       if (value < 1 || value > 64) return set_error(DHR_ERR_INVALID, "main_chunks must be in [1,64]");
       ix->main_chunks = (int)value; return DHR_OK;
     case DHR_PARAM_GEMM_VARIANT:
-      if (value != 0 && value != 2 && value != 3) return set_error(DHR_ERR_INVALID, "gemm_variant must be 0, 2 or 3");
+      if (value != 0 && (value < 2 || value > 4)) return set_error(DHR_ERR_INVALID, "gemm_variant must be 0, 2, 3 or 4");
       dhr::g_gemm_variant = (int)value; return DHR_OK;
     case DHR_PARAM_MAX_GROWTH:
       if (value < 1 || value > 1024) return set_error(DHR_ERR_INVALID, "max_growth must be in [1,1024] sixteenths");
@@ -163,8 +164,12 @@ static int ingest(dhr_index* ix, const dhr_index_desc* d, bool first_pass, uint3
       HIP_TRY(launch_copy_rows(src, ld, rows, ix->k, ix->k_rm, ix->vals_rm + lo * ix->k_rm, s));
     }
     const int64_t fill = (lo + rows == n) ? round_up(lo + rows, TILE_ROWS) - lo : rows;   // zero the tail of the last tile
-    HIP_TRY(launch_tile_rows(src, ld, lo, rows, fill, ix->d_dlr, ix->d_cls, ix->n_buckets, ix->kt, ix->c_idx, ix->idx_dtype,
-                             ix->bucket_map, ix->abs_mode, ix->tiles, s));
+    if (ix->ts > 0)
+      HIP_TRY(launch_tile_rows_sparse(src, ld, lo, rows, fill, ix->d_dlr, ix->d_cls, ix->ts, ix->td, ix->c_idx, ix->idx_dtype,
+                                      ix->bucket_map, ix->abs_mode, (char*)ix->tiles, s));
+    else
+      HIP_TRY(launch_tile_rows(src, ld, lo, rows, fill, ix->d_dlr, ix->d_cls, ix->n_buckets, ix->kt, ix->c_idx, ix->idx_dtype,
+                               ix->bucket_map, ix->abs_mode, ix->tiles, s));
     if (d->mem_kind == DHR_MEM_HOST) HIP_TRY(hipStreamSynchronize(s));   // the staging buffer is reused
   }
   return DHR_OK;
@@ -219,8 +224,18 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
   ix->d_cls = d->d_cls;
   ix->k = d->d_dlr + d->d_cls;
   ix->k_rm = (int)round_up(ix->k, TILE_K);
-  ix->n_buckets = has_idx ? (d->idx_buckets > 0 ? d->idx_buckets : 3) : 1;
-  ix->kt = (int)round_up((int64_t)ix->n_buckets * ix->d_dlr + ix->d_cls, TILE_K);
+  // default for gated indexes: two buckets on the sparse matrix cores (needs 32-slice stages);
+  // idx_buckets = 1,3,4,... selects the dense bucket-split operands instead
+  const bool sparse_ok = has_idx && (d->d_dlr % 32 == 0);
+  if (sparse_ok && (d->idx_buckets == 0 || d->idx_buckets == 2)) {
+    ix->n_buckets = 2;
+    ix->ts = d->d_dlr / 32;
+    ix->td = (d->d_cls + TILE_K - 1) / TILE_K;
+    ix->kt = (ix->ts + ix->td) * TILE_K;
+  } else {
+    ix->n_buckets = has_idx ? (d->idx_buckets > 0 ? d->idx_buckets : 3) : 1;
+    ix->kt = (int)round_up((int64_t)ix->n_buckets * ix->d_dlr + ix->d_cls, TILE_K);
+  }
   ix->ksteps = ix->kt / TILE_K;
   ix->idx_dtype = has_idx ? d->index_dtype : DHR_IDX_NONE;
   ix->n_tiles = (d->n_rows + TILE_ROWS - 1) / TILE_ROWS;
@@ -231,7 +246,8 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
   int rc = DHR_OK;
   auto fail = [&](int code) { hipFree(stage); hipFree(d_flags); hipFree(d_hist); dhr_index_destroy(ix); return code; };
 
-  const size_t tile_bytes = (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2;
+  const size_t tile_bytes = ix->ts > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * SP_STAGE_A + (size_t)ix->td * TILE_HALVES * 2)
+                                       : (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2;
   if (hipMalloc((void**)&ix->tiles, tile_bytes) != hipSuccess)
     return fail(set_error(DHR_ERR_HIP, "hipMalloc of " + std::to_string(tile_bytes) + " bytes for the corpus tiles failed"));
   const size_t rm_bytes = (size_t)ix->n_rows * ix->k_rm * 2;
@@ -377,7 +393,7 @@ static int prep_queries(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, 
   HIP_TRY(launch_query_prep(v, qb->value_dtype == DHR_VAL_F32, ldv, (ix->d_dlr > 0 && qb->index) ? qi : nullptr, qb->index_dtype, ldi,
                             qb->n_queries, w.q_pad, ix->d_dlr, ix->d_cls, ix->k_rm, ix->n_buckets, ix->kt, ix->bucket_map,
                             ix->abs_mode, ix->dmax, w.q_tiles, w.q32,
-                            w.q_idx, w.margin, w.tau, w.thr, s));
+                            w.q_idx, w.margin, w.tau, w.thr, ix->ts, ix->td, s));
   return DHR_OK;
 }
 
@@ -410,7 +426,7 @@ static RescoreArgs base_rescore_args(const dhr_index* ix, const Workspace& w, in
 static int gemm_phase(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi, int map_mode, int period, int64_t head,
                       Timer& tm, dhr_search_stats& st, hipStream_t s, uint32_t* maxc, unsigned long long* sumc) {
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td;
   g.seq_lo = lo; g.seq_hi = hi; g.map_mode = map_mode; g.period = period; g.head = head; g.n_tiles = ix->n_tiles;
   g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt;
   g.cap = (uint32_t)w.cap; g.n_queries = Q;
@@ -566,7 +582,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       const int64_t lo = (int64_t)i * per, hi = std::min<int64_t>(n_main, lo + per);
       if (i >= 2) HIP_TRY(hipStreamWaitEvent(s, ev_done[i - 2], 0));      // list set is free again
       GemmArgs g{};
-      g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K;
+      g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td;
       g.seq_lo = lo; g.seq_hi = hi; g.map_mode = 2; g.period = S; g.head = head; g.n_tiles = ix->n_tiles;
       g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr_hat; g.cand = cand; g.cnt = cnt;
       g.cap = (uint32_t)w.cap; g.n_queries = Q;
@@ -741,7 +757,7 @@ extern "C" int dhr_debug_bound_scores(dhr_index* ix, const dhr_query_batch* qb, 
   if ((rc = ensure_ws(ix, w, qb->n_queries, 1, 0)) != DHR_OK) return rc;
   if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.seq_lo = row_lo / TILE_ROWS;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.seq_lo = row_lo / TILE_ROWS;
   g.seq_hi = (row_hi + TILE_ROWS - 1) / TILE_ROWS; g.map_mode = 0; g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
   g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
   g.dump = out_dev; g.dump_ld = row_hi - row_lo; g.dump_row0 = row_lo;
@@ -765,7 +781,7 @@ extern "C" int dhr_debug_gemm_time(dhr_index* ix, const dhr_query_batch* qb, int
   std::vector<float> inf((size_t)w.q_pad, INFINITY);
   HIP_TRY(hipMemcpyAsync(w.thr, inf.data(), (size_t)w.q_pad * 4, hipMemcpyHostToDevice, s));
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.seq_lo = 0; g.seq_hi = ix->n_tiles; g.map_mode = 0;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.seq_lo = 0; g.seq_hi = ix->n_tiles; g.map_mode = 0;
   g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
   g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
   HIP_TRY(launch_gemm_filter(g, s));                      // warm-up

@@ -20,6 +20,10 @@ constexpr int TILE_ROWS = 256;
 constexpr int TILE_K = 64;
 constexpr int CHUNK = 8;                                   // fp16 per 16-byte chunk
 constexpr int TILE_HALVES = TILE_ROWS * TILE_K;            // 16384 fp16 = 32 KiB
+constexpr int SP_A_BYTES = 16384;      // sparse stage: 256 rows x 32 stored slice values
+constexpr int SP_IDX_BYTES = 2048;     //               256 rows x [lane half][block] u16 position bits
+constexpr int SP_STAGE_A = SP_A_BYTES + SP_IDX_BYTES;   // corpus bytes per sparse stage (18 KiB)
+constexpr int SP_STAGE_B = 32768;      // query bytes per sparse stage: 256 rows x 64 bucket columns
 constexpr int DOC_GROUP = 4;                               // doc tiles that share one XCD sweep
 
 __host__ __device__ inline int64_t tiled_chunk_offset(int64_t row, int chunk, int ksteps) {
@@ -55,6 +59,7 @@ struct GemmArgs {
   const __half* b_tiles;      // query operand tiles
   int ksteps;                 // K_pad / 64
   int k_split;                // K-steps [0,k_split) are the gated (DLR) half; informational
+  int ts, td;                 // sparse layout only: 32-slice 2:4 stages, then 64-column dense stages (ts > 0 selects it)
   // corpus tiles of this launch: sequence positions [seq_lo, seq_hi) mapped to tile ids by
   //   map_mode 0: tile = i                 (contiguous)
   //   map_mode 1: tile = head + i*period   (the strided sample)
@@ -116,12 +121,15 @@ hipError_t launch_scan_rows(const __half* src, int64_t ld, int64_t n_rows, int d
 hipError_t launch_tile_rows(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
                             int d_dlr, int d_cls, int n_buckets, int kt, const void* idx, int idx_dtype,
                             const uint8_t* map, bool abs_dlr, __half* tiles, hipStream_t s);
+hipError_t launch_tile_rows_sparse(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
+                                   int d_dlr, int d_cls, int ts, int td, const void* idx, int idx_dtype, const uint8_t* map,
+                                   bool abs_dlr, char* tiles, hipStream_t s);
 hipError_t launch_copy_rows(const __half* src, int64_t ld, int64_t n_rows, int k, int k_rm, __half* dst, hipStream_t s);
 hipError_t launch_idx_hist(const uint8_t* idx, int64_t n_rows, int d_dlr, uint32_t* hist, hipStream_t s);
 hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const void* idx, int idx_dtype, int64_t ld_idx,
                              int n_queries, int q_pad, int d_dlr, int d_cls, int k_rm, int n_buckets, int kt,
                              const uint8_t* map, bool abs_dlr, float dmax, __half* q_tiles, float* q32, int16_t* q_idx,
-                             float* margin, float* tau, float* thr, hipStream_t s);
+                             float* margin, float* tau, float* thr, int ts, int td, hipStream_t s);
 hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s);
 hipError_t launch_rescore(const RescoreArgs& a, hipStream_t s);
 hipError_t launch_select(const SelectArgs& a, hipStream_t s);

@@ -154,6 +154,76 @@ hipError_t launch_tile_rows(const __half* src, int64_t ld, int64_t row_lo, int64
   return hipGetLastError();
 }
 
+// ---- 2:4 layout (two index buckets, sparse matrix cores).  Logical gated columns are (slice, bucket)
+// pairs, k = 2*slice + bucket: every group of four logical columns = two slices holds exactly two
+// values, which is the structured sparsity v_smfmac_f32_32x32x32_f16 wants on its A operand.  So the
+// corpus side stores just the ORIGINAL slice values (32 per stage) plus 2 position bits per value
+// (position = 2*(slice&1) + bucket); only the query side is expanded to the two bucket columns.
+// Register layouts were measured on gfx950 (tools/probe/smfmac_probe.hip, gpurun_out/smfmac_probe.txt):
+//   A: lane l holds row l&31, stored elements E=0..7 = slices 8*(l>>5)+E of the 16-slice block,
+//      position bits of element E at idx[2E+1:2E] (low 16 bits with abid=0, high 16 with abid=1);
+//   B: lane l holds column l&31, element e: group g=e>>2 (position e&3) where the logical group
+//      G = 4*(g>>1) + 2*(l>>5) + (g&1) covers slices 2G, 2G+1 of the block.
+// Stage image of the corpus (18 KiB): [256 rows][4 chunks of 8 slices, chunk ^ ((row>>2)&3)] fp16, then
+// [256 rows][lane half][block] u16 position words.  Tile = ts sparse stages, then td dense 32 KiB stages.
+__global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __restrict__ src, int64_t ld, int64_t row_lo,
+                                                               int64_t n_rows_src, int64_t n_rows_fill, int d_dlr,
+                                                               int d_cls, int ts, int td, const void* __restrict__ idx,
+                                                               int idx_dtype, const uint8_t* __restrict__ map, int abs_dlr,
+                                                               char* __restrict__ tiles) {
+  const int k = d_dlr + d_cls;
+  const int sp_chunks = ts * 4, dn_chunks = td * 8;
+  const int cpr = sp_chunks + dn_chunks;
+  const int64_t tile_bytes = (int64_t)ts * SP_STAGE_A + (int64_t)td * (TILE_HALVES * 2);
+  const int64_t total = n_rows_fill * cpr;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t rl = g / cpr;
+    const int c = (int)(g - rl * cpr);
+    const int64_t row = row_lo + rl;
+    const int r = (int)(row & 255);
+    char* tile = tiles + (row >> 8) * tile_bytes;
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
+    if (c < sp_chunks) {
+      const int st = c >> 2, cc = c & 3, j0 = c * 8;
+      uint32_t bits = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int bucket = 0;
+        if (rl < n_rows_src && j0 + e < d_dlr) {
+          _Float16 x = (_Float16)__half2float(src[rl * ld + j0 + e]);
+          if (abs_dlr && x < (_Float16)0.f) x = -x;
+          v[e] = x;
+          bucket = bucket_of(load_idx(idx, idx_dtype, row * d_dlr + j0 + e), j0 + e, map, 2);
+        }
+        bits |= (uint32_t)(((e & 1) << 1) | bucket) << (2 * e);
+      }
+      char* stg = tile + (int64_t)st * SP_STAGE_A;
+      *(half8*)(stg + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = v;
+      *(uint16_t*)(stg + SP_A_BYTES + r * 8 + (cc & 1) * 4 + (cc >> 1) * 2) = (uint16_t)bits;
+    } else {
+      const int dc = c - sp_chunks, st = dc >> 3, cc = dc & 7, j0 = d_dlr + dc * 8;
+      if (rl < n_rows_src)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (j0 + e < k) v[e] = (_Float16)__half2float(src[rl * ld + j0 + e]);
+      char* stg = tile + (int64_t)ts * SP_STAGE_A + (int64_t)st * (TILE_HALVES * 2);
+      *(half8*)(stg + r * 128 + ((cc ^ ((r >> 1) & 7)) * 16)) = v;
+    }
+  }
+}
+hipError_t launch_tile_rows_sparse(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
+                                   int d_dlr, int d_cls, int ts, int td, const void* idx, int idx_dtype, const uint8_t* map,
+                                   bool abs_dlr, char* tiles, hipStream_t s) {
+  if (n_rows_fill <= 0) return hipSuccess;
+  const int64_t total = n_rows_fill * (ts * 4 + td * 8);
+  const int64_t blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(tile_rows_sparse_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, src, ld,
+                     row_lo, n_rows_src, n_rows_fill, d_dlr, d_cls, ts, td, idx, idx_dtype, map, abs_dlr ? 1 : 0, tiles);
+  return hipGetLastError();
+}
+
 // Row-major fp16 copy [n][k_rm] (zero padded) that the exact rescoring reads: one contiguous row per pair.
 __global__ void __launch_bounds__(256) copy_rows_kernel(const __half* __restrict__ src, int64_t ld, int64_t n_rows, int k,
                                                         int k_rm, __half* __restrict__ dst) {
@@ -213,7 +283,7 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
                                                          int abs_dlr, float dmax, __half* __restrict__ q_tiles,
                                                          float* __restrict__ q32, int16_t* __restrict__ q_idx,
                                                          float* __restrict__ margin, float* __restrict__ tau,
-                                                         float* __restrict__ thr) {
+                                                         float* __restrict__ thr, int ts, int td) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= q_pad) return;
@@ -236,6 +306,34 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
     sr += (v - back) * (v - back);
   }
   for (int j = lane; j < d_dlr; j += 64) q_idx[(int64_t)q * d_dlr + j] = (int16_t)qidx(j);
+  if (ts > 0) {
+    // 2:4 layout: per sparse stage 64 bucket columns per row in smfmac B-operand order, then dense stages
+    char* tile = (char*)q_tiles + (int64_t)(q >> 8) * ((int64_t)(ts + td) * (TILE_HALVES * 2));
+    const int r = q & 255;
+    for (int c = lane; c < (ts + td) * 8; c += 64) {
+      half8 h8;
+      const int st = c >> 3, cc = c & 7;
+#pragma unroll
+      for (int e8 = 0; e8 < 8; ++e8) {
+        float v = 0.f;
+        if (st < ts) {
+          const int kb = cc >> 2, hh = (cc >> 1) & 1, e = (cc & 1) * 8 + e8;      // chunk = (kb*2+h)*2 + (e>>3)
+          const int gq = e >> 2, pos = e & 3;
+          const int G = 4 * (gq >> 1) + 2 * hh + (gq & 1);
+          const int j = st * 32 + kb * 16 + 2 * G + (pos >> 1);
+          if (j < d_dlr) {
+            v = qval(j);
+            if (idx && bucket_of(qidx(j), j, map, 2) != (pos & 1)) v = 0.f;
+            if (abs_dlr) v = fabsf(v);
+          }
+        } else {
+          v = qval(d_dlr + (st - ts) * 64 + cc * 8 + e8);
+        }
+        h8[e8] = (_Float16)v;
+      }
+      *(half8*)(tile + (int64_t)st * (TILE_HALVES * 2) + r * 128 + ((cc ^ ((r >> 1) & 7)) * 16)) = h8;
+    }
+  } else
   // operand tile image: gated value in the segment of its bucket (all segments when the batch is
   // ungated: then every bucket pair "matches" and the product is the plain inner product)
   for (int c = lane; c * 8 < kt; c += 64) {
@@ -269,10 +367,10 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
 hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const void* idx, int idx_dtype, int64_t ld_idx,
                              int n_queries, int q_pad, int d_dlr, int d_cls, int k_rm, int n_buckets, int kt,
                              const uint8_t* map, bool abs_dlr, float dmax, __half* q_tiles, float* q32, int16_t* q_idx,
-                             float* margin, float* tau, float* thr, hipStream_t s) {
+                             float* margin, float* tau, float* thr, int ts, int td, hipStream_t s) {
   hipLaunchKernelGGL(query_prep_kernel, dim3((q_pad + 3) / 4), dim3(256), 0, s, src, src_is_f32, ld, idx, idx_dtype,
                      ld_idx, n_queries, q_pad, d_dlr, d_cls, k_rm, n_buckets, kt, map, abs_dlr ? 1 : 0, dmax, q_tiles, q32,
-                     q_idx, margin, tau, thr);
+                     q_idx, margin, tau, thr, ts, td);
   return hipGetLastError();
 }
 
@@ -421,7 +519,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_filter_kernel(GemmArgs p) {
 // SIMD is always in its MFMA stream while the other pays the DMA issue cost; (2) fragments are
 // software-pipelined one 16-deep k-slice ahead (two register sets); (3) the single hand-over barrier of a
 // K-step sits BEFORE the last k-slice's MFMAs, and the first fragments of the next K-step are read under them.
-template <bool DUMP>
+template <bool DUMP, int ABL = 0>   // ABL (timing experiments only, wrong results): 3 = relaxed DMA wait, 4 = no hand-over barrier
 __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_v3_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int64_t b = blockIdx.x;
@@ -496,26 +594,279 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_v3_kernel(GemmArg
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   V3_READ(a0, b0, 0, 0);
+  V3_READ(a1, b1, 0, 1);
   const int last = ksteps - 1;
   for (int t = 0; t < ksteps; ++t) {
     const int buf = t & 1;
     const int ks1 = t + 1 < last ? t + 1 : last;     // past the end: re-stage the last K-step into the dead buffer
-    if (wm == 0) stage(buf ^ 1, ks1);
-    V3_READ(a1, b1, buf, 1);
+    if (wm == 0 && ABL < 5) stage(buf ^ 1, ks1);
+    if (ABL != 6) V3_READ(a1, b1, buf, 1);
     V3_MFMA8(a0, b0);
-    V3_READ(a0, b0, buf, 2);
+    if (ABL != 6) V3_READ(a0, b0, buf, 2);
     V3_MFMA8(a1, b1);
-    if (wm == 1) stage(buf ^ 1, ks1);
-    V3_READ(a1, b1, buf, 3);
+    if (wm == 1 && ABL < 5) stage(buf ^ 1, ks1);
+    if (ABL != 6) V3_READ(a1, b1, buf, 3);
     V3_MFMA8(a0, b0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    V3_READ(a0, b0, buf ^ 1, 0);
+    if (ABL == 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (ABL != 4) __builtin_amdgcn_s_barrier();
+    if (ABL != 6) V3_READ(a0, b0, buf ^ 1, 0);
     V3_MFMA8(a1, b1);
   }
 #undef V3_READ
 #undef V3_MFMA8
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane);
+}
+
+// Variant 4: variant 3's tiling and fragment pipeline, but every wave spreads its 8 LDS-DMA instructions
+// of a K-step over three k-slices (3 + 3 + 2, the first three right after the hand-over barrier of the
+// previous K-step), interleaved with the MFMAs by sched_group_barrier, so that the texture-address queue
+// is never hit by a burst.  The loop body is branch-free (stages past the end are clamped / dead).
+template <bool DUMP>
+__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_v4_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int64_t b = blockIdx.x;
+  const int xcd = (int)(b & 7);
+  const int64_t i = b >> 3;
+  const int per_group = DOC_GROUP * p.n_qtiles;
+  const int64_t g_local = i / per_group;
+  const int r = (int)(i - g_local * per_group);
+  const int qt = r / DOC_GROUP;
+  const int dl = r - qt * DOC_GROUP;
+  const int64_t seq = p.seq_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
+  if (seq >= p.seq_hi) return;
+  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head);
+  if (dt >= p.n_tiles) return;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2;
+  const int wn = wave & 3;
+  const int ksteps = p.ksteps;
+  const char* a_src = (const char*)(p.a_tiles + dt * (int64_t)ksteps * TILE_HALVES);
+  const char* b_src = (const char*)(p.b_tiles + (int64_t)qt * ksteps * TILE_HALVES);
+  const int piece0 = wave * 4;
+
+  // DMA instruction n (0..7) of this wave for K-step ks: pieces of A for even n, of B for odd n
+  auto dma = [&](int buf, int ks, int n) {
+    char* l = smem + buf * (2 * TILE_HALVES * 2) + (n & 1) * (TILE_HALVES * 2);
+    const char* g = ((n & 1) ? b_src : a_src) + (int64_t)ks * (TILE_HALVES * 2);
+    const int off = (piece0 + (n >> 1)) * 1024;
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g + off + lane * 16), LDS_PTR(l + off), 16, 0, 0);
+  };
+
+  floatx16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+  const int swz = (frow >> 1) & 7;
+  int a_off[4], b_off[2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) a_off[mi] = (wm * 128 + mi * 32 + frow) * 128;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) b_off[ni] = (wn * 64 + ni * 32 + frow) * 128;
+
+  half8 a0[4], b0[2], a1[4], b1[2];
+#define V4_READ(AF, BF, BUF, KK)                                                               \
+  {                                                                                            \
+    const char* la_ = smem + (BUF) * (2 * TILE_HALVES * 2);                                    \
+    const char* lb_ = la_ + TILE_HALVES * 2;                                                   \
+    const int coff_ = ((((KK) * 2) + fhalf) ^ swz) * 16;                                       \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) AF[mi] = *(const half8*)(la_ + a_off[mi] + coff_); \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) BF[ni] = *(const half8*)(lb_ + b_off[ni] + coff_); \
+  }
+#define V4_MFMA8(AF, BF)                                                                       \
+  {                                                                                            \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                           \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                           \
+      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[mi], BF[ni], acc[mi][ni], 0, 0, 0); \
+  }
+#define V4_INTERLEAVE(NV)                                                    \
+  _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                         \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       \
+    if (g_ < (NV)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        \
+  }                                                                          \
+  __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+
+  const int last = ksteps - 1;
+#pragma unroll
+  for (int n = 0; n < 8; ++n) dma(0, 0, n);
+#pragma unroll
+  for (int n = 0; n < 8; ++n) dma(1, last < 1 ? last : 1, n);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  V4_READ(a0, b0, 0, 0);
+  for (int t = 0; t < ksteps; ++t) {
+    const int buf = t & 1;
+    const int ks1 = t + 1 < last ? t + 1 : last;
+    const int ks2 = t + 2 < last ? t + 2 : last;
+    dma(buf ^ 1, ks1, 3); dma(buf ^ 1, ks1, 4); dma(buf ^ 1, ks1, 5);
+    V4_READ(a1, b1, buf, 1);
+    V4_MFMA8(a0, b0);
+    V4_INTERLEAVE(3);
+    dma(buf ^ 1, ks1, 6); dma(buf ^ 1, ks1, 7);
+    V4_READ(a0, b0, buf, 2);
+    V4_MFMA8(a1, b1);
+    V4_INTERLEAVE(2);
+    V4_READ(a1, b1, buf, 3);
+    V4_MFMA8(a0, b0);
+    V4_INTERLEAVE(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    dma(buf, ks2, 0); dma(buf, ks2, 1); dma(buf, ks2, 2);
+    V4_READ(a0, b0, buf ^ 1, 0);
+    V4_MFMA8(a1, b1);
+    V4_INTERLEAVE(3);
+  }
+#undef V4_READ
+#undef V4_MFMA8
+#undef V4_INTERLEAVE
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane);
+}
+
+// Sparse-core bound GEMM (two index buckets): ts stages of 32 slices on v_smfmac_f32_32x32x32_f16
+// (corpus = 2:4 sparse A operand: stored slice values + position bits; queries = dense B operand with the
+// two bucket columns per slice), then td ordinary 64-column stages for the ungated dense columns.
+// Same 256 x 256 tile / 8 waves / 128 x 64 per wave / double-buffered 2 x 64 KiB LDS ring as gemm_filter_kernel.
+typedef _Float16 half16 __attribute__((ext_vector_type(16)));
+
+template <bool DUMP>
+__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_sparse_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int64_t b = blockIdx.x;
+  const int xcd = (int)(b & 7);
+  const int64_t i = b >> 3;
+  const int per_group = DOC_GROUP * p.n_qtiles;
+  const int64_t g_local = i / per_group;
+  const int r = (int)(i - g_local * per_group);
+  const int qt = r / DOC_GROUP;
+  const int dl = r - qt * DOC_GROUP;
+  const int64_t seq = p.seq_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
+  if (seq >= p.seq_hi) return;
+  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head);
+  if (dt >= p.n_tiles) return;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2;
+  const int wn = wave & 3;
+  const int ts = p.ts, td = p.td, nst = ts + td;
+  const char* a_src = (const char*)p.a_tiles + dt * ((int64_t)ts * SP_STAGE_A + (int64_t)td * (TILE_HALVES * 2));
+  const char* b_src = (const char*)p.b_tiles + (int64_t)qt * nst * (TILE_HALVES * 2);
+  constexpr int BUF = 2 * TILE_HALVES * 2;          // 64 KiB per ring slot: corpus part at +0, query part at +32 KiB
+
+  auto stage = [&](int buf, int u) {
+    char* la = smem + buf * BUF;
+    char* lb = la + TILE_HALVES * 2;
+    const char* gb = b_src + (int64_t)u * (TILE_HALVES * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                      // query part: 32 pieces, 4 per wave
+      const int off = (wave * 4 + j) * 1024;
+      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gb + off + lane * 16), LDS_PTR(lb + off), 16, 0, 0);
+    }
+    if (u < ts) {                                                      // corpus part: 16 value pieces + 2 position pieces
+      const char* ga = a_src + (int64_t)u * SP_STAGE_A;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int off = (wave * 2 + j) * 1024;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga + off + lane * 16), LDS_PTR(la + off), 16, 0, 0);
+      }
+      if (wave < 2) {
+        const int off = SP_A_BYTES + wave * 1024;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga + off + lane * 16), LDS_PTR(la + off), 16, 0, 0);
+      }
+    } else {
+      const char* ga = a_src + (int64_t)ts * SP_STAGE_A + (int64_t)(u - ts) * (TILE_HALVES * 2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int off = (wave * 4 + j) * 1024;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga + off + lane * 16), LDS_PTR(la + off), 16, 0, 0);
+      }
+    }
+  };
+
+  floatx16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+  const int swz8 = (frow >> 1) & 7;      // dense / query images: 8 chunks per 128-byte row
+  const int swz4 = (frow >> 2) & 3;      // sparse corpus image: 4 chunks per 64-byte row
+
+  stage(0, 0);
+  __syncthreads();
+  // ---- gated columns on the sparse matrix cores
+  for (int u = 0; u < ts; ++u) {
+    const int buf = u & 1;
+    if (u + 1 < nst) stage(buf ^ 1, u + 1);
+    const char* la = smem + buf * BUF;
+    const char* lb = la + TILE_HALVES * 2;
+    uint32_t pw[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+      pw[mi] = *(const uint32_t*)(la + SP_A_BYTES + (wm * 128 + mi * 32 + frow) * 8 + fhalf * 4);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      half8 af[4];
+      half16 bf[2];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        af[mi] = *(const half8*)(la + (wm * 128 + mi * 32 + frow) * 64 + (((kb * 2 + fhalf) ^ swz4) * 16));
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const char* rowp = lb + (wn * 64 + ni * 32 + frow) * 128;
+        const int c0 = (kb * 2 + fhalf) * 2;
+        const half8 lo = *(const half8*)(rowp + ((c0 ^ swz8) * 16));
+        const half8 hi = *(const half8*)(rowp + (((c0 + 1) ^ swz8) * 16));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bf[ni][e] = lo[e]; bf[ni][8 + e] = hi[e]; }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          if (kb == 0) acc[mi][ni] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(af[mi], bf[ni], acc[mi][ni], (int)pw[mi], 0, 0);
+          else acc[mi][ni] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(af[mi], bf[ni], acc[mi][ni], (int)pw[mi], 0, 1);
+        }
+    }
+    __syncthreads();
+  }
+  // ---- ungated dense columns
+  for (int u = ts; u < nst; ++u) {
+    const int buf = u & 1;
+    if (u + 1 < nst) stage(buf ^ 1, u + 1);
+    const char* la = smem + buf * BUF;
+    const char* lb = la + TILE_HALVES * 2;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int coff = ((kk * 2 + fhalf) ^ swz8) * 16;
+      half8 af[4], bf[2];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) af[mi] = *(const half8*)(la + (wm * 128 + mi * 32 + frow) * 128 + coff);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) bf[ni] = *(const half8*)(lb + (wn * 64 + ni * 32 + frow) * 128 + coff);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();
+  }
   gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane);
 }
 
@@ -699,7 +1050,7 @@ __global__ void __launch_bounds__(GEMM_W4_THREADS, 1) gemm_filter_w4_kernel(Gemm
 }
 
 int g_gemm_ablate = 0;    // tuning only (DHR_GEMM_ABLATE environment variable)
-int g_gemm_variant = 0;   // 0 single-phase, 2 one wave per SIMD, 3 staggered DMA + pipelined fragments
+int g_gemm_variant = 3;   // 0 single-phase, 2 one wave per SIMD, 3 staggered DMA + pipelined fragments
 
 hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
   static bool env_read = false;
@@ -729,7 +1080,18 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  if (g_gemm_variant == 2) {
+  if (a.ts > 0) {
+    static bool attrs = false;
+    if (!attrs) {
+      (void)hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+      attrs = true;
+    }
+    if (a.dump)
+      hipLaunchKernelGGL(gemm_filter_sparse_kernel<true>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+    else
+      hipLaunchKernelGGL(gemm_filter_sparse_kernel<false>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+  } else if (g_gemm_variant == 2) {
     static bool attr2 = false;
     if (!attr2) {
       hipError_t e = hipFuncSetAttribute((const void*)gemm_filter_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -749,10 +1111,33 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
       hipLaunchKernelGGL((gemm_filter_w4_kernel<false, 2>), dim3((unsigned)blocks), dim3(GEMM_W4_THREADS), GEMM_LDS_BYTES, s, a);
     } else
       hipLaunchKernelGGL(gemm_filter_w4_kernel<false>, dim3((unsigned)blocks), dim3(GEMM_W4_THREADS), GEMM_LDS_BYTES, s, a);
+  } else if (g_gemm_variant == 4) {
+    static bool attr4 = false;
+    if (!attr4) {
+      (void)hipFuncSetAttribute((const void*)gemm_filter_v4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_filter_v4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+      attr4 = true;
+    }
+    if (a.dump)
+      hipLaunchKernelGGL(gemm_filter_v4_kernel<true>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+    else
+      hipLaunchKernelGGL(gemm_filter_v4_kernel<false>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
   } else if (g_gemm_variant == 3) {
     if (a.dump)
       hipLaunchKernelGGL(gemm_filter_v3_kernel<true>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
-    else
+    else if (g_gemm_ablate == 3) {
+      (void)hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+      hipLaunchKernelGGL((gemm_filter_v3_kernel<false, 3>), dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+    } else if (g_gemm_ablate == 4) {
+      (void)hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+      hipLaunchKernelGGL((gemm_filter_v3_kernel<false, 4>), dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+    } else if (g_gemm_ablate == 5) {
+      (void)hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+      hipLaunchKernelGGL((gemm_filter_v3_kernel<false, 5>), dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+    } else if (g_gemm_ablate == 6) {
+      (void)hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+      hipLaunchKernelGGL((gemm_filter_v3_kernel<false, 6>), dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+    } else
       hipLaunchKernelGGL(gemm_filter_v3_kernel<false>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
   } else if (a.dump)
     hipLaunchKernelGGL(gemm_filter_kernel<true>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
