@@ -48,11 +48,16 @@ struct Workspace {
   float* tau_hat = nullptr;
   float* thr_hat = nullptr;              // frozen main-pass threshold (tau_hat - margin)
   uint32_t* fail_flags = nullptr;
+  uint32_t* q_pack = nullptr;            // [q_pad][d_dlr] refine operand words
+  uint2* cand_r = nullptr;               // refine survivors
+  uint32_t* cnt_r = nullptr;
   uint2* cand2 = nullptr;                // second candidate list set: chunk i+1's GEMM overlaps chunk i's rescoring
   uint32_t* cnt2 = nullptr;
   void* h_pinned = nullptr;              // 16 bytes pinned mirror
   char* h_pinned2 = nullptr;             // 2 x 16 bytes pinned (main-pass chunk statistics)
   uint32_t* d_max2 = nullptr;            // 2 x 16 bytes device
+  uint32_t* d_ref = nullptr;             // 16 bytes device: refine survivors {max, pad, sum64}
+  void* h_ref = nullptr;                 // pinned mirror
   void* q_stage = nullptr;  size_t q_stage_bytes = 0;
   void* qi_stage = nullptr; size_t qi_stage_bytes = 0;
   void* out_stage = nullptr; size_t out_stage_bytes = 0;
@@ -72,6 +77,8 @@ struct dhr_index {
   __half* vals_rm = nullptr;
   void* c_idx = nullptr;
   uint8_t* bucket_map = nullptr;   // [d_dlr][256] for 8-bit index dtypes, else null (value % n_buckets)
+  uint32_t* heavy_key = nullptr;   // [n_rows][HEAVY] refine lists (largest gated entries of every row), or null
+  __half* heavy_val = nullptr;
   bool abs_mode = false;
   float dmax = 0.f;
   int64_t index_bytes = 0;
@@ -87,10 +94,11 @@ struct dhr_index {
 
 static void free_ws(Workspace& w) {
   hipFree(w.q_tiles); hipFree(w.q32); hipFree(w.q_idx); hipFree(w.margin); hipFree(w.tau); hipFree(w.thr);
-  hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2);
+  hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2); hipFree(w.q_pack); hipFree(w.cand_r); hipFree(w.cnt_r);
   if (w.h_pinned) hipHostFree(w.h_pinned);
   if (w.h_pinned2) hipHostFree(w.h_pinned2);
-  hipFree(w.d_max2);
+  hipFree(w.d_max2); hipFree(w.d_ref);
+  if (w.h_ref) hipHostFree(w.h_ref);
   hipFree(w.q_stage); hipFree(w.qi_stage); hipFree(w.out_stage);
   w = Workspace();
 }
@@ -105,7 +113,7 @@ extern "C" void dhr_index_destroy(dhr_index* ix) {
   free_ws(ix->ws_fb[0]);
   free_ws(ix->ws_fb[1]);
   if (ix->s_aux) hipStreamDestroy(ix->s_aux);
-  hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map);
+  hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map); hipFree(ix->heavy_key); hipFree(ix->heavy_val);
   delete ix;
 }
 
@@ -296,6 +304,15 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
     ix->abs_mode = true;
     if ((rc = ingest(ix, d, false, d_flags, stage, block_rows, s)) != DHR_OK) return fail(rc);
   }
+  if (has_idx && d->d_dlr <= 1024) {
+    const size_t hkb = (size_t)d->n_rows * HEAVY * 4, hvb = (size_t)d->n_rows * HEAVY * 2;
+    if (hipMalloc((void**)&ix->heavy_key, hkb) != hipSuccess || hipMalloc((void**)&ix->heavy_val, hvb) != hipSuccess)
+      return fail(set_error(DHR_ERR_HIP, "hipMalloc of the refine lists failed"));
+    ix->index_bytes += (int64_t)(hkb + hvb);
+    if (launch_heavy_build(ix->vals_rm, ix->k_rm, ix->c_idx, ix->idx_dtype, d->n_rows, d->d_dlr, ix->bucket_map, ix->n_buckets,
+                           ix->heavy_key, ix->heavy_val, s) != hipSuccess)
+      return fail(set_error(DHR_ERR_HIP, "heavy_build launch failed"));
+  }
   if (hipStreamSynchronize(s) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "index build failed on the device"));
   hipFree(stage);
   hipFree(d_flags);
@@ -337,9 +354,16 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.tau_hat, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.fail_flags, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.thr_hat, (size_t)q_pad * 4, tot));
+  if (ix->heavy_key) {
+    HIP_TRY(re_malloc(w.q_pack, (size_t)q_pad * ix->d_dlr * 4, tot));
+    HIP_TRY(re_malloc(w.cand_r, (size_t)q_pad * cap * 8, tot));
+    HIP_TRY(re_malloc(w.cnt_r, (size_t)q_pad * 4, tot));
+  }
   HIP_TRY(hipHostMalloc(&w.h_pinned, 16, hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&w.h_pinned2, 32, hipHostMallocDefault));
   HIP_TRY(re_malloc(w.d_max2, 32, tot));
+  HIP_TRY(re_malloc(w.d_ref, 16, tot));
+  HIP_TRY(hipHostMalloc(&w.h_ref, 16, hipHostMallocDefault));
   w.q_pad = q_pad; w.kp = kp; w.cap = cap; w.keys_ld = keys_ld; w.kt = ix->kt; w.d_dlr = ix->d_dlr;
   w.bytes = tot;
   return DHR_OK;
@@ -393,7 +417,7 @@ static int prep_queries(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, 
   HIP_TRY(launch_query_prep(v, qb->value_dtype == DHR_VAL_F32, ldv, (ix->d_dlr > 0 && qb->index) ? qi : nullptr, qb->index_dtype, ldi,
                             qb->n_queries, w.q_pad, ix->d_dlr, ix->d_cls, ix->k_rm, ix->n_buckets, ix->kt, ix->bucket_map,
                             ix->abs_mode, ix->dmax, w.q_tiles, w.q32,
-                            w.q_idx, w.margin, w.tau, w.thr, ix->ts, ix->td, s));
+                            w.q_idx, w.margin, w.tau, w.thr, ix->ts, ix->td, w.q_pack, s));
   return DHR_OK;
 }
 
@@ -446,16 +470,39 @@ static int gemm_phase(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi
   return DHR_OK;
 }
 
-static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, uint32_t maxc, Timer& tm,
-                          hipStream_t s) {
-  const uint32_t maxr = std::min<uint32_t>(maxc, (uint32_t)w.cap);
+// Candidates of one phase -> [refine on the heavy lists] -> exact rescoring -> top-k merge, all on `s`.
+// The refine step needs one host read-back (size of the surviving lists) to size the rescoring grid.
+static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, const uint2* cand,
+                          const uint32_t* cnt, const float* thr, uint32_t maxc, Timer& tm, dhr_search_stats& st,
+                          hipStream_t s, int64_t bound_sum) {
+  uint32_t maxr = std::min<uint32_t>(maxc, (uint32_t)w.cap);
+  if (maxr == 0) return DHR_OK;
+  int64_t exact = bound_sum;
+  if (gate && ix->heavy_key) {
+    RefineArgs f{};
+    f.cand = cand; f.cnt = cnt; f.cap = (uint32_t)w.cap; f.heavy_key = ix->heavy_key; f.heavy_val = ix->heavy_val;
+    f.q_pack = w.q_pack; f.d_dlr = ix->d_dlr; f.thr = thr; f.out = w.cand_r; f.out_cnt = w.cnt_r; f.out_max = w.d_ref;
+    f.n_queries = Q; f.max_count = maxr;
+    HIP_TRY(hipMemsetAsync(w.cnt_r, 0, (size_t)w.q_pad * 4, s));
+    HIP_TRY(hipMemsetAsync(w.d_ref, 0, 16, s));
+    tm.begin_on(T_REFINE, s); HIP_TRY(launch_refine(f, s)); tm.end_on(s);
+    HIP_TRY(launch_max_u32(w.cnt_r, Q, w.d_ref, (unsigned long long*)(w.d_ref + 2), s));
+    HIP_TRY(hipMemcpyAsync(w.h_ref, w.d_ref, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    maxr = ((uint32_t*)w.h_ref)[0];
+    unsigned long long sum;
+    memcpy(&sum, (uint32_t*)w.h_ref + 2, 8);
+    exact = (int64_t)sum;
+    cand = w.cand_r; cnt = w.cnt_r;
+  }
+  st.candidates_exact += exact;
   if (maxr == 0) return DHR_OK;
   RescoreArgs r = base_rescore_args(ix, w, Q, gate);
-  r.cand = w.cand; r.cnt = w.cnt; r.cap = (uint32_t)w.cap; r.max_count = maxr;
+  r.cand = cand; r.cnt = cnt; r.cap = (uint32_t)w.cap; r.max_count = maxr;
   r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
-  tm.begin(T_RESCORE); HIP_TRY(launch_rescore(r, s)); tm.end();
-  sel.cnt = w.cnt; sel.count_all = 0;
-  tm.begin(T_SELECT); HIP_TRY(launch_select(sel, s)); tm.end();
+  tm.begin_on(T_RESCORE, s); HIP_TRY(launch_rescore(r, s)); tm.end_on(s);
+  sel.cnt = cnt; sel.count_all = 0;
+  tm.begin_on(T_SELECT, s); HIP_TRY(launch_select(sel, s)); tm.end_on(s);
   return DHR_OK;
 }
 
@@ -479,8 +526,7 @@ static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectAr
       continue;
     }
     st.candidates_bound += (int64_t)sumc;
-    st.candidates_exact += (int64_t)sumc;
-    if ((rc = rescore_select(ix, w, Q, gate, sel, maxc, tm, s)) != DHR_OK) return rc;
+    if ((rc = rescore_select(ix, w, Q, gate, sel, w.cand, w.cnt, w.thr, maxc, tm, st, s, (int64_t)sumc)) != DHR_OK) return rc;
     pos = hi;
     seen_rows += chunk_rows;
     // next chunk: aim at cap/4 candidates for the fullest query, never more than growth * rows seen
@@ -608,19 +654,10 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       unsigned long long sumc;
       memcpy(&sumc, w.h_pinned2 + 16 * (i & 1) + 8, 8);
       st.candidates_bound += (int64_t)sumc;
-      st.candidates_exact += (int64_t)sumc;
       uint2* cand = (i & 1) ? w.cand2 : w.cand;
       uint32_t* cnt = (i & 1) ? w.cnt2 : w.cnt;
       HIP_TRY(launch_mark_overflow(cnt, (uint32_t)w.cap, Q, w.fail_flags, sb));
-      const uint32_t maxr = std::min<uint32_t>(maxc, (uint32_t)w.cap);
-      if (maxr > 0) {
-        RescoreArgs r = base_rescore_args(ix, w, Q, gate);
-        r.cand = cand; r.cnt = cnt; r.cap = (uint32_t)w.cap; r.max_count = maxr;
-        r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
-        tm.begin_on(T_RESCORE, sb); HIP_TRY(launch_rescore(r, sb)); tm.end_on(sb);
-        sel.cnt = cnt; sel.count_all = 0;
-        tm.begin_on(T_SELECT, sb); HIP_TRY(launch_select(sel, sb)); tm.end_on(sb);
-      }
+      if ((rc = rescore_select(ix, w, Q, gate, sel, cand, cnt, w.thr_hat, maxc, tm, st, sb, (int64_t)sumc)) != DHR_OK) return rc;
       HIP_TRY(hipEventRecord(ev_done[i], sb));
     }
     HIP_TRY(hipStreamWaitEvent(s, ev_done[M - 1], 0));

@@ -24,6 +24,7 @@ constexpr int SP_A_BYTES = 16384;      // sparse stage: 256 rows x 32 stored sli
 constexpr int SP_IDX_BYTES = 2048;     //               256 rows x [lane half][block] u16 position bits
 constexpr int SP_STAGE_A = SP_A_BYTES + SP_IDX_BYTES;   // corpus bytes per sparse stage (18 KiB)
 constexpr int SP_STAGE_B = 32768;      // query bytes per sparse stage: 256 rows x 64 bucket columns
+constexpr int HEAVY = 64;               // per-row list of the largest gated values used by the refine step
 constexpr int DOC_GROUP = 4;                               // doc tiles that share one XCD sweep
 
 __host__ __device__ inline int64_t tiled_chunk_offset(int64_t row, int chunk, int ksteps) {
@@ -129,8 +130,19 @@ hipError_t launch_idx_hist(const uint8_t* idx, int64_t n_rows, int d_dlr, uint32
 hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const void* idx, int idx_dtype, int64_t ld_idx,
                              int n_queries, int q_pad, int d_dlr, int d_cls, int k_rm, int n_buckets, int kt,
                              const uint8_t* map, bool abs_dlr, float dmax, __half* q_tiles, float* q32, int16_t* q_idx,
-                             float* margin, float* tau, float* thr, int ts, int td, hipStream_t s);
+                             float* margin, float* tau, float* thr, int ts, int td, uint32_t* q_pack, hipStream_t s);
 hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s);
+hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, int idx_dtype, int64_t n_rows, int d_dlr,
+                              const uint8_t* map, int n_buckets, uint32_t* heavy_key, __half* heavy_val, hipStream_t s);
+struct RefineArgs {
+  const uint2* cand; const uint32_t* cnt; uint32_t cap;      // bound candidates (row, U bits)
+  const uint32_t* heavy_key; const __half* heavy_val;       // [n_rows][HEAVY]
+  const uint32_t* q_pack; int d_dlr;                         // [Q_pad][d_dlr]: fp16 value | bucket | idx low bits
+  const float* thr;                                          // [Q_pad]
+  uint2* out; uint32_t* out_cnt; uint32_t* out_max;          // survivors (row, refined bound), per-query count, max count
+  int n_queries; uint32_t max_count;
+};
+hipError_t launch_refine(const RefineArgs& a, hipStream_t s);
 hipError_t launch_rescore(const RescoreArgs& a, hipStream_t s);
 hipError_t launch_select(const SelectArgs& a, hipStream_t s);
 hipError_t launch_emit(const uint64_t* topk_keys, int kp, int n_queries, int k, int64_t row_offset, float* out_scores,

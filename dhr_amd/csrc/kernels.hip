@@ -283,7 +283,8 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
                                                          int abs_dlr, float dmax, __half* __restrict__ q_tiles,
                                                          float* __restrict__ q32, int16_t* __restrict__ q_idx,
                                                          float* __restrict__ margin, float* __restrict__ tau,
-                                                         float* __restrict__ thr, int ts, int td) {
+                                                         float* __restrict__ thr, int ts, int td,
+                                                         uint32_t* __restrict__ q_pack) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= q_pad) return;
@@ -305,7 +306,15 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
     s16 += back * back;
     sr += (v - back) * (v - back);
   }
-  for (int j = lane; j < d_dlr; j += 64) q_idx[(int64_t)q * d_dlr + j] = (int16_t)qidx(j);
+  for (int j = lane; j < d_dlr; j += 64) {
+    const int iv = qidx(j);
+    q_idx[(int64_t)q * d_dlr + j] = (int16_t)iv;
+    if (q_pack) {      // refine step: fp16 bound-operand value << 16 | bucket << 12 | idx low 12 bits
+      union { _Float16 h; uint16_t u; } cv; cv.h = (_Float16)(abs_dlr ? fabsf(qval(j)) : fmaxf(qval(j), 0.f));   // the bound operand
+      const uint32_t bk = (n_buckets > 1 && idx) ? (uint32_t)bucket_of(iv, j, map, n_buckets) : 0u;
+      q_pack[(int64_t)q * d_dlr + j] = ((uint32_t)cv.u << 16) | (bk << 12) | ((uint32_t)iv & 0xFFFu);
+    }
+  }
   if (ts > 0) {
     // 2:4 layout: per sparse stage 64 bucket columns per row in smfmac B-operand order, then dense stages
     char* tile = (char*)q_tiles + (int64_t)(q >> 8) * ((int64_t)(ts + td) * (TILE_HALVES * 2));
@@ -324,7 +333,7 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
           if (j < d_dlr) {
             v = qval(j);
             if (idx && bucket_of(qidx(j), j, map, 2) != (pos & 1)) v = 0.f;
-            if (abs_dlr) v = fabsf(v);
+            v = abs_dlr ? fabsf(v) : fmaxf(v, 0.f);
           }
         } else {
           v = qval(d_dlr + (st - ts) * 64 + cc * 8 + e8);
@@ -346,7 +355,7 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
         const int b = col0 / d_dlr, j = col0 - b * d_dlr + e;
         v = qval(j);
         if (n_buckets > 1 && idx && bucket_of(qidx(j), j, map, n_buckets) != b) v = 0.f;
-        if (abs_dlr) v = fabsf(v);
+        v = abs_dlr ? fabsf(v) : fmaxf(v, 0.f);          // corpus values are >= 0 here: q+ d bounds the gated product
       } else {
         v = qval(d_dlr + (col0 - dlr_cols) + e);
       }
@@ -367,10 +376,10 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
 hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const void* idx, int idx_dtype, int64_t ld_idx,
                              int n_queries, int q_pad, int d_dlr, int d_cls, int k_rm, int n_buckets, int kt,
                              const uint8_t* map, bool abs_dlr, float dmax, __half* q_tiles, float* q32, int16_t* q_idx,
-                             float* margin, float* tau, float* thr, int ts, int td, hipStream_t s) {
+                             float* margin, float* tau, float* thr, int ts, int td, uint32_t* q_pack, hipStream_t s) {
   hipLaunchKernelGGL(query_prep_kernel, dim3((q_pad + 3) / 4), dim3(256), 0, s, src, src_is_f32, ld, idx, idx_dtype,
                      ld_idx, n_queries, q_pad, d_dlr, d_cls, k_rm, n_buckets, kt, map, abs_dlr ? 1 : 0, dmax, q_tiles, q32,
-                     q_idx, margin, tau, thr, ts, td);
+                     q_idx, margin, tau, thr, ts, td, q_pack);
   return hipGetLastError();
 }
 
@@ -1143,6 +1152,113 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(gemm_filter_kernel<true>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
   else
     hipLaunchKernelGGL(gemm_filter_kernel<false>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ heavy lists + refine
+// Build (once per index): per row the HEAVY largest-magnitude gated entries, as
+//   key = slice << 20 | bucket << 16 | index value (16 bits),  val = the fp16 value;  unused slots key = ~0.
+// One wave per row, HEAVY rounds of wave-wide arg-max over a register copy of the row (d_dlr <= 1024).
+__global__ void __launch_bounds__(256) heavy_build_kernel(const __half* __restrict__ vals_rm, int k_rm,
+                                                          const void* __restrict__ idx, int idx_dtype, int64_t n_rows,
+                                                          int d_dlr, const uint8_t* __restrict__ map, int n_buckets,
+                                                          uint32_t* __restrict__ heavy_key, __half* __restrict__ heavy_val) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t row = wave0; row < n_rows; row += nwaves) {
+    uint32_t key[16];        // (|fp16| bits << 16) | (1023 - slice): larger value first, lower slice on ties
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) {
+      const int j = lane + 64 * sl;
+      key[sl] = 0u;
+      if (j < d_dlr) {
+        union { _Float16 h; uint16_t u; } cv; cv.h = (_Float16)__half2float(vals_rm[row * k_rm + j]);
+        const uint32_t mag = cv.u & 0x7FFFu;
+        if (mag) key[sl] = (mag << 16) | (uint32_t)(1023 - j);
+      }
+    }
+    for (int r = 0; r < HEAVY; ++r) {
+      uint32_t best = 0u;
+#pragma unroll
+      for (int sl = 0; sl < 16; ++sl) best = key[sl] > best ? key[sl] : best;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const uint32_t ob = __shfl_xor(best, o, 64); best = ob > best ? ob : best; }
+      if (best == 0u) {                       // fewer than HEAVY non-zero entries: pad
+        if (lane == 0) for (int rr = r; rr < HEAVY; ++rr) { heavy_key[row * HEAVY + rr] = 0xFFFFFFFFu; heavy_val[row * HEAVY + rr] = __float2half(0.f); }
+        break;
+      }
+      const int j = 1023 - (int)(best & 0xFFFFu);
+      if ((j & 63) == lane) {                 // owner lane writes the entry and retires it
+        const int iv = load_idx(idx, idx_dtype, row * d_dlr + j);
+        const uint32_t bk = n_buckets > 1 ? (uint32_t)bucket_of(iv, j, map, n_buckets) : 0u;
+        heavy_key[row * HEAVY + r] = ((uint32_t)j << 20) | (bk << 16) | ((uint32_t)iv & 0xFFFFu);
+        heavy_val[row * HEAVY + r] = vals_rm[row * k_rm + j];
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) if (sl == (j >> 6)) key[sl] = 0u;
+      }
+    }
+  }
+}
+hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, int idx_dtype, int64_t n_rows, int d_dlr,
+                              const uint8_t* map, int n_buckets, uint32_t* heavy_key, __half* heavy_val, hipStream_t s) {
+  if (n_rows <= 0) return hipSuccess;
+  const int64_t blocks = (n_rows + 3) / 4;
+  hipLaunchKernelGGL(heavy_build_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, vals_rm, k_rm,
+                     idx, idx_dtype, n_rows, d_dlr, map, n_buckets, heavy_key, heavy_val);
+  return hipGetLastError();
+}
+
+// Refine: the bound U of a candidate counted every gated slice whose BUCKETS agree; for the row's heavy
+// entries we can afford to look at the real index: same bucket but different index value contributes
+// nothing to the exact score, so |q_j d_j| is taken off the bound.  U2 = U - sum(corr) is still an
+// upper bound of the exact score (only certain mismatches are removed; the query side keeps 12 index
+// bits, an alias there only makes the bound looser).  8 lanes per candidate, 8 heavy entries per lane.
+__global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
+  const int q = blockIdx.y;
+  uint32_t count = p.cnt[q];
+  if (count > p.cap) count = p.cap;
+  const uint32_t i = blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (blockIdx.x * 32 >= count) return;
+  const int sub = threadIdx.x & 7;
+  float corr = 0.f;
+  uint2 c = make_uint2(0u, 0u);
+  if (i < count) {
+    c = p.cand[(int64_t)q * p.cap + i];
+    const uint32_t* hk = p.heavy_key + (int64_t)c.x * HEAVY + sub * 8;
+    const uint4 k0 = *(const uint4*)hk, k1 = *(const uint4*)(hk + 4);
+    const half8 hv = *(const half8*)(p.heavy_val + (int64_t)c.x * HEAVY + sub * 8);
+    const uint32_t keys[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+    const uint32_t* qp = p.q_pack + (int64_t)q * p.d_dlr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t key = keys[e];
+      if (key != 0xFFFFFFFFu) {
+        const uint32_t w = qp[key >> 20];
+        const bool same_bucket = ((w >> 12) & 0xFu) == ((key >> 16) & 0xFu);
+        const bool mismatch = (w & 0xFFFu) != (key & 0xFFFu);
+        if (same_bucket && mismatch) {
+          union { uint16_t u; _Float16 h; } qv; qv.u = (uint16_t)(w >> 16);
+          corr += fabsf((float)qv.h * (float)hv[e]);
+        }
+      }
+    }
+  }
+  corr += __shfl_xor(corr, 1, 64);
+  corr += __shfl_xor(corr, 2, 64);
+  corr += __shfl_xor(corr, 4, 64);
+  if (sub == 0 && i < count) {
+    const float u2 = __uint_as_float(c.y) - corr;
+    if (u2 >= p.thr[q]) {
+      const uint32_t slot = atomicAdd(p.out_cnt + q, 1u);
+      p.out[(int64_t)q * p.cap + slot] = make_uint2(c.x, __float_as_uint(u2));
+      atomicMax(p.out_max, slot + 1);
+    }
+  }
+}
+hipError_t launch_refine(const RefineArgs& a, hipStream_t s) {
+  if (a.max_count == 0 || a.n_queries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(refine_kernel, dim3((a.max_count + 31) / 32, (unsigned)a.n_queries), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

@@ -394,3 +394,15 @@ def test_config1_bm25_100k(G):
     cv, ci, qv, qi = synth.make_pair(19, 100_000, 48, 768, 0, kind="bm25")
     _, _, st = _search_check(G, cv, ci, qv.astype(np.float32), qi, 1000, queries=[0, 13, 47])
     print(st)
+
+
+@pytest.mark.parametrize("nb", [0, 1, 3])
+def test_negative_query_values_on_nonneg_corpus(G, nb):
+    """Corpus gated values >= 0 (no |.| mode) but the QUERY carries negative gated values: the bound
+    operand must clamp them (q+ d >= gated q d), else rows would be lost."""
+    from dhr_amd import synth
+    cv, ci, qv, qi = synth.make_pair(20, 8000, 8, 768, 64)
+    rng = np.random.default_rng(1)
+    qv = qv.copy()
+    qv[:, :768] *= rng.choice([-1, 1], size=(8, 768)).astype(np.float16)
+    _search_check(G, cv, ci, qv.astype(np.float32), qi, 100, idx_buckets=nb)

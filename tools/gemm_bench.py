@@ -15,7 +15,9 @@ def main():
     ap.add_argument("--k", type=int, default=1536)
     ap.add_argument("--queries", type=int, default=6980)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--variant", type=int, default=1)
+    ap.add_argument("--variant", type=int, default=3)
+    ap.add_argument("--dlr", type=int, default=0, help="gated columns (with a random uint8 slice index); the rest of --k is dense")
+    ap.add_argument("--idx-buckets", type=int, default=0)
     a = ap.parse_args()
     import torch
     from dhr_amd import _lib
@@ -23,13 +25,18 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(1)
     cv = (torch.randn((a.rows, a.k), generator=g, device="cuda") * 0.1).half()
     qv = (torch.randn((a.queries, a.k), generator=g, device="cuda") * 0.1).half()
-    ix = GipIndex(cv, None)
+    ci = qi = None
+    if a.dlr:
+        cv[:, :a.dlr] = cv[:, :a.dlr].abs(); qv[:, :a.dlr] = qv[:, :a.dlr].abs()
+        ci = torch.randint(0, 39, (a.rows, a.dlr), generator=g, device="cuda", dtype=torch.uint8)
+        qi = torch.randint(0, 39, (a.queries, a.dlr), generator=g, device="cuda", dtype=torch.uint8)
+    ix = GipIndex(cv, ci, idx_buckets=a.idx_buckets)
     del cv
     ix.set_param(_lib.PARAM_GEMM_VARIANT, a.variant)
-    qb, keep = _lib.make_query_batch(qv, None)
+    qb, keep = _lib.make_query_batch(qv, qi)
     ms, fl = C.c_double(), C.c_double()
     _lib.check(ix._lib.dhr_debug_gemm_time(ix._h, C.byref(qb), a.iters, C.byref(ms), C.byref(fl), None), "gemm_time")
-    print("variant %d rows %d k %d q %d : %.3f ms/launch  %.1f TFLOP/s issued" % (a.variant, a.rows, a.k, a.queries, ms.value, fl.value / ms.value / 1e9))
+    print("variant %d dlr %d buckets %d rows %d k %d q %d : %.3f ms/launch  %.1f TFLOP/s issued" % (a.variant, a.dlr, a.idx_buckets, a.rows, a.k, a.queries, ms.value, fl.value / ms.value / 1e9))
     ix.close()
 
 
