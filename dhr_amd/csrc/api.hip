@@ -36,7 +36,9 @@ static inline int idx_esize(int dt) { return dt == DHR_IDX_I16 ? 2 : 1; }
 
 struct Workspace {
   int q_pad = 0, kp = 0;
-  int64_t cap = 0, keys_ld = 0, kt = 0, d_dlr = 0;
+  int64_t cap = 0;       // capacity of the bound-candidate lists (cand, cand2)
+  int64_t cap_r = 0;     // capacity of the lists that reach the exact rescoring (refine survivors; == cap without refine)
+  int64_t keys_ld = 0, kt = 0, d_dlr = 0;
   __half* q_tiles = nullptr;
   float* q32 = nullptr;
   int16_t* q_idx = nullptr;
@@ -83,7 +85,7 @@ struct dhr_index {
   float dmax = 0.f;
   int64_t index_bytes = 0;
   // params
-  int64_t cand_cap = 65536, first_rows = 0;
+  int64_t cand_cap = 0, first_rows = 0;   // 0 = default (262144 with refine lists, else 65536)
   int profile = 0, max_growth16 = 32;
   int sample_period = 16;
   int main_chunks = 8;
@@ -335,8 +337,12 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   int kp = 1;
   while (kp < k) kp <<= 1;
   if (kp < 64) kp = 64;
-  const int64_t cap = std::min<int64_t>(ix->cand_cap * cap_mult, (int64_t)1 << 22);
-  const int64_t keys_ld = std::max<int64_t>(cap, keys_ld_min);
+  const bool refine = ix->heavy_key != nullptr;
+  const int64_t base_cap = ix->cand_cap > 0 ? ix->cand_cap : (refine ? 262144 : 65536);
+  // fallback depths serve a handful of queries: 16x deeper lists there cost little memory
+  const int64_t cap = std::min<int64_t>(base_cap * cap_mult, (int64_t)1 << 22);
+  const int64_t cap_r = refine ? std::min<int64_t>(cap, 32768 * cap_mult) : cap;
+  const int64_t keys_ld = std::max<int64_t>(cap_r, keys_ld_min);
   if (w.q_pad == q_pad && w.kp == kp && w.cap == cap && w.keys_ld >= keys_ld && w.kt == ix->kt) return DHR_OK;
   free_ws(w);
   int64_t tot = 0;
@@ -356,7 +362,7 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.thr_hat, (size_t)q_pad * 4, tot));
   if (ix->heavy_key) {
     HIP_TRY(re_malloc(w.q_pack, (size_t)q_pad * ix->d_dlr * 4, tot));
-    HIP_TRY(re_malloc(w.cand_r, (size_t)q_pad * cap * 8, tot));
+    HIP_TRY(re_malloc(w.cand_r, (size_t)q_pad * cap_r * 8, tot));
     HIP_TRY(re_malloc(w.cnt_r, (size_t)q_pad * 4, tot));
   }
   HIP_TRY(hipHostMalloc(&w.h_pinned, 16, hipHostMallocDefault));
@@ -364,7 +370,7 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.d_max2, 32, tot));
   HIP_TRY(re_malloc(w.d_ref, 16, tot));
   HIP_TRY(hipHostMalloc(&w.h_ref, 16, hipHostMallocDefault));
-  w.q_pad = q_pad; w.kp = kp; w.cap = cap; w.keys_ld = keys_ld; w.kt = ix->kt; w.d_dlr = ix->d_dlr;
+  w.q_pad = q_pad; w.kp = kp; w.cap = cap; w.cap_r = cap_r; w.keys_ld = keys_ld; w.kt = ix->kt; w.d_dlr = ix->d_dlr;
   w.bytes = tot;
   return DHR_OK;
 }
@@ -474,14 +480,15 @@ static int gemm_phase(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi
 // The refine step needs one host read-back (size of the surviving lists) to size the rescoring grid.
 static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, const uint2* cand,
                           const uint32_t* cnt, const float* thr, uint32_t maxc, Timer& tm, dhr_search_stats& st,
-                          hipStream_t s, int64_t bound_sum) {
+                          hipStream_t s, int64_t bound_sum, uint32_t* fail_flags) {
   uint32_t maxr = std::min<uint32_t>(maxc, (uint32_t)w.cap);
   if (maxr == 0) return DHR_OK;
   int64_t exact = bound_sum;
+  uint32_t list_cap = (uint32_t)w.cap;
   if (gate && ix->heavy_key) {
     RefineArgs f{};
     f.cand = cand; f.cnt = cnt; f.cap = (uint32_t)w.cap; f.heavy_key = ix->heavy_key; f.heavy_val = ix->heavy_val;
-    f.q_pack = w.q_pack; f.d_dlr = ix->d_dlr; f.thr = thr; f.out = w.cand_r; f.out_cnt = w.cnt_r; f.out_max = w.d_ref;
+    f.q_pack = w.q_pack; f.d_dlr = ix->d_dlr; f.thr = thr; f.out = w.cand_r; f.out_cnt = w.cnt_r; f.out_cap = (uint32_t)w.cap_r;
     f.n_queries = Q; f.max_count = maxr;
     HIP_TRY(hipMemsetAsync(w.cnt_r, 0, (size_t)w.q_pad * 4, s));
     HIP_TRY(hipMemsetAsync(w.d_ref, 0, 16, s));
@@ -489,7 +496,12 @@ static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectA
     HIP_TRY(launch_max_u32(w.cnt_r, Q, w.d_ref, (unsigned long long*)(w.d_ref + 2), s));
     HIP_TRY(hipMemcpyAsync(w.h_ref, w.d_ref, 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    maxr = ((uint32_t*)w.h_ref)[0];
+    maxr = std::min<uint32_t>(((uint32_t*)w.h_ref)[0], (uint32_t)w.cap_r);
+    if (((uint32_t*)w.h_ref)[0] > (uint32_t)w.cap_r) {          // survivors list overflowed: those queries are redone
+      if (fail_flags) HIP_TRY(launch_mark_overflow(w.cnt_r, (uint32_t)w.cap_r, Q, fail_flags, s));
+      else return 1;                                           // streaming controller: redo this chunk in halves
+    }
+    list_cap = (uint32_t)w.cap_r;
     unsigned long long sum;
     memcpy(&sum, (uint32_t*)w.h_ref + 2, 8);
     exact = (int64_t)sum;
@@ -498,10 +510,10 @@ static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectA
   st.candidates_exact += exact;
   if (maxr == 0) return DHR_OK;
   RescoreArgs r = base_rescore_args(ix, w, Q, gate);
-  r.cand = cand; r.cnt = cnt; r.cap = (uint32_t)w.cap; r.max_count = maxr;
+  r.cand = cand; r.cnt = cnt; r.cap = list_cap; r.max_count = maxr;
   r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
   tm.begin_on(T_RESCORE, s); HIP_TRY(launch_rescore(r, s)); tm.end_on(s);
-  sel.cnt = cnt; sel.count_all = 0;
+  sel.cnt = cnt; sel.count_all = 0; sel.cap = list_cap;
   tm.begin_on(T_SELECT, s); HIP_TRY(launch_select(sel, s)); tm.end_on(s);
   return DHR_OK;
 }
@@ -510,7 +522,7 @@ static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectA
 // comes from exact scores already seen, overflowing chunks are re-run in halves).
 static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, int64_t n_seq, int map_mode,
                          int period, int64_t head, int64_t first_chunk, int64_t seen_rows, Timer& tm, dhr_search_stats& st,
-                         hipStream_t s) {
+                         hipStream_t s, double* last_rate = nullptr) {
   int64_t pos = 0;
   int64_t chunk = std::max<int64_t>(DOC_GROUP, first_chunk);
   while (pos < n_seq) {
@@ -526,11 +538,18 @@ static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectAr
       continue;
     }
     st.candidates_bound += (int64_t)sumc;
-    if ((rc = rescore_select(ix, w, Q, gate, sel, w.cand, w.cnt, w.thr, maxc, tm, st, s, (int64_t)sumc)) != DHR_OK) return rc;
+    if (last_rate) *last_rate = (double)maxc / (double)chunk_rows;      // fullest list per corpus row, at the latest thresholds
+    rc = rescore_select(ix, w, Q, gate, sel, w.cand, w.cnt, w.thr, maxc, tm, st, s, (int64_t)sumc, nullptr);
+    if (rc == 1 && chunk > DOC_GROUP) {                    // survivor lists overflowed: same cure as a bound-list overflow
+      st.overflow_retries++;
+      chunk = std::max<int64_t>(DOC_GROUP, round_up(chunk / 2, DOC_GROUP));
+      continue;
+    }
+    if (rc != DHR_OK) return rc < 0 ? rc : set_error(DHR_ERR_INTERNAL, "survivor list overflow at the minimum chunk size");
     pos = hi;
     seen_rows += chunk_rows;
     // next chunk: aim at cap/4 candidates for the fullest query, never more than growth * rows seen
-    const double target = (double)w.cap / 4.0;
+    const double target = (double)w.cap / 2.0;
     double next_rows = (maxc == 0) ? (double)chunk_rows * 4.0 : (double)chunk_rows * target / (double)maxc;
     next_rows = std::min(next_rows, (double)seen_rows * ix->max_growth16 / 16.0);
     chunk = std::max<int64_t>(DOC_GROUP, (int64_t)(next_rows / (DOC_GROUP * TILE_ROWS)) * DOC_GROUP);
@@ -596,7 +615,8 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
 
   // ---- sampled run: top-r_eff of {head rows} + {every S-th tile}  ->  tau_hat
   const int64_t n_sample = (rest + S - 1) / S;
-  if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, head, first_valid, tm, st, s)) != DHR_OK) return rc;
+  double rate = 0.0;
+  if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, head, first_valid, tm, st, s, &rate)) != DHR_OK) return rc;
   HIP_TRY(hipMemcpyAsync(w.tau_hat, w.tau, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
 
   // ---- main pass: all other tiles with the FROZEN threshold tau_hat - margin, in a few chunks; the
@@ -614,7 +634,11 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     }
     if (!ix->s_aux) HIP_TRY(hipStreamCreateWithFlags(&ix->s_aux, hipStreamNonBlocking));
     hipStream_t sb = ix->s_aux;
-    const int M = (int)std::max<int64_t>(1, std::min<int64_t>(ix->main_chunks, n_main / (64 * DOC_GROUP)));
+    // chunk count: at least main_chunks, more when the sampled run predicts that the fullest list would not fit
+    // (rate = bound candidates per corpus row of the fullest query at the final sample thresholds, 1.5x headroom)
+    const int64_t need = (int64_t)std::ceil(1.5 * rate * (double)n_main * TILE_ROWS / (double)w.cap);
+    const int M = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(ix->main_chunks, need), 64),
+                                                              n_main / (64 * DOC_GROUP)));
     const int64_t per = round_up((n_main + M - 1) / M, DOC_GROUP);
     std::vector<hipEvent_t> ev_gemm(M), ev_done(M);
     for (int i = 0; i < M; ++i) {
@@ -657,7 +681,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       uint2* cand = (i & 1) ? w.cand2 : w.cand;
       uint32_t* cnt = (i & 1) ? w.cnt2 : w.cnt;
       HIP_TRY(launch_mark_overflow(cnt, (uint32_t)w.cap, Q, w.fail_flags, sb));
-      if ((rc = rescore_select(ix, w, Q, gate, sel, cand, cnt, w.thr_hat, maxc, tm, st, sb, (int64_t)sumc)) != DHR_OK) return rc;
+      if ((rc = rescore_select(ix, w, Q, gate, sel, cand, cnt, w.thr_hat, maxc, tm, st, sb, (int64_t)sumc, w.fail_flags)) != DHR_OK) return rc;
       HIP_TRY(hipEventRecord(ev_done[i], sb));
     }
     HIP_TRY(hipStreamWaitEvent(s, ev_done[M - 1], 0));

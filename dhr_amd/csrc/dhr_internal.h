@@ -139,7 +139,7 @@ struct RefineArgs {
   const uint32_t* heavy_key; const __half* heavy_val;       // [n_rows][HEAVY]
   const uint32_t* q_pack; int d_dlr;                         // [Q_pad][d_dlr]: fp16 value | bucket | idx low bits
   const float* thr;                                          // [Q_pad]
-  uint2* out; uint32_t* out_cnt; uint32_t* out_max;          // survivors (row, refined bound), per-query count, max count
+  uint2* out; uint32_t* out_cnt; uint32_t out_cap;           // survivors (row, refined bound), per-query count, list capacity
   int n_queries; uint32_t max_count;
 };
 hipError_t launch_refine(const RefineArgs& a, hipStream_t s);

@@ -1214,51 +1214,56 @@ hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, 
 // nothing to the exact score, so |q_j d_j| is taken off the bound.  U2 = U - sum(corr) is still an
 // upper bound of the exact score (only certain mismatches are removed; the query side keeps 12 index
 // bits, an alias there only makes the bound looser).  8 lanes per candidate, 8 heavy entries per lane.
+constexpr int REFINE_PER_WG = 256;       // candidates of ONE query per workgroup (its operand words are staged in LDS once)
 __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
+  __shared__ uint32_t qw[1024];
   const int q = blockIdx.y;
   uint32_t count = p.cnt[q];
   if (count > p.cap) count = p.cap;
-  const uint32_t i = blockIdx.x * 32 + (threadIdx.x >> 3);
-  if (blockIdx.x * 32 >= count) return;
+  const uint32_t base = blockIdx.x * REFINE_PER_WG;
+  if (base >= count) return;
+  for (int j = threadIdx.x; j < p.d_dlr; j += 256) qw[j] = p.q_pack[(int64_t)q * p.d_dlr + j];
+  __syncthreads();
   const int sub = threadIdx.x & 7;
-  float corr = 0.f;
-  uint2 c = make_uint2(0u, 0u);
-  if (i < count) {
-    c = p.cand[(int64_t)q * p.cap + i];
-    const uint32_t* hk = p.heavy_key + (int64_t)c.x * HEAVY + sub * 8;
-    const uint4 k0 = *(const uint4*)hk, k1 = *(const uint4*)(hk + 4);
-    const half8 hv = *(const half8*)(p.heavy_val + (int64_t)c.x * HEAVY + sub * 8);
-    const uint32_t keys[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
-    const uint32_t* qp = p.q_pack + (int64_t)q * p.d_dlr;
+  const float t = p.thr[q];
+  for (uint32_t i = base + (threadIdx.x >> 3); i < base + REFINE_PER_WG; i += 32) {
+    float corr = 0.f;
+    uint2 c = make_uint2(0u, 0u);
+    if (i < count) {
+      c = p.cand[(int64_t)q * p.cap + i];
+      const uint32_t* hk = p.heavy_key + (int64_t)c.x * HEAVY + sub * 8;
+      const uint4 k0 = *(const uint4*)hk, k1 = *(const uint4*)(hk + 4);
+      const half8 hv = *(const half8*)(p.heavy_val + (int64_t)c.x * HEAVY + sub * 8);
+      const uint32_t keys[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const uint32_t key = keys[e];
-      if (key != 0xFFFFFFFFu) {
-        const uint32_t w = qp[key >> 20];
-        const bool same_bucket = ((w >> 12) & 0xFu) == ((key >> 16) & 0xFu);
-        const bool mismatch = (w & 0xFFFu) != (key & 0xFFFu);
-        if (same_bucket && mismatch) {
-          union { uint16_t u; _Float16 h; } qv; qv.u = (uint16_t)(w >> 16);
-          corr += fabsf((float)qv.h * (float)hv[e]);
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t key = keys[e];
+        if (key != 0xFFFFFFFFu) {
+          const uint32_t w = qw[key >> 20];
+          const bool same_bucket = ((w >> 12) & 0xFu) == ((key >> 16) & 0xFu);
+          const bool mismatch = (w & 0xFFFu) != (key & 0xFFFu);
+          if (same_bucket && mismatch) {
+            union { uint16_t u; _Float16 h; } qv; qv.u = (uint16_t)(w >> 16);
+            corr += fabsf((float)qv.h * (float)hv[e]);
+          }
         }
       }
     }
-  }
-  corr += __shfl_xor(corr, 1, 64);
-  corr += __shfl_xor(corr, 2, 64);
-  corr += __shfl_xor(corr, 4, 64);
-  if (sub == 0 && i < count) {
-    const float u2 = __uint_as_float(c.y) - corr;
-    if (u2 >= p.thr[q]) {
-      const uint32_t slot = atomicAdd(p.out_cnt + q, 1u);
-      p.out[(int64_t)q * p.cap + slot] = make_uint2(c.x, __float_as_uint(u2));
-      atomicMax(p.out_max, slot + 1);
+    corr += __shfl_xor(corr, 1, 64);
+    corr += __shfl_xor(corr, 2, 64);
+    corr += __shfl_xor(corr, 4, 64);
+    if (sub == 0 && i < count) {
+      const float u2 = __uint_as_float(c.y) - corr;
+      if (u2 >= t) {
+        const uint32_t slot = atomicAdd(p.out_cnt + q, 1u);
+        if (slot < p.out_cap) p.out[(int64_t)q * p.out_cap + slot] = make_uint2(c.x, __float_as_uint(u2));
+      }
     }
   }
 }
 hipError_t launch_refine(const RefineArgs& a, hipStream_t s) {
   if (a.max_count == 0 || a.n_queries <= 0) return hipSuccess;
-  hipLaunchKernelGGL(refine_kernel, dim3((a.max_count + 31) / 32, (unsigned)a.n_queries), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(refine_kernel, dim3((a.max_count + REFINE_PER_WG - 1) / REFINE_PER_WG, (unsigned)a.n_queries), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
