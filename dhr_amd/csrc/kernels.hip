@@ -397,16 +397,20 @@ hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const 
 constexpr int GEMM_THREADS = 512;
 constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_HALVES * 2;   // 2 stages x (A + B) x 32 KiB = 128 KiB
 
+// Epilogue of the 8-wave kernels.  Filter: accumulators that reach the query's threshold are first queued
+// in LDS (the staging ring is dead by now), then the whole workgroup flushes the queue -- one global
+// atomic + one 8-byte store per survivor, all in flight at once.  (Appending straight from the
+// accumulator loop costs one dependent L2 round trip per hit, ~20 % of the kernel at 0.2 % hit rate.)
+constexpr int EPI_QUEUE = 6144;      // entries of 8 bytes; beyond that a hit is appended directly
 template <bool DUMP>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, floatx16 (&acc)[4][2], int64_t dt, int qt, int wm, int wn,
-                                              int lane) {
+                                              int lane, char* smem) {
   const int fhalf = lane >> 5;
-  // threshold filter (or dump)
   const int64_t row_base = dt * TILE_ROWS + wm * 128;
+  if (DUMP) {
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
-    if (DUMP) {
+    for (int ni = 0; ni < 2; ++ni) {
+      const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
       if (q < p.n_queries) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
@@ -417,22 +421,44 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, floatx16 (&acc)
               p.dump[(int64_t)q * p.dump_ld + (row - p.dump_row0)] = acc[mi][ni][e];
           }
       }
-    } else {
-      const float t = p.thr[q];
+    }
+    return;
+  }
+  uint2* queue = (uint2*)smem;
+  uint32_t* qn = (uint32_t*)(smem + EPI_QUEUE * 8);
+  __syncthreads();                       // every wave is done with the staging ring
+  if (threadIdx.x == 0) *qn = 0u;
+  __syncthreads();
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+  for (int ni = 0; ni < 2; ++ni) {
+    const int ql = wn * 64 + ni * 32 + (lane & 31);
+    const int q = qt * TILE_ROWS + ql;
+    const float t = p.thr[q];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = acc[mi][ni][e];
-          if (v >= t) {
-            const int64_t row = row_base + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
-            if (row < p.n_rows) {
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = acc[mi][ni][e];
+        if (v >= t) {
+          const int rl = wm * 128 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+          if (dt * TILE_ROWS + rl < p.n_rows) {
+            const uint32_t s = atomicAdd(qn, 1u);
+            if (s < EPI_QUEUE) queue[s] = make_uint2((uint32_t)(rl << 8 | ql), __float_as_uint(v));
+            else {
               const uint32_t slot = atomicAdd(p.cnt + q, 1u);
-              if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)row, __float_as_uint(v));
+              if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(dt * TILE_ROWS + rl), __float_as_uint(v));
             }
           }
         }
-    }
+      }
+  }
+  __syncthreads();
+  const uint32_t n = *qn < EPI_QUEUE ? *qn : EPI_QUEUE;
+  for (uint32_t s = threadIdx.x; s < n; s += GEMM_THREADS) {
+    const uint2 en = queue[s];
+    const int q = qt * TILE_ROWS + (int)(en.x & 255u);
+    const uint32_t slot = atomicAdd(p.cnt + q, 1u);
+    if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(dt * TILE_ROWS) + (en.x >> 8), en.y);
   }
 }
 
@@ -519,7 +545,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_filter_kernel(GemmArgs p) {
     __syncthreads();    // drains the DMA of the next stage (vmcnt(0)) and fences the reads of this one
   }
 
-  gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane);
+  gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane, smem);
 }
 
 // Variant 3: same tiling as gemm_filter_kernel (8 waves, 128 x 64 per wave) with three changes aimed at
@@ -625,7 +651,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_v3_kernel(GemmArg
 #undef V3_READ
 #undef V3_MFMA8
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane);
+  gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane, smem);
 }
 
 // Variant 4: variant 3's tiling and fragment pipeline, but every wave spreads its 8 LDS-DMA instructions
@@ -739,7 +765,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_v4_kernel(GemmArg
 #undef V4_MFMA8
 #undef V4_INTERLEAVE
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane);
+  gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane, smem);
 }
 
 // Sparse-core bound GEMM (two index buckets): ts stages of 32 slices on v_smfmac_f32_32x32x32_f16
@@ -876,7 +902,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_sparse_kernel(Gem
     }
     __syncthreads();
   }
-  gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane);
+  gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane, smem);
 }
 
 // One-wave-per-SIMD variant: 4 waves (256 threads), each owns a 128 x 128 quadrant of the 256 x 256
