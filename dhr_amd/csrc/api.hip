@@ -88,7 +88,7 @@ struct dhr_index {
   int64_t cand_cap = 0, first_rows = 0;   // 0 = default (262144 with refine lists, else 65536)
   int profile = 0, max_growth16 = 32;
   int sample_period = 16;
-  int main_chunks = 8;
+  int main_chunks = 2;
   hipStream_t s_aux = nullptr;          // non-blocking stream for rescoring/select overlapped with the main-pass GEMM
   Workspace ws, ws_fb[2];              // ws_fb[d]: workspace of fallback depth d+1 (16x candidate capacity)
   dhr_search_stats stats{};
@@ -565,13 +565,24 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   const bool gate = ix->d_dlr > 0 && qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE;   // else plain IP
   const int64_t n = ix->n_rows;
   const int64_t group_rows = (int64_t)DOC_GROUP * TILE_ROWS;
-  // rows scored exhaustively in phase 0 (>= k so that tau exists afterwards), whole tile groups
-  int64_t first = std::max<int64_t>(ix->first_rows, std::max<int64_t>(2048, 2 * (int64_t)k));
-  first = std::min(round_up(first, group_rows), round_up(n, group_rows));
-  const int64_t first_valid = std::min(first, n);
   // depth 0: sampled thresholds; depth 1 (queries that failed at depth 0): the same with 16x list capacity;
   // depth 2: plain streaming, exact for any input
   const bool allow_sampling = depth < 2;
+  // sampled threshold: period S, conservative rank r (DESIGN.md "controller")
+  int S = allow_sampling ? ix->sample_period : 0;
+  int r_eff = k;
+  if (S >= 2) {
+    const double mean = (double)k / S;
+    r_eff = (int)std::ceil(mean + 4.0 * std::sqrt(mean) + 4.0);
+    const int64_t head_guess = round_up(std::max<int64_t>(1024, 2 * (int64_t)r_eff), group_rows) / TILE_ROWS;
+    const int64_t rest_guess = ix->n_tiles - head_guess;
+    if (r_eff >= k || rest_guess < 32 * (int64_t)S || (rest_guess / S) * TILE_ROWS < 16 * (int64_t)r_eff) S = 0;
+  }
+  if (S < 2) r_eff = k;
+  // rows scored exhaustively in phase 0 (>= the rank that defines tau, so that tau exists afterwards), whole tile groups
+  int64_t first = std::max<int64_t>(ix->first_rows, std::max<int64_t>(1024, 2 * (int64_t)r_eff));
+  first = std::min(round_up(first, group_rows), round_up(n, group_rows));
+  const int64_t first_valid = std::min(first, n);
   if ((rc = ensure_ws(ix, w, Q, k, first_valid, depth == 0 ? 1 : 16)) != DHR_OK) return rc;
 
   tm.begin(T_PREP);
@@ -579,17 +590,8 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   HIP_TRY(hipMemsetAsync(w.topk_keys, 0, (size_t)w.q_pad * w.kp * 8, s));
   tm.end();
 
-  // sampled threshold: period S, conservative rank r (SURVEY hard part 3 / DESIGN.md "controller")
   const int64_t head = first / TILE_ROWS;                       // tiles scored exhaustively
   const int64_t rest = ix->n_tiles - head;
-  int S = allow_sampling ? ix->sample_period : 0;
-  int r_eff = k;
-  if (S >= 2) {
-    const double mean = (double)k / S;
-    r_eff = (int)std::ceil(mean + 4.0 * std::sqrt(mean) + 4.0);
-    if (r_eff >= k || rest < 32 * (int64_t)S || (rest / S) * TILE_ROWS < 16 * (int64_t)r_eff) S = 0;
-  }
-  if (S < 2) r_eff = k;
 
   SelectArgs sel{};
   sel.topk_keys = w.topk_keys; sel.in_keys = w.rs_keys; sel.ld_keys = w.keys_ld; sel.cap = (uint32_t)w.cap;
