@@ -163,7 +163,7 @@ def main():
         gemm_ms += st["gemm_ms"]
         launches += st["phases"]
         gemm_flops_alg += st["gemm_flops_alg"]                  # algorithmic: real Q and K of every launch
-        for key in ("rescore_ms", "select_ms", "prep_ms", "total_ms", "candidates_bound", "candidates_exact",
+        for key in ("refine_ms", "rescore_ms", "select_ms", "prep_ms", "total_ms", "candidates_bound", "candidates_exact",
                     "overflow_retries", "gemm_rows", "sample_fallback_queries"):
             stats_acc[key] = stats_acc.get(key, 0) + st[key]
     barrier()
@@ -183,13 +183,16 @@ def main():
             "metric": "queries/sec (exact top-%d, brute-force dense-hybrid GIP retrieval)" % k,
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f16 (MFMA fp16 x fp16 -> fp32 bound GEMM; exact fp64-accumulated rescoring)", "data": "synthetic",
+            "dtype": "f16 (fp16 x fp16 -> fp32 on the matrix cores for the bound; fp64-accumulated exact rescoring)", "data": "synthetic",
             "config": {"workload": ("MS MARCO-sized corpus %d x (%d DLR + %d dense) fp16%s, %d queries, top-%d, %s"
                                     % (n, d_dlr, d_cls, " + uint8 slice index" if d_dlr else "", nq, k,
                                        "uniform slice index (adversarial)" if args.uniform_idx else "densify-rule slice index")),
                        "baseline_config": "config 3: DeLADE-CLS 768+768 dense-hybrid" if d_dlr else "config 2: Aggretriever 768-d dense-only",
                        "parallelism": "rowshard%d+allgather" % world if world > 1 else "1gpu"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_filter_kernel (bound GEMM + fused threshold filter)",
+            "roofline": {"bound": "mfma",
+                         "kernel": ("gemm_filter_sparse_kernel (bound GEMM on the 2:4 sparse matrix cores + fused threshold filter)"
+                                    if d_dlr and args.idx_buckets in (0, 2) else
+                                    "gemm_filter_v3_kernel (bound GEMM + fused threshold filter)"),
                          "achieved": round(ach_tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach_tf / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "launches": launches, "avg_launch_ms": round(gemm_ms / max(launches, 1), 3),
