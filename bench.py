@@ -139,10 +139,9 @@ def main():
     torch.cuda.empty_cache()
 
     def step():
-        s, r = index.search(qv, qi, k, out_device=True)
         if world > 1:
-            s, r = D.allgather_merge(s, r, k)
-        return s, r
+            return D.sharded_search(index, qv, qi, k)        # common thresholds + one all-gather of the shard lists
+        return index.search(qv, qi, k, out_device=True)
 
     def barrier():
         if world > 1:

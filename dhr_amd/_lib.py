@@ -17,7 +17,8 @@ PARAM_CAND_CAP, PARAM_FIRST_ROWS, PARAM_PROFILE, PARAM_MAX_GROWTH, PARAM_SAMPLE_
 
 EXPORTS = ["dhr_version", "dhr_last_error", "dhr_index_create", "dhr_index_destroy", "dhr_index_set_param",
            "dhr_index_device_bytes", "dhr_search", "dhr_score_rows", "dhr_merge_topk", "dhr_merge_topk_host",
-           "dhr_get_stats", "dhr_debug_bound_scores", "dhr_debug_gemm_time"]
+           "dhr_get_stats", "dhr_debug_bound_scores", "dhr_debug_gemm_time", "dhr_search_sample_rank", "dhr_search_begin",
+           "dhr_search_finish"]
 
 
 class DhrError(RuntimeError):
@@ -87,6 +88,10 @@ def load():
     lib.dhr_debug_bound_scores.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     lib.dhr_debug_gemm_time.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_int32, C.POINTER(C.c_double),
                                         C.POINTER(C.c_double), C.c_void_p]
+    lib.dhr_search_sample_rank.argtypes = [C.c_void_p, C.c_int32]
+    lib.dhr_search_sample_rank.restype = C.c_int32
+    lib.dhr_search_begin.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_int32, C.c_void_p, C.c_void_p]
+    lib.dhr_search_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     _lib = lib
     return lib
 

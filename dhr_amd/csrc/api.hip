@@ -90,6 +90,8 @@ struct dhr_index {
   int sample_period = 16;
   int main_chunks = 2;
   hipStream_t s_aux = nullptr;          // non-blocking stream for rescoring/select overlapped with the main-pass GEMM
+  // staged search (dhr_search_begin / dhr_search_finish): state carried between the two calls
+  struct { bool valid = false, done = false, gate = false; int Q = 0, k = 0; double rate = 0.0; } pend;
   Workspace ws, ws_fb[2];              // ws_fb[d]: workspace of fallback depth d+1 (16x candidate capacity)
   dhr_search_stats stats{};
 };
@@ -558,11 +560,14 @@ static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectAr
 }
 
 // Leaves the sorted top-k keys of every query in w.topk_keys.  qb must already be validated.
+// stage 0: whole search.  stage 1 (dhr_search_begin): stop after the sampled run.  stage 2 (dhr_search_finish):
+// resume at the main pass with the caller's thresholds tau_ext (device [Q]); no local verification.
 static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, int k, int depth, Timer& tm,
-                       dhr_search_stats& st, hipStream_t s) {
+                       dhr_search_stats& st, hipStream_t s, int stage = 0, const float* tau_ext = nullptr) {
   int rc;
-  const int Q = qb->n_queries;
-  const bool gate = ix->d_dlr > 0 && qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE;   // else plain IP
+  const int Q = stage == 2 ? ix->pend.Q : qb->n_queries;
+  const bool gate = stage == 2 ? ix->pend.gate
+                               : (ix->d_dlr > 0 && qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE);   // else plain IP
   const int64_t n = ix->n_rows;
   const int64_t group_rows = (int64_t)DOC_GROUP * TILE_ROWS;
   // depth 0: sampled thresholds; depth 1 (queries that failed at depth 0): the same with 16x list capacity;
@@ -585,10 +590,12 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   const int64_t first_valid = std::min(first, n);
   if ((rc = ensure_ws(ix, w, Q, k, first_valid, depth == 0 ? 1 : 16)) != DHR_OK) return rc;
 
-  tm.begin(T_PREP);
-  if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
-  HIP_TRY(hipMemsetAsync(w.topk_keys, 0, (size_t)w.q_pad * w.kp * 8, s));
-  tm.end();
+  if (stage != 2) {
+    tm.begin(T_PREP);
+    if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
+    HIP_TRY(hipMemsetAsync(w.topk_keys, 0, (size_t)w.q_pad * w.kp * 8, s));
+    tm.end();
+  }
 
   const int64_t head = first / TILE_ROWS;                       // tiles scored exhaustively
   const int64_t rest = ix->n_tiles - head;
@@ -599,7 +606,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   sel.n_queries = Q;
 
   // ---- phase 0: exhaustive exact scoring of rows [0, first_valid)
-  {
+  if (stage != 2) {
     RescoreArgs r = base_rescore_args(ix, w, Q, gate);
     r.row0 = 0; r.count_all = (uint32_t)first_valid; r.max_count = (uint32_t)first_valid;
     r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
@@ -608,18 +615,30 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     tm.begin(T_SELECT); HIP_TRY(launch_select(sel, s)); tm.end();
     st.candidates_exact += (int64_t)first_valid * Q;
   }
-  if (rest <= 0) return DHR_OK;
-
-  if (S < 2) {
+  if (stage == 2 && ix->pend.done) return DHR_OK;              // the begin call already finished the search
+  if (rest <= 0 || S < 2) {
     // plain streaming over all remaining tiles
-    return stream_phases(ix, w, Q, gate, sel, rest, 1, 1, head, head, first_valid, tm, st, s);
+    if (rest > 0 && (rc = stream_phases(ix, w, Q, gate, sel, rest, 1, 1, head, head, first_valid, tm, st, s)) != DHR_OK) return rc;
+    if (stage == 1) { ix->pend.valid = true; ix->pend.done = true; ix->pend.gate = gate; ix->pend.Q = Q; ix->pend.k = k; }
+    return DHR_OK;
   }
 
   // ---- sampled run: top-r_eff of {head rows} + {every S-th tile}  ->  tau_hat
   const int64_t n_sample = (rest + S - 1) / S;
   double rate = 0.0;
-  if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, head, first_valid, tm, st, s, &rate)) != DHR_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(w.tau_hat, w.tau, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
+  if (stage != 2) {
+    if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, head, first_valid, tm, st, s, &rate)) != DHR_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(w.tau_hat, w.tau, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
+    if (stage == 1) {
+      ix->pend.valid = true; ix->pend.done = false; ix->pend.gate = gate; ix->pend.Q = Q; ix->pend.k = k; ix->pend.rate = rate;
+      return DHR_OK;
+    }
+  } else {
+    rate = ix->pend.rate;
+    // thresholds agreed between the shards: tau_ext >= this shard's own tau_hat in general
+    HIP_TRY(hipMemcpyAsync(w.tau_hat, tau_ext, (size_t)Q * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(launch_make_thr(w.tau_hat, w.margin, Q, w.q_pad, w.thr, s));
+  }
 
   // ---- main pass: all other tiles with the FROZEN threshold tau_hat - margin, in a few chunks; the
   // bound GEMM of chunk i+1 (stream s) overlaps the exact rescoring + top-k merge of chunk i (aux stream)
@@ -689,6 +708,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     HIP_TRY(hipStreamWaitEvent(s, ev_done[M - 1], 0));
     for (int i = 0; i < M; ++i) { hipEventDestroy(ev_gemm[i]); hipEventDestroy(ev_done[i]); }
   }
+  if (stage == 2) return DHR_OK;                                // the caller verifies across shards
   // ---- verify; queries whose list overflowed or that found < k rows above tau_hat are redone exactly
   HIP_TRY(hipMemsetAsync(w.d_max, 0, 16, s));
   HIP_TRY(launch_verify(w.topk_keys, w.kp, k, w.tau_hat, Q, w.fail_flags, w.d_max, s));
@@ -770,6 +790,82 @@ extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, f
   st.gemm_ms = ms[T_GEMM]; st.refine_ms = ms[T_REFINE]; st.rescore_ms = ms[T_RESCORE]; st.select_ms = ms[T_SELECT];
   st.prep_ms = ms[T_PREP];
   ix->stats = st;
+  return DHR_OK;
+}
+
+// ---- staged search for the row-sharded path (dhr_amd/dist.py): the shards agree on ONE threshold per
+// query after their sampled runs, so each shard collects only its share of the global top-k.
+extern "C" int32_t dhr_search_sample_rank(const dhr_index* ix, int32_t k) {
+  if (!ix || k <= 0) return 0;
+  const int S = ix->sample_period;
+  if (S < 2) return 0;
+  const double mean = (double)k / S;
+  const int r = (int)std::ceil(mean + 4.0 * std::sqrt(mean) + 4.0);
+  const int64_t group_rows = (int64_t)DOC_GROUP * TILE_ROWS;
+  const int64_t head_guess = round_up(std::max<int64_t>(1024, 2 * (int64_t)r), group_rows) / TILE_ROWS;
+  const int64_t rest_guess = ix->n_tiles - head_guess;
+  if (r >= k || rest_guess < 32 * (int64_t)S || (rest_guess / S) * TILE_ROWS < 16 * (int64_t)r) return 0;
+  return r;
+}
+
+extern "C" int dhr_search_begin(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_sample_scores_dev, void* stream) {
+  int rc = check_queries(ix, qb);
+  if (rc) return rc;
+  if (k <= 0 || k > 16384) return set_error(DHR_ERR_INVALID, "k must be in [1, 16384]");
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = (hipStream_t)stream;
+  ix->pend.valid = false;
+  Timer tm{ix->profile != 0, s, {}, {}};
+  dhr_search_stats st{};
+  st.n_rows = ix->n_rows; st.n_queries = qb->n_queries; st.k = k;
+  if ((rc = search_core(ix, ix->ws, qb, k, 0, tm, st, s, 1)) != DHR_OK) return rc;
+  const int r = dhr_search_sample_rank(ix, k);
+  if (r > 0 && !ix->pend.done) {
+    if (!out_sample_scores_dev) return set_error(DHR_ERR_INVALID, "null sample score buffer");
+    HIP_TRY(launch_emit_scores(ix->ws.topk_keys, ix->ws.kp, qb->n_queries, r, out_sample_scores_dev, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  double ms[5] = {0, 0, 0, 0, 0};
+  tm.collect(ms);
+  st.gemm_ms = ms[T_GEMM]; st.refine_ms = ms[T_REFINE]; st.rescore_ms = ms[T_RESCORE]; st.select_ms = ms[T_SELECT]; st.prep_ms = ms[T_PREP];
+  ix->stats = st;
+  return DHR_OK;
+}
+
+extern "C" int dhr_search_finish(dhr_index* ix, const float* tau_hat_dev, float* out_scores, int64_t* out_rows,
+                                 int32_t* out_count_dev, int32_t out_mem_kind, void* stream) {
+  if (!ix || !ix->pend.valid) return set_error(DHR_ERR_INVALID, "dhr_search_finish without a matching dhr_search_begin");
+  if (!out_scores || !out_rows || !out_count_dev) return set_error(DHR_ERR_INVALID, "null output pointer");
+  if (!ix->pend.done && !tau_hat_dev) return set_error(DHR_ERR_INVALID, "thresholds are required (the shard ran a sampled pass)");
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int Q = ix->pend.Q, k = ix->pend.k;
+  Workspace& w = ix->ws;
+  Timer tm{ix->profile != 0, s, {}, {}};
+  dhr_search_stats st = ix->stats;                     // continue the counters of the begin call
+  int rc;
+  if ((rc = search_core(ix, w, nullptr, k, 0, tm, st, s, 2, tau_hat_dev)) != DHR_OK) return rc;
+  HIP_TRY(launch_count_ge(w.topk_keys, w.kp, k, ix->pend.done ? nullptr : w.tau_hat, ix->pend.done ? nullptr : w.fail_flags, Q,
+                          out_count_dev, s));
+  float* d_scores = out_scores;
+  int64_t* d_rows = out_rows;
+  if (out_mem_kind == DHR_MEM_HOST) {
+    const size_t need = (size_t)Q * k * 12;
+    if ((rc = grow(w.out_stage, w.out_stage_bytes, need, w.bytes)) != DHR_OK) return rc;
+    d_rows = (int64_t*)w.out_stage;
+    d_scores = (float*)((char*)w.out_stage + (size_t)Q * k * 8);
+  }
+  HIP_TRY(launch_emit(w.topk_keys, w.kp, Q, k, ix->row_offset, d_scores, d_rows, s));
+  if (out_mem_kind == DHR_MEM_HOST) {
+    HIP_TRY(hipMemcpyAsync(out_rows, d_rows, (size_t)Q * k * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_scores, d_scores, (size_t)Q * k * 4, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  double ms[5] = {0, 0, 0, 0, 0};
+  tm.collect(ms);
+  st.gemm_ms += ms[T_GEMM]; st.refine_ms += ms[T_REFINE]; st.rescore_ms += ms[T_RESCORE]; st.select_ms += ms[T_SELECT];
+  ix->stats = st;
+  ix->pend.valid = false;
   return DHR_OK;
 }
 

@@ -156,6 +156,10 @@ hipError_t launch_verify(const uint64_t* topk_keys, int kp, int k, const float* 
 hipError_t launch_gather_queries(const float* q32, const int16_t* q_idx, int k_rm, int d_dlr, const int32_t* ids, int n,
                                  float* out32, int16_t* out_idx, hipStream_t s);
 hipError_t launch_scatter_keys(const uint64_t* src, uint64_t* dst, int kp, const int32_t* ids, int n, hipStream_t s);
+hipError_t launch_emit_scores(const uint64_t* topk_keys, int kp, int n_queries, int r, float* out, hipStream_t s);
+hipError_t launch_make_thr(const float* tau, const float* margin, int n_queries, int q_pad, float* thr, hipStream_t s);
+hipError_t launch_count_ge(const uint64_t* topk_keys, int kp, int k, const float* tau, const uint32_t* fail_flags, int n_queries,
+                           int32_t* out, hipStream_t s);
 hipError_t launch_merge_topk(int n_queries, int n_in, const float* in_scores, const int64_t* in_rows, int k_out,
                              float* out_scores, int64_t* out_rows, hipStream_t s);
 

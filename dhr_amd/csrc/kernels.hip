@@ -1642,6 +1642,54 @@ hipError_t launch_scatter_keys(const uint64_t* src, uint64_t* dst, int kp, const
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ staged-search helpers
+__global__ void emit_scores_kernel(const uint64_t* __restrict__ topk_keys, int kp, int n_queries, int r, float* __restrict__ out) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (int64_t)n_queries * r) return;
+  const int q = (int)(g / r), j = (int)(g - (int64_t)q * r);
+  const uint64_t key = topk_keys[(int64_t)q * kp + j];
+  out[g] = key ? ordered_f32((uint32_t)(key >> 32)) : -INFINITY;
+}
+hipError_t launch_emit_scores(const uint64_t* topk_keys, int kp, int n_queries, int r, float* out, hipStream_t s) {
+  const int64_t total = (int64_t)n_queries * r;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(emit_scores_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, topk_keys, kp, n_queries, r, out);
+  return hipGetLastError();
+}
+__global__ void make_thr_kernel(const float* __restrict__ tau, const float* __restrict__ margin, int n_queries, int q_pad,
+                                float* __restrict__ thr) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < q_pad) thr[q] = q < n_queries ? tau[q] - margin[q] : INFINITY;
+}
+hipError_t launch_make_thr(const float* tau, const float* margin, int n_queries, int q_pad, float* thr, hipStream_t s) {
+  hipLaunchKernelGGL(make_thr_kernel, dim3((q_pad + 255) / 256), dim3(256), 0, s, tau, margin, n_queries, q_pad, thr);
+  return hipGetLastError();
+}
+// Rows of the final list that reach tau (all valid rows when tau is null); -1 when the shard's lists overflowed.
+__global__ void count_ge_kernel(const uint64_t* __restrict__ topk_keys, int kp, int k, const float* __restrict__ tau,
+                                const uint32_t* __restrict__ fail_flags, int n_queries, int32_t* __restrict__ out) {
+  const int q = blockIdx.x;
+  if (q >= n_queries) return;
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  const float t = tau ? tau[q] : -INFINITY;
+  int c = 0;
+  for (int j = threadIdx.x; j < k; j += blockDim.x) {
+    const uint64_t key = topk_keys[(int64_t)q * kp + j];
+    if (key && ordered_f32((uint32_t)(key >> 32)) >= t) ++c;
+  }
+  atomicAdd(&cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) out[q] = (fail_flags && fail_flags[q]) ? -1 : cnt;
+}
+hipError_t launch_count_ge(const uint64_t* topk_keys, int kp, int k, const float* tau, const uint32_t* fail_flags, int n_queries,
+                           int32_t* out, hipStream_t s) {
+  if (n_queries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(count_ge_kernel, dim3((unsigned)n_queries), dim3(256), 0, s, topk_keys, kp, k, tau, fail_flags, n_queries, out);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ merge_topk
 // Per query: k_out best of n_in (score,row) pairs, order (score desc, row asc); row < 0 = padding.
 // LDS: ordered score (u32) + position (u32) per entry; ties are resolved on the int64 rows in HBM.

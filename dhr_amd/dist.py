@@ -60,7 +60,55 @@ def allgather_merge(local_scores, local_rows, k: int, group=None):
     return merge_topk(cs, cr, k)
 
 
+def common_threshold(sample_scores_all, r: int):
+    """[world, Q, r] best sample scores of every shard -> [Q] the r-th best of the union per query."""
+    import torch
+    world, q, _ = sample_scores_all.shape
+    cat = sample_scores_all.permute(1, 0, 2).reshape(q, world * r)
+    return torch.topk(cat, r, dim=1).values[:, r - 1].contiguous()
+
+
 def sharded_search(index, q_value, q_index, k: int, group=None):
-    """index: this rank's GipIndex (built on rows shard_bounds(N, world, rank) with row_offset=lo)."""
-    scores, rows = index.search(q_value, q_index, k, out_device=True)
+    """index: this rank's GipIndex (rows shard_bounds(N, world, rank), row_offset=lo).  Returns the global
+    [Q,k] (scores, rows) on every rank.
+
+    The shards agree on ONE threshold per query after their sampled runs (all-gather of [Q, r] scores,
+    r ~ 100), so a shard collects only its share of the global top-k instead of a full local top-k;
+    completeness is verified with one all-reduce of per-query counts, and the queries that fail it
+    (unrepresentative sample, list overflow) are redone with purely local thresholds."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        scores, rows = index.search(q_value, q_index, k, out_device=True)
+        return merge_topk(scores, rows, k)
+    r = index.sample_rank(k)
+    dev = getattr(index, "torch_device", None) or torch.device("cuda", index.device)
+    rr = torch.tensor([r], dtype=torch.int32, device=dev)
+    dist.all_reduce(rr, op=dist.ReduceOp.MIN, group=group)            # shards of different size may disagree
+    if int(rr.item()) != r or r == 0:
+        rmax = torch.tensor([r], dtype=torch.int32, device=rr.device)
+        dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=group)
+        if int(rr.item()) != int(rmax.item()) or r == 0:              # not uniformly samplable: local thresholds
+            scores, rows = index.search(q_value, q_index, k, out_device=True)
+            return allgather_merge(scores, rows, k, group)
+    sample = index.search_begin(q_value, q_index, k)
+    nq = sample.shape[0]
+    gathered = torch.empty((world * nq, r), dtype=torch.float32, device=sample.device)
+    dist.all_gather_into_tensor(gathered, sample, group=group)
+    tau = common_threshold(gathered.view(world, nq, r), r)
+    scores, rows, count = index.search_finish(tau)
+    bad = (count < 0).to(torch.int32)
+    tot = torch.stack([count.clamp(min=0), bad]).to(torch.int32)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    failed = torch.nonzero((tot[0] < k) | (tot[1] > 0)).flatten()
+    if failed.numel() > 0:                                             # identical on every rank
+        ids = failed.cpu().numpy()
+        sub_v = q_value[ids] if not hasattr(q_value, "index_select") else q_value.index_select(0, failed.to(q_value.device))
+        sub_i = None
+        if q_index is not None:
+            sub_i = q_index[ids] if not hasattr(q_index, "index_select") else q_index.index_select(0, failed.to(q_index.device))
+        fs, fr = index.search(sub_v, sub_i, k, out_device=True)
+        scores[failed] = fs
+        rows[failed] = fr
     return allgather_merge(scores, rows, k, group)

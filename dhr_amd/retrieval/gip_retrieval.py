@@ -91,6 +91,42 @@ class GipIndex:
         del keep
         return scores, rows
 
+    # ---- staged search (row-sharded path, dhr_amd/dist.py)
+    def sample_rank(self, k: int) -> int:
+        return int(self._lib.dhr_search_sample_rank(self._h, int(k)))
+
+    def search_begin(self, q_value, q_index, k: int, stream: int = 0):
+        """Runs the sampled part; -> torch cuda tensor [Q, r] with this shard's r best sample scores
+        (None when the shard is too small to sample: then the whole search already ran)."""
+        import torch
+        qb, keep = _lib.make_query_batch(q_value, q_index)
+        r = self.sample_rank(k)
+        out = None
+        if r > 0:
+            out = torch.empty((qb.n_queries, r), dtype=torch.float32, device=torch.device("cuda", self.device))
+        _lib.check(self._lib.dhr_search_begin(self._h, C.byref(qb), int(k), out.data_ptr() if out is not None else None,
+                                              stream), "dhr_search_begin")
+        self._pending = (qb.n_queries, int(k))
+        del keep
+        return out
+
+    def search_finish(self, tau_hat, stream: int = 0):
+        """tau_hat: torch cuda tensor [Q] (or None after a non-sampled begin).  -> (scores [Q,k], rows [Q,k],
+        count [Q] int32 rows reaching tau_hat, -1 = list overflow), all torch cuda tensors."""
+        import torch
+        nq, k = self._pending
+        dev = torch.device("cuda", self.device)
+        scores = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        rows = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        count = torch.empty((nq,), dtype=torch.int32, device=dev)
+        tp = None
+        if tau_hat is not None:
+            tau_hat = tau_hat.to(device=dev, dtype=torch.float32).contiguous()
+            tp = tau_hat.data_ptr()
+        _lib.check(self._lib.dhr_search_finish(self._h, tp, scores.data_ptr(), rows.data_ptr(), count.data_ptr(),
+                                               _lib.MEM_DEVICE, stream), "dhr_search_finish")
+        return scores, rows, count
+
     def score_rows(self, q_value, q_index, rows):
         """Exact gated inner product of each query against its own list of (global) rows [Q, m]."""
         qb, keep = _lib.make_query_batch(q_value, q_index)

@@ -121,6 +121,21 @@ int64_t dhr_index_device_bytes(const dhr_index* index);
 int dhr_search(dhr_index* index, const dhr_query_batch* queries, int32_t k, float* out_scores,
                int64_t* out_rows, int32_t out_mem_kind, void* stream);
 
+/* Staged form of dhr_search for the row-sharded path (one handle per shard / rank).  After
+ * dhr_search_begin every shard holds the r best exact scores of its SAMPLE per query (r =
+ * dhr_search_sample_rank, the same on equally sized shards; 0 = the shard is too small to sample and
+ * begin already ran the whole search).  The caller gathers the [n_queries, r] score blocks of all
+ * shards, takes the r-th best of the union per query as the common threshold tau_hat and hands it to
+ * dhr_search_finish, which runs the main pass with it and returns the shard's top-k plus, per query,
+ * how many of its rows reach tau_hat (-1: a candidate list overflowed).  If the counts of all shards
+ * sum to >= k (and none is -1) the union of the shard lists contains the global top-k; otherwise
+ * those queries are redone with dhr_search.  Replaces one process per shard + merge.result.py.
+ * out_sample_scores_dev / tau_hat_dev / out_count_dev are DEVICE pointers. */
+int32_t dhr_search_sample_rank(const dhr_index* index, int32_t k);
+int dhr_search_begin(dhr_index* index, const dhr_query_batch* queries, int32_t k, float* out_sample_scores_dev, void* stream);
+int dhr_search_finish(dhr_index* index, const float* tau_hat_dev, float* out_scores, int64_t* out_rows,
+                      int32_t* out_count_dev, int32_t out_mem_kind, void* stream);
+
 /* Exact gated inner product of each query against m given rows (stage 2 of --rerank,
  * gip_retrieval.py:144-146 / :207-208).  rows [n_queries, m] int64 GLOBAL rows (row < 0 -> -inf).
  * out_scores [n_queries, m].  Pointers live in mem_kind memory. */

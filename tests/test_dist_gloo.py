@@ -61,3 +61,86 @@ def test_shard_bounds_match_reference_arithmetic():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert all(hi - lo == n // w for lo, hi in spans[:-1])
+
+
+class _FakeShard:
+    """CPU stand-in for GipIndex with the staged-search interface, backed by the oracle (dense scores).
+    Lets the gloo test drive dist.sharded_search -- every collective of the staged path -- without a GPU."""
+
+    def __init__(self, cv, q32, lo, period=4, r=40):
+        import torch
+        self.torch_device = torch.device("cpu")
+        self.device = 0
+        self.cv, self.lo, self.period, self.r = cv.astype(np.float64), lo, period, r
+        self.calls = []
+
+    def sample_rank(self, k):
+        return self.r
+
+    def _scores(self, q):
+        return np.asarray(q, np.float64) @ self.cv.T
+
+    def search_begin(self, q, qi, k):
+        import torch
+        self.q, self.k = np.asarray(q), k
+        s = self._scores(q)[:, ::self.period]
+        top = -np.sort(-s, axis=1)[:, : self.r]
+        self.calls.append("begin")
+        return torch.from_numpy(top.astype(np.float32))
+
+    def search_finish(self, tau):
+        import torch
+        s = self._scores(self.q)
+        k, nq = self.k, s.shape[0]
+        sc = np.full((nq, k), -np.inf, np.float32); rows = np.full((nq, k), -1, np.int64); cnt = np.zeros(nq, np.int32)
+        for i in range(nq):
+            keep = np.nonzero(s[i] >= float(tau[i]))[0]
+            keep = keep[np.lexsort((keep, -s[i][keep]))][:k]
+            sc[i, : len(keep)] = s[i][keep]; rows[i, : len(keep)] = keep + self.lo; cnt[i] = len(keep)
+        self.calls.append("finish")
+        return torch.from_numpy(sc), torch.from_numpy(rows), torch.from_numpy(cnt)
+
+    def search(self, q, qi, k, out_device=True):
+        import torch
+        s = self._scores(np.asarray(q))
+        order = np.argsort(-s, axis=1, kind="stable")[:, :k]
+        self.calls.append("search%d" % len(s))
+        return torch.from_numpy(np.take_along_axis(s, order, 1).astype(np.float32)), torch.from_numpy(order + self.lo)
+
+
+def _staged_worker(rank, world, port, tmp, adversarial):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from dhr_amd import dist as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(7)
+        n, k, nq = 4000, 60, 5
+        cv = rng.standard_normal((n, 16)).astype(np.float32)
+        q = rng.standard_normal((nq, 16)).astype(np.float32)
+        if adversarial:          # the best rows of query 0 all sit on sample positions of shard 0 -> threshold too high
+            cv[0:800:4] += 3.0 * q[0] / np.linalg.norm(q[0])
+        lo, hi = D.shard_bounds(n, world, rank)
+        shard = _FakeShard(cv[lo:hi], q, lo)
+        ms, mr = D.sharded_search(shard, q, None, k)
+        full = q.astype(np.float64) @ cv.astype(np.float64).T
+        for i in range(nq):
+            want = np.argsort(-full[i], kind="stable")[:k]
+            assert set(mr[i].tolist()) == set(want.tolist()), (rank, i)
+        np.save(os.path.join(tmp, f"calls{rank}.npy"), np.array(shard.calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("adversarial", [False, True])
+def test_sharded_search_staged_gloo(tmp_path, adversarial):
+    """dist.sharded_search end to end over gloo (2 ranks): sample exchange, common threshold, count
+    all-reduce and -- in the adversarial layout -- the local-threshold fallback for the failed query."""
+    import torch.multiprocessing as mp
+    port = 29700 + (os.getpid() % 2000) + int(adversarial)
+    mp.spawn(_staged_worker, args=(2, port, str(tmp_path), adversarial), nprocs=2, join=True)
+    calls = [list(np.load(tmp_path / f"calls{r}.npy")) for r in range(2)]
+    assert calls[0][:2] == ["begin", "finish"] and calls[0] == calls[1]
+    assert (len(calls[0]) == 3) == adversarial

@@ -406,3 +406,76 @@ def test_negative_query_values_on_nonneg_corpus(G, nb):
     qv = qv.copy()
     qv[:, :768] *= rng.choice([-1, 1], size=(8, 768)).astype(np.float16)
     _search_check(G, cv, ci, qv.astype(np.float32), qi, 100, idx_buckets=nb)
+
+
+def _fake_world_search(G, shards, q32, qi, k):
+    """dist.sharded_search with the collectives replaced by in-process tensor ops (one GPU, S shards)."""
+    import torch
+    from dhr_amd import dist as D
+    r = shards[0].sample_rank(k)
+    assert r > 0 and all(s.sample_rank(k) == r for s in shards)
+    samples = [s.search_begin(q32, qi, k) for s in shards]
+    tau = D.common_threshold(torch.stack(samples), r)
+    outs = [s.search_finish(tau) for s in shards]
+    count = torch.stack([o[2] for o in outs])
+    tot = count.clamp(min=0).sum(0)
+    failed = torch.nonzero((tot < k) | (count < 0).any(0)).flatten()
+    scores = [o[0] for o in outs]
+    rows = [o[1] for o in outs]
+    if failed.numel():
+        ids = failed.cpu().numpy()
+        for i, s in enumerate(shards):
+            fs, fr = s.search(q32[ids], None if qi is None else qi[ids], k, out_device=True)
+            scores[i][failed] = fs
+            rows[i][failed] = fr
+    ms, mr = D.merge_topk(torch.cat(scores, 1), torch.cat(rows, 1), k)
+    return ms.cpu().numpy(), mr.cpu().numpy(), int(failed.numel()), [int(x) for x in tot[:4]]
+
+
+@pytest.mark.parametrize("kind", ["hybrid", "dense"])
+def test_staged_sharded_search_common_threshold(G, kind):
+    """Shards exchange their sample scores, agree on one threshold per query, and the union of their
+    (now much shorter) lists still equals the unsharded exact result."""
+    from dhr_amd import synth, _lib
+    n, k, ns = 400_000, 1000, 4
+    if kind == "hybrid":
+        cv, ci, qv, qi = synth.make_pair(22, n, 12, 768, 64)
+    else:
+        cv, ci, qv, qi = synth.make_pair(23, n, 12, 0, 256, kind="dense")
+    q32 = qv.astype(np.float32)
+    full = G.GipIndex(cv, ci)
+    fs, fr = full.search(q32, qi, k)
+    full.close()
+    shards = []
+    for sh in range(ns):
+        lo, hi = G.shard_bounds(n, ns, sh)
+        shards.append(G.GipIndex(cv[lo:hi], None if ci is None else ci[lo:hi], row_offset=lo))
+        shards[-1].set_param(_lib.PARAM_SAMPLE_PERIOD, 4)          # 100k-row shards: sample every 4th tile
+    ms, mr, n_failed, tot = _fake_world_search(G, shards, q32, qi, k)
+    exact_per_shard = [s.stats()["candidates_exact"] for s in shards]
+    for s in shards:
+        s.close()
+    np.testing.assert_array_equal(mr, fr)
+    np.testing.assert_array_equal(ms, fs)
+    print(kind, "failed", n_failed, "counts>=tau", tot, "rows rescored per shard and query", [e // 12 for e in exact_per_shard])
+
+
+def test_staged_sharded_search_failure_path(G):
+    """All high-scoring rows sit in sample tiles of shard 0: the common threshold is too high for the
+    union to reach k rows, the count check must catch it and the local fallback must repair it."""
+    n, k, ns = 400_000, 1000, 2
+    cv, qv = _structured_corpus(n, 0)
+    q32 = qv.astype(np.float32)
+    full = G.GipIndex(cv, None)
+    fs, fr = full.search(q32, None, k)
+    full.close()
+    shards = []
+    for sh in range(ns):
+        lo, hi = G.shard_bounds(n, ns, sh)
+        shards.append(G.GipIndex(cv[lo:hi], None, row_offset=lo))
+    ms, mr, n_failed, tot = _fake_world_search(G, shards, q32, None, k)
+    for s in shards:
+        s.close()
+    assert n_failed == 5
+    np.testing.assert_array_equal(mr, fr)
+    np.testing.assert_array_equal(ms, fs)
