@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--idx-buckets", type=int, default=0)
     ap.add_argument("--sample-period", type=int, default=-1)
     ap.add_argument("--main-chunks", type=int, default=0)
+    ap.add_argument("--first-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=200_000)
     ap.add_argument("--cpu-queries", type=int, default=12)
@@ -128,6 +129,8 @@ def main():
         index.set_param(_lib.PARAM_SAMPLE_PERIOD, args.sample_period)
     if args.main_chunks:
         index.set_param(_lib.PARAM_MAIN_CHUNKS, args.main_chunks)
+    if args.first_rows:
+        index.set_param(_lib.PARAM_FIRST_ROWS, args.first_rows)
 
     # host sample for the CPU baseline + an in-bench parity check (rank 0, N=1 only)
     sample = None

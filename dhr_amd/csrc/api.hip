@@ -579,14 +579,14 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   if (S >= 2) {
     const double mean = (double)k / S;
     r_eff = (int)std::ceil(mean + 4.0 * std::sqrt(mean) + 4.0);
-    const int64_t head_guess = round_up(std::max<int64_t>(1024, 2 * (int64_t)r_eff), group_rows) / TILE_ROWS;
+    const int64_t head_guess = round_up(std::max<int64_t>(1024, 2 * (int64_t)r_eff), TILE_ROWS) / TILE_ROWS;
     const int64_t rest_guess = ix->n_tiles - head_guess;
     if (r_eff >= k || rest_guess < 32 * (int64_t)S || (rest_guess / S) * TILE_ROWS < 16 * (int64_t)r_eff) S = 0;
   }
   if (S < 2) r_eff = k;
   // rows scored exhaustively in phase 0 (>= the rank that defines tau, so that tau exists afterwards), whole tile groups
   int64_t first = std::max<int64_t>(ix->first_rows, std::max<int64_t>(1024, 2 * (int64_t)r_eff));
-  first = std::min(round_up(first, group_rows), round_up(n, group_rows));
+  first = std::min(round_up(first, TILE_ROWS), round_up(n, TILE_ROWS));
   const int64_t first_valid = std::min(first, n);
   if ((rc = ensure_ws(ix, w, Q, k, first_valid, depth == 0 ? 1 : 16)) != DHR_OK) return rc;
 
@@ -602,7 +602,8 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
 
   SelectArgs sel{};
   sel.topk_keys = w.topk_keys; sel.in_keys = w.rs_keys; sel.ld_keys = w.keys_ld; sel.cap = (uint32_t)w.cap;
-  sel.k = r_eff; sel.kp = w.kp; sel.sort_n = 4 * w.kp; sel.margin = w.margin; sel.tau = w.tau; sel.thr = w.thr;
+  sel.k = r_eff; sel.kp = w.kp; sel.sort_n = 4 * w.kp;
+  sel.kps = 64; while (sel.kps < r_eff) sel.kps <<= 1; sel.margin = w.margin; sel.tau = w.tau; sel.thr = w.thr;
   sel.n_queries = Q;
 
   // ---- phase 0: exhaustive exact scoring of rows [0, first_valid)
@@ -627,7 +628,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   const int64_t n_sample = (rest + S - 1) / S;
   double rate = 0.0;
   if (stage != 2) {
-    if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, head, first_valid, tm, st, s, &rate)) != DHR_OK) return rc;
+    if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, std::max<int64_t>(head, DOC_GROUP), first_valid, tm, st, s, &rate)) != DHR_OK) return rc;
     HIP_TRY(hipMemcpyAsync(w.tau_hat, w.tau, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
     if (stage == 1) {
       ix->pend.valid = true; ix->pend.done = false; ix->pend.gate = gate; ix->pend.Q = Q; ix->pend.k = k; ix->pend.rate = rate;
@@ -642,7 +643,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
 
   // ---- main pass: all other tiles with the FROZEN threshold tau_hat - margin, in a few chunks; the
   // bound GEMM of chunk i+1 (stream s) overlaps the exact rescoring + top-k merge of chunk i (aux stream)
-  sel.k = k;
+  sel.k = k; sel.kps = w.kp;
   const int64_t n_main = rest - n_sample;
   {
     HIP_TRY(hipMemcpyAsync(w.thr_hat, w.thr, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
@@ -660,7 +661,18 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     const int64_t need = (int64_t)std::ceil(1.5 * rate * (double)n_main * TILE_ROWS / (double)w.cap);
     const int M = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(ix->main_chunks, need), 64),
                                                               n_main / (64 * DOC_GROUP)));
-    const int64_t per = round_up((n_main + M - 1) / M, DOC_GROUP);
+    // chunk i covers [bound[i], bound[i+1]): sizes fall off linearly (weights M, M-1, ..., 1 on top of an equal
+    // share) so that the refine/rescoring tail that cannot overlap a GEMM (the last chunk's) is short
+    std::vector<int64_t> bound(M + 1, 0);
+    {
+      double acc = 0.0, tot = 0.0;
+      for (int i = 0; i < M; ++i) tot += 1.0 + 2.0 * (M - 1 - i) / std::max(1, M - 1);
+      for (int i = 0; i < M; ++i) {
+        acc += 1.0 + 2.0 * (M - 1 - i) / std::max(1, M - 1);
+        bound[i + 1] = std::min<int64_t>(n_main, round_up((int64_t)(n_main * acc / tot), DOC_GROUP));
+      }
+      bound[M] = n_main;
+    }
     std::vector<hipEvent_t> ev_gemm(M), ev_done(M);
     for (int i = 0; i < M; ++i) {
       HIP_TRY(hipEventCreateWithFlags(&ev_gemm[i], hipEventDisableTiming));
@@ -670,7 +682,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     auto enqueue_gemm = [&](int i) -> int {
       uint2* cand = (i & 1) ? w.cand2 : w.cand;
       uint32_t* cnt = (i & 1) ? w.cnt2 : w.cnt;
-      const int64_t lo = (int64_t)i * per, hi = std::min<int64_t>(n_main, lo + per);
+      const int64_t lo = bound[i], hi = bound[i + 1];
       if (i >= 2) HIP_TRY(hipStreamWaitEvent(s, ev_done[i - 2], 0));      // list set is free again
       GemmArgs g{};
       g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td;
@@ -802,7 +814,7 @@ extern "C" int32_t dhr_search_sample_rank(const dhr_index* ix, int32_t k) {
   const double mean = (double)k / S;
   const int r = (int)std::ceil(mean + 4.0 * std::sqrt(mean) + 4.0);
   const int64_t group_rows = (int64_t)DOC_GROUP * TILE_ROWS;
-  const int64_t head_guess = round_up(std::max<int64_t>(1024, 2 * (int64_t)r), group_rows) / TILE_ROWS;
+  const int64_t head_guess = round_up(std::max<int64_t>(1024, 2 * (int64_t)r), TILE_ROWS) / TILE_ROWS;
   const int64_t rest_guess = ix->n_tiles - head_guess;
   if (r >= k || rest_guess < 32 * (int64_t)S || (rest_guess / S) * TILE_ROWS < 16 * (int64_t)r) return 0;
   return r;

@@ -110,6 +110,7 @@ struct SelectArgs {
   const uint32_t* cnt;        // per query count (null -> count_all)
   uint32_t count_all, cap;
   int k, kp, sort_n;
+  int kps;                    // slots of the running list actually in use (power of two >= k, <= kp): sizes the LDS sort
   const float* margin;        // [Q_pad]
   float* tau;                 // [Q_pad] exact k-th best so far (-inf until k results exist)
   float* thr;                 // [Q_pad] tau - margin

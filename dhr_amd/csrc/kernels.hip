@@ -1389,17 +1389,18 @@ __device__ __forceinline__ void bitonic_desc(uint64_t* keys, int n, int tid, int
 __global__ void __launch_bounds__(SELECT_THREADS) select_kernel(SelectArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint64_t* keys = (uint64_t*)smem;
-  int& fill = *(int*)(smem + (size_t)p.sort_n * 8);   // all LDS in the dynamic region (keeps it 16-B aligned)
+  int& fill = *(int*)(smem + (size_t)p.sort_n * 8);
+  const int kps = p.kps;                      // <= p.kp: only this prefix of the running list is live   // all LDS in the dynamic region (keeps it 16-B aligned)
   const int q = blockIdx.x;
   const int tid = threadIdx.x;
   uint32_t count = p.cnt ? p.cnt[q] : p.count_all;
   if (p.cnt && count > p.cap) count = p.cap;
   uint64_t* topk = p.topk_keys + (int64_t)q * p.kp;
   const uint64_t* in = p.in_keys + (int64_t)q * p.ld_keys;
-  for (int j = tid; j < p.kp; j += SELECT_THREADS) keys[j] = topk[j];
-  if (tid == 0) fill = p.kp;
+  for (int j = tid; j < kps; j += SELECT_THREADS) keys[j] = topk[j];
+  if (tid == 0) fill = kps;
   __syncthreads();
-  const uint32_t room = p.sort_n - p.kp;
+  const uint32_t room = p.sort_n - kps;
   for (uint32_t base = 0; base < count; base += room) {
     const uint64_t kth = keys[p.k - 1];
     __syncthreads();
@@ -1410,15 +1411,15 @@ __global__ void __launch_bounds__(SELECT_THREADS) select_kernel(SelectArgs p) {
     }
     __syncthreads();
     const int live = fill;
-    int n = p.kp;
+    int n = kps;
     while (n < live) n <<= 1;
     for (int j = live + tid; j < n; j += SELECT_THREADS) keys[j] = 0ull;
     __syncthreads();
-    if (live > p.kp) bitonic_desc(keys, n, tid, SELECT_THREADS);
-    if (tid == 0) fill = p.kp;
+    if (live > kps) bitonic_desc(keys, n, tid, SELECT_THREADS);
+    if (tid == 0) fill = kps;
     __syncthreads();
   }
-  for (int j = tid; j < p.kp; j += SELECT_THREADS) topk[j] = (j < p.k) ? keys[j] : 0ull;
+  for (int j = tid; j < kps; j += SELECT_THREADS) topk[j] = (j < p.k) ? keys[j] : 0ull;
   if (tid == 0) {
     const uint64_t kth = keys[p.k - 1];
     const float t = kth ? ordered_f32((uint32_t)(kth >> 32)) : -INFINITY;

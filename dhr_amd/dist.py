@@ -111,4 +111,9 @@ def sharded_search(index, q_value, q_index, k: int, group=None):
         fs, fr = index.search(sub_v, sub_i, k, out_device=True)
         scores[failed] = fs
         rows[failed] = fr
-    return allgather_merge(scores, rows, k, group)
+        return allgather_merge(scores, rows, k, group)
+    # every global top-k row reaches tau, and a shard holds `count` of those: the tails of the lists are dead
+    cmax = count.max().to(torch.int32).reshape(1)
+    dist.all_reduce(cmax, op=dist.ReduceOp.MAX, group=group)
+    kk = min(k, (int(cmax.item()) + 63) // 64 * 64)
+    return allgather_merge(scores[:, :kk].contiguous(), rows[:, :kk].contiguous(), k, group)

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Estimate the N-GPU step time on ONE GPU: build the N row shards of the bench corpus one after the
+other on the same device, run the staged search exactly like dist.sharded_search would (collectives
+replaced by in-process tensor ops) and report the slowest shard's begin / finish time."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shards", type=int, default=8)
+    ap.add_argument("--workload", default="hybrid")
+    ap.add_argument("--n-docs", type=int, default=8_841_823)
+    ap.add_argument("--n-queries", type=int, default=6980)
+    a = ap.parse_args()
+    import torch
+    import bench
+    from dhr_amd import dist as D, synth, _lib
+    from dhr_amd.retrieval.gip_retrieval import GipIndex
+    dev = torch.device("cuda", 0)
+    d_dlr, d_cls = (768, 768) if a.workload == "hybrid" else (0, 768)
+    k = 1000
+    qv, qi = bench.gen_shard(torch, synth, dev, 1237 + 999_983, a.n_queries, d_dlr, d_cls, 4, 12, False)
+    # per-shard: begin; keep sample; destroy? the finish needs the handle -> keep all shards resident (fits: ~13 GB each)
+    shards = []
+    for r in range(a.shards):
+        lo, hi = D.shard_bounds(a.n_docs, a.shards, r)
+        cv, ci = bench.gen_shard(torch, synth, dev, 1237 + 1000 * r, hi - lo, d_dlr, d_cls, 30, 90, False)
+        ix = GipIndex(cv, ci, row_offset=lo)
+        ix.set_param(_lib.PARAM_PROFILE, 1)
+        ix.set_param(_lib.PARAM_CAND_CAP, 65536)
+        shards.append(ix)
+        del cv, ci
+        torch.cuda.empty_cache()
+    rnk = shards[0].sample_rank(k)
+    for it in range(2):
+        tb, tf, samples, outs = [], [], [], []
+        for ix in shards:
+            torch.cuda.synchronize(); t = time.perf_counter()
+            samples.append(ix.search_begin(qv, qi, k)); torch.cuda.synchronize(); tb.append(time.perf_counter() - t)
+        t = time.perf_counter(); tau = D.common_threshold(torch.stack(samples), rnk); torch.cuda.synchronize(); tt = time.perf_counter() - t
+        for ix in shards:
+            torch.cuda.synchronize(); t = time.perf_counter()
+            outs.append(ix.search_finish(tau)); torch.cuda.synchronize(); tf.append(time.perf_counter() - t)
+        t = time.perf_counter()
+        cnts = torch.stack([o[2] for o in outs]); kk = min(k, (int(cnts.max()) + 63) // 64 * 64)
+        ms, mr = D.merge_topk(torch.cat([o[0][:, :kk] for o in outs], 1), torch.cat([o[1][:, :kk] for o in outs], 1), k); torch.cuda.synchronize(); tm = time.perf_counter() - t
+        tot = torch.stack([o[2] for o in outs]).clamp(min=0).sum(0)
+        failed = int(((tot < k) | (torch.stack([o[2] for o in outs]) < 0).any(0)).sum())
+    st = shards[0].stats()
+    print("shards %d rank r=%d : begin max %.1f ms  finish max %.1f ms  tau %.2f ms  merge %.2f ms  -> est. step %.1f ms (+ all-gather)  failed queries %d"
+          % (a.shards, rnk, max(tb) * 1e3, max(tf) * 1e3, tt * 1e3, tm * 1e3, (max(tb) + max(tf) + tt + tm) * 1e3, failed))
+    print("shard0 stats:", {k_: (round(v, 2) if isinstance(v, float) else v) for k_, v in st.items()})
+
+
+if __name__ == "__main__":
+    main()
