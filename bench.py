@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--idx-buckets", type=int, default=0)
     ap.add_argument("--sample-period", type=int, default=-1)
     ap.add_argument("--main-chunks", type=int, default=0)
+    ap.add_argument("--aux-cus", type=int, default=-1, help="tuning: CUs the refine/rescoring stream is confined to (0 = no mask)")
+    ap.add_argument("--gemm-exclusive", type=int, default=-1)
+    ap.add_argument("--no-progressive-thr", action="store_true", help="A/B: keep the sampled thresholds frozen over the main pass")
     ap.add_argument("--first-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=200_000)
@@ -127,6 +130,12 @@ def main():
         index.set_param(_lib.PARAM_CAND_CAP, args.cand_cap)
     if args.sample_period >= 0:
         index.set_param(_lib.PARAM_SAMPLE_PERIOD, args.sample_period)
+    if args.aux_cus >= 0:
+        index.set_param(_lib.PARAM_AUX_CUS, args.aux_cus)
+    if args.gemm_exclusive >= 0:
+        index.set_param(_lib.PARAM_GEMM_EXCLUSIVE, args.gemm_exclusive)
+    if args.no_progressive_thr:
+        index.set_param(_lib.PARAM_PROGRESSIVE_THR, 0)
     if args.main_chunks:
         index.set_param(_lib.PARAM_MAIN_CHUNKS, args.main_chunks)
     if args.first_rows:

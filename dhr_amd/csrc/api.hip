@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "dhr_internal.h"
+#include <hip/hip_ext.h>
 
 using namespace dhr;
 
@@ -39,6 +40,7 @@ struct Workspace {
   int64_t cap = 0;       // capacity of the bound-candidate lists (cand, cand2)
   int64_t cap_r = 0;     // capacity of the lists that reach the exact rescoring (refine survivors; == cap without refine)
   int64_t keys_ld = 0, kt = 0, d_dlr = 0;
+  int ts_q = 0;          // sparse stages of the current query operand (2:4 layout)
   __half* q_tiles = nullptr;
   float* q32 = nullptr;
   int16_t* q_idx = nullptr;
@@ -89,6 +91,11 @@ struct dhr_index {
   int profile = 0, max_growth16 = 32;
   int sample_period = 16;
   int main_chunks = 2;
+  int progressive_thr = 1;
+  int n_cu = 256;
+  int aux_cus = 0, gemm_exclusive = 0;   // CU-masked streams of the main pass (0 = off)
+  int aux_cus_made = -1, gemm_excl_made = -1;
+  hipStream_t s_gemm = nullptr;         // main-pass GEMM stream when CU masks are in use
   hipStream_t s_aux = nullptr;          // non-blocking stream for rescoring/select overlapped with the main-pass GEMM
   // staged search (dhr_search_begin / dhr_search_finish): state carried between the two calls
   struct { bool valid = false, done = false, gate = false; int Q = 0, k = 0; double rate = 0.0; } pend;
@@ -117,6 +124,7 @@ extern "C" void dhr_index_destroy(dhr_index* ix) {
   free_ws(ix->ws_fb[0]);
   free_ws(ix->ws_fb[1]);
   if (ix->s_aux) hipStreamDestroy(ix->s_aux);
+  if (ix->s_gemm) hipStreamDestroy(ix->s_gemm);
   hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map); hipFree(ix->heavy_key); hipFree(ix->heavy_val);
   delete ix;
 }
@@ -137,6 +145,11 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
     case DHR_PARAM_MAIN_CHUNKS:
       if (value < 1 || value > 64) return set_error(DHR_ERR_INVALID, "main_chunks must be in [1,64]");
       ix->main_chunks = (int)value; return DHR_OK;
+    case DHR_PARAM_PROGRESSIVE_THR: ix->progressive_thr = value != 0; return DHR_OK;
+    case DHR_PARAM_AUX_CUS:
+      if (value < 0 || value > 192 || value % 8) return set_error(DHR_ERR_INVALID, "aux_cus must be a multiple of 8 in [0,192]");
+      ix->aux_cus = (int)value; return DHR_OK;
+    case DHR_PARAM_GEMM_EXCLUSIVE: ix->gemm_exclusive = value != 0; return DHR_OK;
     case DHR_PARAM_GEMM_VARIANT:
       if (value != 0 && (value < 2 || value > 4)) return set_error(DHR_ERR_INVALID, "gemm_variant must be 0, 2, 3 or 4");
       dhr::g_gemm_variant = (int)value; return DHR_OK;
@@ -230,6 +243,7 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
 
   dhr_index* ix = new dhr_index();
   ix->device = d->device;
+  { hipDeviceProp_t pr; HIP_TRY(hipGetDeviceProperties(&pr, d->device)); ix->n_cu = pr.multiProcessorCount; }
   ix->n_rows = d->n_rows;
   ix->row_offset = d->row_offset;
   ix->d_dlr = d->d_dlr;
@@ -242,13 +256,13 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
   if (sparse_ok && (d->idx_buckets == 0 || d->idx_buckets == 2)) {
     ix->n_buckets = 2;
     ix->ts = d->d_dlr / 32;
-    ix->td = (d->d_cls + TILE_K - 1) / TILE_K;
-    ix->kt = (ix->ts + ix->td) * TILE_K;
+    ix->td = (d->d_cls + 31) / 32;                     // ungated columns in 32-column stages
+    ix->kt = ix->ts * TILE_K + ix->td * 32;            // logical operand columns (two bucket columns per gated slice)
   } else {
     ix->n_buckets = has_idx ? (d->idx_buckets > 0 ? d->idx_buckets : 3) : 1;
     ix->kt = (int)round_up((int64_t)ix->n_buckets * ix->d_dlr + ix->d_cls, TILE_K);
   }
-  ix->ksteps = ix->kt / TILE_K;
+  ix->ksteps = (ix->kt + TILE_K - 1) / TILE_K;
   ix->idx_dtype = has_idx ? d->index_dtype : DHR_IDX_NONE;
   ix->n_tiles = (d->n_rows + TILE_ROWS - 1) / TILE_ROWS;
   hipStream_t s = nullptr;
@@ -258,7 +272,7 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
   int rc = DHR_OK;
   auto fail = [&](int code) { hipFree(stage); hipFree(d_flags); hipFree(d_hist); dhr_index_destroy(ix); return code; };
 
-  const size_t tile_bytes = ix->ts > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * SP_STAGE_A + (size_t)ix->td * TILE_HALVES * 2)
+  const size_t tile_bytes = ix->ts > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * SP_STAGE_A + (size_t)ix->td * SP_DENSE)
                                        : (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2;
   if (hipMalloc((void**)&ix->tiles, tile_bytes) != hipSuccess)
     return fail(set_error(DHR_ERR_HIP, "hipMalloc of " + std::to_string(tile_bytes) + " bytes for the corpus tiles failed"));
@@ -340,7 +354,10 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   while (kp < k) kp <<= 1;
   if (kp < 64) kp = 64;
   const bool refine = ix->heavy_key != nullptr;
-  const int64_t base_cap = ix->cand_cap > 0 ? ix->cand_cap : (refine ? 262144 : 65536);
+  // default list depth: 262144 (refine) / 65536, but never more than ~32 GiB for the two bound-list sets of a big batch
+  int64_t base_cap = refine ? 262144 : 65536;
+  while (base_cap > 4096 && (int64_t)q_pad * base_cap * 16 > ((int64_t)32 << 30)) base_cap >>= 1;
+  if (ix->cand_cap > 0) base_cap = ix->cand_cap;
   // fallback depths serve a handful of queries: 16x deeper lists there cost little memory
   const int64_t cap = std::min<int64_t>(base_cap * cap_mult, (int64_t)1 << 22);
   const int64_t cap_r = refine ? std::min<int64_t>(cap, 32768 * cap_mult) : cap;
@@ -422,6 +439,7 @@ static int prep_queries(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, 
       qi = w.qi_stage; ldi = ix->d_dlr;
     }
   }
+  w.ts_q = sparse_query_stages(ix->ts, ix->d_dlr > 0 && qb->index);
   HIP_TRY(launch_query_prep(v, qb->value_dtype == DHR_VAL_F32, ldv, (ix->d_dlr > 0 && qb->index) ? qi : nullptr, qb->index_dtype, ldi,
                             qb->n_queries, w.q_pad, ix->d_dlr, ix->d_cls, ix->k_rm, ix->n_buckets, ix->kt, ix->bucket_map,
                             ix->abs_mode, ix->dmax, w.q_tiles, w.q32,
@@ -458,7 +476,7 @@ static RescoreArgs base_rescore_args(const dhr_index* ix, const Workspace& w, in
 static int gemm_phase(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi, int map_mode, int period, int64_t head,
                       Timer& tm, dhr_search_stats& st, hipStream_t s, uint32_t* maxc, unsigned long long* sumc) {
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q;
   g.seq_lo = lo; g.seq_hi = hi; g.map_mode = map_mode; g.period = period; g.head = head; g.n_tiles = ix->n_tiles;
   g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt;
   g.cap = (uint32_t)w.cap; g.n_queries = Q;
@@ -654,8 +672,37 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       HIP_TRY(re_malloc(w.cnt2, (size_t)w.q_pad * 4, tot));
       w.bytes += tot;
     }
-    if (!ix->s_aux) HIP_TRY(hipStreamCreateWithFlags(&ix->s_aux, hipStreamNonBlocking));
+    // Streams of the main pass.  Default: the bound GEMM on the caller's stream, refine/rescoring/select on a
+    // non-blocking aux stream.  With aux_cus = N the aux stream is confined to N CUs (the low N bits of the CU
+    // mask are spread evenly over the 8 XCDs) so that the memory-bound aux kernels take only the CUs they need
+    // from the GEMM; gemm_exclusive additionally keeps the GEMM (on an internal stream) off those CUs.
+    if (ix->aux_cus_made != ix->aux_cus || ix->gemm_excl_made != ix->gemm_exclusive) {
+      if (ix->s_aux) { hipStreamDestroy(ix->s_aux); ix->s_aux = nullptr; }
+      if (ix->s_gemm) { hipStreamDestroy(ix->s_gemm); ix->s_gemm = nullptr; }
+      if (ix->aux_cus > 0) {
+        uint32_t m_aux[8], m_gemm[8];
+        for (int i = 0; i < 8; ++i) {
+          const int lo = i * 32;
+          const int n = std::max(0, std::min(32, ix->aux_cus - lo));
+          m_aux[i] = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+          m_gemm[i] = ix->gemm_exclusive ? ~m_aux[i] : 0xffffffffu;
+        }
+        HIP_TRY(hipExtStreamCreateWithCUMask(&ix->s_aux, 8, m_aux));
+        HIP_TRY(hipExtStreamCreateWithCUMask(&ix->s_gemm, 8, m_gemm));
+      } else {
+        HIP_TRY(hipStreamCreateWithFlags(&ix->s_aux, hipStreamNonBlocking));
+      }
+      ix->aux_cus_made = ix->aux_cus; ix->gemm_excl_made = ix->gemm_exclusive;
+    }
     hipStream_t sb = ix->s_aux;
+    hipStream_t sg = ix->s_gemm ? ix->s_gemm : s;
+    hipEvent_t ev_enter = nullptr;
+    if (sg != s) {
+      HIP_TRY(hipEventCreateWithFlags(&ev_enter, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(ev_enter, s));
+      HIP_TRY(hipStreamWaitEvent(sg, ev_enter, 0));
+      HIP_TRY(hipStreamWaitEvent(sb, ev_enter, 0));
+    }
     // chunk count: at least main_chunks, more when the sampled run predicts that the fullest list would not fit
     // (rate = bound candidates per corpus row of the fullest query at the final sample thresholds, 1.5x headroom)
     const int64_t need = (int64_t)std::ceil(1.5 * rate * (double)n_main * TILE_ROWS / (double)w.cap);
@@ -683,18 +730,18 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       uint2* cand = (i & 1) ? w.cand2 : w.cand;
       uint32_t* cnt = (i & 1) ? w.cnt2 : w.cnt;
       const int64_t lo = bound[i], hi = bound[i + 1];
-      if (i >= 2) HIP_TRY(hipStreamWaitEvent(s, ev_done[i - 2], 0));      // list set is free again
+      if (i >= 2) HIP_TRY(hipStreamWaitEvent(sg, ev_done[i - 2], 0));      // list set is free again
       GemmArgs g{};
-      g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td;
+      g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q;
       g.seq_lo = lo; g.seq_hi = hi; g.map_mode = 2; g.period = S; g.head = head; g.n_tiles = ix->n_tiles;
       g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr_hat; g.cand = cand; g.cnt = cnt;
       g.cap = (uint32_t)w.cap; g.n_queries = Q;
-      HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)w.q_pad * 4, s));
-      HIP_TRY(hipMemsetAsync(w.d_max2 + 4 * (i & 1), 0, 16, s));
-      tm.begin(T_GEMM); HIP_TRY(launch_gemm_filter(g, s)); tm.end();
-      HIP_TRY(launch_max_u32(cnt, Q, w.d_max2 + 4 * (i & 1), (unsigned long long*)(w.d_max2 + 4 * (i & 1) + 2), s));
-      HIP_TRY(hipMemcpyAsync(w.h_pinned2 + 16 * (i & 1), w.d_max2 + 4 * (i & 1), 16, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipEventRecord(ev_gemm[i], s));
+      HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)w.q_pad * 4, sg));
+      HIP_TRY(hipMemsetAsync(w.d_max2 + 4 * (i & 1), 0, 16, sg));
+      tm.begin_on(T_GEMM, sg); HIP_TRY(launch_gemm_filter(g, sg)); tm.end_on(sg);
+      HIP_TRY(launch_max_u32(cnt, Q, w.d_max2 + 4 * (i & 1), (unsigned long long*)(w.d_max2 + 4 * (i & 1) + 2), sg));
+      HIP_TRY(hipMemcpyAsync(w.h_pinned2 + 16 * (i & 1), w.d_max2 + 4 * (i & 1), 16, hipMemcpyDeviceToHost, sg));
+      HIP_TRY(hipEventRecord(ev_gemm[i], sg));
       const double rows = (double)(hi - lo) * TILE_ROWS;
       st.phases++;
       st.gemm_rows += (int64_t)rows;
@@ -715,10 +762,12 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       uint32_t* cnt = (i & 1) ? w.cnt2 : w.cnt;
       HIP_TRY(launch_mark_overflow(cnt, (uint32_t)w.cap, Q, w.fail_flags, sb));
       if ((rc = rescore_select(ix, w, Q, gate, sel, cand, cnt, w.thr_hat, maxc, tm, st, sb, (int64_t)sumc, w.fail_flags)) != DHR_OK) return rc;
+      if (ix->progressive_thr) HIP_TRY(launch_raise_thr(w.thr_hat, sel.thr, Q, sb));   // later chunks filter with the running exact thresholds
       HIP_TRY(hipEventRecord(ev_done[i], sb));
     }
     HIP_TRY(hipStreamWaitEvent(s, ev_done[M - 1], 0));
     for (int i = 0; i < M; ++i) { hipEventDestroy(ev_gemm[i]); hipEventDestroy(ev_done[i]); }
+    if (ev_enter) hipEventDestroy(ev_enter);
   }
   if (stage == 2) return DHR_OK;                                // the caller verifies across shards
   // ---- verify; queries whose list overflowed or that found < k rows above tau_hat are redone exactly
@@ -928,7 +977,7 @@ extern "C" int dhr_debug_bound_scores(dhr_index* ix, const dhr_query_batch* qb, 
   if ((rc = ensure_ws(ix, w, qb->n_queries, 1, 0)) != DHR_OK) return rc;
   if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.seq_lo = row_lo / TILE_ROWS;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.seq_lo = row_lo / TILE_ROWS;
   g.seq_hi = (row_hi + TILE_ROWS - 1) / TILE_ROWS; g.map_mode = 0; g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
   g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
   g.dump = out_dev; g.dump_ld = row_hi - row_lo; g.dump_row0 = row_lo;
@@ -952,7 +1001,7 @@ extern "C" int dhr_debug_gemm_time(dhr_index* ix, const dhr_query_batch* qb, int
   std::vector<float> inf((size_t)w.q_pad, INFINITY);
   HIP_TRY(hipMemcpyAsync(w.thr, inf.data(), (size_t)w.q_pad * 4, hipMemcpyHostToDevice, s));
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.seq_lo = 0; g.seq_hi = ix->n_tiles; g.map_mode = 0;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.seq_lo = 0; g.seq_hi = ix->n_tiles; g.map_mode = 0;
   g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
   g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
   HIP_TRY(launch_gemm_filter(g, s));                      // warm-up

@@ -23,7 +23,9 @@ constexpr int TILE_HALVES = TILE_ROWS * TILE_K;            // 16384 fp16 = 32 Ki
 constexpr int SP_A_BYTES = 16384;      // sparse stage: 256 rows x 32 stored slice values
 constexpr int SP_IDX_BYTES = 2048;     //               256 rows x [lane half][block] u16 position bits
 constexpr int SP_STAGE_A = SP_A_BYTES + SP_IDX_BYTES;   // corpus bytes per sparse stage (18 KiB)
-constexpr int SP_STAGE_B = 32768;      // query bytes per sparse stage: 256 rows x 64 bucket columns
+constexpr int SP_STAGE_B = 16384;      // query bytes per sparse stage: 256 rows x 32 slice values, bucket in the sign bit (expanded to the two bucket columns in registers)
+constexpr int SP_DENSE = 16384;        // 2:4 layout, ungated columns: 32-column stages, 256 rows x 64 bytes, for corpus and queries
+constexpr int SP_SLOT = SP_STAGE_A + SP_STAGE_B;   // LDS ring slot (34 KiB): corpus part at +0, query part at +SP_STAGE_A
 constexpr int HEAVY = 64;               // per-row list of the largest gated values used by the refine step
 constexpr int DOC_GROUP = 4;                               // doc tiles that share one XCD sweep
 
@@ -60,7 +62,8 @@ struct GemmArgs {
   const __half* b_tiles;      // query operand tiles
   int ksteps;                 // K_pad / 64
   int k_split;                // K-steps [0,k_split) are the gated (DLR) half; informational
-  int ts, td;                 // sparse layout only: 32-slice 2:4 stages, then 64-column dense stages (ts > 0 selects it)
+  int ts, td;                 // 2:4 layout only (ts > 0 selects it): ts 32-slice sparse stages, then td 32-column dense stages
+  int ts_q;                   // sparse stages on the query side: ts, or 2*ts for an ungated batch (stage u pairs with corpus stage u % ts)
   // corpus tiles of this launch: sequence positions [seq_lo, seq_hi) mapped to tile ids by
   //   map_mode 0: tile = i                 (contiguous)
   //   map_mode 1: tile = head + i*period   (the strided sample)
@@ -132,6 +135,7 @@ hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const 
                              int n_queries, int q_pad, int d_dlr, int d_cls, int k_rm, int n_buckets, int kt,
                              const uint8_t* map, bool abs_dlr, float dmax, __half* q_tiles, float* q32, int16_t* q_idx,
                              float* margin, float* tau, float* thr, int ts, int td, uint32_t* q_pack, hipStream_t s);
+inline int sparse_query_stages(int ts, bool gated) { return ts > 0 ? (gated ? ts : 2 * ts) : 0; }
 hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s);
 hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, int idx_dtype, int64_t n_rows, int d_dlr,
                               const uint8_t* map, int n_buckets, uint32_t* heavy_key, __half* heavy_val, hipStream_t s);
@@ -159,6 +163,7 @@ hipError_t launch_gather_queries(const float* q32, const int16_t* q_idx, int k_r
 hipError_t launch_scatter_keys(const uint64_t* src, uint64_t* dst, int kp, const int32_t* ids, int n, hipStream_t s);
 hipError_t launch_emit_scores(const uint64_t* topk_keys, int kp, int n_queries, int r, float* out, hipStream_t s);
 hipError_t launch_make_thr(const float* tau, const float* margin, int n_queries, int q_pad, float* thr, hipStream_t s);
+hipError_t launch_raise_thr(float* thr_hat, const float* thr_run, int n_queries, hipStream_t s);
 hipError_t launch_count_ge(const uint64_t* topk_keys, int kp, int k, const float* tau, const uint32_t* fail_flags, int n_queries,
                            int32_t* out, hipStream_t s);
 hipError_t launch_merge_topk(int n_queries, int n_in, const float* in_scores, const int64_t* in_rows, int k_out,

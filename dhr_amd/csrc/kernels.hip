@@ -165,16 +165,17 @@ hipError_t launch_tile_rows(const __half* src, int64_t ld, int64_t row_lo, int64
 //   B: lane l holds column l&31, element e: group g=e>>2 (position e&3) where the logical group
 //      G = 4*(g>>1) + 2*(l>>5) + (g&1) covers slices 2G, 2G+1 of the block.
 // Stage image of the corpus (18 KiB): [256 rows][4 chunks of 8 slices, chunk ^ ((row>>2)&3)] fp16, then
-// [256 rows][lane half][block] u16 position words.  Tile = ts sparse stages, then td dense 32 KiB stages.
+// [256 rows][lane half][block] u16 position words.  Tile = ts sparse stages, then td dense stages of 32 columns
+// ([256 rows][4 chunks, chunk ^ ((row>>2)&3)] fp16 = 16 KiB, the same image for corpus and queries).
 __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __restrict__ src, int64_t ld, int64_t row_lo,
                                                                int64_t n_rows_src, int64_t n_rows_fill, int d_dlr,
                                                                int d_cls, int ts, int td, const void* __restrict__ idx,
                                                                int idx_dtype, const uint8_t* __restrict__ map, int abs_dlr,
                                                                char* __restrict__ tiles) {
   const int k = d_dlr + d_cls;
-  const int sp_chunks = ts * 4, dn_chunks = td * 8;
+  const int sp_chunks = ts * 4, dn_chunks = td * 4;
   const int cpr = sp_chunks + dn_chunks;
-  const int64_t tile_bytes = (int64_t)ts * SP_STAGE_A + (int64_t)td * (TILE_HALVES * 2);
+  const int64_t tile_bytes = (int64_t)ts * SP_STAGE_A + (int64_t)td * SP_DENSE;
   const int64_t total = n_rows_fill * cpr;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
     const int64_t rl = g / cpr;
@@ -203,13 +204,13 @@ __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __r
       *(half8*)(stg + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = v;
       *(uint16_t*)(stg + SP_A_BYTES + r * 8 + (cc & 1) * 4 + (cc >> 1) * 2) = (uint16_t)bits;
     } else {
-      const int dc = c - sp_chunks, st = dc >> 3, cc = dc & 7, j0 = d_dlr + dc * 8;
+      const int dc = c - sp_chunks, st = dc >> 2, cc = dc & 3, j0 = d_dlr + dc * 8;
       if (rl < n_rows_src)
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (j0 + e < k) v[e] = (_Float16)__half2float(src[rl * ld + j0 + e]);
-      char* stg = tile + (int64_t)ts * SP_STAGE_A + (int64_t)st * (TILE_HALVES * 2);
-      *(half8*)(stg + r * 128 + ((cc ^ ((r >> 1) & 7)) * 16)) = v;
+      char* stg = tile + (int64_t)ts * SP_STAGE_A + (int64_t)st * SP_DENSE;
+      *(half8*)(stg + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = v;
     }
   }
 }
@@ -217,7 +218,7 @@ hipError_t launch_tile_rows_sparse(const __half* src, int64_t ld, int64_t row_lo
                                    int d_dlr, int d_cls, int ts, int td, const void* idx, int idx_dtype, const uint8_t* map,
                                    bool abs_dlr, char* tiles, hipStream_t s) {
   if (n_rows_fill <= 0) return hipSuccess;
-  const int64_t total = n_rows_fill * (ts * 4 + td * 8);
+  const int64_t total = n_rows_fill * (ts * 4 + td * 4);
   const int64_t blocks = (total + 255) / 256;
   hipLaunchKernelGGL(tile_rows_sparse_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, src, ld,
                      row_lo, n_rows_src, n_rows_fill, d_dlr, d_cls, ts, td, idx, idx_dtype, map, abs_dlr ? 1 : 0, tiles);
@@ -316,31 +317,39 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
     }
   }
   if (ts > 0) {
-    // 2:4 layout: per sparse stage 64 bucket columns per row in smfmac B-operand order, then dense stages
-    char* tile = (char*)q_tiles + (int64_t)(q >> 8) * ((int64_t)(ts + td) * (TILE_HALVES * 2));
+    // 2:4 layout.  A sparse stage holds the row's 32 slice values once, the bucket in the sign bit (the bound
+    // operand is >= 0): the GEMM expands a value v into its two bucket columns (max(v,0), max(-v,0)) in
+    // registers.  Order inside a 16-slice block: [0-3, 8-11 | 4-7, 12-15], the two 16-byte chunks the two
+    // lane halves of the smfmac B operand read.  An ungated batch (plain inner product over a gated index)
+    // carries the sparse stages twice, all values in bucket 0, then all in bucket 1.  Then 32-column dense stages.
+    const int ts_q = idx ? ts : 2 * ts;
+    char* tile = (char*)q_tiles + (int64_t)(q >> 8) * ((int64_t)ts_q * SP_STAGE_B + (int64_t)td * SP_DENSE);
     const int r = q & 255;
-    for (int c = lane; c < (ts + td) * 8; c += 64) {
+    for (int c = lane; c < ts_q * 4 + td * 4; c += 64) {
       half8 h8;
-      const int st = c >> 3, cc = c & 7;
+      if (c < ts_q * 4) {
+        const int st = c >> 2, cc = c & 3;
+        const int kb = cc >> 1, hh = cc & 1;
+        const int cst = st < ts ? st : st - ts;
 #pragma unroll
-      for (int e8 = 0; e8 < 8; ++e8) {
-        float v = 0.f;
-        if (st < ts) {
-          const int kb = cc >> 2, hh = (cc >> 1) & 1, e = (cc & 1) * 8 + e8;      // chunk = (kb*2+h)*2 + (e>>3)
-          const int gq = e >> 2, pos = e & 3;
-          const int G = 4 * (gq >> 1) + 2 * hh + (gq & 1);
-          const int j = st * 32 + kb * 16 + 2 * G + (pos >> 1);
+        for (int e8 = 0; e8 < 8; ++e8) {
+          float v = 0.f;
+          const int j = cst * 32 + kb * 16 + 8 * (e8 >> 2) + 4 * hh + (e8 & 3);
           if (j < d_dlr) {
             v = qval(j);
-            if (idx && bucket_of(qidx(j), j, map, 2) != (pos & 1)) v = 0.f;
             v = abs_dlr ? fabsf(v) : fmaxf(v, 0.f);
+            const int bucket = idx ? bucket_of(qidx(j), j, map, 2) : (st >= ts);
+            if (bucket) v = -v;
           }
-        } else {
-          v = qval(d_dlr + (st - ts) * 64 + cc * 8 + e8);
+          h8[e8] = (_Float16)v;
         }
-        h8[e8] = (_Float16)v;
+        *(half8*)(tile + (int64_t)st * SP_STAGE_B + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = h8;
+      } else {
+        const int dc = c - ts_q * 4, st = dc >> 2, cc = dc & 3;
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) h8[e8] = (_Float16)qval(d_dlr + dc * 8 + e8);
+        *(half8*)(tile + (int64_t)ts_q * SP_STAGE_B + (int64_t)st * SP_DENSE + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = h8;
       }
-      *(half8*)(tile + (int64_t)st * (TILE_HALVES * 2) + r * 128 + ((cc ^ ((r >> 1) & 7)) * 16)) = h8;
     }
   } else
   // operand tile image: gated value in the segment of its bucket (all segments when the batch is
@@ -401,27 +410,32 @@ constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_HALVES * 2;   // 2 stages x (A + B) 
 // in LDS (the staging ring is dead by now), then the whole workgroup flushes the queue -- one global
 // atomic + one 8-byte store per survivor, all in flight at once.  (Appending straight from the
 // accumulator loop costs one dependent L2 round trip per hit, ~20 % of the kernel at 0.2 % hit rate.)
+__device__ __forceinline__ void gemm_dump_tile(const GemmArgs& p, floatx16 (&acc)[4][2], int64_t dt, int qt, int wm, int wn, int lane) {
+  const int fhalf = lane >> 5;
+  const int64_t row_base = dt * TILE_ROWS + wm * 128;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
+    if (q < p.n_queries) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t row = row_base + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+          if (row < p.n_rows && row >= p.dump_row0 && row - p.dump_row0 < p.dump_ld)
+            p.dump[(int64_t)q * p.dump_ld + (row - p.dump_row0)] = acc[mi][ni][e];
+        }
+    }
+  }
+}
 constexpr int EPI_QUEUE = 6144;      // entries of 8 bytes; beyond that a hit is appended directly
-template <bool DUMP>
+template <bool DUMP, int NTHREADS = 512>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, floatx16 (&acc)[4][2], int64_t dt, int qt, int wm, int wn,
-                                              int lane, char* smem) {
+                                              int lane, char* smem, bool has_acc = true) {
   const int fhalf = lane >> 5;
   const int64_t row_base = dt * TILE_ROWS + wm * 128;
   if (DUMP) {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
-      if (q < p.n_queries) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int64_t row = row_base + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
-            if (row < p.n_rows && row >= p.dump_row0 && row - p.dump_row0 < p.dump_ld)
-              p.dump[(int64_t)q * p.dump_ld + (row - p.dump_row0)] = acc[mi][ni][e];
-          }
-      }
-    }
+    if (has_acc) gemm_dump_tile(p, acc, dt, qt, wm, wn, lane);
     return;
   }
   uint2* queue = (uint2*)smem;
@@ -429,6 +443,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, floatx16 (&acc)
   __syncthreads();                       // every wave is done with the staging ring
   if (threadIdx.x == 0) *qn = 0u;
   __syncthreads();
+  if (has_acc)
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int ql = wn * 64 + ni * 32 + (lane & 31);
@@ -454,7 +469,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, floatx16 (&acc)
   }
   __syncthreads();
   const uint32_t n = *qn < EPI_QUEUE ? *qn : EPI_QUEUE;
-  for (uint32_t s = threadIdx.x; s < n; s += GEMM_THREADS) {
+  for (uint32_t s = threadIdx.x; s < n; s += NTHREADS) {
     const uint2 en = queue[s];
     const int q = qt * TILE_ROWS + (int)(en.x & 255u);
     const uint32_t slot = atomicAdd(p.cnt + q, 1u);
@@ -768,14 +783,43 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_v4_kernel(GemmArg
   gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane, smem);
 }
 
-// Sparse-core bound GEMM (two index buckets): ts stages of 32 slices on v_smfmac_f32_32x32x32_f16
-// (corpus = 2:4 sparse A operand: stored slice values + position bits; queries = dense B operand with the
-// two bucket columns per slice), then td ordinary 64-column stages for the ungated dense columns.
-// Same 256 x 256 tile / 8 waves / 128 x 64 per wave / double-buffered 2 x 64 KiB LDS ring as gemm_filter_kernel.
+// Sparse-core bound GEMM (two index buckets), producer / consumer wave specialisation.
+//   ts_q stages of 32 gated slices on v_smfmac_f32_32x32x32_f16 (corpus = 2:4 sparse A operand: stored slice
+//   values + position bits; queries = B operand, held compressed -- one fp16 per slice, bucket in the sign
+//   bit -- and expanded to the two bucket columns per slice with one v_pk_max_f16 per register), then td
+//   stages of 32 ungated columns on v_mfma_f32_32x32x16_f16.  Every stage is 16 matrix instructions per
+//   consumer wave and 32-34 KiB of operand bytes per 256 x 256 tile (the expanded query image would be 50 KiB:
+//   measured, the LDS-DMA stream alone then takes as long as the matrix work).
+// 12 waves: waves 0-7 are CONSUMERS (256 x 256 tile, 128 x 64 per wave, LDS fragment reads + matrix
+// instructions only), waves 8-11 are PRODUCERS (one per SIMD) that do nothing but issue the LDS-DMA of the
+// stage three ahead into a 4-slot ring of 34 KiB slots.  One barrier per stage hands a slot over: producers
+// pass it once the NEXT stage has landed (counted vmcnt, the two stages after that stay in flight),
+// consumers once they are done reading the current slot.
+constexpr int GEMM_PC_THREADS = 768;
+constexpr int GEMM_PC_SLOTS = 4;
+constexpr int GEMM_PC_LDS = GEMM_PC_SLOTS * SP_SLOT + 64;      // 136 KiB ring (the filter epilogue's hit queue reuses it, + its counter word)
 typedef _Float16 half16 __attribute__((ext_vector_type(16)));
 
-template <bool DUMP>
-__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_sparse_kernel(GemmArgs p) {
+// Compressed query fragment -> smfmac B operand: each fp16 slice value v (bucket in the sign bit) becomes its two
+// bucket columns (max(v,0), max(-v,0)), one v_pk_max_f16 per output register.  One asm block, so that the two
+// wait states a matrix instruction needs after a VALU write of its operand (the compiler cannot see through
+// inline asm) are inside it.
+__device__ __forceinline__ void expand_bucket_columns(const uint32_t (&r)[4], uint32_t (&o)[8]) {
+  asm("v_pk_max_f16 %0, %8, 0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
+      "v_pk_max_f16 %1, %8, 0 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
+      "v_pk_max_f16 %2, %9, 0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
+      "v_pk_max_f16 %3, %9, 0 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
+      "v_pk_max_f16 %4, %10, 0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
+      "v_pk_max_f16 %5, %10, 0 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
+      "v_pk_max_f16 %6, %11, 0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
+      "v_pk_max_f16 %7, %11, 0 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
+      "s_nop 1"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
+}
+
+template <bool DUMP, int ABL = 0>   // ABL (timing experiments only, wrong results): 1 no in-loop DMA, 2 no fragment reads, 3 no matrix instructions, 4 no epilogue, 5 = 1 + 2
+__global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int64_t b = blockIdx.x;
   const int xcd = (int)(b & 7);
@@ -792,117 +836,139 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_sparse_kernel(Gem
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2;
-  const int wn = wave & 3;
-  const int ts = p.ts, td = p.td, nst = ts + td;
-  const char* a_src = (const char*)p.a_tiles + dt * ((int64_t)ts * SP_STAGE_A + (int64_t)td * (TILE_HALVES * 2));
-  const char* b_src = (const char*)p.b_tiles + (int64_t)qt * nst * (TILE_HALVES * 2);
-  constexpr int BUF = 2 * TILE_HALVES * 2;          // 64 KiB per ring slot: corpus part at +0, query part at +32 KiB
-
-  auto stage = [&](int buf, int u) {
-    char* la = smem + buf * BUF;
-    char* lb = la + TILE_HALVES * 2;
-    const char* gb = b_src + (int64_t)u * (TILE_HALVES * 2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {                                      // query part: 32 pieces, 4 per wave
-      const int off = (wave * 4 + j) * 1024;
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gb + off + lane * 16), LDS_PTR(lb + off), 16, 0, 0);
-    }
-    if (u < ts) {                                                      // corpus part: 16 value pieces + 2 position pieces
-      const char* ga = a_src + (int64_t)u * SP_STAGE_A;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int off = (wave * 2 + j) * 1024;
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga + off + lane * 16), LDS_PTR(la + off), 16, 0, 0);
-      }
-      if (wave < 2) {
-        const int off = SP_A_BYTES + wave * 1024;
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga + off + lane * 16), LDS_PTR(la + off), 16, 0, 0);
-      }
-    } else {
-      const char* ga = a_src + (int64_t)ts * SP_STAGE_A + (int64_t)(u - ts) * (TILE_HALVES * 2);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int off = (wave * 4 + j) * 1024;
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga + off + lane * 16), LDS_PTR(la + off), 16, 0, 0);
-      }
-    }
-  };
+  const int ts = p.ts, tsq = p.ts_q, td = p.td, nst = tsq + td;
+  const char* a_src = (const char*)p.a_tiles + dt * ((int64_t)ts * SP_STAGE_A + (int64_t)td * SP_DENSE);
+  const char* b_src = (const char*)p.b_tiles + (int64_t)qt * ((int64_t)tsq * SP_STAGE_B + (int64_t)td * SP_DENSE);
 
   floatx16 acc[4][2];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+  const int wm = (wave >> 2) & 1;
+  const int wn = wave & 3;
 
-  const int frow = lane & 31;
-  const int fhalf = lane >> 5;
-  const int swz8 = (frow >> 1) & 7;      // dense / query images: 8 chunks per 128-byte row
-  const int swz4 = (frow >> 2) & 3;      // sparse corpus image: 4 chunks per 64-byte row
-
-  stage(0, 0);
-  __syncthreads();
-  // ---- gated columns on the sparse matrix cores
-  for (int u = 0; u < ts; ++u) {
-    const int buf = u & 1;
-    if (u + 1 < nst) stage(buf ^ 1, u + 1);
-    const char* la = smem + buf * BUF;
-    const char* lb = la + TILE_HALVES * 2;
-    uint32_t pw[4];
+  if (wave >= 8) {
+    // ------------------------------------------------------------------ producers
+    // Fixed roles keep the issue loop to a few scalar instructions per piece (measured: a generic piece loop of
+    // ~20 instructions per piece made the DMA stream itself the bottleneck): producers 0,1 stream the corpus
+    // half-stages (9 + 9 KiB of a sparse stage, 8 + 8 of a dense one), producers 2,3 the query half-stages (8 + 8).
+    const int pw = wave - 8;
+    __builtin_amdgcn_s_setprio(3);     // a producer has a dozen instructions per stage: never let them queue behind the consumers'
+    const bool is_a = pw < 2;
+    const int hf = pw & 1;
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    const char* a_dense = a_src + (int64_t)ts * SP_STAGE_A;
+    const char* b_dense = b_src + (int64_t)tsq * SP_STAGE_B;
+    auto issue = [&](int u) {
+      const bool sp = u < tsq;
+      const char* g;
+      int l;
+      if (is_a) {
+        g = sp ? a_src + (int64_t)(u < ts ? u : u - ts) * SP_STAGE_A + hf * 9216 : a_dense + (int64_t)(u - tsq) * SP_DENSE + hf * 8192;
+        l = sp ? hf * 9216 : hf * 8192;
+      } else {
+        g = (sp ? b_src + (int64_t)u * SP_STAGE_B : b_dense + (int64_t)(u - tsq) * SP_DENSE) + hf * 8192;
+        l = SP_STAGE_A + hf * 8192;
+      }
+      char* lds = smem + (u & (GEMM_PC_SLOTS - 1)) * SP_SLOT + l;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g + j * 1024 + lane_off), LDS_PTR(lds + j * 1024), 16, 0, 0);
+      if (is_a && sp) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g + 8192 + lane_off), LDS_PTR(lds + 8192), 16, 0, 0);
+    };
+    issue(0);
+    if (nst > 1) issue(1);
+    if (nst > 2) issue(2);
+    // every stage is >= 8 pieces per producer: waiting for "<= 8 per stage that may stay in flight" is safe
+    if (nst > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (nst > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                     // stage 0 landed
+#pragma unroll 1
+    for (int u = 0; u < nst; ++u) {
+      // slot (u+3)&3 was read during stage u-1; every consumer passed the barrier that ended it
+      if (u + 3 < nst && ABL != 1 && ABL != 5) issue(u + 3);
+      // stage u+1 must have landed before the barrier; the stages after it stay in flight
+      const int after = (nst - 1 < u + 3 ? nst - 1 : u + 3) - (u + 1);
+      if (ABL == 1 || ABL == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    // ------------------------------------------------------------------ consumers
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
-      pw[mi] = *(const uint32_t*)(la + SP_A_BYTES + (wm * 128 + mi * 32 + frow) * 8 + fhalf * 4);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      half8 af[4];
-      half16 bf[2];
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-        af[mi] = *(const half8*)(la + (wm * 128 + mi * 32 + frow) * 64 + (((kb * 2 + fhalf) ^ swz4) * 16));
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+    const int frow = lane & 31;
+    const int fhalf = lane >> 5;
+    // Per-lane LDS offsets inside a ring slot, kept in a handful of registers (everything else is an
+    // immediate offset of the ds_read): the wave has 168 registers at 3 waves per SIMD, 128 are accumulators.
+    // All three images (corpus values, query values, dense columns of either side) have 64-byte rows with the
+    // 16-byte chunk c stored at c ^ ((row>>2)&3); 16-slice / 16-column block kb is chunk kb*2 + fhalf.
+    const int swz4 = (frow >> 2) & 3;
+    const int a_row = (wm * 128 + frow) * 64;                         // + mi*2048
+    const int a_c0 = a_row + ((fhalf ^ swz4) << 4);
+    const int a_c1 = a_row + (((2 + fhalf) ^ swz4) << 4);
+    const int q_row = SP_STAGE_A + (wn * 64 + frow) * 64;             // + ni*2048
+    const int q_c0 = q_row + ((fhalf ^ swz4) << 4), q_c1 = q_row + (((2 + fhalf) ^ swz4) << 4);
+    const int p_off = SP_A_BYTES + (wm * 128 + frow) * 8 + fhalf * 4; // position words, + mi*256
+    half8 abl_f;
+    if (ABL == 2 || ABL == 5) { for (int e = 0; e < 8; ++e) abl_f[e] = (_Float16)(0.001f * (float)(lane + e)); asm volatile("" : "+v"(abl_f)); }
+    __builtin_amdgcn_s_barrier();
+    // ---- gated columns: sparse matrix cores
+#pragma unroll 1
+    for (int u = 0; u < tsq; ++u) {
+      const char* sl = smem + (u & (GEMM_PC_SLOTS - 1)) * SP_SLOT;
+      uint32_t pwd[4];
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const char* rowp = lb + (wn * 64 + ni * 32 + frow) * 128;
-        const int c0 = (kb * 2 + fhalf) * 2;
-        const half8 lo = *(const half8*)(rowp + ((c0 ^ swz8) * 16));
-        const half8 hi = *(const half8*)(rowp + (((c0 + 1) ^ swz8) * 16));
+      for (int mi = 0; mi < 4; ++mi) pwd[mi] = (ABL == 2 || ABL == 5) ? 0x44444444u : *(const uint32_t*)(sl + p_off + mi * 256);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { bf[ni][e] = lo[e]; bf[ni][8 + e] = hi[e]; }
-      }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          if (kb == 0) acc[mi][ni] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(af[mi], bf[ni], acc[mi][ni], (int)pw[mi], 0, 0);
-          else acc[mi][ni] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(af[mi], bf[ni], acc[mi][ni], (int)pw[mi], 0, 1);
+          // compressed query fragment -> the lane's 16 B-operand elements: slice value v becomes (max(v,0), max(-v,0))
+          union { half8 h; uint32_t w[4]; } raw;
+          raw.h = (ABL == 2 || ABL == 5) ? abl_f : *(const half8*)(sl + (kb ? q_c1 : q_c0) + ni * 2048);
+          union { half16 h; uint32_t w[8]; } bf;
+          expand_bucket_columns(raw.w, bf.w);
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) {
+            const half8 af = (ABL == 2 || ABL == 5) ? abl_f : *(const half8*)(sl + (kb ? a_c1 : a_c0) + mi * 2048);
+            if (ABL == 3) { asm volatile("" :: "v"(af), "v"(bf.w[0]), "v"(bf.w[7]), "v"(pwd[mi])); continue; }
+            if (kb == 0) acc[mi][ni] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(af, bf.h, acc[mi][ni], (int)pwd[mi], 0, 0);
+            else acc[mi][ni] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(af, bf.h, acc[mi][ni], (int)pwd[mi], 0, 1);
+          }
         }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of the slot are complete
+      __builtin_amdgcn_s_barrier();
     }
-    __syncthreads();
-  }
-  // ---- ungated dense columns
-  for (int u = ts; u < nst; ++u) {
-    const int buf = u & 1;
-    if (u + 1 < nst) stage(buf ^ 1, u + 1);
-    const char* la = smem + buf * BUF;
-    const char* lb = la + TILE_HALVES * 2;
+    // ---- ungated columns: 32 per stage
+#pragma unroll 1
+    for (int u = tsq; u < nst; ++u) {
+      const char* sl = smem + (u & (GEMM_PC_SLOTS - 1)) * SP_SLOT;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int coff = ((kk * 2 + fhalf) ^ swz8) * 16;
-      half8 af[4], bf[2];
+      for (int kk = 0; kk < 2; ++kk) {
+        half8 bf[2];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) af[mi] = *(const half8*)(la + (wm * 128 + mi * 32 + frow) * 128 + coff);
+        for (int ni = 0; ni < 2; ++ni) bf[ni] = (ABL == 2 || ABL == 5) ? abl_f : *(const half8*)(sl + (kk ? q_c1 : q_c0) + ni * 2048);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) bf[ni] = *(const half8*)(lb + (wn * 64 + ni * 32 + frow) * 128 + coff);
+        for (int mi = 0; mi < 4; ++mi) {
+          const half8 af = (ABL == 2 || ABL == 5) ? abl_f : *(const half8*)(sl + (kk ? a_c1 : a_c0) + mi * 2048);
+          if (ABL == 3) { asm volatile("" :: "v"(af), "v"(bf[0]), "v"(bf[1])); continue; }
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[ni], acc[mi][ni], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
-    __syncthreads();
   }
-  gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane, smem);
+  if (ABL == 4) { if (wave < 8) asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1])); return; }
+  gemm_epilogue<DUMP, GEMM_PC_THREADS>(p, acc, dt, qt, wm, wn, lane, smem, wave < 8);
 }
 
 // One-wave-per-SIMD variant: 4 waves (256 threads), each owns a 128 x 128 quadrant of the 256 x 256
@@ -1118,14 +1184,22 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
   if (a.ts > 0) {
     static bool attrs = false;
     if (!attrs) {
-      (void)hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-      (void)hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_PC_LDS);
+      if (e != hipSuccess) return e;
+      e = hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_PC_LDS);
+      if (e != hipSuccess) return e;
       attrs = true;
     }
+    const unsigned grid = (unsigned)blocks;
     if (a.dump)
-      hipLaunchKernelGGL(gemm_filter_sparse_kernel<true>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
-    else
-      hipLaunchKernelGGL(gemm_filter_sparse_kernel<false>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+      hipLaunchKernelGGL(gemm_filter_sparse_kernel<true>, dim3(grid), dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a);
+    else if (g_gemm_ablate >= 1 && g_gemm_ablate <= 5) {
+#define SP_ABL(N) { (void)hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_PC_LDS); \
+      hipLaunchKernelGGL((gemm_filter_sparse_kernel<false, N>), dim3(grid), dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a); }
+      if (g_gemm_ablate == 1) SP_ABL(1) else if (g_gemm_ablate == 2) SP_ABL(2) else if (g_gemm_ablate == 3) SP_ABL(3) else if (g_gemm_ablate == 4) SP_ABL(4) else SP_ABL(5)
+#undef SP_ABL
+    } else
+      hipLaunchKernelGGL(gemm_filter_sparse_kernel<false>, dim3(grid), dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a);
   } else if (g_gemm_variant == 2) {
     static bool attr2 = false;
     if (!attr2) {
@@ -1252,6 +1326,8 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
   __syncthreads();
   const int sub = threadIdx.x & 7;
   const float t = p.thr[q];
+  // (A variant that issued the loads of all 8 candidates of a lane group up front ran 30 % SLOWER: 4x the gathers
+  // in flight per CU only thrash the memory system; the dependent chain below at 8 waves per SIMD is the sweet spot.)
   for (uint32_t i = base + (threadIdx.x >> 3); i < base + REFINE_PER_WG; i += 32) {
     float corr = 0.f;
     uint2 c = make_uint2(0u, 0u);
@@ -1664,6 +1740,17 @@ __global__ void make_thr_kernel(const float* __restrict__ tau, const float* __re
 }
 hipError_t launch_make_thr(const float* tau, const float* margin, int n_queries, int q_pad, float* thr, hipStream_t s) {
   hipLaunchKernelGGL(make_thr_kernel, dim3((q_pad + 255) / 256), dim3(256), 0, s, tau, margin, n_queries, q_pad, thr);
+  return hipGetLastError();
+}
+// Main pass: raise the filter thresholds to the running exact ones (the k-th best exact score found so far is a
+// valid threshold at any time; the sampled tau_hat is only the starting point).  The bound GEMM of the next
+// chunk may be reading thr_hat meanwhile: either value of a word is a valid threshold.
+__global__ void raise_thr_kernel(float* __restrict__ thr_hat, const float* __restrict__ thr_run, int n_queries) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n_queries) thr_hat[q] = fmaxf(thr_hat[q], thr_run[q]);
+}
+hipError_t launch_raise_thr(float* thr_hat, const float* thr_run, int n_queries, hipStream_t s) {
+  hipLaunchKernelGGL(raise_thr_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, thr_hat, thr_run, n_queries);
   return hipGetLastError();
 }
 // Rows of the final list that reach tau (all valid rows when tau is null); -1 when the shard's lists overflowed.

@@ -53,7 +53,7 @@ typedef struct dhr_index_desc {
   int64_t ld_value;    /* elements between consecutive rows (>= d_dlr + d_cls) */
   const void* index;   /* or NULL */
   int32_t index_dtype; /* dhr_idx_dtype */
-  int32_t idx_buckets; /* index buckets per gated slice in the bound GEMM operands (0 = default 3; 1 = ungated bound) */
+  int32_t idx_buckets; /* index buckets per gated slice in the bound GEMM operands (0 = default: 2, on the 2:4 sparse matrix cores; 1 = ungated bound) */
   int64_t ld_index;    /* elements between consecutive rows (>= d_dlr) */
   int64_t row_offset;  /* global row id of local row 0; added to every returned row */
 } dhr_index_desc;
@@ -93,8 +93,11 @@ typedef enum dhr_param {
   DHR_PARAM_FIRST_ROWS = 2,   /* rows scored exhaustively to seed the thresholds (>= k enforced) */
   DHR_PARAM_PROFILE = 3,      /* 1: record per-kernel hipEvent timings into dhr_search_stats */
   DHR_PARAM_MAX_GROWTH = 4,   /* max (next chunk rows) / (rows seen), in 1/16ths (default 32 = 2x) */
-  DHR_PARAM_MAIN_CHUNKS = 7,  /* main-pass chunks whose rescoring overlaps the next chunk's GEMM (default 4) */
-  DHR_PARAM_GEMM_VARIANT = 6, /* process-wide: 0 = single-phase bound GEMM, 1 = ping-pong wave groups (default) */
+  DHR_PARAM_MAIN_CHUNKS = 7,  /* lower limit of the number of main-pass chunks (the controller adds chunks so that the candidate lists fit) */
+  DHR_PARAM_AUX_CUS = 9,      /* main pass: confine refine / rescoring / select to this many CUs (multiple of 8, spread over the XCDs; 0 = no CU mask) */
+  DHR_PARAM_GEMM_EXCLUSIVE = 10, /* with AUX_CUS: 1 = run the bound GEMM on the other CUs only */
+  DHR_PARAM_PROGRESSIVE_THR = 8, /* 1 (default): later main-pass chunks filter with the running exact k-th best, not only the sampled threshold */
+  DHR_PARAM_GEMM_VARIANT = 6, /* process-wide, dense-only / >2-bucket bound GEMM: 3 (default), 0, 2, 4 = tuning variants */
   DHR_PARAM_SAMPLE_PERIOD = 5 /* every S-th corpus tile seeds the thresholds (default 16; 0 = plain streaming) */
 } dhr_param;
 
