@@ -93,7 +93,7 @@ struct dhr_index {
   int main_chunks = 2;
   int progressive_thr = 1;
   int n_cu = 256;
-  int aux_cus = 0, gemm_exclusive = 0;   // CU-masked streams of the main pass (0 = off)
+  int aux_cus = 128, gemm_exclusive = 0;   // CU-masked streams of the main pass (0 = off)
   int aux_cus_made = -1, gemm_excl_made = -1;
   hipStream_t s_gemm = nullptr;         // main-pass GEMM stream when CU masks are in use
   hipStream_t s_aux = nullptr;          // non-blocking stream for rescoring/select overlapped with the main-pass GEMM

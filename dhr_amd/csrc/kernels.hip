@@ -1462,42 +1462,87 @@ __device__ __forceinline__ void bitonic_desc(uint64_t* keys, int n, int tid, int
   }
 }
 
-__global__ void __launch_bounds__(SELECT_THREADS) select_kernel(SelectArgs p) {
+__device__ __forceinline__ int count_greater(const uint64_t* arr, int n, uint64_t key) {   // arr sorted descending
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (arr[mid] > key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// Merge one query's rescored keys into its running top-k list (k <= 4096).  LDS: A = the running list (kps keys,
+// sorted descending), B = the new keys that beat the current k-th (a chunk of the main pass brings ~k/M of them).
+// Only B is sorted (bitonic, next power of two >= its fill); A and B are then merged by rank: every key's final
+// position is its own index plus the number of keys of the other list that beat it (keys are unique: the row
+// id is part of the key).  A full re-sort of kps + |B| keys per call cost 2.5x the barriers.
+constexpr int SELECT_SM_THREADS = 256;
+__global__ void __launch_bounds__(SELECT_SM_THREADS) select_kernel(SelectArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint64_t* keys = (uint64_t*)smem;
-  int& fill = *(int*)(smem + (size_t)p.sort_n * 8);
-  const int kps = p.kps;                      // <= p.kp: only this prefix of the running list is live   // all LDS in the dynamic region (keeps it 16-B aligned)
+  uint64_t* A = (uint64_t*)smem;
+  int& fill = *(int*)(smem + (size_t)p.sort_n * 8);      // all LDS in the dynamic region (keeps it 16-B aligned)
+  const int kps = p.kps;                      // <= p.kp: only this prefix of the running list is live
+  uint64_t* B = A + kps;
   const int q = blockIdx.x;
   const int tid = threadIdx.x;
   uint32_t count = p.cnt ? p.cnt[q] : p.count_all;
   if (p.cnt && count > p.cap) count = p.cap;
   uint64_t* topk = p.topk_keys + (int64_t)q * p.kp;
   const uint64_t* in = p.in_keys + (int64_t)q * p.ld_keys;
-  for (int j = tid; j < kps; j += SELECT_THREADS) keys[j] = topk[j];
-  if (tid == 0) fill = kps;
+  for (int j = tid; j < kps; j += SELECT_SM_THREADS) A[j] = topk[j];
+  if (tid == 0) fill = 0;
   __syncthreads();
-  const uint32_t room = p.sort_n - kps;
+  uint32_t room = 64;                         // input keys per round: a power of two that fits behind A, at most 2048
+  while (room * 2 <= (uint32_t)(p.sort_n - kps) && room < 2048) room <<= 1;
   for (uint32_t base = 0; base < count; base += room) {
-    const uint64_t kth = keys[p.k - 1];
+    const uint64_t kth = A[p.k - 1];
     __syncthreads();
     const uint32_t end = (base + room < count) ? base + room : count;
-    for (uint32_t j = base + tid; j < end; j += SELECT_THREADS) {
+    for (uint32_t j = base + tid; j < end; j += SELECT_SM_THREADS) {
       const uint64_t key = in[j];
-      if (key > kth) keys[atomicAdd(&fill, 1)] = key;
+      if (key > kth) B[atomicAdd(&fill, 1)] = key;
     }
     __syncthreads();
-    const int live = fill;
-    int n = kps;
-    while (n < live) n <<= 1;
-    for (int j = live + tid; j < n; j += SELECT_THREADS) keys[j] = 0ull;
+    const int m = fill;
+    if (m > 0) {
+      int m2 = 2;
+      while (m2 < m) m2 <<= 1;
+      for (int j = m + tid; j < m2; j += SELECT_SM_THREADS) B[j] = 0ull;
+      __syncthreads();
+      bitonic_desc(B, m2, tid, SELECT_SM_THREADS);
+      uint64_t ka[16], kb[8];
+      int da[16], db[8];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = tid + e * SELECT_SM_THREADS;
+        da[e] = kps;
+        if (i < kps) { ka[e] = A[i]; da[e] = ka[e] ? i + count_greater(B, m, ka[e]) : kps; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = tid + e * SELECT_SM_THREADS;
+        db[e] = kps;
+        if (j < m) { kb[e] = B[j]; db[e] = j + count_greater(A, kps, kb[e]); }
+      }
+      // every live key has a distinct final position; positions no key lands on (the tail, when the list is
+      // not full yet) must read as empty
+      const int total = min(kps, m + count_greater(A, kps, 0ull));
+      __syncthreads();
+      for (int j = total + tid; j < kps; j += SELECT_SM_THREADS) A[j] = 0ull;
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (da[e] < kps) A[da[e]] = ka[e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (db[e] < kps) A[db[e]] = kb[e];
+    }
     __syncthreads();
-    if (live > kps) bitonic_desc(keys, n, tid, SELECT_THREADS);
-    if (tid == 0) fill = kps;
+    if (tid == 0) fill = 0;
     __syncthreads();
   }
-  for (int j = tid; j < kps; j += SELECT_THREADS) topk[j] = (j < p.k) ? keys[j] : 0ull;
+  for (int j = tid; j < kps; j += SELECT_SM_THREADS) topk[j] = (j < p.k) ? A[j] : 0ull;
   if (tid == 0) {
-    const uint64_t kth = keys[p.k - 1];
+    const uint64_t kth = A[p.k - 1];
     const float t = kth ? ordered_f32((uint32_t)(kth >> 32)) : -INFINITY;
     p.tau[q] = t;
     p.thr[q] = (q < p.n_queries) ? t - p.margin[q] : INFINITY;
@@ -1509,14 +1554,6 @@ __global__ void __launch_bounds__(SELECT_THREADS) select_kernel(SelectArgs p) {
 // and new key computes its final position (own index + number of keys of the other sequence that beat
 // it, by binary search), then all keys are written at once.
 constexpr int SELECT_BIG_BATCH = 2048;
-__device__ __forceinline__ int count_greater(const uint64_t* arr, int n, uint64_t key) {   // arr sorted descending
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (arr[mid] > key) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
 __global__ void __launch_bounds__(SELECT_THREADS) select_big_kernel(SelectArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint64_t* A = (uint64_t*)smem;
@@ -1597,7 +1634,7 @@ hipError_t launch_select(const SelectArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_bytes = bytes;
   }
-  hipLaunchKernelGGL(select_kernel, dim3((unsigned)a.n_queries), dim3(SELECT_THREADS), bytes, s, a);
+  hipLaunchKernelGGL(select_kernel, dim3((unsigned)a.n_queries), dim3(SELECT_SM_THREADS), bytes, s, a);
   return hipGetLastError();
 }
 
