@@ -926,19 +926,24 @@ __global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(
       for (int mi = 0; mi < 4; ++mi) pwd[mi] = (ABL == 2 || ABL == 5) ? 0x44444444u : *(const uint32_t*)(sl + p_off + mi * 256);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
+        // all six fragment reads of the 16-slice block go out first (4 corpus, 2 compressed query), so that the
+        // LDS latency is paid once per 8 matrix instructions
+        half8 af[4];
+        union { half8 h; uint32_t w[4]; } raw[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) raw[ni].h = (ABL == 2 || ABL == 5) ? abl_f : *(const half8*)(sl + (kb ? q_c1 : q_c0) + ni * 2048);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[mi] = (ABL == 2 || ABL == 5) ? abl_f : *(const half8*)(sl + (kb ? a_c1 : a_c0) + mi * 2048);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           // compressed query fragment -> the lane's 16 B-operand elements: slice value v becomes (max(v,0), max(-v,0))
-          union { half8 h; uint32_t w[4]; } raw;
-          raw.h = (ABL == 2 || ABL == 5) ? abl_f : *(const half8*)(sl + (kb ? q_c1 : q_c0) + ni * 2048);
           union { half16 h; uint32_t w[8]; } bf;
-          expand_bucket_columns(raw.w, bf.w);
+          expand_bucket_columns(raw[ni].w, bf.w);
 #pragma unroll
           for (int mi = 0; mi < 4; ++mi) {
-            const half8 af = (ABL == 2 || ABL == 5) ? abl_f : *(const half8*)(sl + (kb ? a_c1 : a_c0) + mi * 2048);
-            if (ABL == 3) { asm volatile("" :: "v"(af), "v"(bf.w[0]), "v"(bf.w[7]), "v"(pwd[mi])); continue; }
-            if (kb == 0) acc[mi][ni] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(af, bf.h, acc[mi][ni], (int)pwd[mi], 0, 0);
-            else acc[mi][ni] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(af, bf.h, acc[mi][ni], (int)pwd[mi], 0, 1);
+            if (ABL == 3) { asm volatile("" :: "v"(af[mi]), "v"(bf.w[0]), "v"(bf.w[7]), "v"(pwd[mi])); continue; }
+            if (kb == 0) acc[mi][ni] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(af[mi], bf.h, acc[mi][ni], (int)pwd[mi], 0, 0);
+            else acc[mi][ni] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(af[mi], bf.h, acc[mi][ni], (int)pwd[mi], 0, 1);
           }
         }
       }

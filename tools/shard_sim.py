@@ -12,6 +12,9 @@ def main():
     ap.add_argument("--workload", default="hybrid")
     ap.add_argument("--n-docs", type=int, default=8_841_823)
     ap.add_argument("--n-queries", type=int, default=6980)
+    ap.add_argument("--first-rows", type=int, default=0)
+    ap.add_argument("--cand-cap", type=int, default=65536)
+    ap.add_argument("--sample-period", type=int, default=-1)
     a = ap.parse_args()
     import torch
     import bench
@@ -28,7 +31,11 @@ def main():
         cv, ci = bench.gen_shard(torch, synth, dev, 1237 + 1000 * r, hi - lo, d_dlr, d_cls, 30, 90, False)
         ix = GipIndex(cv, ci, row_offset=lo)
         ix.set_param(_lib.PARAM_PROFILE, 1)
-        ix.set_param(_lib.PARAM_CAND_CAP, 65536)
+        ix.set_param(_lib.PARAM_CAND_CAP, a.cand_cap)
+        if a.first_rows:
+            ix.set_param(_lib.PARAM_FIRST_ROWS, a.first_rows)
+        if a.sample_period >= 0:
+            ix.set_param(_lib.PARAM_SAMPLE_PERIOD, a.sample_period)
         shards.append(ix)
         del cv, ci
         torch.cuda.empty_cache()
