@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--idx-buckets", type=int, default=0)
     ap.add_argument("--sample-period", type=int, default=-1)
     ap.add_argument("--main-chunks", type=int, default=0)
+    ap.add_argument("--max-growth", type=int, default=0, help="tuning: max (next sampled chunk) / (rows seen) in 1/16ths")
     ap.add_argument("--aux-cus", type=int, default=-1, help="tuning: CUs the refine/rescoring stream is confined to (0 = no mask)")
     ap.add_argument("--gemm-exclusive", type=int, default=-1)
     ap.add_argument("--no-progressive-thr", action="store_true", help="A/B: keep the sampled thresholds frozen over the main pass")
@@ -130,6 +131,8 @@ def main():
         index.set_param(_lib.PARAM_CAND_CAP, args.cand_cap)
     if args.sample_period >= 0:
         index.set_param(_lib.PARAM_SAMPLE_PERIOD, args.sample_period)
+    if args.max_growth:
+        index.set_param(_lib.PARAM_MAX_GROWTH, args.max_growth)
     if args.aux_cus >= 0:
         index.set_param(_lib.PARAM_AUX_CUS, args.aux_cus)
     if args.gemm_exclusive >= 0:
@@ -205,7 +208,13 @@ def main():
                                     if d_dlr and args.idx_buckets in (0, 2) else
                                     "gemm_filter_v3_kernel (bound GEMM + fused threshold filter)"),
                          "achieved": round(ach_tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach_tf / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach_tf / MFMA_PEAK_TFLOPS, 4),
+                         # fabric-side (Infinity Cache + HBM) read bytes per launch: PMC passes cannot run inside this process,
+                         # so this is the per-corpus-row figure of profiles/r01d_gemm_pmc.txt (FETCH_SIZE x2, rocprofv3 --pmc on
+                         # the same kernel, 6 980 queries) x the average rows per launch; only quoted for that configuration
+                         "traffic": (round(35.6e3 * stats_acc.get("gemm_rows", 0) / max(launches, 1), 0)
+                                     if d_dlr == 768 and d_cls == 768 and nq == 6980 and args.idx_buckets in (0, 2) and world == 1 else None),
+                         "traffic_unit": "bytes per launch (FETCH_SIZE, gfx950-corrected; profiles/r01d_gemm_pmc.txt)",
                          "launches": launches, "avg_launch_ms": round(gemm_ms / max(launches, 1), 3),
                          "alg_flops_per_step": gemm_flops_alg / args.steps},
             "whole_job_frac_of_gemm_roofline": round(qps * 2.0 * n * K / (MFMA_PEAK_TFLOPS * 1e12 * world), 4),

@@ -687,11 +687,15 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
           m_aux[i] = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
           m_gemm[i] = ix->gemm_exclusive ? ~m_aux[i] : 0xffffffffu;
         }
-        HIP_TRY(hipExtStreamCreateWithCUMask(&ix->s_aux, 8, m_aux));
-        HIP_TRY(hipExtStreamCreateWithCUMask(&ix->s_gemm, 8, m_gemm));
-      } else {
-        HIP_TRY(hipStreamCreateWithFlags(&ix->s_aux, hipStreamNonBlocking));
+        // (a runtime that refuses the mask -- other CU count, masking disabled -- just gets the unmasked streams)
+        if (hipExtStreamCreateWithCUMask(&ix->s_aux, 8, m_aux) != hipSuccess ||
+            hipExtStreamCreateWithCUMask(&ix->s_gemm, 8, m_gemm) != hipSuccess) {
+          (void)hipGetLastError();
+          if (ix->s_aux) { hipStreamDestroy(ix->s_aux); ix->s_aux = nullptr; }
+          if (ix->s_gemm) { hipStreamDestroy(ix->s_gemm); ix->s_gemm = nullptr; }
+        }
       }
+      if (!ix->s_aux) HIP_TRY(hipStreamCreateWithFlags(&ix->s_aux, hipStreamNonBlocking));
       ix->aux_cus_made = ix->aux_cus; ix->gemm_excl_made = ix->gemm_exclusive;
     }
     hipStream_t sb = ix->s_aux;

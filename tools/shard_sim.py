@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--n-docs", type=int, default=8_841_823)
     ap.add_argument("--n-queries", type=int, default=6980)
     ap.add_argument("--first-rows", type=int, default=0)
+    ap.add_argument("--max-growth", type=int, default=0)
     ap.add_argument("--cand-cap", type=int, default=65536)
     ap.add_argument("--sample-period", type=int, default=-1)
     a = ap.parse_args()
@@ -32,6 +33,8 @@ def main():
         ix = GipIndex(cv, ci, row_offset=lo)
         ix.set_param(_lib.PARAM_PROFILE, 1)
         ix.set_param(_lib.PARAM_CAND_CAP, a.cand_cap)
+        if a.max_growth:
+            ix.set_param(_lib.PARAM_MAX_GROWTH, a.max_growth)
         if a.first_rows:
             ix.set_param(_lib.PARAM_FIRST_ROWS, a.first_rows)
         if a.sample_period >= 0:
