@@ -18,7 +18,7 @@ PARAM_CAND_CAP, PARAM_FIRST_ROWS, PARAM_PROFILE, PARAM_MAX_GROWTH, PARAM_SAMPLE_
 EXPORTS = ["dhr_version", "dhr_last_error", "dhr_index_create", "dhr_index_destroy", "dhr_index_set_param",
            "dhr_index_device_bytes", "dhr_search", "dhr_score_rows", "dhr_merge_topk", "dhr_merge_topk_host",
            "dhr_get_stats", "dhr_debug_bound_scores", "dhr_debug_gemm_time", "dhr_search_sample_rank", "dhr_search_begin",
-           "dhr_search_finish"]
+           "dhr_search_finish", "dhr_search_rerank"]
 
 
 class DhrError(RuntimeError):
@@ -80,6 +80,8 @@ def load():
     lib.dhr_index_device_bytes.argtypes = [C.c_void_p]
     lib.dhr_index_device_bytes.restype = C.c_int64
     lib.dhr_search.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.dhr_search_rerank.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.POINTER(QueryBatch), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.c_int32, C.c_void_p]
     lib.dhr_score_rows.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.dhr_merge_topk.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p]

@@ -858,6 +858,85 @@ extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, f
   return DHR_OK;
 }
 
+// Two-stage approximate GIP on the device (gip_retrieval.py:128-156): stage 1 is an ordinary search of the
+// restricted batch for k1 rows, stage 2 the exact gated inner product of the full batch on exactly those rows
+// and the top-k of that; the k1 rows never leave the device.
+extern "C" int dhr_search_rerank(dhr_index* ix, const dhr_query_batch* qb1, const dhr_query_batch* qb2, int32_t k1, int32_t k,
+                                 float* out_scores, int64_t* out_rows, int32_t out_mem_kind, void* stream) {
+  int rc = check_queries(ix, qb1);
+  if (rc) return rc;
+  if ((rc = check_queries(ix, qb2)) != DHR_OK) return rc;
+  if (qb1->n_queries != qb2->n_queries) return set_error(DHR_ERR_INVALID, "the two query batches differ in n_queries");
+  if (k <= 0 || k1 < k) return set_error(DHR_ERR_INVALID, "need 0 < k <= k1");
+  if (k1 > 16384) return set_error(DHR_ERR_UNSUPPORTED, "k1 > 16384 is not supported by the LDS top-k merge");
+  if (!out_scores || !out_rows) return set_error(DHR_ERR_INVALID, "null output pointer");
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int Q = qb1->n_queries;
+  hipEvent_t ev0, ev1;
+  HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
+  HIP_TRY(hipEventRecord(ev0, s));
+  Timer tm{ix->profile != 0, s, {}, {}};
+  dhr_search_stats st{};
+  st.n_rows = ix->n_rows; st.n_queries = Q; st.k = k;
+  Workspace& w = ix->ws;
+  // ---- stage 1
+  if ((rc = search_core(ix, w, qb1, k1, 0, tm, st, s)) != DHR_OK) return rc;
+  // ---- stage 2: exact scores of the stage-1 rows under the full batch, top-k of those
+  uint32_t* d_rows32 = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_rows32, (size_t)Q * k1 * 4));
+  auto done = [&](int code) { hipFree(d_rows32); return code; };
+  if (launch_keys_to_rows(w.topk_keys, w.kp, Q, k1, d_rows32, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "keys_to_rows launch failed"));
+  if (w.keys_ld < k1) return done(set_error(DHR_ERR_INTERNAL, "key buffer smaller than k1"));
+  const bool gate2 = ix->d_dlr > 0 && qb2->index != nullptr && qb2->index_dtype != DHR_IDX_NONE;
+  tm.begin(T_PREP);
+  if ((rc = prep_queries(ix, w, qb2, s)) != DHR_OK) return done(rc);
+  if (hipMemsetAsync(w.topk_keys, 0, (size_t)w.q_pad * w.kp * 8, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "memset failed"));
+  tm.end();
+  RescoreArgs r = base_rescore_args(ix, w, Q, gate2);
+  r.rows32 = d_rows32; r.ld_rows = k1; r.count_all = (uint32_t)k1; r.max_count = (uint32_t)k1;
+  r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
+  tm.begin(T_RESCORE);
+  if (launch_rescore(r, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "rescore launch failed"));
+  tm.end();
+  st.candidates_exact += (int64_t)Q * k1;
+  SelectArgs sel{};
+  sel.topk_keys = w.topk_keys; sel.in_keys = w.rs_keys; sel.ld_keys = w.keys_ld; sel.cap = (uint32_t)w.cap;
+  sel.cnt = nullptr; sel.count_all = (uint32_t)k1;
+  sel.k = k; sel.kp = w.kp; sel.sort_n = 4 * w.kp;
+  sel.kps = 64; while (sel.kps < k) sel.kps <<= 1;
+  sel.margin = w.margin; sel.tau = w.tau; sel.thr = w.thr; sel.n_queries = Q;
+  tm.begin(T_SELECT);
+  if (launch_select(sel, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "select launch failed"));
+  tm.end();
+  // ---- results
+  float* d_scores = out_scores;
+  int64_t* d_rows = out_rows;
+  if (out_mem_kind == DHR_MEM_HOST) {
+    const size_t need = (size_t)Q * k * 12;
+    if ((rc = grow(w.out_stage, w.out_stage_bytes, need, w.bytes)) != DHR_OK) return done(rc);
+    d_rows = (int64_t*)w.out_stage;
+    d_scores = (float*)((char*)w.out_stage + (size_t)Q * k * 8);
+  }
+  if (launch_emit(w.topk_keys, w.kp, Q, k, ix->row_offset, d_scores, d_rows, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "emit launch failed"));
+  if (out_mem_kind == DHR_MEM_HOST) {
+    if (hipMemcpyAsync(out_rows, d_rows, (size_t)Q * k * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(out_scores, d_scores, (size_t)Q * k * 4, hipMemcpyDeviceToHost, s) != hipSuccess)
+      return done(set_error(DHR_ERR_HIP, "D2H failed"));
+  }
+  if (hipEventRecord(ev1, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "two-stage search failed on the device"));
+  float total = 0.f;
+  hipEventElapsedTime(&total, ev0, ev1);
+  hipEventDestroy(ev0); hipEventDestroy(ev1);
+  st.total_ms = total;
+  double ms[5] = {0, 0, 0, 0, 0};
+  tm.collect(ms);
+  st.gemm_ms = ms[T_GEMM]; st.refine_ms = ms[T_REFINE]; st.rescore_ms = ms[T_RESCORE]; st.select_ms = ms[T_SELECT];
+  st.prep_ms = ms[T_PREP];
+  ix->stats = st;
+  return done(DHR_OK);
+}
+
 // ---- staged search for the row-sharded path (dhr_amd/dist.py): the shards agree on ONE threshold per
 // query after their sampled runs, so each shard collects only its share of the global top-k.
 extern "C" int32_t dhr_search_sample_rank(const dhr_index* ix, int32_t k) {

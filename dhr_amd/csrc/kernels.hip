@@ -1658,6 +1658,21 @@ __global__ void emit_kernel(const uint64_t* __restrict__ topk_keys, int kp, int 
     out_rows[g] = -1;
   }
 }
+// Stage 2 of the two-stage modes: the rows of a sorted key list as a dense [n_queries][k] table of local rows
+// (0xFFFFFFFF = empty slot) for the exact rescoring.
+__global__ void keys_to_rows_kernel(const uint64_t* __restrict__ topk_keys, int kp, int n_queries, int k, uint32_t* __restrict__ rows) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (int64_t)n_queries * k) return;
+  const int q = (int)(g / k), j = (int)(g - (int64_t)q * k);
+  const uint64_t key = topk_keys[(int64_t)q * kp + j];
+  rows[g] = key ? 0xFFFFFFFFu - (uint32_t)key : 0xFFFFFFFFu;
+}
+hipError_t launch_keys_to_rows(const uint64_t* topk_keys, int kp, int n_queries, int k, uint32_t* rows, hipStream_t s) {
+  const int64_t total = (int64_t)n_queries * k;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(keys_to_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, topk_keys, kp, n_queries, k, rows);
+  return hipGetLastError();
+}
 hipError_t launch_emit(const uint64_t* topk_keys, int kp, int n_queries, int k, int64_t row_offset, float* out_scores,
                        int64_t* out_rows, hipStream_t s) {
   const int64_t total = (int64_t)n_queries * k;

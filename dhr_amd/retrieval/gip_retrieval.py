@@ -91,6 +91,19 @@ class GipIndex:
         del keep
         return scores, rows
 
+    def search_rerank(self, q1_value, q1_index, q_value, q_index, k1: int, k: int, *, stream: int = 0):
+        """Two-stage search on the device (dhr_search_rerank): top-k1 of the stage-1 batch, exact GIP of the full
+        batch on those rows, top-k of that.  -> (scores fp32 [Q,k], rows int64 [Q,k]) numpy."""
+        qb1, keep1 = _lib.make_query_batch(q1_value, q1_index)
+        qb2, keep2 = _lib.make_query_batch(q_value, q_index)
+        nq = qb1.n_queries
+        scores = np.empty((nq, k), np.float32)
+        rows = np.empty((nq, k), np.int64)
+        _lib.check(self._lib.dhr_search_rerank(self._h, C.byref(qb1), C.byref(qb2), int(k1), int(k), scores.ctypes.data,
+                                               rows.ctypes.data, _lib.MEM_HOST, stream), "dhr_search_rerank")
+        del keep1, keep2
+        return scores, rows
+
     # ---- staged search (row-sharded path, dhr_amd/dist.py)
     def sample_rank(self, k: int) -> int:
         return int(self._lib.dhr_search_sample_rank(self._h, int(k)))
@@ -216,17 +229,19 @@ def GIP_retrieval(qids, query_embs, query_arg_idxs, corpus_embs, corpus_arg_idxs
             if k1 > n and not getattr(args, "allow_short", False):
                 raise RuntimeError("selected index k out of range")
             if not args.IP:
-                q1 = np.where(q > theta, q, np.float32(0))                    # restrict to the important columns
-                s1, r1 = index.search(q1, qi, k1)
+                q1, qi1 = np.where(q > theta, q, np.float32(0)), qi           # restrict to the important columns
             else:
-                s1, r1 = index.search(q, None, k1)                            # ungated inner product
-            if args.rerank:
+                q1, qi1 = q, None                                             # ungated inner product
+            if args.rerank and k1 <= 16384:
+                scores, rows = index.search_rerank(q1, qi1, q, qi, k1, min(args.topk, k1))   # both stages on the device
+            elif args.rerank:
+                s1, r1 = index.search(q1, qi1, k1)
                 s2 = index.score_rows(q, qi, r1)
                 order = np.lexsort((r1, -s2.astype(np.float64)), axis=1)[:, : args.topk]
                 rows = np.take_along_axis(r1, order, axis=1)
                 scores = np.take_along_axis(s2, order, axis=1)
             else:
-                scores, rows = s1, r1
+                scores, rows = index.search(q1, qi1, k1)
         res = _to_dicts(qids, rows, scores, index.row_offset)
     finally:
         if owned:

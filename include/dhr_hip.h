@@ -124,6 +124,15 @@ int64_t dhr_index_device_bytes(const dhr_index* index);
 int dhr_search(dhr_index* index, const dhr_query_batch* queries, int32_t k, float* out_scores,
                int64_t* out_rows, int32_t out_mem_kind, void* stream);
 
+/* Two-stage approximate GIP, both stages on the device (gip_retrieval.py:128-156):
+ *   stage 1 = dhr_search(stage1, k1): the caller has restricted the batch the way the reference does -- values
+ *             <= theta zeroed (:130-136), or index = NULL for the ungated --IP first stage (:139);
+ *   stage 2 = exact gated inner product of the FULL batch on exactly those k1 rows (:144-146), top-k of that
+ *             (score desc, row asc; fewer than k valid rows -> (-inf, -1) padding).
+ * Same n_queries in both batches; 0 < k <= k1 <= 16384. */
+int dhr_search_rerank(dhr_index* index, const dhr_query_batch* stage1, const dhr_query_batch* full, int32_t k1, int32_t k,
+                      float* out_scores, int64_t* out_rows, int32_t out_mem_kind, void* stream);
+
 /* Staged form of dhr_search for the row-sharded path (one handle per shard / rank).  After
  * dhr_search_begin every shard holds the r best exact scores of its SAMPLE per query (r =
  * dhr_search_sample_rank, the same on equally sized shards; 0 = the shard is too small to sample and

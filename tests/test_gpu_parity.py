@@ -388,6 +388,34 @@ def test_two_stage_default_agip_topk(G):
         assert len(set(res[qid]) ^ set(eres[qid])) <= 4
 
 
+@pytest.mark.parametrize("mode,k1,k", [("theta", 512, 100), ("ip", 300, 300), ("theta", 5000, 1000)])
+def test_search_rerank_device_equals_composed(G, mode, k1, k):
+    """dhr_search_rerank (both stages on the device) == dhr_search + dhr_score_rows + host top-k,
+    and stage 2 == the oracle's exact GIP on the stage-1 rows (gip_retrieval.py:141-153)."""
+    from dhr_amd import synth
+    cv, ci, qv, qi = synth.make_pair(23, 30000, 24, 768, 128)
+    q = qv.astype(np.float32)
+    ix = G.GipIndex(cv, ci)
+    try:
+        if mode == "theta":
+            q1, qi1 = np.where(q > 0.3, q, np.float32(0)), qi
+        else:
+            q1, qi1 = q, None
+        s1, r1 = ix.search(q1, qi1, k1)
+        s2 = ix.score_rows(q, qi, r1)
+        order = np.lexsort((r1, -s2.astype(np.float64)), axis=1)[:, :k]
+        rows_c = np.take_along_axis(r1, order, axis=1)
+        sc_c = np.take_along_axis(s2, order, axis=1)
+        sc_d, rows_d = ix.search_rerank(q1, qi1, q, qi, k1, k)
+        np.testing.assert_array_equal(rows_d, rows_c)
+        np.testing.assert_array_equal(sc_d, sc_c)
+        for i in range(0, 24, 5):
+            ex = O.gip_scores_f64(q[i], qi[i], cv[r1[i]].astype(np.float32), ci[r1[i]])
+            np.testing.assert_allclose(sc_d[i], np.sort(ex)[::-1][:k], rtol=2e-6, atol=2e-6)
+    finally:
+        ix.close()
+
+
 def test_config1_bm25_100k(G):
     """BASELINE config 1 shape: DLR-only BM25-like vectors, int16 slice index, 100k passages."""
     from dhr_amd import synth
