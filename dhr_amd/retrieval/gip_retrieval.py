@@ -12,6 +12,7 @@ There is no CPU path here.  If the HIP library or a GPU is missing every entry p
 from __future__ import annotations
 
 import argparse
+import os
 import ctypes as C
 import pickle
 import time
@@ -53,6 +54,40 @@ class GipIndex:
         _lib.check(lib.dhr_index_create(C.byref(desc), C.byref(h)), "dhr_index_create")
         self._h, self._lib = h, lib
         self.n_rows, self.k, self.d_dlr, self.device, self.row_offset = n, k, d_dlr, device, row_offset
+
+    # ---- device-ready index file (dhr_index_save / dhr_index_load)
+    def save(self, path: str, docids=None):
+        """Write the built device images to `path`; `docids` (the third element of the reference's index record)
+        travels as the file's blob so that one file replaces the pickle."""
+        blob = pickle.dumps(list(docids), protocol=4) if docids is not None else b""
+        _lib.check(self._lib.dhr_index_save(self._h, os.fsencode(path), blob if blob else None, len(blob)), "dhr_index_save")
+
+    @staticmethod
+    def is_device_file(path: str) -> bool:
+        try:
+            with open(path, "rb") as f:
+                return f.read(8) == _lib.FILE_MAGIC
+        except OSError:
+            return False
+
+    @classmethod
+    def load(cls, path: str, device: int = 0, row_offset: int = -1):
+        """-> (GipIndex, docids or None): mmap + stream the sections to the device, no re-layout."""
+        lib = _lib.load()
+        info = _lib.FileInfo()
+        _lib.check(lib.dhr_index_file_info(os.fsencode(path), C.byref(info)), "dhr_index_file_info")
+        h = C.c_void_p()
+        _lib.check(lib.dhr_index_load(os.fsencode(path), device, row_offset, C.byref(h)), "dhr_index_load")
+        self = cls.__new__(cls)
+        self._h, self._lib = h, lib
+        self.n_rows, self.k, self.d_dlr, self.device = int(info.n_rows), int(info.d_dlr + info.d_cls), int(info.d_dlr), device
+        self.row_offset = int(info.row_offset) if row_offset < 0 else row_offset
+        docids = None
+        if info.blob_bytes > 0:
+            with open(path, "rb") as f:
+                f.seek(info.blob_offset)
+                docids = pickle.loads(f.read(info.blob_bytes))
+        return self, docids
 
     def close(self):
         if getattr(self, "_h", None):
@@ -280,6 +315,9 @@ def build_parser():
     parser.add_argument("--run_name", type=str, default='h2oloo')
     # not in the reference: which GPU holds the shard (the reference hard-wires cuda:0, :261)
     parser.add_argument("--device", type=int, default=0)
+    parser.add_argument("--save_device_index", type=str, default=None,
+                        help="(not in the reference) also write the built index as a device-ready file; pass that file as "
+                             "--index_path later to skip the pickle load and the re-layout")
     parser.add_argument("--output", type=str, default=None, help="override the result file name")
     return parser
 
@@ -337,17 +375,34 @@ def main(argv=None):
     print('Load query embeddings ...')
     query_embs, query_arg_idxs, qids = load_queries(args.query_emb_path, args.emb_dim, args.lamda)
     print('Load index ...')
-    corpus_embs, corpus_arg_idxs, docids, _lo = load_corpus_shard(args.index_path, args.total_shrad, args.shrad)
-    if query_arg_idxs is not None and corpus_arg_idxs is None:
-        raise ValueError("the query file has an index array but the corpus index has none")
+    if GipIndex.is_device_file(args.index_path):
+        # device-ready file written by --save_device_index: no pickle, no re-layout (one file = one shard)
+        if args.total_shrad != 1:
+            raise ValueError("a device-ready index file holds exactly one shard: write one file per shard "
+                             "(--save_device_index together with --shrad/--total_shrad) and run without --total_shrad")
+        index, docids = GipIndex.load(args.index_path, device=args.device)
+        if docids is None:
+            raise ValueError("the device-ready index file carries no docid list")
+        if (query_arg_idxs is not None) != (index.d_dlr > 0):
+            raise ValueError("query file and index disagree about the slice-index array")
+        if query_arg_idxs is not None and args.emb_dim != index.d_dlr:
+            raise ValueError(f"--emb_dim {args.emb_dim} does not match the index array width {index.d_dlr}")
+    else:
+        corpus_embs, corpus_arg_idxs, docids, _lo = load_corpus_shard(args.index_path, args.total_shrad, args.shrad)
+        if query_arg_idxs is not None and corpus_arg_idxs is None:
+            raise ValueError("the query file has an index array but the corpus index has none")
+        if query_arg_idxs is not None:
+            index = GipIndex(corpus_embs, corpus_arg_idxs, emb_dim=args.emb_dim, device=args.device)
+        else:
+            index = GipIndex(corpus_embs, None, device=args.device)
+        if args.save_device_index:
+            index.save(args.save_device_index, docids)
     if query_arg_idxs is not None:
-        index = GipIndex(corpus_embs, corpus_arg_idxs, emb_dim=args.emb_dim, device=args.device)
         if not args.PQIP:
             results, scores = GIP_retrieval(qids, query_embs, query_arg_idxs, index, None, args)
         else:
             results, scores = PQ_IP_retrieval(qids, query_embs, query_arg_idxs, index, None, args)
     else:
-        index = GipIndex(corpus_embs, None, device=args.device)
         results, scores = IP_retrieval(qids, query_embs, index, args)
     index.close()
     if args.output:

@@ -112,6 +112,24 @@ int dhr_index_set_param(dhr_index* index, int32_t param, int64_t value);
 /* Device bytes held by the handle (index + workspaces). */
 int64_t dhr_index_device_bytes(const dhr_index* index);
 
+/* Index file.  The reference keeps ONE monolithic pickle that every run unpickles,
+ * casts to fp32 and copies to the GPU (gip_retrieval.py:289-315).  dhr_index_save writes the corpus of a built
+ * index as page-aligned raw sections of one file -- row-major fp16 values (rows padded to a multiple of 64
+ * columns), row-major slice indices -- plus an opaque caller blob (the docid list); dhr_index_load mmaps the
+ * file and streams it to the device through the ordinary ingest path: no unpickling, no host copies.  The
+ * device images (operand tiles, refine lists) are NOT stored: re-tiling from device memory costs 0.06 s per
+ * 2 M rows, the images would double the file.  row_offset < 0 keeps the stored value. */
+typedef struct dhr_file_info {
+  int64_t n_rows, row_offset;
+  int32_t d_dlr, d_cls, index_dtype, idx_buckets;
+  uint32_t file_version, reserved;
+  int64_t payload_bytes;           /* value + index bytes in the file */
+  int64_t blob_offset, blob_bytes; /* the caller blob: plain file bytes [blob_offset, blob_offset + blob_bytes) */
+} dhr_file_info;
+int dhr_index_save(const dhr_index* index, const char* path, const void* blob, int64_t blob_bytes);
+int dhr_index_file_info(const char* path, dhr_file_info* out);
+int dhr_index_load(const char* path, int32_t device, int64_t row_offset, dhr_index** out);
+
 /* Replaces the query loop of GIP_retrieval (brute force, gip_retrieval.py:115-126) and of
  * IP_retrieval (:70-79) for ALL queries of the batch at once:
  *   score[q][n] = sum_{j<d_dlr} [c_idx[n][j]==q_idx[j]] * c_val[n][j]*q_val[j] + sum_{c} c_val*q_val

@@ -81,3 +81,22 @@ def test_host_merge_matches_oracle():
     valid = (r >= 0).sum(1)
     for i in range(q):
         assert np.all(hr2[i, valid[i]:] == -1) and np.all(np.isneginf(hs2[i, valid[i]:]))
+
+
+def test_file_info_struct_and_bad_files(tmp_path):
+    """dhr_file_info layout matches the header; a file that is not a device-ready index is rejected without a GPU."""
+    import ctypes as C
+    from dhr_amd import _lib
+    assert C.sizeof(_lib.FileInfo) == 64
+    lib = _lib.load()
+    info = _lib.FileInfo()
+    bad = tmp_path / "not_an_index.bin"
+    bad.write_bytes(b"\x80\x04" + b"x" * 8000)                     # e.g. somebody passes the pickle
+    assert lib.dhr_index_file_info(str(bad).encode(), C.byref(info)) < 0
+    assert b"not a device-ready index file" in lib.dhr_last_error()
+    short = tmp_path / "short.bin"
+    short.write_bytes(_lib.FILE_MAGIC + b"\0" * 100)
+    assert lib.dhr_index_file_info(str(short).encode(), C.byref(info)) < 0
+    assert lib.dhr_index_file_info(str(tmp_path / "missing").encode(), C.byref(info)) < 0
+    h = C.c_void_p()
+    assert lib.dhr_index_load(str(bad).encode(), 0, -1, C.byref(h)) < 0 and not h.value

@@ -507,3 +507,65 @@ def test_staged_sharded_search_failure_path(G):
     assert n_failed == 5
     np.testing.assert_array_equal(mr, fr)
     np.testing.assert_array_equal(ms, fs)
+
+
+@pytest.mark.parametrize("kind", ["hybrid", "dense", "hybrid3"])
+def test_device_index_file_round_trip(G, tmp_path, kind):
+    """dhr_index_save -> dhr_index_load: the loaded index answers bit-identically, the docid blob
+    survives, row_offset can be overridden, a file of another format version is refused."""
+    import ctypes as C
+    from dhr_amd import _lib, synth
+    d_dlr = 0 if kind == "dense" else 768
+    if d_dlr:
+        cv, ci, qv, qi = synth.make_pair(31, 5000, 16, d_dlr, 128)
+    else:
+        rng = np.random.default_rng(31)
+        cv, qv = (rng.standard_normal((5000, 768)) * 0.1).astype(np.float16), (rng.standard_normal((16, 768)) * 0.1).astype(np.float16)
+        ci = qi = None
+    q = qv.astype(np.float32)
+    docids = ["D%d" % i for i in range(5000)]
+    ix = G.GipIndex(cv, ci, row_offset=1000, idx_buckets=3 if kind == "hybrid3" else 0)
+    path = str(tmp_path / "corpus.dhr")
+    try:
+        s0, r0 = ix.search(q, qi, 100)
+        ix.save(path, docids)
+    finally:
+        ix.close()
+    assert G.GipIndex.is_device_file(path)
+    ix2, ids2 = G.GipIndex.load(path)
+    try:
+        assert ids2 == docids and ix2.n_rows == 5000 and ix2.row_offset == 1000 and ix2.d_dlr == d_dlr
+        s1, r1 = ix2.search(q, qi, 100)
+        np.testing.assert_array_equal(r1, r0)
+        np.testing.assert_array_equal(s1, s0)
+        sc = ix2.score_rows(q, qi, r1[:, :7])
+        np.testing.assert_array_equal(sc, s0[:, :7])
+    finally:
+        ix2.close()
+    ix3, _ = G.GipIndex.load(path, row_offset=0)
+    try:
+        _, r3 = ix3.search(q, qi, 100)
+        np.testing.assert_array_equal(r3, r0 - 1000)
+    finally:
+        ix3.close()
+    raw = bytearray(open(path, "rb").read(4096))
+    raw[8:12] = (77).to_bytes(4, "little")                           # version field of the header
+    with open(path, "r+b") as f:
+        f.write(raw)
+    with pytest.raises(_lib.DhrError, match="file format version 77"):
+        G.GipIndex.load(path)
+
+
+def test_cli_device_index_file(G, golden, tmp_path, monkeypatch):
+    """main(): --save_device_index writes the file, a second run with it as --index_path gives the same TREC run."""
+    import pickle
+    d = golden.inputs("hyb")
+    monkeypatch.chdir(tmp_path)
+    with open("q.pt", "wb") as f:
+        pickle.dump([d["qv"], d["qi"], list(d["qids"])], f, protocol=4)
+    with open("c.pt", "wb") as f:
+        pickle.dump([d["cv"], d["ci"], list(d["docids"])], f, protocol=4)
+    common = ["--query_emb_path", "q.pt", "--emb_dim", "768", "--brute_force", "--topk", "50"]
+    G.main(common + ["--index_path", "c.pt", "--output", "a.trec", "--save_device_index", "c.dhr"])
+    G.main(common + ["--index_path", "c.dhr", "--output", "b.trec"])
+    assert open("a.trec").read() == open("b.trec").read() and len(open("a.trec").read()) > 1000
