@@ -1185,6 +1185,55 @@ extern "C" int dhr_score_rows(dhr_index* ix, const dhr_query_batch* qb, int32_t 
   return done(DHR_OK);
 }
 
+extern "C" int dhr_densify(int32_t device, int32_t mem_kind, const void* lexical, int32_t value_dtype, int64_t ld, int64_t batch, int32_t vocab,
+                           int32_t remove_dims, int32_t dims, void* out_value, int32_t out_value_dtype, int64_t ld_value, void* out_index,
+                           int32_t index_dtype, int64_t ld_index, void* stream) {
+  if (!lexical || !out_value || !out_index) return set_error(DHR_ERR_INVALID, "null pointer");
+  if (batch < 0 || vocab <= 0 || dims <= 0 || remove_dims < 0 || remove_dims >= vocab || ld < vocab || ld_value < dims || ld_index < dims)
+    return set_error(DHR_ERR_INVALID, "bad sizes / strides");
+  if ((vocab - remove_dims) % dims != 0)
+    return set_error(DHR_ERR_INVALID, "Input lexical representation cannot be densified, please fix dims or remove_dims");
+  if ((value_dtype != DHR_VAL_F16 && value_dtype != DHR_VAL_F32) || (out_value_dtype != DHR_VAL_F16 && out_value_dtype != DHR_VAL_F32))
+    return set_error(DHR_ERR_INVALID, "bad value dtype");
+  const int n_groups = (vocab - remove_dims) / dims;
+  if (index_dtype != DHR_IDX_U8 && index_dtype != DHR_IDX_I16) return set_error(DHR_ERR_INVALID, "index dtype must be uint8 or int16");
+  if (index_dtype == DHR_IDX_U8 && n_groups > 256) return set_error(DHR_ERR_UNSUPPORTED, "more than 256 groups need the int16 index dtype");
+  if (n_groups > 32767) return set_error(DHR_ERR_UNSUPPORTED, "more than 32767 groups");
+  if (batch == 0) return DHR_OK;
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  const int ies = value_dtype == DHR_VAL_F32 ? 4 : 2, oes = out_value_dtype == DHR_VAL_F32 ? 4 : 2, xes = index_dtype == DHR_IDX_I16 ? 2 : 1;
+  if (mem_kind == DHR_MEM_DEVICE) {
+    HIP_TRY(launch_densify(lexical, value_dtype == DHR_VAL_F32, ld, batch, remove_dims, dims, n_groups, out_value, out_value_dtype == DHR_VAL_F32,
+                           ld_value, out_index, index_dtype == DHR_IDX_I16, ld_index, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return DHR_OK;
+  }
+  // host arrays: stage blocks of rows through the device
+  const int64_t block = std::max<int64_t>(1, std::min<int64_t>(batch, ((int64_t)256 << 20) / ((int64_t)vocab * ies)));
+  void *d_in = nullptr, *d_val = nullptr, *d_idx = nullptr;
+  auto done = [&](int code) { hipFree(d_in); hipFree(d_val); hipFree(d_idx); return code; };
+  if (hipMalloc(&d_in, (size_t)block * vocab * ies) != hipSuccess || hipMalloc(&d_val, (size_t)block * dims * oes) != hipSuccess ||
+      hipMalloc(&d_idx, (size_t)block * dims * xes) != hipSuccess)
+    return done(set_error(DHR_ERR_HIP, "hipMalloc failed"));
+  for (int64_t lo = 0; lo < batch; lo += block) {
+    const int64_t rows = std::min(block, batch - lo);
+    if (hipMemcpy2DAsync(d_in, (size_t)vocab * ies, (const char*)lexical + lo * ld * ies, (size_t)ld * ies, (size_t)vocab * ies, (size_t)rows,
+                         hipMemcpyHostToDevice, s) != hipSuccess)
+      return done(set_error(DHR_ERR_HIP, "H2D failed"));
+    if (launch_densify(d_in, value_dtype == DHR_VAL_F32, vocab, rows, remove_dims, dims, n_groups, d_val, out_value_dtype == DHR_VAL_F32, dims, d_idx,
+                       index_dtype == DHR_IDX_I16, dims, s) != hipSuccess)
+      return done(set_error(DHR_ERR_HIP, "densify launch failed"));
+    if (hipMemcpy2DAsync((char*)out_value + lo * ld_value * oes, (size_t)ld_value * oes, d_val, (size_t)dims * oes, (size_t)dims * oes, (size_t)rows,
+                         hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpy2DAsync((char*)out_index + lo * ld_index * xes, (size_t)ld_index * xes, d_idx, (size_t)dims * xes, (size_t)dims * xes, (size_t)rows,
+                         hipMemcpyDeviceToHost, s) != hipSuccess)
+      return done(set_error(DHR_ERR_HIP, "D2H failed"));
+    if (hipStreamSynchronize(s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "densify failed on the device"));
+  }
+  return done(DHR_OK);
+}
+
 extern "C" int dhr_debug_bound_scores(dhr_index* ix, const dhr_query_batch* qb, int64_t row_lo, int64_t row_hi,
                                       float* out_dev, void* stream) {
   int rc = check_queries(ix, qb);

@@ -1643,6 +1643,52 @@ hipError_t launch_select(const SelectArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ densify
+// Fused densify (tevatron/DHR/utils.py:5-22 + the casts of tevatron/driver/encode.py:155-158): one pass over the
+// [batch, vocab] lexical representations; thread (row, j) walks the n_groups vocabulary entries remove + g*dims + j
+// (coalesced across j), keeps the maximum and the FIRST group attaining it, and writes the value (fp16 or fp32) and
+// the group (uint8 / int16) straight into the caller's index-record arrays.  HBM-bound: every input byte is read once.
+template <typename TIN>
+__global__ void __launch_bounds__(256) densify_kernel(const TIN* __restrict__ lex, int64_t ld, int64_t batch, int remove, int dims,
+                                                      int n_groups, void* __restrict__ out_val, int val_is_f32, int64_t ld_val,
+                                                      void* __restrict__ out_idx, int idx_is_i16, int64_t ld_idx) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int64_t b = blockIdx.y;
+  if (j >= dims || b >= batch) return;
+  const TIN* src = lex + b * ld + remove + j;
+  float best = (float)src[0];
+  int arg = 0;
+  int g = 1;
+  for (; g + 8 <= n_groups; g += 8) {          // 8 independent loads in flight per thread
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (float)src[(int64_t)(g + u) * dims];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (v[u] > best) { best = v[u]; arg = g + u; }
+  }
+  for (; g < n_groups; ++g) {
+    const float v = (float)src[(int64_t)g * dims];
+    if (v > best) { best = v; arg = g; }
+  }
+  if (val_is_f32) ((float*)out_val)[b * ld_val + j] = best;
+  else ((__half*)out_val)[b * ld_val + j] = __float2half(best);
+  if (idx_is_i16) ((int16_t*)out_idx)[b * ld_idx + j] = (int16_t)arg;
+  else ((uint8_t*)out_idx)[b * ld_idx + j] = (uint8_t)arg;
+}
+hipError_t launch_densify(const void* lex, int in_is_f32, int64_t ld, int64_t batch, int remove, int dims, int n_groups, void* out_val,
+                          int val_is_f32, int64_t ld_val, void* out_idx, int idx_is_i16, int64_t ld_idx, hipStream_t s) {
+  if (batch <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((dims + 255) / 256), (unsigned)batch);
+  if (in_is_f32)
+    hipLaunchKernelGGL(densify_kernel<float>, grid, dim3(256), 0, s, (const float*)lex, ld, batch, remove, dims, n_groups, out_val, val_is_f32,
+                       ld_val, out_idx, idx_is_i16, ld_idx);
+  else
+    hipLaunchKernelGGL(densify_kernel<_Float16>, grid, dim3(256), 0, s, (const _Float16*)lex, ld, batch, remove, dims, n_groups, out_val,
+                       val_is_f32, ld_val, out_idx, idx_is_i16, ld_idx);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------ emit / helpers
 __global__ void emit_kernel(const uint64_t* __restrict__ topk_keys, int kp, int n_queries, int k, int64_t row_offset,
                             float* __restrict__ out_scores, int64_t* __restrict__ out_rows) {

@@ -182,6 +182,18 @@ int dhr_merge_topk(int32_t device, int32_t n_queries, int32_t n_in, const float*
 int dhr_merge_topk_host(int32_t n_queries, int32_t n_in, const float* in_scores, const int64_t* in_rows,
                         int32_t k_out, float* out_scores, int64_t* out_rows);
 
+/* Fused densify, the step immediately upstream of the index (tevatron/DHR/utils.py:5-22 and the
+ * casts of tevatron/driver/encode.py:155-158,180-183).  lexical is [batch, vocab] (value_dtype DHR_VAL_F32 or DHR_VAL_F16,
+ * row stride ld); the columns [remove_dims, vocab) are viewed as [n_groups, dims] and
+ *   out_value[b][j] = max_g lexical[b][remove_dims + g*dims + j]     (out_value_dtype: DHR_VAL_F16 rounds to fp16, DHR_VAL_F32 exact)
+ *   out_index[b][j] = the FIRST g attaining it                        (index_dtype DHR_IDX_U8, needs n_groups <= 256, or DHR_IDX_I16)
+ * written with row strides ld_value / ld_index, i.e. directly into the value / index arrays of an index record (the
+ * CLS columns follow at out_value + dims).  DHR_ERR_INVALID when (vocab - remove_dims) is not a multiple of dims
+ * (the reference raises ValueError).  All three arrays live in mem_kind memory. */
+int dhr_densify(int32_t device, int32_t mem_kind, const void* lexical, int32_t value_dtype, int64_t ld, int64_t batch, int32_t vocab,
+                int32_t remove_dims, int32_t dims, void* out_value, int32_t out_value_dtype, int64_t ld_value, void* out_index,
+                int32_t index_dtype, int64_t ld_index, void* stream);
+
 int dhr_get_stats(const dhr_index* index, dhr_search_stats* out);
 
 /* Debug/test hook: the bound-GEMM scores U[q][row] for rows [row_lo,row_hi) of the shard, written

@@ -569,3 +569,64 @@ def test_cli_device_index_file(G, golden, tmp_path, monkeypatch):
     G.main(common + ["--index_path", "c.pt", "--output", "a.trec", "--save_device_index", "c.dhr"])
     G.main(common + ["--index_path", "c.dhr", "--output", "b.trec"])
     assert open("a.trec").read() == open("b.trec").read() and len(open("a.trec").read()) > 1000
+
+
+def test_densify_golden_and_random(G):
+    """dhr_densify == the reference's recorded outputs and the oracle: values bit-exact, first maximum wins,
+    numpy (host) and torch (device) inputs, fp16 / fp32, direct write into an index record, error messages."""
+    import os
+    import torch
+    from dhr_amd import densify as DZ
+    from oracle import densify_oracle as DO
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "densify_golden.npz"))
+    for name, kw in (("a", dict(dims=768)), ("b", dict(dims=8, remove_dims=3)), ("c", dict(dims=16, remove_dims=0))):
+        v, i = DZ.densify(g[name + "_in"], **kw)
+        np.testing.assert_array_equal(v, g[name + "_val"])
+        np.testing.assert_array_equal(i, g[name + "_idx"])
+        assert v.dtype == g[name + "_val"].dtype and i.dtype == np.int64
+        tv, ti = DZ.densify(torch.from_numpy(g[name + "_in"]).cuda(), **kw)
+        np.testing.assert_array_equal(tv.cpu().numpy(), g[name + "_val"])
+        np.testing.assert_array_equal(ti.cpu().numpy(), g[name + "_idx"])
+        assert ti.dtype == torch.int64 and tv.is_cuda
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((513, 30522)).astype(np.float32)
+    x[:, ::7] = np.float32(0.25)                                       # many exact ties
+    ev, ei = DO.densify(x)
+    v, i = DZ.densify(x)
+    np.testing.assert_array_equal(v, ev)
+    np.testing.assert_array_equal(i, ei)
+    # the encoder driver's layout: fp16 values into the first 768 columns of a [B, 768+128] record, uint8 groups
+    rec_v = np.zeros((513, 896), np.float16)
+    rec_i = np.zeros((513, 768), np.uint8)
+    DZ.densify_into(x, rec_v, rec_i)
+    e16, e8 = DO.densify_encoded(x)
+    np.testing.assert_array_equal(rec_v[:, :768], e16)
+    np.testing.assert_array_equal(rec_i, e8)
+    assert not rec_v[:, 768:].any()
+    xd = torch.from_numpy(x).cuda().half()
+    dv = torch.zeros((513, 896), dtype=torch.float16, device="cuda")
+    di = torch.zeros((513, 768), dtype=torch.uint8, device="cuda")
+    DZ.densify_into(xd, dv, di)
+    h16, h8 = DO.densify_encoded(x.astype(np.float16))
+    np.testing.assert_array_equal(dv[:, :768].cpu().numpy(), h16)
+    np.testing.assert_array_equal(di.cpu().numpy(), h8)
+    errs = list(g["errors"])
+    with pytest.raises(ValueError) as e:
+        DZ.densify(np.zeros((2, 3, 4), np.float32), dims=4, remove_dims=0)
+    assert str(e.value) == errs[0]
+    with pytest.raises(ValueError) as e:
+        DZ.densify(np.zeros((2, 30), np.float32), dims=7, remove_dims=1)
+    assert str(e.value) == errs[1]
+    # throughput note (HBM-bound: every input byte once)
+    big = torch.randn((4096, 30522), device="cuda")
+    bv = torch.empty((4096, 768), dtype=torch.float16, device="cuda")
+    bi = torch.empty((4096, 768), dtype=torch.uint8, device="cuda")
+    DZ.densify_into(big, bv, bi)
+    torch.cuda.synchronize()
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(5):
+        DZ.densify_into(big, bv, bi)
+    t1.record(); torch.cuda.synchronize()
+    ms = t0.elapsed_time(t1) / 5
+    print("densify 4096 x 30522 fp32: %.3f ms, %.2f TB/s" % (ms, 4096 * 29952 * 4 / ms / 1e9))

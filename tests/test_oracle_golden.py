@@ -163,3 +163,26 @@ def test_merge_results_equals_unsharded(golden):
         f_docs = [x[0] for x in full[qid]]
         m_docs = [x[0] for x in merged[qid]][: len(f_docs)]
         assert len(set(f_docs) ^ set(m_docs)) <= 2
+
+
+def test_densify_oracle_matches_reference_outputs():
+    """oracle/densify_oracle.py == the reference's densify (tevatron/DHR/utils.py:5-22) on the recorded cases."""
+    import os
+    import numpy as np
+    import pytest
+    from oracle import densify_oracle as DO
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "densify_golden.npz"))
+    for name, kw in (("a", dict(dims=768)), ("b", dict(dims=8, remove_dims=3)), ("c", dict(dims=16, remove_dims=0))):
+        v, i = DO.densify(g[name + "_in"], **kw)
+        np.testing.assert_array_equal(v, g[name + "_val"])
+        np.testing.assert_array_equal(i, g[name + "_idx"])
+        assert v.dtype == g[name + "_val"].dtype and i.dtype == np.int64
+    errs = list(g["errors"])
+    with pytest.raises(ValueError) as e:
+        DO.densify(np.zeros((2, 3, 4), np.float32), dims=4, remove_dims=0)
+    assert str(e.value) == errs[0]
+    with pytest.raises(ValueError) as e:
+        DO.densify(np.zeros((2, 30), np.float32), dims=7, remove_dims=1)
+    assert str(e.value) == errs[1]
+    v16, i8 = DO.densify_encoded(g["a_in"])
+    assert v16.dtype == np.float16 and i8.dtype == np.uint8
