@@ -18,7 +18,7 @@ PARAM_CAND_CAP, PARAM_FIRST_ROWS, PARAM_PROFILE, PARAM_MAX_GROWTH, PARAM_SAMPLE_
 EXPORTS = ["dhr_version", "dhr_last_error", "dhr_index_create", "dhr_index_destroy", "dhr_index_set_param",
            "dhr_index_device_bytes", "dhr_search", "dhr_score_rows", "dhr_merge_topk", "dhr_merge_topk_host",
            "dhr_get_stats", "dhr_debug_bound_scores", "dhr_debug_gemm_time", "dhr_search_sample_rank", "dhr_search_begin",
-           "dhr_search_finish", "dhr_search_rerank", "dhr_index_save", "dhr_index_file_info", "dhr_index_load", "dhr_densify"]
+           "dhr_search_finish", "dhr_search_rerank", "dhr_index_save", "dhr_index_file_info", "dhr_index_load", "dhr_densify", "dhr_pq_train", "dhr_pq_encode", "dhr_pq_decode"]
 
 
 class DhrError(RuntimeError):
@@ -95,6 +95,10 @@ def load():
     lib.dhr_index_load.argtypes = [C.c_char_p, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]
     lib.dhr_densify.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                 C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
+    lib.dhr_pq_train.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
+                                 C.POINTER(C.c_double), C.c_void_p]
+    lib.dhr_pq_encode.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dhr_pq_decode.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.dhr_score_rows.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.dhr_merge_topk.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p]

@@ -1234,6 +1234,147 @@ extern "C" int dhr_densify(int32_t device, int32_t mem_kind, const void* lexical
   return done(DHR_OK);
 }
 
+// ------------------------------------------------------------------------------------------ product quantiser
+namespace {
+int pq_check(const void* a, const void* b, int64_t n, int d, int M, int64_t ld) {
+  if (!a || !b) return set_error(DHR_ERR_INVALID, "null pointer");
+  if (n < 0 || d <= 0 || M <= 0 || d % M != 0 || ld < d) return set_error(DHR_ERR_INVALID, "bad sizes (d must be a multiple of M, ld >= d)");
+  if (d / M > 64) return set_error(DHR_ERR_UNSUPPORTED, "sub-vectors wider than 64 columns are not supported");
+  return DHR_OK;
+}
+// host arrays are staged whole (PQ inputs are at most the corpus, which has to fit the device anyway)
+struct Staged {
+  void* dev = nullptr; bool owned = false;
+  int in(const void* p, size_t bytes, int mem_kind, hipStream_t s) {
+    if (mem_kind == DHR_MEM_DEVICE) { dev = const_cast<void*>(p); return DHR_OK; }
+    if (hipMalloc(&dev, bytes ? bytes : 16) != hipSuccess) return set_error(DHR_ERR_HIP, "hipMalloc failed");
+    owned = true;
+    if (p && hipMemcpyAsync(dev, p, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return set_error(DHR_ERR_HIP, "H2D failed");
+    return DHR_OK;
+  }
+  int out(void* p, size_t bytes, hipStream_t s) {
+    if (!owned) return DHR_OK;
+    if (hipMemcpyAsync(p, dev, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return set_error(DHR_ERR_HIP, "D2H failed");
+    return DHR_OK;
+  }
+  ~Staged() { if (owned) hipFree(dev); }
+};
+}  // namespace
+
+extern "C" int dhr_pq_train(int32_t device, int32_t mem_kind, const void* values, int64_t ld, int64_t n, int32_t d, int32_t M, int32_t iters,
+                            int64_t max_points, float* codebooks, double* out_error, void* stream) {
+  int rc = pq_check(values, codebooks, n, d, M, ld);
+  if (rc) return rc;
+  if (n < 1 || iters < 0 || max_points < 256) return set_error(DHR_ERR_INVALID, "need n >= 1, iters >= 0, max_points >= 256");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  const int dsub = d / M;
+  // training rows: every `stride`-th row (host arrays: only those rows are staged)
+  const int64_t stride = std::max<int64_t>(1, n / max_points);
+  const int64_t np = (n + stride - 1) / stride;
+  Staged v, cb;
+  int64_t v_ld = ld, v_stride = stride;
+  if (mem_kind == DHR_MEM_HOST) {
+    if (hipMalloc(&v.dev, (size_t)np * d * 2) != hipSuccess) return set_error(DHR_ERR_HIP, "hipMalloc failed");
+    v.owned = true;
+    HIP_TRY(hipMemcpy2DAsync(v.dev, (size_t)d * 2, values, (size_t)ld * stride * 2, (size_t)d * 2, (size_t)np, hipMemcpyHostToDevice, s));
+    v_ld = d; v_stride = 1;
+  } else {
+    v.dev = const_cast<void*>(values);
+  }
+  const size_t cb_bytes = (size_t)M * 256 * dsub * 4;
+  if ((rc = cb.in(nullptr, cb_bytes, mem_kind == DHR_MEM_HOST ? DHR_MEM_HOST : DHR_MEM_DEVICE, s)) != DHR_OK) return rc;
+  if (mem_kind == DHR_MEM_DEVICE) cb.dev = codebooks;
+  float* d_cb = (float*)cb.dev;
+  float* sums = nullptr; uint32_t* counts = nullptr; float* err = nullptr;
+  auto done = [&](int code) { hipFree(sums); hipFree(counts); hipFree(err); return code; };
+  if (hipMalloc((void**)&sums, cb_bytes) != hipSuccess || hipMalloc((void**)&counts, (size_t)M * 256 * 4) != hipSuccess ||
+      hipMalloc((void**)&err, (size_t)M * 4) != hipSuccess)
+    return done(set_error(DHR_ERR_HIP, "hipMalloc failed"));
+  if (launch_pq_init((const __half*)v.dev, v_ld, np, v_stride, dsub, M, d_cb, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "pq_init launch failed"));
+  for (int it = 0; it <= iters; ++it) {
+    if (hipMemsetAsync(sums, 0, cb_bytes, s) != hipSuccess || hipMemsetAsync(counts, 0, (size_t)M * 256 * 4, s) != hipSuccess ||
+        hipMemsetAsync(err, 0, (size_t)M * 4, s) != hipSuccess)
+      return done(set_error(DHR_ERR_HIP, "memset failed"));
+    if (launch_pq_assign((const __half*)v.dev, v_ld, np, v_stride, dsub, M, d_cb, nullptr, 0, sums, counts, err, s) != hipSuccess)
+      return done(set_error(DHR_ERR_HIP, "pq_assign launch failed"));
+    if (it == iters) break;                               // the last pass only measures the error
+    if (launch_pq_update(d_cb, sums, counts, dsub, M, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "pq_update launch failed"));
+  }
+  if (out_error) {
+    std::vector<float> e(M);
+    if (hipMemcpyAsync(e.data(), err, (size_t)M * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return done(set_error(DHR_ERR_HIP, "D2H failed"));
+    double t = 0;
+    for (float x : e) t += x;
+    *out_error = t / (double)np;
+  }
+  if ((rc = cb.out(codebooks, cb_bytes, s)) != DHR_OK) return done(rc);
+  if (hipStreamSynchronize(s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "PQ training failed on the device"));
+  return done(DHR_OK);
+}
+
+extern "C" int dhr_pq_encode(int32_t device, int32_t mem_kind, const void* values, int64_t ld, int64_t n, int32_t d, int32_t M,
+                             const float* codebooks, uint8_t* codes, void* stream) {
+  int rc = pq_check(values, codebooks, n, d, M, ld);
+  if (rc) return rc;
+  if (!codes) return set_error(DHR_ERR_INVALID, "null pointer");
+  if (n == 0) return DHR_OK;
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  const int dsub = d / M;
+  Staged cb, cd;
+  if ((rc = cb.in(codebooks, (size_t)M * 256 * dsub * 4, mem_kind, s)) != DHR_OK) return rc;
+  if ((rc = cd.in(nullptr, (size_t)n * M, mem_kind == DHR_MEM_HOST ? DHR_MEM_HOST : DHR_MEM_DEVICE, s)) != DHR_OK) return rc;
+  if (mem_kind == DHR_MEM_DEVICE) cd.dev = codes;
+  if (mem_kind == DHR_MEM_DEVICE) {
+    HIP_TRY(launch_pq_assign((const __half*)values, ld, n, 1, dsub, M, (const float*)cb.dev, (uint8_t*)cd.dev, M, nullptr, nullptr, nullptr, s));
+  } else {
+    const int64_t block = 1 << 18;                          // rows per staged block
+    void* stage = nullptr;
+    if (hipMalloc(&stage, (size_t)std::min<int64_t>(block, n) * d * 2) != hipSuccess) return set_error(DHR_ERR_HIP, "hipMalloc failed");
+    for (int64_t lo = 0; lo < n; lo += block) {
+      const int64_t rows = std::min(block, n - lo);
+      if (hipMemcpy2DAsync(stage, (size_t)d * 2, (const char*)values + lo * ld * 2, (size_t)ld * 2, (size_t)d * 2, (size_t)rows, hipMemcpyHostToDevice, s) != hipSuccess ||
+          launch_pq_assign((const __half*)stage, d, rows, 1, dsub, M, (const float*)cb.dev, (uint8_t*)cd.dev + lo * M, M, nullptr, nullptr, nullptr, s) != hipSuccess ||
+          hipStreamSynchronize(s) != hipSuccess) {
+        hipFree(stage);
+        return set_error(DHR_ERR_HIP, "PQ encoding failed on the device");
+      }
+    }
+    hipFree(stage);
+  }
+  if ((rc = cd.out(codes, (size_t)n * M, s)) != DHR_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  return DHR_OK;
+}
+
+extern "C" int dhr_pq_decode(int32_t device, int32_t mem_kind, const uint8_t* codes, int64_t n, int32_t d, int32_t M, const float* codebooks,
+                             void* out_values, int64_t ld_out, void* stream) {
+  int rc = pq_check(codes, codebooks, n, d, M, ld_out);
+  if (rc) return rc;
+  if (!out_values) return set_error(DHR_ERR_INVALID, "null pointer");
+  if (n == 0) return DHR_OK;
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  const int dsub = d / M;
+  Staged cb, cd, ov;
+  if ((rc = cb.in(codebooks, (size_t)M * 256 * dsub * 4, mem_kind, s)) != DHR_OK) return rc;
+  if ((rc = cd.in(codes, (size_t)n * M, mem_kind, s)) != DHR_OK) return rc;
+  int64_t ld_dev = ld_out;
+  if (mem_kind == DHR_MEM_HOST) {
+    if ((rc = ov.in(nullptr, (size_t)n * d * 2, DHR_MEM_HOST, s)) != DHR_OK) return rc;
+    ld_dev = d;
+  } else {
+    ov.dev = out_values;
+  }
+  HIP_TRY(launch_pq_decode((const uint8_t*)cd.dev, M, n, M, dsub, (const float*)cb.dev, (__half*)ov.dev, ld_dev, s));
+  if (mem_kind == DHR_MEM_HOST)
+    HIP_TRY(hipMemcpy2DAsync(out_values, (size_t)ld_out * 2, ov.dev, (size_t)d * 2, (size_t)d * 2, (size_t)n, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return DHR_OK;
+}
+
 extern "C" int dhr_debug_bound_scores(dhr_index* ix, const dhr_query_batch* qb, int64_t row_lo, int64_t row_hi,
                                       float* out_dev, void* stream) {
   int rc = check_queries(ix, qb);

@@ -287,9 +287,44 @@ def GIP_retrieval(qids, query_embs, query_arg_idxs, corpus_embs, corpus_arg_idxs
     return res
 
 
-def PQ_IP_retrieval(*_a, **_k):
-    raise NotImplementedError("--PQIP needs the faiss product-quantised first stage (gip_retrieval.py:167-231); "
-                              "not built yet (SURVEY.md section 8f row 3)")
+def PQ_IP_retrieval(qids, query_embs, query_arg_idxs, corpus_embs, corpus_arg_idxs, args):
+    """gip_retrieval.py:167-231: first stage = product-quantised inner product over the WHOLE vector (no gate), agip_topk
+    candidates; --rerank: exact GIP of those candidates, top-k (:205-215); otherwise the first topk PQ results (:218-221).
+    The PQ index is the library's own (retrieval/quantize_index.py mirror; faiss files are not readable here): the codes are
+    decoded once on the device and searched with the dense bound GEMM -- an exact inner product on the decoded vectors is
+    the ADC score.  Parity with faiss unpinned."""
+    from . import quantize_index as QI
+    assert args.faiss_pq_index_path is not None, 'you do not spesify your PQ index through --faiss_pq_index_path'
+    print('Load PQ index ...')
+    pq = QI.load_pq(args.faiss_pq_index_path)
+    index, owned = _corpus_index(corpus_embs, corpus_arg_idxs, args)
+    if pq["codes"].shape[0] != index.n_rows or pq["d"] != index.k:
+        raise ValueError("the PQ index does not describe the same corpus as --index_path")
+    import torch
+    dev = torch.device("cuda", getattr(args, "device", 0))
+    decoded = QI.decode(torch.from_numpy(pq["codebooks"]).to(dev), torch.from_numpy(pq["codes"]).to(dev), device=dev.index or 0)
+    pq_index = GipIndex(decoded, None, device=dev.index or 0, row_offset=index.row_offset)
+    del decoded
+    start_time = time.time()
+    try:
+        q = _np(query_embs).astype(np.float32)
+        k1 = min(args.agip_topk, index.n_rows)
+        s1, r1 = pq_index.search(q, None, k1)
+        if args.rerank:
+            s2 = index.score_rows(q, _np(query_arg_idxs), r1)
+            order = np.lexsort((r1, -s2.astype(np.float64)), axis=1)[:, : args.topk]
+            rows = np.take_along_axis(r1, order, axis=1)
+            scores = np.take_along_axis(s2, order, axis=1)
+        else:
+            scores, rows = s1[:, : args.topk], r1[:, : args.topk]
+        res = _to_dicts(qids, rows, scores, index.row_offset)
+    finally:
+        pq_index.close()
+        if owned:
+            index.close()
+    time_per_query = (time.time() - start_time) / len(qids)
+    print('Retrieving {} queries ({:0.3f} s/query)'.format(len(qids), time_per_query))
+    return res
 
 
 # ----------------------------------------------------------------------------------------------- main()

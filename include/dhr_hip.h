@@ -194,6 +194,24 @@ int dhr_densify(int32_t device, int32_t mem_kind, const void* lexical, int32_t v
                 int32_t remove_dims, int32_t dims, void* out_value, int32_t out_value_dtype, int64_t ld_value, void* out_index,
                 int32_t index_dtype, int64_t ld_index, void* stream);
 
+/* Product quantiser for the first stage of --PQIP.  The reference calls faiss
+ * IndexPQ(d, M = 64, nbits = 8, METRIC_INNER_PRODUCT) (retrieval/quantize_index.py:27-37, gip_retrieval.py:167-231); faiss is not
+ * part of the reference tree, so these restate its published algorithm (per-subspace Lloyd k-means, nearest-centroid codes, ADC
+ * inner-product scores) -- codebooks differ from faiss's (different initialisation and sub-sampling): PARITY UNPINNED, judged
+ * by recall against the exact search.  All arrays live in mem_kind memory; values are the fp16 rows of an index record
+ * (row stride ld, d = M * dsub columns used), codebooks fp32 [M][256][dsub], codes uint8 [n][M].
+ *   dhr_pq_train : k-means on at most max_points evenly spaced rows, `iters` Lloyd iterations; out_error (host, may be NULL)
+ *                  receives the mean squared quantisation error per training row after the last assignment.
+ *   dhr_pq_encode: nearest centroid per subspace (first minimum).
+ *   dhr_pq_decode: fp16 reconstruction [n][ld_out]; an exact inner-product search over it (dhr_index_create with index = NULL,
+ *                  then dhr_search) returns exactly the ADC ranking, on the matrix cores. */
+int dhr_pq_train(int32_t device, int32_t mem_kind, const void* values_f16, int64_t ld, int64_t n, int32_t d, int32_t M, int32_t iters,
+                 int64_t max_points, float* codebooks, double* out_error, void* stream);
+int dhr_pq_encode(int32_t device, int32_t mem_kind, const void* values_f16, int64_t ld, int64_t n, int32_t d, int32_t M,
+                  const float* codebooks, uint8_t* codes, void* stream);
+int dhr_pq_decode(int32_t device, int32_t mem_kind, const uint8_t* codes, int64_t n, int32_t d, int32_t M, const float* codebooks,
+                  void* out_values_f16, int64_t ld_out, void* stream);
+
 int dhr_get_stats(const dhr_index* index, dhr_search_stats* out);
 
 /* Debug/test hook: the bound-GEMM scores U[q][row] for rows [row_lo,row_hi) of the shard, written

@@ -9,7 +9,7 @@ Parity pin: every function here is checked against outputs of the reference itse
 build container by tests/golden/make_golden.py (the reference is imported from /root/reference with
 `pickle5`/`faiss`/`progressbar` stubbed) and committed as fixtures under tests/golden/*.npz|*.trec.
 tests/test_oracle_golden.py replays them.  The PQ first stage (`PQ_IP_retrieval`, faiss, absent
-here) is NOT restated: parity unpinned for that row.
+here) is restated separately in oracle/pq_oracle.py from the published algorithm: parity unpinned for that row.
 
 All file:line citations are relative to /root/reference/.
 """

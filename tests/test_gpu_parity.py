@@ -630,3 +630,68 @@ def test_densify_golden_and_random(G):
     t1.record(); torch.cuda.synchronize()
     ms = t0.elapsed_time(t1) / 5
     print("densify 4096 x 30522 fp32: %.3f ms, %.2f TB/s" % (ms, 4096 * 29952 * 4 / ms / 1e9))
+
+
+def test_pq_first_stage(G, tmp_path, monkeypatch):
+    """--PQIP (parity with faiss UNPINNED): encode / decode / ADC search exact against the oracle with the same
+    codebooks; the trained codebooks quantise as well as the oracle's k-means; recall of the first stage and the final
+    top-k after the exact rerank against the brute-force search; CLI round trip."""
+    import pickle
+    from dhr_amd import synth
+    from dhr_amd.retrieval import quantize_index as QI
+    from oracle import pq_oracle as PO
+    cv, ci, qv, qi = synth.make_pair(41, 20000, 16, 768, 128)            # d = 896, M = 64 -> dsub = 14
+    q = qv.astype(np.float32)
+    cb, codes, err = QI.train_and_encode(cv, 64, 8, iters=8)
+    assert cb.shape == (64, 256, 14) and codes.shape == (20000, 64) and codes.dtype == np.uint8
+    # encoding == oracle encoding under the same codebooks (ties aside)
+    ecodes = PO.encode(cv[:3000].astype(np.float32), cb)
+    assert (ecodes != codes[:3000]).mean() < 2e-3
+    # training quality: within 3 % of the oracle's k-means with the same schedule (float summation order differs)
+    ocb = PO.train(cv, 64, iters=8)
+    assert PO.mse(cv[:4000], cb) <= 1.03 * PO.mse(cv[:4000], ocb)
+    assert abs(err - PO.mse(cv[::max(1, 20000 // 65536)], cb)) <= 0.02 * err + 1e-6
+    # decode == oracle decode (rounded to fp16)
+    dec = QI.decode(cb, codes)
+    np.testing.assert_array_equal(dec, PO.decode(codes, cb).astype(np.float16))
+    # ADC search: exact inner product on the decoded vectors == table-based ADC scores of the oracle (fp16 rounding of the
+    # reconstruction is the only difference)
+    pix = G.GipIndex(dec, None)
+    ix = G.GipIndex(cv, ci)
+    try:
+        s1, r1 = pix.search(q, None, 500)
+        adc = PO.adc_scores(q, codes, cb)
+        for i in range(16):
+            top = np.sort(adc[i])[::-1][:500]
+            np.testing.assert_allclose(s1[i], top, rtol=2e-3, atol=2e-3)
+        # recall of the PQ first stage and of the reranked result against the exact search
+        se, re_ = ix.search(q, qi, 100)
+        sip, rip = ix.search(q, None, 100)
+        rec1 = np.mean([len(set(rip[i, :10]) & set(r1[i])) / 10.0 for i in range(16)])
+        assert rec1 >= 0.8, rec1
+        s2 = ix.score_rows(q, qi, r1)
+        order = np.lexsort((r1, -s2.astype(np.float64)), axis=1)[:, :10]
+        rr = np.take_along_axis(r1, order, axis=1)
+        rec2 = np.mean([len(set(re_[i, :10]) & set(rr[i])) / 10.0 for i in range(16)])
+        assert rec2 >= 0.7, rec2
+    finally:
+        pix.close(); ix.close()
+    # CLI: quantize_index + gip_retrieval --PQIP --rerank
+    monkeypatch.chdir(tmp_path)
+    qids = ["q%d" % i for i in range(16)]
+    docids = ["d%d" % i for i in range(20000)]
+    with open("q.pt", "wb") as f:
+        pickle.dump([qv, qi, qids], f, protocol=4)
+    with open("c.pt", "wb") as f:
+        pickle.dump([cv, ci, docids], f, protocol=4)
+    QI.main(["--index_path", "c.pt", "--output_index_path", "pq64_index"])
+    G.main(["--query_emb_path", "q.pt", "--index_path", "c.pt", "--emb_dim", "768", "--PQIP", "--faiss_pq_index_path", "pq64_index",
+            "--rerank", "--agip_topk", "500", "--topk", "10", "--output", "pq.trec"])
+    lines = open("pq.trec").read().splitlines()
+    assert len(lines) == 160
+    first = {}
+    for ln in lines:
+        qid, _, did, rank, score, _ = ln.split()
+        first.setdefault(qid, []).append(int(did[1:]))
+    hit = np.mean([len(set(first["q%d" % i]) & set(re_[i, :10].tolist())) / 10.0 for i in range(16)])
+    assert hit >= 0.6, hit

@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--n-queries", type=int, default=6980)
     ap.add_argument("--first-rows", type=int, default=0)
     ap.add_argument("--max-growth", type=int, default=0)
+    ap.add_argument("--main-chunks", type=int, default=0)
     ap.add_argument("--cand-cap", type=int, default=65536)
     ap.add_argument("--sample-period", type=int, default=-1)
     a = ap.parse_args()
@@ -33,6 +34,8 @@ def main():
         ix = GipIndex(cv, ci, row_offset=lo)
         ix.set_param(_lib.PARAM_PROFILE, 1)
         ix.set_param(_lib.PARAM_CAND_CAP, a.cand_cap)
+        if a.main_chunks:
+            ix.set_param(_lib.PARAM_MAIN_CHUNKS, a.main_chunks)
         if a.max_growth:
             ix.set_param(_lib.PARAM_MAX_GROWTH, a.max_growth)
         if a.first_rows:
