@@ -186,3 +186,24 @@ def test_densify_oracle_matches_reference_outputs():
     assert str(e.value) == errs[1]
     v16, i8 = DO.densify_encoded(g["a_in"])
     assert v16.dtype == np.float16 and i8.dtype == np.uint8
+
+
+def test_pq_oracle_self_consistency():
+    """oracle/pq_oracle.py has no golden vectors (faiss absent: parity unpinned); this only checks that the restatement is
+    internally consistent: k-means lowers the quantisation error, codes are nearest centroids, and the table-based ADC score
+    equals the inner product with the reconstruction."""
+    import numpy as np
+    from oracle import pq_oracle as PO
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((3000, 32)) * 0.2 + rng.integers(0, 4, (3000, 1))).astype(np.float16)
+    q = rng.standard_normal((5, 32)).astype(np.float32)
+    cb0 = PO.train(x, 4, iters=0)
+    cb = PO.train(x, 4, iters=10)
+    assert cb.shape == (4, 256, 8) and PO.mse(x, cb) < 0.8 * PO.mse(x, cb0)
+    codes = PO.encode(x, cb)
+    xr = PO.decode(codes, cb)
+    for m in range(4):
+        sub = x[:50, m * 8:(m + 1) * 8].astype(np.float32)
+        d = ((sub[:, None, :] - cb[m][None]) ** 2).sum(2)
+        assert (np.abs(d[np.arange(50), codes[:50, m]] - d.min(1)) < 1e-5).all()
+    np.testing.assert_allclose(PO.adc_scores(q, codes, cb), q.astype(np.float64) @ xr.T.astype(np.float64), rtol=1e-6, atol=1e-6)
