@@ -695,3 +695,27 @@ def test_pq_first_stage(G, tmp_path, monkeypatch):
         first.setdefault(qid, []).append(int(did[1:]))
     hit = np.mean([len(set(first["q%d" % i]) & set(re_[i, :10].tolist())) / 10.0 for i in range(16)])
     assert hit >= 0.6, hit
+
+
+@pytest.mark.parametrize("n,q,d_dlr,d_cls,k", [(300, 3, 96, 32, 10), (257, 1, 768, 0, 5), (5000, 7, 64, 8, 100), (1000, 2, 104, 24, 50),
+                                               (70, 5, 32, 96, 70), (4097, 9, 768, 8, 33), (900, 4, 104, 27, 20), (900, 4, 8, 3, 20)])
+def test_odd_shapes(G, n, q, d_dlr, d_cls, k):
+    """Small / ragged / unusual widths: fewer rows than a tile, no dense tail, widths that are not multiples of 32 or 64
+    (d_dlr % 32 != 0 takes the dense bucket-split layout), k == n."""
+    rng = np.random.default_rng(n + d_dlr)
+    cv = np.abs(rng.standard_normal((n, d_dlr + d_cls)) * 0.3).astype(np.float16)
+    cv[:, d_dlr:] = (rng.standard_normal((n, d_cls)) * 0.1).astype(np.float16)
+    qv = np.abs(rng.standard_normal((q, d_dlr + d_cls)) * 0.3).astype(np.float16)
+    qv[:, d_dlr:] = (rng.standard_normal((q, d_cls)) * 0.1).astype(np.float16)
+    ci = rng.integers(0, 5, (n, d_dlr)).astype(np.uint8)
+    qi = rng.integers(0, 5, (q, d_dlr)).astype(np.uint8)
+    _search_check(G, cv, ci, qv.astype(np.float32), qi, k)
+
+
+def test_unsupported_width_is_refused_loudly(G):
+    """--emb_dim that is not a multiple of 8 is outside what the kernels cover: explicit DHR_ERR_UNSUPPORTED, no silent fallback."""
+    from dhr_amd import _lib
+    cv = np.zeros((64, 100 + 28), np.float16)
+    ci = np.zeros((64, 100), np.uint8)
+    with pytest.raises(_lib.DhrError, match="multiple of 8"):
+        G.GipIndex(cv, ci)
