@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=200_000)
     ap.add_argument("--cpu-queries", type=int, default=12)
     ap.add_argument("--seed", type=int, default=1237)
+    ap.add_argument("--dist-backend", default="nccl", help="testing only: 'gloo' lets several ranks share ONE GPU (with DHR_BENCH_SINGLE_DEVICE=1)")
     args = ap.parse_args()
 
     import torch
@@ -105,11 +106,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("DHR_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0                                   # testing only: every rank on device 0 (needs --dist-backend gloo)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     d_dlr, d_cls = (768, 768) if args.workload == "hybrid" else (0, 768)
     K = d_dlr + d_cls
