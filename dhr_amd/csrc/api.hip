@@ -59,6 +59,7 @@ struct Workspace {
   uint32_t* q_pack = nullptr;            // [q_pad][d_dlr] refine operand words
   uint2* cand_r = nullptr;               // refine survivors
   uint32_t* cnt_r = nullptr;
+  uint32_t* blk_off = nullptr;           // 2 x (q_pad + 1): block offsets of the flat refine / rescoring launches
   uint2* cand2 = nullptr;                // second candidate list set: chunk i+1's GEMM overlaps chunk i's rescoring
   uint32_t* cnt2 = nullptr;
   void* h_pinned = nullptr;              // 16 bytes pinned mirror
@@ -110,7 +111,7 @@ struct dhr_index {
 
 static void free_ws(Workspace& w) {
   hipFree(w.q_tiles); hipFree(w.q32); hipFree(w.q_idx); hipFree(w.margin); hipFree(w.tau); hipFree(w.thr);
-  hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2); hipFree(w.q_pack); hipFree(w.cand_r); hipFree(w.cnt_r);
+  hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2); hipFree(w.q_pack); hipFree(w.cand_r); hipFree(w.cnt_r); hipFree(w.blk_off);
   if (w.h_pinned) hipHostFree(w.h_pinned);
   if (w.h_pinned2) hipHostFree(w.h_pinned2);
   hipFree(w.d_max2); hipFree(w.d_ref);
@@ -515,6 +516,7 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.tau_hat, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.fail_flags, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.thr_hat, (size_t)q_pad * 4, tot));
+  HIP_TRY(re_malloc(w.blk_off, (size_t)2 * (q_pad + 1) * 4, tot));
   if (ix->heavy_key) {
     HIP_TRY(re_malloc(w.q_pack, (size_t)q_pad * ix->d_dlr * 4, tot));
     HIP_TRY(re_malloc(w.cand_r, (size_t)q_pad * cap_r * 8, tot));
@@ -646,6 +648,9 @@ static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectA
     f.cand = cand; f.cnt = cnt; f.cap = (uint32_t)w.cap; f.heavy_key = ix->heavy_key; f.heavy_val = ix->heavy_val;
     f.q_pack = w.q_pack; f.d_dlr = ix->d_dlr; f.thr = thr; f.out = w.cand_r; f.out_cnt = w.cnt_r; f.out_cap = (uint32_t)w.cap_r;
     f.n_queries = Q; f.max_count = maxr;
+    // flat launch: one workgroup per REAL block of 256 candidates (bound_sum / 256 + Q is an upper bound of their number)
+    HIP_TRY(launch_block_offsets(cnt, (uint32_t)w.cap, Q, 256, w.blk_off, s));
+    f.blk_off = w.blk_off; f.flat_blocks = (uint32_t)std::min<int64_t>(bound_sum / 256 + Q, (int64_t)0x7fffffff);
     HIP_TRY(hipMemsetAsync(w.cnt_r, 0, (size_t)w.q_pad * 4, s));
     HIP_TRY(hipMemsetAsync(w.d_ref, 0, 16, s));
     tm.begin_on(T_REFINE, s); HIP_TRY(launch_refine(f, s)); tm.end_on(s);
@@ -668,6 +673,8 @@ static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectA
   RescoreArgs r = base_rescore_args(ix, w, Q, gate);
   r.cand = cand; r.cnt = cnt; r.cap = list_cap; r.max_count = maxr;
   r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
+  HIP_TRY(launch_block_offsets(cnt, list_cap, Q, RESCORE_CANDS_PER_WG, w.blk_off + w.q_pad + 1, s));
+  r.blk_off = w.blk_off + w.q_pad + 1; r.flat_blocks = (uint32_t)std::min<int64_t>(exact / RESCORE_CANDS_PER_WG + Q, (int64_t)0x7fffffff);
   tm.begin_on(T_RESCORE, s); HIP_TRY(launch_rescore(r, s)); tm.end_on(s);
   sel.cnt = cnt; sel.count_all = 0; sel.cap = list_cap;
   tm.begin_on(T_SELECT, s); HIP_TRY(launch_select(sel, s)); tm.end_on(s);

@@ -104,6 +104,8 @@ struct RescoreArgs {
   int64_t ld_scores;
   int n_queries;
   uint32_t max_count;         // grid.x * CANDS_PER_WG covers this many
+  // flat launch (candidate-list mode): workgroup b serves the query q with blk_off[q] <= b < blk_off[q+1]; grid = flat_blocks
+  const uint32_t* blk_off; uint32_t flat_blocks;
 };
 
 struct SelectArgs {
@@ -146,6 +148,7 @@ struct RefineArgs {
   const float* thr;                                          // [Q_pad]
   uint2* out; uint32_t* out_cnt; uint32_t out_cap;           // survivors (row, refined bound), per-query count, list capacity
   int n_queries; uint32_t max_count;
+  const uint32_t* blk_off; uint32_t flat_blocks;             // flat launch, as in RescoreArgs
 };
 hipError_t launch_refine(const RefineArgs& a, hipStream_t s);
 hipError_t launch_rescore(const RescoreArgs& a, hipStream_t s);
@@ -161,6 +164,8 @@ hipError_t launch_pq_assign(const __half* vals, int64_t ld, int64_t n, int64_t s
 hipError_t launch_pq_update(float* cb, const float* sums, const uint32_t* counts, int dsub, int M, hipStream_t s);
 hipError_t launch_pq_decode(const uint8_t* codes, int64_t ld_codes, int64_t n, int M, int dsub, const float* cb, __half* out, int64_t ld_out,
                             hipStream_t s);
+// exclusive scan of ceil(min(cnt[q], cap) / per) over the queries -> offs[0 .. n_queries] (one workgroup)
+hipError_t launch_block_offsets(const uint32_t* cnt, uint32_t cap, int n_queries, uint32_t per, uint32_t* offs, hipStream_t s);
 hipError_t launch_max_u32(const uint32_t* v, int n, uint32_t* out_max, unsigned long long* out_sum, hipStream_t s);
 hipError_t launch_rows_to_local(const int64_t* rows, int64_t n, int64_t row_offset, int64_t n_rows, uint32_t* out,
                                 hipStream_t s);

@@ -1260,6 +1260,45 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Flat launches of the per-candidate kernels.  Their natural grid is (blocks of the LONGEST list) x (queries), which
+// is mostly empty workgroups when the list lengths are skewed (measured: 0.5-1.2 ms per launch for a few hundred
+// thousand candidates).  Instead: offs = exclusive scan of every query's block count, one workgroup per real block,
+// which finds its query by binary search.
+__global__ void __launch_bounds__(1024) block_offsets_kernel(const uint32_t* __restrict__ cnt, uint32_t cap, int n_queries, uint32_t per,
+                                                             uint32_t* __restrict__ offs) {
+  __shared__ uint32_t part[1024];
+  const int tid = threadIdx.x;
+  const int chunk = (n_queries + 1023) / 1024;
+  const int lo = tid * chunk, hi = min(lo + chunk, n_queries);
+  uint32_t s = 0;
+  for (int q = lo; q < hi; ++q) { uint32_t c = cnt[q]; if (c > cap) c = cap; s += (c + per - 1) / per; }
+  part[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint32_t v = tid >= d ? part[tid - d] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = tid ? part[tid - 1] : 0u;
+  for (int q = lo; q < hi; ++q) { offs[q] = run; uint32_t c = cnt[q]; if (c > cap) c = cap; run += (c + per - 1) / per; }
+  if (tid == 1023) offs[n_queries] = part[1023];
+}
+hipError_t launch_block_offsets(const uint32_t* cnt, uint32_t cap, int n_queries, uint32_t per, uint32_t* offs, hipStream_t s) {
+  hipLaunchKernelGGL(block_offsets_kernel, dim3(1), dim3(1024), 0, s, cnt, cap, n_queries, per, offs);
+  return hipGetLastError();
+}
+__device__ __forceinline__ bool flat_block(const uint32_t* __restrict__ offs, int n_queries, uint32_t b, int& q, uint32_t& blk) {
+  if (b >= offs[n_queries]) return false;
+  int lo = 0, hi = n_queries;              // largest q with offs[q] <= b (offs[q+1] > b picks the non-empty one)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (offs[mid] <= b) lo = mid; else hi = mid;
+  }
+  q = lo; blk = b - offs[lo];
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------ heavy lists + refine
 // Build (once per index): per row the HEAVY largest-magnitude gated entries, as
 //   key = slice << 20 | bucket << 16 | index value (16 bits),  val = the fp16 value;  unused slots key = ~0.
@@ -1322,10 +1361,12 @@ hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, 
 constexpr int REFINE_PER_WG = 256;       // candidates of ONE query per workgroup (its operand words are staged in LDS once)
 __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
   __shared__ uint32_t qw[1024];
-  const int q = blockIdx.y;
+  int q = blockIdx.y;
+  uint32_t blk = blockIdx.x;
+  if (p.blk_off && !flat_block(p.blk_off, p.n_queries, blockIdx.x, q, blk)) return;
   uint32_t count = p.cnt[q];
   if (count > p.cap) count = p.cap;
-  const uint32_t base = blockIdx.x * REFINE_PER_WG;
+  const uint32_t base = blk * REFINE_PER_WG;
   if (base >= count) return;
   for (int j = threadIdx.x; j < p.d_dlr; j += 256) qw[j] = p.q_pack[(int64_t)q * p.d_dlr + j];
   __syncthreads();
@@ -1370,7 +1411,10 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
 }
 hipError_t launch_refine(const RefineArgs& a, hipStream_t s) {
   if (a.max_count == 0 || a.n_queries <= 0) return hipSuccess;
-  hipLaunchKernelGGL(refine_kernel, dim3((a.max_count + REFINE_PER_WG - 1) / REFINE_PER_WG, (unsigned)a.n_queries), dim3(256), 0, s, a);
+  if (a.blk_off) {
+    if (a.flat_blocks) hipLaunchKernelGGL(refine_kernel, dim3(a.flat_blocks), dim3(256), 0, s, a);
+  } else
+    hipLaunchKernelGGL(refine_kernel, dim3((a.max_count + REFINE_PER_WG - 1) / REFINE_PER_WG, (unsigned)a.n_queries), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
@@ -1382,12 +1426,14 @@ hipError_t launch_refine(const RefineArgs& a, hipStream_t s) {
 __global__ void __launch_bounds__(256) rescore_kernel(RescoreArgs p) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int q = blockIdx.y;
+  int q = blockIdx.y;
+  uint32_t blk = blockIdx.x;
+  if (p.blk_off && !flat_block(p.blk_off, p.n_queries, blockIdx.x, q, blk)) return;
   uint32_t count;
   if (p.cand) { count = p.cnt[q]; if (count > p.cap) count = p.cap; }
   else if (p.rows32) count = p.count_all;
   else count = p.count_all;
-  const uint32_t base = blockIdx.x * RESCORE_CANDS_PER_WG;
+  const uint32_t base = blk * RESCORE_CANDS_PER_WG;
   if (base >= count) return;
   const float* q32 = p.q32 + (int64_t)q * p.k_rm;
   const int16_t* qi = p.q_idx + (int64_t)q * p.d_dlr;
@@ -1444,6 +1490,10 @@ __global__ void __launch_bounds__(256) rescore_kernel(RescoreArgs p) {
 
 hipError_t launch_rescore(const RescoreArgs& a, hipStream_t s) {
   if (a.max_count == 0 || a.n_queries <= 0) return hipSuccess;
+  if (a.blk_off) {
+    if (a.flat_blocks) hipLaunchKernelGGL(rescore_kernel, dim3(a.flat_blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
   const unsigned gx = (a.max_count + RESCORE_CANDS_PER_WG - 1) / RESCORE_CANDS_PER_WG;
   hipLaunchKernelGGL(rescore_kernel, dim3(gx, (unsigned)a.n_queries), dim3(256), 0, s, a);
   return hipGetLastError();

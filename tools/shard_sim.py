@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--first-rows", type=int, default=0)
     ap.add_argument("--max-growth", type=int, default=0)
     ap.add_argument("--main-chunks", type=int, default=0)
+    ap.add_argument("--only", type=int, default=0, help="build only the first N shards of the partition (lets the default list capacity fit one GPU)")
     ap.add_argument("--cand-cap", type=int, default=65536)
     ap.add_argument("--sample-period", type=int, default=-1)
     a = ap.parse_args()
@@ -28,12 +29,13 @@ def main():
     qv, qi = bench.gen_shard(torch, synth, dev, 1237 + 999_983, a.n_queries, d_dlr, d_cls, 4, 12, False)
     # per-shard: begin; keep sample; destroy? the finish needs the handle -> keep all shards resident (fits: ~13 GB each)
     shards = []
-    for r in range(a.shards):
+    for r in range(a.only or a.shards):
         lo, hi = D.shard_bounds(a.n_docs, a.shards, r)
         cv, ci = bench.gen_shard(torch, synth, dev, 1237 + 1000 * r, hi - lo, d_dlr, d_cls, 30, 90, False)
         ix = GipIndex(cv, ci, row_offset=lo)
         ix.set_param(_lib.PARAM_PROFILE, 1)
-        ix.set_param(_lib.PARAM_CAND_CAP, a.cand_cap)
+        if a.cand_cap:
+            ix.set_param(_lib.PARAM_CAND_CAP, a.cand_cap)
         if a.main_chunks:
             ix.set_param(_lib.PARAM_MAIN_CHUNKS, a.main_chunks)
         if a.max_growth:
