@@ -48,6 +48,9 @@ struct Workspace {
   __half* q_tiles = nullptr;
   float* q32 = nullptr;
   int16_t* q_idx = nullptr;
+  __half* q16 = nullptr;                 // fp16 copy of the queries + index bytes + 'not fp16-representable' flag (fast rescoring path)
+  uint8_t* q_idx8 = nullptr;
+  uint32_t* q_inexact = nullptr;
   float *margin = nullptr, *tau = nullptr, *thr = nullptr;
   uint32_t* cnt = nullptr;
   uint2* cand = nullptr;
@@ -110,7 +113,7 @@ struct dhr_index {
 };
 
 static void free_ws(Workspace& w) {
-  hipFree(w.q_tiles); hipFree(w.q32); hipFree(w.q_idx); hipFree(w.margin); hipFree(w.tau); hipFree(w.thr);
+  hipFree(w.q_tiles); hipFree(w.q32); hipFree(w.q_idx); hipFree(w.q16); hipFree(w.q_idx8); hipFree(w.q_inexact); hipFree(w.margin); hipFree(w.tau); hipFree(w.thr);
   hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2); hipFree(w.q_pack); hipFree(w.cand_r); hipFree(w.cnt_r); hipFree(w.blk_off);
   if (w.h_pinned) hipHostFree(w.h_pinned);
   if (w.h_pinned2) hipHostFree(w.h_pinned2);
@@ -505,6 +508,9 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.q_tiles, (size_t)q_pad * ix->kt * 2, tot));
   HIP_TRY(re_malloc(w.q32, (size_t)q_pad * ix->k_rm * 4, tot));
   HIP_TRY(re_malloc(w.q_idx, (size_t)q_pad * std::max(ix->d_dlr, 8) * 2, tot));
+  HIP_TRY(re_malloc(w.q16, (size_t)q_pad * ix->k_rm * 2, tot));
+  HIP_TRY(re_malloc(w.q_idx8, (size_t)q_pad * std::max(ix->d_dlr, 8), tot));
+  HIP_TRY(re_malloc(w.q_inexact, 16, tot));
   HIP_TRY(re_malloc(w.margin, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.tau, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.thr, (size_t)q_pad * 4, tot));
@@ -578,10 +584,11 @@ static int prep_queries(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, 
     }
   }
   w.ts_q = sparse_query_stages(ix->ts, ix->d_dlr > 0 && qb->index);
+  HIP_TRY(hipMemsetAsync(w.q_inexact, 0, 4, s));
   HIP_TRY(launch_query_prep(v, qb->value_dtype == DHR_VAL_F32, ldv, (ix->d_dlr > 0 && qb->index) ? qi : nullptr, qb->index_dtype, ldi,
                             qb->n_queries, w.q_pad, ix->d_dlr, ix->d_cls, ix->k_rm, ix->n_buckets, ix->kt, ix->bucket_map,
                             ix->abs_mode, ix->dmax, w.q_tiles, w.q32,
-                            w.q_idx, w.margin, w.tau, w.thr, ix->ts, ix->td, w.q_pack, s));
+                            w.q_idx, w.margin, w.tau, w.thr, ix->ts, ix->td, w.q_pack, w.q16, w.q_idx8, w.q_inexact, ix->idx_dtype, s));
   return DHR_OK;
 }
 
@@ -606,6 +613,7 @@ static RescoreArgs base_rescore_args(const dhr_index* ix, const Workspace& w, in
   RescoreArgs r{};
   r.vals_rm = ix->vals_rm; r.c_idx = ix->c_idx; r.c_idx_dtype = ix->idx_dtype;
   r.q32 = w.q32; r.q_idx = w.q_idx; r.d_dlr = ix->d_dlr; r.k_rm = ix->k_rm;
+  r.q16 = w.q16; r.q_idx8 = w.q_idx8; r.q_inexact = w.q_inexact;
   r.n_rows = ix->n_rows; r.n_queries = n_queries; r.gate = gate ? 1 : 0;
   return r;
 }

@@ -89,6 +89,9 @@ struct RescoreArgs {
   int c_idx_dtype;            // dhr_idx_dtype
   const float* q32;           // [Q_pad][K_pad]
   const int16_t* q_idx;       // [Q_pad][d_dlr]
+  // fast path (queries exactly representable in fp16, 1-byte index dtype): fp16 copy of the queries (gated values whose index
+  // cannot equal any corpus index byte are zeroed), the query indices as bytes, and the batch flag that disables it
+  const __half* q16; const uint8_t* q_idx8; const uint32_t* q_inexact;
   int d_dlr, k_rm;
   int gate;                   // 0: ungated inner product over all columns (--IP stage 1)
   int64_t n_rows;
@@ -136,7 +139,8 @@ hipError_t launch_idx_hist(const uint8_t* idx, int64_t n_rows, int d_dlr, uint32
 hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const void* idx, int idx_dtype, int64_t ld_idx,
                              int n_queries, int q_pad, int d_dlr, int d_cls, int k_rm, int n_buckets, int kt,
                              const uint8_t* map, bool abs_dlr, float dmax, __half* q_tiles, float* q32, int16_t* q_idx,
-                             float* margin, float* tau, float* thr, int ts, int td, uint32_t* q_pack, hipStream_t s);
+                             float* margin, float* tau, float* thr, int ts, int td, uint32_t* q_pack, __half* q16, uint8_t* q_idx8,
+                             uint32_t* q_inexact, int c_idx_dtype, hipStream_t s);
 inline int sparse_query_stages(int ts, bool gated) { return ts > 0 ? (gated ? ts : 2 * ts) : 0; }
 hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s);
 hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, int idx_dtype, int64_t n_rows, int d_dlr,
