@@ -102,6 +102,7 @@ struct dhr_index {
   int main_chunks = 2;
   int progressive_thr = 1;
   int n_cu = 256;
+  int overlap_aux = 1;                     // 0: refine / rescoring / select run on the GEMM's stream (every kernel gets the whole chip)
   int aux_cus = 128, gemm_exclusive = 0;   // CU-masked streams of the main pass (0 = off)
   int aux_cus_made = -1, gemm_excl_made = -1;
   hipStream_t s_gemm = nullptr;         // main-pass GEMM stream when CU masks are in use
@@ -159,6 +160,7 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
       if (value < 0 || value > 192 || value % 8) return set_error(DHR_ERR_INVALID, "aux_cus must be a multiple of 8 in [0,192]");
       ix->aux_cus = (int)value; return DHR_OK;
     case DHR_PARAM_GEMM_EXCLUSIVE: ix->gemm_exclusive = value != 0; return DHR_OK;
+    case DHR_PARAM_OVERLAP_AUX: ix->overlap_aux = value != 0; return DHR_OK;
     case DHR_PARAM_GEMM_VARIANT:
       if (value != 0 && (value < 2 || value > 4)) return set_error(DHR_ERR_INVALID, "gemm_variant must be 0, 2, 3 or 4");
       dhr::g_gemm_variant = (int)value; return DHR_OK;
@@ -849,8 +851,8 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       if (!ix->s_aux) HIP_TRY(hipStreamCreateWithFlags(&ix->s_aux, hipStreamNonBlocking));
       ix->aux_cus_made = ix->aux_cus; ix->gemm_excl_made = ix->gemm_exclusive;
     }
-    hipStream_t sb = ix->s_aux;
     hipStream_t sg = ix->s_gemm ? ix->s_gemm : s;
+    hipStream_t sb = ix->overlap_aux ? ix->s_aux : sg;
     hipEvent_t ev_enter = nullptr;
     if (sg != s) {
       HIP_TRY(hipEventCreateWithFlags(&ev_enter, hipEventDisableTiming));
@@ -1422,8 +1424,16 @@ extern "C" int dhr_debug_gemm_time(dhr_index* ix, const dhr_query_batch* qb, int
   Workspace& w = ix->ws;
   if ((rc = ensure_ws(ix, w, qb->n_queries, 1, 0)) != DHR_OK) return rc;
   if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
-  std::vector<float> inf((size_t)w.q_pad, INFINITY);
-  HIP_TRY(hipMemcpyAsync(w.thr, inf.data(), (size_t)w.q_pad * 4, hipMemcpyHostToDevice, s));
+  // DHR_GEMM_TIME_OPEN=1 (tuning): filter with the final thresholds of the previous dhr_search on this handle (same queries),
+  // i.e. a realistic hit rate in the epilogue, instead of the closed filter
+  const bool open = getenv("DHR_GEMM_TIME_OPEN") && atoi(getenv("DHR_GEMM_TIME_OPEN")) != 0 && w.thr_hat;
+  if (open) {
+    HIP_TRY(hipMemcpyAsync(w.thr, w.thr_hat, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
+  } else {
+    std::vector<float> inf((size_t)w.q_pad, INFINITY);
+    HIP_TRY(hipMemcpyAsync(w.thr, inf.data(), (size_t)w.q_pad * 4, hipMemcpyHostToDevice, s));
+  }
+  HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));
   GemmArgs g{};
   g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.seq_lo = 0; g.seq_hi = ix->n_tiles; g.map_mode = 0;
   g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;

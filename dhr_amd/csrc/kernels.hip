@@ -445,22 +445,32 @@ __device__ __forceinline__ void gemm_dump_tile(const GemmArgs& p, floatx16 (&acc
     }
   }
 }
-constexpr int EPI_QUEUE = 6144;      // entries of 8 bytes; beyond that a hit is appended directly
+// Filter epilogue of the bound GEMM: every accumulator that reaches its query's threshold becomes a (row, bound)
+// candidate of that query.  Hit rates are tiny on average (0.2 %) but extremely skewed (the fullest query of the bench
+// passes 37 % of the rows), so neither "one global atomic per hit" nor "LDS queue with one LDS atomic per hit" works:
+// the first pays a dependent L2 round trip inside a divergent branch per hit, the second a dependent LDS round trip
+// (measured +9 % on the kernel at the mean rate, far more in waves that hold a hot query).  Here a hit costs ONE
+// fire-and-forget LDS store: each consumer thread has a private stack of EPI_STACK slots in the (now idle) staging ring,
+// laid out [slot][thread] so that stores never conflict, indexed by a register counter.  After the scan the thread
+// reserves room in the global list with ONE atomic per (thread, query) -- a hot query's 24 hits per tile cost one
+// atomic -- and copies its own stack out.  Only hits beyond the stack (a thread with more than 32 of its 128
+// accumulators passing) fall back to one-by-one appends.
+constexpr int EPI_STACK = 32;
 template <bool DUMP, int NTHREADS = 512>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, floatx16 (&acc)[4][2], int64_t dt, int qt, int wm, int wn,
                                               int lane, char* smem, bool has_acc = true) {
-  const int fhalf = lane >> 5;
-  const int64_t row_base = dt * TILE_ROWS + wm * 128;
   if (DUMP) {
     if (has_acc) gemm_dump_tile(p, acc, dt, qt, wm, wn, lane);
     return;
   }
-  uint2* queue = (uint2*)smem;
-  uint32_t* qn = (uint32_t*)(smem + EPI_QUEUE * 8);
   __syncthreads();                       // every wave is done with the staging ring
-  if (threadIdx.x == 0) *qn = 0u;
-  __syncthreads();
-  if (has_acc)
+  if (!has_acc) return;
+  const int fhalf = lane >> 5;
+  const int64_t row0 = dt * TILE_ROWS;
+  const int rows_valid = (int)(p.n_rows - row0 < TILE_ROWS ? p.n_rows - row0 : TILE_ROWS);
+  const int tid = (wm * 4 + wn) * 64 + lane;               // consumer thread 0..511
+  uint2* stack = (uint2*)smem + tid;                       // slot j at stack[j * 512]
+  uint32_t j = 0, j0 = 0;
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const int ql = wn * 64 + ni * 32 + (lane & 31);
@@ -472,25 +482,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, floatx16 (&acc)
       for (int e = 0; e < 16; ++e) {
         const float v = acc[mi][ni][e];
         if (v >= t) {
+          asm volatile("");                // keep this a (rarely taken) branch: as a select chain the 128 predicates spill
           const int rl = wm * 128 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
-          if (dt * TILE_ROWS + rl < p.n_rows) {
-            const uint32_t s = atomicAdd(qn, 1u);
-            if (s < EPI_QUEUE) queue[s] = make_uint2((uint32_t)(rl << 8 | ql), __float_as_uint(v));
+          if (rl < rows_valid) {           // (zero padding behind the last row of the shard)
+            if (j < EPI_STACK) stack[j * 512] = make_uint2((uint32_t)rl, __float_as_uint(v));
             else {
               const uint32_t slot = atomicAdd(p.cnt + q, 1u);
-              if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(dt * TILE_ROWS + rl), __float_as_uint(v));
+              if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(row0 + rl), __float_as_uint(v));
             }
+            ++j;
           }
         }
       }
+    if (ni == 0) j0 = j;
   }
-  __syncthreads();
-  const uint32_t n = *qn < EPI_QUEUE ? *qn : EPI_QUEUE;
-  for (uint32_t s = threadIdx.x; s < n; s += NTHREADS) {
-    const uint2 en = queue[s];
-    const int q = qt * TILE_ROWS + (int)(en.x & 255u);
-    const uint32_t slot = atomicAdd(p.cnt + q, 1u);
-    if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(dt * TILE_ROWS) + (en.x >> 8), en.y);
+  if (j == 0) return;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const uint32_t lo = ni ? (j0 < EPI_STACK ? j0 : EPI_STACK) : 0u;
+    const uint32_t hi = ni ? (j < EPI_STACK ? j : EPI_STACK) : (j0 < EPI_STACK ? j0 : EPI_STACK);
+    if (hi > lo) {
+      const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
+      const uint32_t base = atomicAdd(p.cnt + q, hi - lo);
+      for (uint32_t i = lo; i < hi; ++i) {
+        const uint2 en = stack[i * 512];
+        const uint32_t slot = base + (i - lo);
+        if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)row0 + en.x, en.y);
+      }
+    }
   }
 }
 

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--variant", type=int, default=3)
     ap.add_argument("--dlr", type=int, default=0, help="gated columns (with a random uint8 slice index); the rest of --k is dense")
     ap.add_argument("--idx-buckets", type=int, default=0)
+    ap.add_argument("--synth", action="store_true", help="the bench's synthetic hybrid data instead of uniform random operands")
+    ap.add_argument("--open", action="store_true", help="run a search first and keep its final thresholds in the filter (DHR_GEMM_TIME_OPEN)")
     a = ap.parse_args()
     import torch
     from dhr_amd import _lib
@@ -30,7 +32,16 @@ def main():
         cv[:, :a.dlr] = cv[:, :a.dlr].abs(); qv[:, :a.dlr] = qv[:, :a.dlr].abs()
         ci = torch.randint(0, 39, (a.rows, a.dlr), generator=g, device="cuda", dtype=torch.uint8)
         qi = torch.randint(0, 39, (a.queries, a.dlr), generator=g, device="cuda", dtype=torch.uint8)
+    if a.synth:
+        import bench
+        from dhr_amd import synth
+        dev = torch.device("cuda", 0)
+        cv, ci = bench.gen_shard(torch, synth, dev, 4242, a.rows, a.dlr or 768, a.k - (a.dlr or 768), 30, 90, False)
+        qv, qi = bench.gen_shard(torch, synth, dev, 777, a.queries, a.dlr or 768, a.k - (a.dlr or 768), 4, 12, False)
     ix = GipIndex(cv, ci, idx_buckets=a.idx_buckets)
+    if a.open:
+        os.environ["DHR_GEMM_TIME_OPEN"] = "1"
+        ix.search(qv, qi, 1000, out_device=True)
     del cv
     ix.set_param(_lib.PARAM_GEMM_VARIANT, a.variant)
     qb, keep = _lib.make_query_batch(qv, qi)
