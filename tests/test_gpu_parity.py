@@ -719,3 +719,51 @@ def test_unsupported_width_is_refused_loudly(G):
     ci = np.zeros((64, 100), np.uint8)
     with pytest.raises(_lib.DhrError, match="multiple of 8"):
         G.GipIndex(cv, ci)
+
+
+@pytest.mark.parametrize("kind", ["hybrid", "dense"])
+def test_full_size_properties(G, kind):
+    """BASELINE config 3 (hybrid) / config 2 (dense-only) at FULL size (8 841 823 x (768+768), 6 980 queries, top-1000), where the oracle cannot run: properties
+    that do not depend on the size.  (1) lists are sorted (score desc, row asc) with distinct valid rows; (2) the search is
+    idempotent; (3) every returned score is the exact score of its row (dhr_score_rows, an independent code path);
+    (4) completeness spot check: for sampled queries, none of 200 000 random rows outside the list beats the k-th score;
+    (5) a 200 000-row slice of the same corpus searched alone agrees with the oracle (ties the generator to the CPU path)."""
+    import sys, os
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    from dhr_amd import synth
+    dev = torch.device("cuda", 0)
+    n, nq, k = 8_841_823, 6980, 1000
+    d_dlr = 768 if kind == "hybrid" else 0
+    cv, ci = bench.gen_shard(torch, synth, dev, 1237, n, d_dlr, 768, 30, 90, False)
+    qv, qi = bench.gen_shard(torch, synth, dev, 1237 + 999_983, nq, d_dlr, 768, 4, 12, False)
+    ix = G.GipIndex(cv, ci)
+    try:
+        s1, r1 = ix.search(qv, qi, k, out_device=True)
+        s2, r2 = ix.search(qv, qi, k, out_device=True)
+        assert torch.equal(r1, r2) and torch.equal(s1, s2)                                       # (2)
+        assert bool((r1 >= 0).all()) and bool((r1 < n).all())
+        ds = s1[:, 1:] - s1[:, :-1]
+        assert bool((ds <= 0).all())                                                              # (1) scores descending
+        tie = ds == 0
+        assert bool((r1[:, 1:][tie] > r1[:, :-1][tie]).all())                                     #     row ascending on ties
+        assert int(torch.sort(r1, dim=1).values.diff(dim=1).eq(0).sum()) == 0                     #     distinct rows
+        sub = torch.arange(0, nq, 97, device=dev)
+        qs, qis = qv[sub].cpu().numpy().astype(np.float32), (None if qi is None else qi[sub].cpu().numpy())
+        rows = r1[sub].cpu().numpy()
+        sc = ix.score_rows(qs, qis, rows)
+        np.testing.assert_array_equal(sc, s1[sub].cpu().numpy())                                 # (3)
+        g = torch.Generator(device="cpu").manual_seed(7)
+        rnd = torch.randint(0, n, (len(sub), 200_000), generator=g).numpy().astype(np.int64)
+        rs = ix.score_rows(qs, qis, rnd)
+        kth = s1[sub, k - 1].cpu().numpy()[:, None]
+        inlist = np.stack([np.isin(rnd[i], rows[i]) for i in range(len(sub))])
+        assert not np.any((rs > kth) & ~inlist)                                                   # (4)
+    finally:
+        ix.close()
+    m = 200_000
+    cvs, cis = cv[:m].cpu().numpy(), (None if ci is None else ci[:m].cpu().numpy())
+    del cv, ci
+    torch.cuda.empty_cache()
+    _search_check(G, cvs, cis, qs[:6], None if qis is None else qis[:6], 100)                     # (5)
