@@ -162,7 +162,7 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
     case DHR_PARAM_GEMM_EXCLUSIVE: ix->gemm_exclusive = value != 0; return DHR_OK;
     case DHR_PARAM_OVERLAP_AUX: ix->overlap_aux = value != 0; return DHR_OK;
     case DHR_PARAM_GEMM_VARIANT:
-      if (value != 0 && (value < 2 || value > 4)) return set_error(DHR_ERR_INVALID, "gemm_variant must be 0, 2, 3 or 4");
+      if (value != 3) return set_error(DHR_ERR_INVALID, "gemm_variant: only 3 is built (the other variants measured no better and were removed)");
       dhr::g_gemm_variant = (int)value; return DHR_OK;
     case DHR_PARAM_MAX_GROWTH:
       if (value < 1 || value > 1024) return set_error(DHR_ERR_INVALID, "max_growth must be in [1,1024] sixteenths");

@@ -523,100 +523,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, floatx16 (&acc)
   }
 }
 
-template <bool DUMP>
-__global__ void __launch_bounds__(GEMM_THREADS) gemm_filter_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // ---- tile assignment
-  const int64_t b = blockIdx.x;
-  const int xcd = (int)(b & 7);
-  const int64_t i = b >> 3;
-  const int per_group = DOC_GROUP * p.n_qtiles;
-  const int64_t g_local = i / per_group;
-  const int r = (int)(i - g_local * per_group);
-  const int qt = r / DOC_GROUP;
-  const int dl = r - qt * DOC_GROUP;
-  const int64_t seq = p.seq_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
-  if (seq >= p.seq_hi) return;
-  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head);
-  if (dt >= p.n_tiles) return;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2;            // 0..1 : 128-row half
-  const int wn = wave & 3;             // 0..3 : 64-query quarter
-  const int ksteps = p.ksteps;
-
-  const char* a_src = (const char*)(p.a_tiles + dt * (int64_t)ksteps * TILE_HALVES);
-  const char* b_src = (const char*)(p.b_tiles + (int64_t)qt * ksteps * TILE_HALVES);
-  // this wave's 4 x 1 KiB pieces of each 32 KiB tile
-  const int piece0 = wave * 4;
-
-  auto stage = [&](int buf, int ks) {
-    char* la = smem + buf * (2 * TILE_HALVES * 2);
-    char* lb = la + TILE_HALVES * 2;
-    const char* ga = a_src + (int64_t)ks * (TILE_HALVES * 2);
-    const char* gb = b_src + (int64_t)ks * (TILE_HALVES * 2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int off = (piece0 + j) * 1024;
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga + off + lane * 16), LDS_PTR(la + off), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gb + off + lane * 16), LDS_PTR(lb + off), 16, 0, 0);
-    }
-  };
-
-  floatx16 acc[4][2];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-
-  // fragment read offsets (bytes) inside a 32 KiB tile image: row*128 + ((chunk ^ ((row>>1)&7)) * 16)
-  const int frow = lane & 31;
-  const int fhalf = lane >> 5;
-  const int swz = (frow >> 1) & 7;      // row bases are multiples of 32, so only lane bits matter
-  int a_off[4], b_off[2];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) a_off[mi] = (wm * 128 + mi * 32 + frow) * 128;
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) b_off[ni] = (wn * 64 + ni * 32 + frow) * 128;
-
-  stage(0, 0);
-  __syncthreads();
-  for (int ks = 0; ks < ksteps; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < ksteps) stage(buf ^ 1, ks + 1);
-    const char* la = smem + buf * (2 * TILE_HALVES * 2);
-    const char* lb = la + TILE_HALVES * 2;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int coff = ((kk * 2 + fhalf) ^ swz) * 16;
-      half8 af[4], bf[2];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) af[mi] = *(const half8*)(la + a_off[mi] + coff);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) bf[ni] = *(const half8*)(lb + b_off[ni] + coff);
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-    }
-    __syncthreads();    // drains the DMA of the next stage (vmcnt(0)) and fences the reads of this one
-  }
-
-  gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane, smem);
-}
-
-// Variant 3: same tiling as gemm_filter_kernel (8 waves, 128 x 64 per wave) with three changes aimed at
+// Bound GEMM for the K-step tile layout (dense-only indexes, bucket counts other than two): 256 x 256 tile, 8 waves
+// (128 x 64 per wave), each wave DMAs 4 + 4 KiB per K-step with global_load_lds_dwordx4 into a double-buffered
+// 2 x 64 KiB LDS ring, with three refinements aimed at
 // the matrix pipe's idle time: (1) the two wave groups (one wave of each per SIMD) issue their LDS-DMA
 // at DIFFERENT points of the K-step (group 0 at the start, group 1 in the middle), so one wave of every
 // SIMD is always in its MFMA stream while the other pays the DMA issue cost; (2) fragments are
 // software-pipelined one 16-deep k-slice ahead (two register sets); (3) the single hand-over barrier of a
 // K-step sits BEFORE the last k-slice's MFMAs, and the first fragments of the next K-step are read under them.
-template <bool DUMP, int ABL = 0>   // ABL (timing experiments only, wrong results): 3 = relaxed DMA wait, 4 = no hand-over barrier
+template <bool DUMP>
 __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_v3_kernel(GemmArgs p) {
+  constexpr int ABL = 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int64_t b = blockIdx.x;
   const int xcd = (int)(b & 7);
@@ -711,120 +628,6 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_v3_kernel(GemmArg
   }
 #undef V3_READ
 #undef V3_MFMA8
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane, smem);
-}
-
-// Variant 4: variant 3's tiling and fragment pipeline, but every wave spreads its 8 LDS-DMA instructions
-// of a K-step over three k-slices (3 + 3 + 2, the first three right after the hand-over barrier of the
-// previous K-step), interleaved with the MFMAs by sched_group_barrier, so that the texture-address queue
-// is never hit by a burst.  The loop body is branch-free (stages past the end are clamped / dead).
-template <bool DUMP>
-__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_v4_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int64_t b = blockIdx.x;
-  const int xcd = (int)(b & 7);
-  const int64_t i = b >> 3;
-  const int per_group = DOC_GROUP * p.n_qtiles;
-  const int64_t g_local = i / per_group;
-  const int r = (int)(i - g_local * per_group);
-  const int qt = r / DOC_GROUP;
-  const int dl = r - qt * DOC_GROUP;
-  const int64_t seq = p.seq_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
-  if (seq >= p.seq_hi) return;
-  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head);
-  if (dt >= p.n_tiles) return;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2;
-  const int wn = wave & 3;
-  const int ksteps = p.ksteps;
-  const char* a_src = (const char*)(p.a_tiles + dt * (int64_t)ksteps * TILE_HALVES);
-  const char* b_src = (const char*)(p.b_tiles + (int64_t)qt * ksteps * TILE_HALVES);
-  const int piece0 = wave * 4;
-
-  // DMA instruction n (0..7) of this wave for K-step ks: pieces of A for even n, of B for odd n
-  auto dma = [&](int buf, int ks, int n) {
-    char* l = smem + buf * (2 * TILE_HALVES * 2) + (n & 1) * (TILE_HALVES * 2);
-    const char* g = ((n & 1) ? b_src : a_src) + (int64_t)ks * (TILE_HALVES * 2);
-    const int off = (piece0 + (n >> 1)) * 1024;
-    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g + off + lane * 16), LDS_PTR(l + off), 16, 0, 0);
-  };
-
-  floatx16 acc[4][2];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-
-  const int frow = lane & 31;
-  const int fhalf = lane >> 5;
-  const int swz = (frow >> 1) & 7;
-  int a_off[4], b_off[2];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) a_off[mi] = (wm * 128 + mi * 32 + frow) * 128;
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) b_off[ni] = (wn * 64 + ni * 32 + frow) * 128;
-
-  half8 a0[4], b0[2], a1[4], b1[2];
-#define V4_READ(AF, BF, BUF, KK)                                                               \
-  {                                                                                            \
-    const char* la_ = smem + (BUF) * (2 * TILE_HALVES * 2);                                    \
-    const char* lb_ = la_ + TILE_HALVES * 2;                                                   \
-    const int coff_ = ((((KK) * 2) + fhalf) ^ swz) * 16;                                       \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) AF[mi] = *(const half8*)(la_ + a_off[mi] + coff_); \
-    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) BF[ni] = *(const half8*)(lb_ + b_off[ni] + coff_); \
-  }
-#define V4_MFMA8(AF, BF)                                                                       \
-  {                                                                                            \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                           \
-    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                           \
-      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[mi], BF[ni], acc[mi][ni], 0, 0, 0); \
-  }
-#define V4_INTERLEAVE(NV)                                                    \
-  _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                         \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       \
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       \
-    if (g_ < (NV)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        \
-  }                                                                          \
-  __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-
-  const int last = ksteps - 1;
-#pragma unroll
-  for (int n = 0; n < 8; ++n) dma(0, 0, n);
-#pragma unroll
-  for (int n = 0; n < 8; ++n) dma(1, last < 1 ? last : 1, n);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  V4_READ(a0, b0, 0, 0);
-  for (int t = 0; t < ksteps; ++t) {
-    const int buf = t & 1;
-    const int ks1 = t + 1 < last ? t + 1 : last;
-    const int ks2 = t + 2 < last ? t + 2 : last;
-    dma(buf ^ 1, ks1, 3); dma(buf ^ 1, ks1, 4); dma(buf ^ 1, ks1, 5);
-    V4_READ(a1, b1, buf, 1);
-    V4_MFMA8(a0, b0);
-    V4_INTERLEAVE(3);
-    dma(buf ^ 1, ks1, 6); dma(buf ^ 1, ks1, 7);
-    V4_READ(a0, b0, buf, 2);
-    V4_MFMA8(a1, b1);
-    V4_INTERLEAVE(2);
-    V4_READ(a1, b1, buf, 3);
-    V4_MFMA8(a0, b0);
-    V4_INTERLEAVE(0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    dma(buf, ks2, 0); dma(buf, ks2, 1); dma(buf, ks2, 2);
-    V4_READ(a0, b0, buf ^ 1, 0);
-    V4_MFMA8(a1, b1);
-    V4_INTERLEAVE(3);
-  }
-#undef V4_READ
-#undef V4_MFMA8
-#undef V4_INTERLEAVE
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane, smem);
 }
@@ -1022,193 +825,15 @@ __global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(
   gemm_epilogue<DUMP, GEMM_PC_THREADS>(p, acc, dt, qt, wm, wn, lane, smem, wave < 8);
 }
 
-// One-wave-per-SIMD variant: 4 waves (256 threads), each owns a 128 x 128 quadrant of the 256 x 256
-// output tile = 4x4 blocks of v_mfma_f32_32x32x16_f16 (256 fp32 accumulators; the unified 512-entry
-// register file of gfx950 holds them next to two fragment sets).  A wave issues the LDS reads of the
-// next 16-deep k-slice, then the 16 MFMAs of the current one, so LDS latency sits in the matrix-pipe
-// shadow; one barrier per K-step (placed before the last k-slice) hands the double-buffered LDS ring
-// over, with the next K-step's LDS-DMA issued a full K-step (64 MFMAs) before it is needed.
-constexpr int GEMM_W4_THREADS = 256;
+int g_gemm_ablate = 0;    // tuning only (DHR_GEMM_ABLATE environment variable): timing ablations of the 2:4 kernel, wrong results
+int g_gemm_variant = 3;   // kept for the C ABI's DHR_PARAM_GEMM_VARIANT; only variant 3 is built (the others measured no better and were removed)
 
-template <bool DUMP>
-__device__ __forceinline__ void gemm_epilogue_w4(const GemmArgs& p, floatx16 (&acc)[4][4], int64_t dt, int qt, int wm, int wn,
-                                                 int lane) {
-  const int fhalf = lane >> 5;
-  const int64_t row_base = dt * TILE_ROWS + wm * 128;
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const int q = qt * TILE_ROWS + wn * 128 + ni * 32 + (lane & 31);
-    if (DUMP) {
-      if (q < p.n_queries) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int64_t row = row_base + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
-            if (row < p.n_rows && row >= p.dump_row0 && row - p.dump_row0 < p.dump_ld)
-              p.dump[(int64_t)q * p.dump_ld + (row - p.dump_row0)] = acc[mi][ni][e];
-          }
-      }
-    } else {
-      const float t = p.thr[q];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = acc[mi][ni][e];
-          if (v >= t) {
-            const int64_t row = row_base + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
-            if (row < p.n_rows) {
-              const uint32_t slot = atomicAdd(p.cnt + q, 1u);
-              if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)row, __float_as_uint(v));
-            }
-          }
-        }
-    }
-  }
-}
-
-template <bool DUMP, int ABLATE = 0>   // ABLATE (tuning only): 1 = no in-loop staging, 2 = no MFMA
-__global__ void __launch_bounds__(GEMM_W4_THREADS, 1) gemm_filter_w4_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int64_t b = blockIdx.x;
-  const int xcd = (int)(b & 7);
-  const int64_t i = b >> 3;
-  const int per_group = DOC_GROUP * p.n_qtiles;
-  const int64_t g_local = i / per_group;
-  const int r = (int)(i - g_local * per_group);
-  const int qt = r / DOC_GROUP;
-  const int dl = r - qt * DOC_GROUP;
-  const int64_t seq = p.seq_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
-  if (seq >= p.seq_hi) return;
-  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head);
-  if (dt >= p.n_tiles) return;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1;            // 128-row half of the tile
-  const int wn = wave & 1;             // 128-query half
-  const int ksteps = p.ksteps;
-  const char* a_src = (const char*)(p.a_tiles + dt * (int64_t)ksteps * TILE_HALVES);
-  const char* b_src = (const char*)(p.b_tiles + (int64_t)qt * ksteps * TILE_HALVES);
-  const int piece0 = wave * 8;         // this wave's 8 x 1 KiB pieces of each 32 KiB tile
-
-  auto stage = [&](int buf, int ks) {
-    char* la = smem + buf * (2 * TILE_HALVES * 2);
-    char* lb = la + TILE_HALVES * 2;
-    const char* ga = a_src + (int64_t)ks * (TILE_HALVES * 2);
-    const char* gb = b_src + (int64_t)ks * (TILE_HALVES * 2);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int off = (piece0 + j) * 1024;
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga + off + lane * 16), LDS_PTR(la + off), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gb + off + lane * 16), LDS_PTR(lb + off), 16, 0, 0);
-    }
-  };
-
-  floatx16 acc[4][4];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-
-  const int frow = lane & 31;
-  const int fhalf = lane >> 5;
-  const int swz = (frow >> 1) & 7;
-  int a_off[4], b_off[4];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) a_off[mi] = (wm * 128 + mi * 32 + frow) * 128;
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) b_off[ni] = (wn * 128 + ni * 32 + frow) * 128;
-
-  half8 a0[4], b0[4], a1[4], b1[4];     // two fragment sets (even / odd k-slices)
-#define DHR_READ_FRAGS(AF, BF, BUF, KK)                                                        \
-  {                                                                                            \
-    const char* la_ = smem + (BUF) * (2 * TILE_HALVES * 2);                                    \
-    const char* lb_ = la_ + TILE_HALVES * 2;                                                   \
-    const int coff_ = ((((KK) * 2) + fhalf) ^ swz) * 16;                                       \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) AF[mi] = *(const half8*)(la_ + a_off[mi] + coff_); \
-    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) BF[ni] = *(const half8*)(lb_ + b_off[ni] + coff_); \
-  }
-#define DHR_MFMA16(AF, BF)                                                                     \
-  {                                                                                            \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                           \
-    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                           \
-      if (ABLATE == 2) { asm volatile("" :: "v"(AF[mi]), "v"(BF[ni])); }                       \
-      else acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[mi], BF[ni], acc[mi][ni], 0, 0, 0); \
-  }
-
-  // this wave's pieces [j_lo, j_hi) of K-step ks into LDS buffer buf (2 LDS-DMA instructions per piece pair)
-  auto stage_part = [&](int buf, int ks, int j_lo, int j_hi) {
-    if (ABLATE == 1) return;
-    char* la = smem + buf * (2 * TILE_HALVES * 2);
-    char* lb = la + TILE_HALVES * 2;
-    const char* ga = a_src + (int64_t)ks * (TILE_HALVES * 2);
-    const char* gb = b_src + (int64_t)ks * (TILE_HALVES * 2);
-#pragma unroll
-    for (int j = j_lo; j < j_hi; ++j) {
-      const int off = (piece0 + j) * 1024;
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga + off + lane * 16), LDS_PTR(la + off), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gb + off + lane * 16), LDS_PTR(lb + off), 16, 0, 0);
-    }
-  };
-// interleave: 2 MFMA, 1 LDS read, 1 LDS-DMA issue, ... so that neither the 8 fragment reads nor the
-// DMA issue (expensive: ~100 cycles each) ever sit in front of the matrix pipe as a block
-#define DHR_INTERLEAVE(NVMEM)                                                \
-  _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                         \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                       \
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       \
-    if (g_ < (NVMEM)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     \
-  }
-
-  stage(0, 0);
-  if (ksteps > 1) stage(1, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  DHR_READ_FRAGS(a0, b0, 0, 0);
-  // The loop body is branch-free so that the scheduler can interleave across the whole K-step: stages
-  // past the last K-step are clamped to it and land in a buffer nobody reads any more (idempotent or dead).
-  const int last = ksteps - 1;
-  for (int t = 0; t < ksteps; ++t) {
-    const int buf = t & 1;
-    const int ks1 = t + 1 < last ? t + 1 : last;
-    const int ks2 = t + 2 < last ? t + 2 : last;
-    DHR_READ_FRAGS(a1, b1, buf, 1);
-    stage_part(buf ^ 1, ks1, 3, 6);
-    DHR_MFMA16(a0, b0);
-    DHR_INTERLEAVE(6);
-    DHR_READ_FRAGS(a0, b0, buf, 2);
-    stage_part(buf ^ 1, ks1, 6, 8);
-    DHR_MFMA16(a1, b1);
-    DHR_INTERLEAVE(4);
-    DHR_READ_FRAGS(a1, b1, buf, 3);
-    DHR_MFMA16(a0, b0);
-    DHR_INTERLEAVE(0);
-    // hand-over: every wave has finished reading K-step t, K-step t+1 has landed for everyone
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    DHR_READ_FRAGS(a0, b0, buf ^ 1, 0);
-    stage_part(buf, ks2, 0, 3);
-    DHR_MFMA16(a1, b1);
-    DHR_INTERLEAVE(6);
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#undef DHR_INTERLEAVE
-#undef DHR_READ_FRAGS
-#undef DHR_MFMA16
-  gemm_epilogue_w4<DUMP>(p, acc, dt, qt, wm, wn, lane);
-}
-
-int g_gemm_ablate = 0;    // tuning only (DHR_GEMM_ABLATE environment variable)
-int g_gemm_variant = 3;   // 0 single-phase, 2 one wave per SIMD, 3 staggered DMA + pipelined fragments
-
+// The bound GEMM + filter over the tiles [seq_lo, seq_hi) of the sequence: gemm_filter_sparse_kernel for the 2:4 layout
+// (a.ts > 0), gemm_filter_v3_kernel for the K-step tile layout (dense-only indexes, other bucket counts).
 hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
   static bool env_read = false;
   if (!env_read) {
     if (const char* e = getenv("DHR_GEMM_ABLATE")) g_gemm_ablate = atoi(e);
-    if (const char* e = getenv("DHR_GEMM_VARIANT")) g_gemm_variant = atoi(e);
     env_read = true;
   }
   const int64_t n_tiles = a.seq_hi - a.seq_lo;
@@ -1218,91 +843,31 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
   const int64_t blocks = groups_per_xcd * 8 * DOC_GROUP * a.n_qtiles;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_filter_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       GEMM_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)gemm_filter_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            GEMM_LDS_BYTES);
+    e = hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            GEMM_LDS_BYTES);
+    e = hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_PC_LDS);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            GEMM_LDS_BYTES);
+    e = hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_PC_LDS);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
+  const dim3 grid((unsigned)blocks);
   if (a.ts > 0) {
-    static bool attrs = false;
-    if (!attrs) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_PC_LDS);
-      if (e != hipSuccess) return e;
-      e = hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_PC_LDS);
-      if (e != hipSuccess) return e;
-      attrs = true;
-    }
-    const unsigned grid = (unsigned)blocks;
     if (a.dump)
-      hipLaunchKernelGGL(gemm_filter_sparse_kernel<true>, dim3(grid), dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a);
+      hipLaunchKernelGGL(gemm_filter_sparse_kernel<true>, grid, dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a);
     else if (g_gemm_ablate >= 1 && g_gemm_ablate <= 5) {
 #define SP_ABL(N) { (void)hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_PC_LDS); \
-      hipLaunchKernelGGL((gemm_filter_sparse_kernel<false, N>), dim3(grid), dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a); }
+      hipLaunchKernelGGL((gemm_filter_sparse_kernel<false, N>), grid, dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a); }
       if (g_gemm_ablate == 1) SP_ABL(1) else if (g_gemm_ablate == 2) SP_ABL(2) else if (g_gemm_ablate == 3) SP_ABL(3) else if (g_gemm_ablate == 4) SP_ABL(4) else SP_ABL(5)
 #undef SP_ABL
     } else
-      hipLaunchKernelGGL(gemm_filter_sparse_kernel<false>, dim3(grid), dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a);
-  } else if (g_gemm_variant == 2) {
-    static bool attr2 = false;
-    if (!attr2) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm_filter_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         GEMM_LDS_BYTES);
-      if (e != hipSuccess) return e;
-      e = hipFuncSetAttribute((const void*)gemm_filter_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-      if (e != hipSuccess) return e;
-      attr2 = true;
-    }
-    if (a.dump)
-      hipLaunchKernelGGL(gemm_filter_w4_kernel<true>, dim3((unsigned)blocks), dim3(GEMM_W4_THREADS), GEMM_LDS_BYTES, s, a);
-    else if (g_gemm_ablate == 1) {
-      (void)hipFuncSetAttribute((const void*)gemm_filter_w4_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-      hipLaunchKernelGGL((gemm_filter_w4_kernel<false, 1>), dim3((unsigned)blocks), dim3(GEMM_W4_THREADS), GEMM_LDS_BYTES, s, a);
-    } else if (g_gemm_ablate == 2) {
-      (void)hipFuncSetAttribute((const void*)gemm_filter_w4_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-      hipLaunchKernelGGL((gemm_filter_w4_kernel<false, 2>), dim3((unsigned)blocks), dim3(GEMM_W4_THREADS), GEMM_LDS_BYTES, s, a);
-    } else
-      hipLaunchKernelGGL(gemm_filter_w4_kernel<false>, dim3((unsigned)blocks), dim3(GEMM_W4_THREADS), GEMM_LDS_BYTES, s, a);
-  } else if (g_gemm_variant == 4) {
-    static bool attr4 = false;
-    if (!attr4) {
-      (void)hipFuncSetAttribute((const void*)gemm_filter_v4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-      (void)hipFuncSetAttribute((const void*)gemm_filter_v4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-      attr4 = true;
-    }
-    if (a.dump)
-      hipLaunchKernelGGL(gemm_filter_v4_kernel<true>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
-    else
-      hipLaunchKernelGGL(gemm_filter_v4_kernel<false>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
-  } else if (g_gemm_variant == 3) {
-    if (a.dump)
-      hipLaunchKernelGGL(gemm_filter_v3_kernel<true>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
-    else if (g_gemm_ablate == 3) {
-      (void)hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-      hipLaunchKernelGGL((gemm_filter_v3_kernel<false, 3>), dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
-    } else if (g_gemm_ablate == 4) {
-      (void)hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-      hipLaunchKernelGGL((gemm_filter_v3_kernel<false, 4>), dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
-    } else if (g_gemm_ablate == 5) {
-      (void)hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-      hipLaunchKernelGGL((gemm_filter_v3_kernel<false, 5>), dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
-    } else if (g_gemm_ablate == 6) {
-      (void)hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-      hipLaunchKernelGGL((gemm_filter_v3_kernel<false, 6>), dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
-    } else
-      hipLaunchKernelGGL(gemm_filter_v3_kernel<false>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+      hipLaunchKernelGGL(gemm_filter_sparse_kernel<false>, grid, dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a);
   } else if (a.dump)
-    hipLaunchKernelGGL(gemm_filter_kernel<true>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+    hipLaunchKernelGGL(gemm_filter_v3_kernel<true>, grid, dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
   else
-    hipLaunchKernelGGL(gemm_filter_kernel<false>, dim3((unsigned)blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
+    hipLaunchKernelGGL(gemm_filter_v3_kernel<false>, grid, dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
   return hipGetLastError();
 }
 

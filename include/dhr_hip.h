@@ -98,7 +98,7 @@ typedef enum dhr_param {
   DHR_PARAM_GEMM_EXCLUSIVE = 10, /* with AUX_CUS: 1 = run the bound GEMM on the other CUs only */
   DHR_PARAM_OVERLAP_AUX = 11,  /* 1 (default): refine / rescoring / select of chunk i run beside the GEMM of chunk i+1; 0: one after the other */
   DHR_PARAM_PROGRESSIVE_THR = 8, /* 1 (default): later main-pass chunks filter with the running exact k-th best, not only the sampled threshold */
-  DHR_PARAM_GEMM_VARIANT = 6, /* process-wide, dense-only / >2-bucket bound GEMM: 3 (default), 0, 2, 4 = tuning variants */
+  DHR_PARAM_GEMM_VARIANT = 6, /* reserved: only 3 (the built kernel) is accepted */
   DHR_PARAM_SAMPLE_PERIOD = 5 /* every S-th corpus tile seeds the thresholds (default 16; 0 = plain streaming) */
 } dhr_param;
 
