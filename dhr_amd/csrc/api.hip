@@ -179,8 +179,10 @@ extern "C" int dhr_get_stats(const dhr_index* ix, dhr_search_stats* out) {
 }
 
 // ------------------------------------------------------------------------------------------ index build
-static int ingest(dhr_index* ix, const dhr_index_desc* d, bool first_pass, uint32_t* d_flags /* {max_sq, neg} */,
-                  void* stage, int64_t block_rows, hipStream_t s) {
+// Pass 1 of the index build: the caller's rows (host rows staged block by block) -> row-major device copy vals_rm, norms and
+// sign scan.  Everything else (bucket maps, operand tiles, refine lists) is derived from vals_rm / c_idx on the device.
+static int ingest(dhr_index* ix, const dhr_index_desc* d, uint32_t* d_flags /* {max_sq, neg} */, void* stage, int64_t block_rows,
+                  hipStream_t s) {
   const int64_t n = ix->n_rows;
   for (int64_t lo = 0; lo < n; lo += block_rows) {
     const int64_t rows = std::min(block_rows, n - lo);
@@ -195,30 +197,32 @@ static int ingest(dhr_index* ix, const dhr_index_desc* d, bool first_pass, uint3
       src = (const __half*)d->value + lo * d->ld_value;
       ld = d->ld_value;
     }
-    if (first_pass) {
-      HIP_TRY(launch_scan_rows(src, ld, rows, ix->d_dlr, ix->k, d_flags, d_flags + 1, s));
-      HIP_TRY(launch_copy_rows(src, ld, rows, ix->k, ix->k_rm, ix->vals_rm + lo * ix->k_rm, s));
-    }
-    const int64_t fill = (lo + rows == n) ? round_up(lo + rows, TILE_ROWS) - lo : rows;   // zero the tail of the last tile
-    if (ix->ts > 0)
-      HIP_TRY(launch_tile_rows_sparse(src, ld, lo, rows, fill, ix->d_dlr, ix->d_cls, ix->ts, ix->td, ix->c_idx, ix->idx_dtype,
-                                      ix->bucket_map, ix->abs_mode, (char*)ix->tiles, s));
-    else
-      HIP_TRY(launch_tile_rows(src, ld, lo, rows, fill, ix->d_dlr, ix->d_cls, ix->n_buckets, ix->kt, ix->c_idx, ix->idx_dtype,
-                               ix->bucket_map, ix->abs_mode, ix->tiles, s));
+    HIP_TRY(launch_scan_rows(src, ld, rows, ix->d_dlr, ix->k, d_flags, d_flags + 1, s));
+    HIP_TRY(launch_copy_rows(src, ld, rows, ix->k, ix->k_rm, ix->vals_rm + lo * ix->k_rm, s));
     if (d->mem_kind == DHR_MEM_HOST) HIP_TRY(hipStreamSynchronize(s));   // the staging buffer is reused
   }
   return DHR_OK;
 }
+// Pass 2: the bound-GEMM operand tiles from the device copy (needs the bucket map and abs_mode).
+static int build_tiles(dhr_index* ix, hipStream_t s) {
+  const int64_t n = ix->n_rows, fill = ix->n_tiles * TILE_ROWS;
+  if (ix->ts > 0)
+    HIP_TRY(launch_tile_rows_sparse(ix->vals_rm, ix->k_rm, 0, n, fill, ix->d_dlr, ix->d_cls, ix->ts, ix->td, ix->c_idx, ix->idx_dtype,
+                                    ix->bucket_map, ix->abs_mode, (char*)ix->tiles, s));
+  else
+    HIP_TRY(launch_tile_rows(ix->vals_rm, ix->k_rm, 0, n, fill, ix->d_dlr, ix->d_cls, ix->n_buckets, ix->kt, ix->c_idx, ix->idx_dtype,
+                             ix->bucket_map, ix->abs_mode, ix->tiles, s));
+  return DHR_OK;
+}
 
-// Per-slice index-value -> bucket table, balanced by corpus frequency (greedy: most frequent value first
-// into the lightest bucket), so that two different values of one slice rarely share a bucket.
-static void build_bucket_map(const std::vector<uint32_t>& hist, int d_dlr, int nb, std::vector<uint8_t>& map) {
+// Per-slice index-value -> bucket table, balanced by value MASS (greedy: heaviest value first into the lightest bucket;
+// values that never occur with a non-zero entry are dealt round-robin).
+static void build_bucket_map(const std::vector<float>& hist, int d_dlr, int nb, std::vector<uint8_t>& map) {
   map.assign((size_t)d_dlr * 256, 0);
   std::vector<int> order(256);
-  std::vector<uint64_t> load(nb);
+  std::vector<double> load(nb);
   for (int j = 0; j < d_dlr; ++j) {
-    const uint32_t* h = &hist[(size_t)j * 256];
+    const float* h = &hist[(size_t)j * 256];
     for (int v = 0; v < 256; ++v) order[v] = v;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h[a] > h[b]; });
     std::fill(load.begin(), load.end(), 0);
@@ -294,7 +298,7 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
   ix->index_bytes = (int64_t)(tile_bytes + rm_bytes);
   if (hipMalloc((void**)&d_flags, 16) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMalloc failed"));
   if (hipMemsetAsync(d_flags, 0, 16, s) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMemsetAsync failed"));
-  // the index array first: the tile builder needs it for the bucket split
+  // the index array
   if (has_idx) {
     const int es = idx_esize(d->index_dtype);
     const size_t ib = (size_t)d->n_rows * d->d_dlr * es;
@@ -304,36 +308,36 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
                          (size_t)d->n_rows, d->mem_kind == DHR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
                          s) != hipSuccess)
       return fail(set_error(DHR_ERR_HIP, "copy of the index array failed"));
-    if (ix->n_buckets > 1 && es == 1) {
-      const size_t hb = (size_t)d->d_dlr * 256 * 4;
-      if (hipMalloc((void**)&d_hist, hb) != hipSuccess || hipMemsetAsync(d_hist, 0, hb, s) != hipSuccess)
-        return fail(set_error(DHR_ERR_HIP, "hipMalloc (index histogram) failed"));
-      if (launch_idx_hist((const uint8_t*)ix->c_idx, d->n_rows, d->d_dlr, d_hist, s) != hipSuccess)
-        return fail(set_error(DHR_ERR_HIP, "idx_hist launch failed"));
-      std::vector<uint32_t> hist((size_t)d->d_dlr * 256);
-      if (hipMemcpy(hist.data(), d_hist, hb, hipMemcpyDeviceToHost) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMemcpy failed"));
-      std::vector<uint8_t> map;
-      build_bucket_map(hist, d->d_dlr, ix->n_buckets, map);
-      if (hipMalloc((void**)&ix->bucket_map, map.size()) != hipSuccess ||
-          hipMemcpy(ix->bucket_map, map.data(), map.size(), hipMemcpyHostToDevice) != hipSuccess)
-        return fail(set_error(DHR_ERR_HIP, "bucket map upload failed"));
-    }
   }
+  // pass 1: row-major device copy of the values (+ norms, sign scan)
   const int64_t block_rows = 65536;
   if (d->mem_kind == DHR_MEM_HOST &&
       hipMalloc(&stage, (size_t)std::min<int64_t>(block_rows, d->n_rows) * ix->k * 2) != hipSuccess)
     return fail(set_error(DHR_ERR_HIP, "hipMalloc of the staging buffer failed"));
-  if ((rc = ingest(ix, d, true, d_flags, stage, block_rows, s)) != DHR_OK) return fail(rc);
+  if ((rc = ingest(ix, d, d_flags, stage, block_rows, s)) != DHR_OK) return fail(rc);
   uint32_t flags[2] = {0, 0};
   if (hipMemcpy(flags, d_flags, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMemcpy failed"));
   float max_sq;
   memcpy(&max_sq, &flags[0], 4);
   ix->dmax = std::sqrt(max_sq) * 1.0005f + 1e-30f;
-  if (flags[1]) {
-    // negative gated values: the bound needs |q|.|d| on the gated half -> rebuild the tile image with |.|
-    ix->abs_mode = true;
-    if ((rc = ingest(ix, d, false, d_flags, stage, block_rows, s)) != DHR_OK) return fail(rc);
+  ix->abs_mode = flags[1] != 0;     // negative gated values: the bound needs |q|.|d| on the gated half
+  // bucket maps from the value mass per (slice, index value)
+  if (has_idx && ix->n_buckets > 1 && idx_esize(d->index_dtype) == 1) {
+    const size_t hb = (size_t)d->d_dlr * 256 * 4;
+    if (hipMalloc((void**)&d_hist, hb) != hipSuccess || hipMemsetAsync(d_hist, 0, hb, s) != hipSuccess)
+      return fail(set_error(DHR_ERR_HIP, "hipMalloc (index histogram) failed"));
+    if (launch_idx_hist((const uint8_t*)ix->c_idx, ix->vals_rm, ix->k_rm, d->n_rows, d->d_dlr, (float*)d_hist, s) != hipSuccess)
+      return fail(set_error(DHR_ERR_HIP, "idx_hist launch failed"));
+    std::vector<float> hist((size_t)d->d_dlr * 256);
+    if (hipMemcpy(hist.data(), d_hist, hb, hipMemcpyDeviceToHost) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMemcpy failed"));
+    std::vector<uint8_t> map;
+    build_bucket_map(hist, d->d_dlr, ix->n_buckets, map);
+    if (hipMalloc((void**)&ix->bucket_map, map.size()) != hipSuccess ||
+        hipMemcpy(ix->bucket_map, map.data(), map.size(), hipMemcpyHostToDevice) != hipSuccess)
+      return fail(set_error(DHR_ERR_HIP, "bucket map upload failed"));
   }
+  // pass 2: operand tiles
+  if ((rc = build_tiles(ix, s)) != DHR_OK) return fail(rc);
   if (has_idx && d->d_dlr <= 1024) {
     const size_t hkb = (size_t)d->n_rows * HEAVY * 4, hvb = (size_t)d->n_rows * HEAVY * 2;
     if (hipMalloc((void**)&ix->heavy_key, hkb) != hipSuccess || hipMalloc((void**)&ix->heavy_val, hvb) != hipSuccess)

@@ -135,7 +135,7 @@ hipError_t launch_tile_rows_sparse(const __half* src, int64_t ld, int64_t row_lo
                                    int d_dlr, int d_cls, int ts, int td, const void* idx, int idx_dtype, const uint8_t* map,
                                    bool abs_dlr, char* tiles, hipStream_t s);
 hipError_t launch_copy_rows(const __half* src, int64_t ld, int64_t n_rows, int k, int k_rm, __half* dst, hipStream_t s);
-hipError_t launch_idx_hist(const uint8_t* idx, int64_t n_rows, int d_dlr, uint32_t* hist, hipStream_t s);
+hipError_t launch_idx_hist(const uint8_t* idx, const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, float* hist, hipStream_t s);
 hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const void* idx, int idx_dtype, int64_t ld_idx,
                              int n_queries, int q_pad, int d_dlr, int d_cls, int k_rm, int n_buckets, int kt,
                              const uint8_t* map, bool abs_dlr, float dmax, __half* q_tiles, float* q32, int16_t* q_idx,

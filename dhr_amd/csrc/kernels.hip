@@ -247,26 +247,32 @@ hipError_t launch_copy_rows(const __half* src, int64_t ld, int64_t n_rows, int k
   return hipGetLastError();
 }
 
-// Histogram of the 8-bit slice-index values per slice: hist[j][v] (u32), for the bucket maps.
-__global__ void __launch_bounds__(256) idx_hist_kernel(const uint8_t* __restrict__ idx, int64_t n_rows, int d_dlr,
-                                                       uint32_t* __restrict__ hist) {
+// Value MASS per (slice, 8-bit index value): hist[j][v] = sum of |value| over the rows whose index in slice j is v.
+// The bucket maps balance this mass: under independence the expected bound slack of a slice is
+// sum_b Mq_b * Md_b - (matches), which for similar query / corpus distributions is least when the buckets carry equal mass
+// (balancing the COUNTS instead put the few index values of the tiny-valued background slices on one side and nearly
+// all large entries on the other).
+__global__ void __launch_bounds__(256) idx_hist_kernel(const uint8_t* __restrict__ idx, const __half* __restrict__ vals_rm, int k_rm,
+                                                       int64_t n_rows, int d_dlr, float* __restrict__ hist) {
   // block = (slice group of 64 slices) x (row stripe); LDS histogram 64 x 256
-  __shared__ uint32_t h[64 * 256];
-  for (int i = threadIdx.x; i < 64 * 256; i += 256) h[i] = 0;
+  __shared__ float h[64 * 256];
+  for (int i = threadIdx.x; i < 64 * 256; i += 256) h[i] = 0.f;
   __syncthreads();
   const int j0 = blockIdx.x * 64;
   const int lane_j = threadIdx.x & 63;
   const int sub = threadIdx.x >> 6;
   if (j0 + lane_j < d_dlr)
-    for (int64_t r = (int64_t)blockIdx.y * 4 + sub; r < n_rows; r += (int64_t)gridDim.y * 4)
-      atomicAdd(&h[lane_j * 256 + idx[r * d_dlr + j0 + lane_j]], 1u);
+    for (int64_t r = (int64_t)blockIdx.y * 4 + sub; r < n_rows; r += (int64_t)gridDim.y * 4) {
+      const float v = fabsf(__half2float(vals_rm[r * k_rm + j0 + lane_j]));
+      if (v > 0.f) atomicAdd(&h[lane_j * 256 + idx[r * d_dlr + j0 + lane_j]], v);
+    }
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * 256; i += 256)
-    if (h[i] && j0 + (i >> 8) < d_dlr) atomicAdd(&hist[(int64_t)(j0 + (i >> 8)) * 256 + (i & 255)], h[i]);
+    if (h[i] > 0.f && j0 + (i >> 8) < d_dlr) atomicAdd(&hist[(int64_t)(j0 + (i >> 8)) * 256 + (i & 255)], h[i]);
 }
-hipError_t launch_idx_hist(const uint8_t* idx, int64_t n_rows, int d_dlr, uint32_t* hist, hipStream_t s) {
+hipError_t launch_idx_hist(const uint8_t* idx, const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, float* hist, hipStream_t s) {
   const int64_t stripes = std::min<int64_t>(256, (n_rows + 1023) / 1024);
-  hipLaunchKernelGGL(idx_hist_kernel, dim3((d_dlr + 63) / 64, (unsigned)(stripes < 1 ? 1 : stripes)), dim3(256), 0, s, idx,
+  hipLaunchKernelGGL(idx_hist_kernel, dim3((d_dlr + 63) / 64, (unsigned)(stripes < 1 ? 1 : stripes)), dim3(256), 0, s, idx, vals_rm, k_rm,
                      n_rows, d_dlr, hist);
   return hipGetLastError();
 }
