@@ -767,3 +767,13 @@ def test_full_size_properties(G, kind):
     del cv, ci
     torch.cuda.empty_cache()
     _search_check(G, cvs, cis, qs[:6], None if qis is None else qis[:6], 100)                     # (5)
+
+
+def test_random_configurations(G, monkeypatch):
+    """A slice of tools/stress.py (randomised shapes / dtypes / signs / fp32-or-fp16 queries / bucket counts / mixed query and
+    corpus index dtypes, each checked against the oracle's float64 scores)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import stress
+    monkeypatch.setattr(sys, "argv", ["stress.py", "80", "11"])
+    stress.main()
