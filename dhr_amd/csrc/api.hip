@@ -754,13 +754,13 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   if (S >= 2) {
     const double mean = (double)k / S;
     r_eff = (int)std::ceil(mean + 4.0 * std::sqrt(mean) + 4.0);
-    const int64_t head_guess = round_up(std::max<int64_t>(1024, 2 * (int64_t)r_eff), TILE_ROWS) / TILE_ROWS;
+    const int64_t head_guess = round_up(std::max<int64_t>(512, 2 * (int64_t)r_eff), TILE_ROWS) / TILE_ROWS;
     const int64_t rest_guess = ix->n_tiles - head_guess;
     if (r_eff >= k || rest_guess < 32 * (int64_t)S || (rest_guess / S) * TILE_ROWS < 16 * (int64_t)r_eff) S = 0;
   }
   if (S < 2) r_eff = k;
   // rows scored exhaustively in phase 0 (>= the rank that defines tau, so that tau exists afterwards), whole tile groups
-  int64_t first = std::max<int64_t>(ix->first_rows, std::max<int64_t>(1024, 2 * (int64_t)r_eff));
+  int64_t first = ix->first_rows > 0 ? std::max<int64_t>(ix->first_rows, 2 * (int64_t)r_eff) : std::max<int64_t>(512, 2 * (int64_t)r_eff);
   first = std::min(round_up(first, TILE_ROWS), round_up(n, TILE_ROWS));
   const int64_t first_valid = std::min(first, n);
   if ((rc = ensure_ws(ix, w, Q, k, first_valid, depth == 0 ? 1 : 16)) != DHR_OK) return rc;
@@ -1103,7 +1103,7 @@ extern "C" int32_t dhr_search_sample_rank(const dhr_index* ix, int32_t k) {
   const double mean = (double)k / S;
   const int r = (int)std::ceil(mean + 4.0 * std::sqrt(mean) + 4.0);
   const int64_t group_rows = (int64_t)DOC_GROUP * TILE_ROWS;
-  const int64_t head_guess = round_up(std::max<int64_t>(1024, 2 * (int64_t)r), TILE_ROWS) / TILE_ROWS;
+  const int64_t head_guess = round_up(std::max<int64_t>(512, 2 * (int64_t)r), TILE_ROWS) / TILE_ROWS;
   const int64_t rest_guess = ix->n_tiles - head_guess;
   if (r >= k || rest_guess < 32 * (int64_t)S || (rest_guess / S) * TILE_ROWS < 16 * (int64_t)r) return 0;
   return r;

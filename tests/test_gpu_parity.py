@@ -317,7 +317,7 @@ def test_larger_random_hybrid(G):
     print(st)
 
 
-def _structured_corpus(n, boosted_mod, period=16, head_tiles=4):   # head = 1024 exhaustive rows for k=1000
+def _structured_corpus(n, boosted_mod, period=16, head_tiles=2):   # head = 512 exhaustive rows for k=1000
     """Dense-only corpus whose best rows all sit in tiles with (tile - head) % period == boosted_mod."""
     rng = np.random.default_rng(5)
     cv = (rng.standard_normal((n, 64)) * 0.05).astype(np.float16)
