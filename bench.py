@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--first-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=200_000)
-    ap.add_argument("--cpu-queries", type=int, default=12)
+    ap.add_argument("--cpu-queries", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1237)
     ap.add_argument("--dist-backend", default="nccl", help="testing only: 'gloo' lets several ranks share ONE GPU (with DHR_BENCH_SINGLE_DEVICE=1)")
     args = ap.parse_args()
