@@ -165,7 +165,7 @@ hipError_t launch_tile_rows(const __half* src, int64_t ld, int64_t row_lo, int64
 //   B: lane l holds column l&31, element e: group g=e>>2 (position e&3) where the logical group
 //      G = 4*(g>>1) + 2*(l>>5) + (g&1) covers slices 2G, 2G+1 of the block.
 // Stage image of the corpus (18 KiB): [256 rows][4 chunks of 8 slices, chunk ^ ((row>>2)&3)] fp16, then
-// [256 rows][lane half][block] u16 position words.  Tile = ts sparse stages, then td dense stages of 32 columns
+// [8 blocks of 32 rows][lane half][32 rows] u32 position words (low 16 bits: block 0 of the stage, high: block 1).  Tile = ts sparse stages, then td dense stages of 32 columns
 // ([256 rows][4 chunks, chunk ^ ((row>>2)&3)] fp16 = 16 KiB, the same image for corpus and queries).
 __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __restrict__ src, int64_t ld, int64_t row_lo,
                                                                int64_t n_rows_src, int64_t n_rows_fill, int d_dlr,
@@ -202,7 +202,9 @@ __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __r
       }
       char* stg = tile + (int64_t)st * SP_STAGE_A;
       *(half8*)(stg + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = v;
-      *(uint16_t*)(stg + SP_A_BYTES + r * 8 + (cc & 1) * 4 + (cc >> 1) * 2) = (uint16_t)bits;
+      // position words: [32-row block][lane half][row in block] u32 = (block-1 bits << 16 | block-0 bits), so that the 32 lanes
+      // of a half read 32 consecutive words (the row-major [row][half] order cost a 2-way bank conflict on every read)
+      *(uint16_t*)(stg + SP_A_BYTES + ((((r >> 5) * 2 + (cc & 1)) * 32 + (r & 31)) * 4) + (cc >> 1) * 2) = (uint16_t)bits;
     } else {
       const int dc = c - sp_chunks, st = dc >> 2, cc = dc & 3, j0 = d_dlr + dc * 8;
       if (rl < n_rows_src)
@@ -768,7 +770,7 @@ __global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(
     const int a_c1 = a_row + (((2 + fhalf) ^ swz4) << 4);
     const int q_row = SP_STAGE_A + (wn * 64 + frow) * 64;             // + ni*2048
     const int q_c0 = q_row + ((fhalf ^ swz4) << 4), q_c1 = q_row + (((2 + fhalf) ^ swz4) << 4);
-    const int p_off = SP_A_BYTES + (wm * 128 + frow) * 8 + fhalf * 4; // position words, + mi*256
+    const int p_off = SP_A_BYTES + ((wm * 8 + fhalf) * 32 + frow) * 4; // position words, + mi*256
     half8 abl_f;
     if (ABL == 2 || ABL == 5) { for (int e = 0; e < 8; ++e) abl_f[e] = (_Float16)(0.001f * (float)(lane + e)); asm volatile("" : "+v"(abl_f)); }
     __builtin_amdgcn_s_barrier();
