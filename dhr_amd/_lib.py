@@ -16,7 +16,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 PARAM_CAND_CAP, PARAM_FIRST_ROWS, PARAM_PROFILE, PARAM_MAX_GROWTH, PARAM_SAMPLE_PERIOD, PARAM_GEMM_VARIANT, PARAM_MAIN_CHUNKS, PARAM_PROGRESSIVE_THR, PARAM_AUX_CUS, PARAM_GEMM_EXCLUSIVE, PARAM_OVERLAP_AUX = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 
 EXPORTS = ["dhr_version", "dhr_last_error", "dhr_index_create", "dhr_index_destroy", "dhr_index_set_param",
-           "dhr_index_device_bytes", "dhr_search", "dhr_score_rows", "dhr_merge_topk", "dhr_merge_topk_host",
+           "dhr_index_device_bytes", "dhr_search", "dhr_score_rows", "dhr_merge_topk", "dhr_merge_topk_host", "dhr_merge_topk_lists", "dhr_merge_topk_lists_host",
            "dhr_get_stats", "dhr_debug_bound_scores", "dhr_debug_gemm_time", "dhr_search_sample_rank", "dhr_search_begin",
            "dhr_search_finish", "dhr_search_rerank", "dhr_index_save", "dhr_index_file_info", "dhr_index_load", "dhr_densify", "dhr_pq_train", "dhr_pq_encode", "dhr_pq_decode"]
 
@@ -103,6 +103,10 @@ def load():
     lib.dhr_merge_topk.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_void_p, C.c_void_p]
     lib.dhr_merge_topk_host.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.dhr_merge_topk_lists.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dhr_merge_topk_lists_host.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                              C.c_void_p]
     lib.dhr_get_stats.argtypes = [C.c_void_p, C.POINTER(SearchStats)]
     lib.dhr_debug_bound_scores.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     lib.dhr_debug_gemm_time.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_int32, C.POINTER(C.c_double),

@@ -98,7 +98,7 @@ struct dhr_index {
   // params
   int64_t cand_cap = 0, first_rows = 0;   // 0 = default (262144 with refine lists, else 65536)
   int profile = 0, max_growth16 = 32;
-  int sample_period = 16;
+  int sample_period = 32;
   int main_chunks = 2;
   int progressive_thr = 1;
   int n_cu = 256;
@@ -1465,6 +1465,45 @@ extern "C" int dhr_merge_topk(int32_t device, int32_t n_queries, int32_t n_in, c
   if (n_in > 16384) return set_error(DHR_ERR_UNSUPPORTED, "more than 16384 entries per query in the device reduce");
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(launch_merge_topk(n_queries, n_in, in_scores, in_rows, k_out, out_scores, out_rows, (hipStream_t)stream));
+  return DHR_OK;
+}
+
+extern "C" int dhr_merge_topk_lists(int32_t device, int32_t n_queries, int32_t n_lists, int32_t list_len, const float* in_scores,
+                                    const int64_t* in_rows, int32_t k_out, float* out_scores, int64_t* out_rows, void* stream) {
+  if (n_queries <= 0 || n_lists <= 0 || list_len <= 0 || k_out <= 0 || !in_scores || !out_scores || (in_rows && !out_rows))
+    return set_error(DHR_ERR_INVALID, "bad argument");
+  if (((int64_t)n_lists * list_len + k_out) * (in_rows ? 12 : 4) > 160 * 1024 || n_lists > 64)
+    return set_error(DHR_ERR_UNSUPPORTED, "the lists of one query do not fit the LDS ((n_lists*list_len + k_out)*12 B > 160 KiB) or n_lists > 64");
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(launch_merge_lists(n_queries, n_lists, list_len, in_scores, in_rows, k_out, out_scores, in_rows ? out_rows : nullptr,
+                             (hipStream_t)stream));
+  return DHR_OK;
+}
+
+extern "C" int dhr_merge_topk_lists_host(int32_t n_queries, int32_t n_lists, int32_t list_len, const float* in_scores,
+                                         const int64_t* in_rows, int32_t k_out, float* out_scores, int64_t* out_rows) {
+  if (n_queries <= 0 || n_lists <= 0 || list_len <= 0 || k_out <= 0 || !in_scores || !out_scores || (in_rows && !out_rows))
+    return set_error(DHR_ERR_INVALID, "bad argument");
+  std::vector<int64_t> order;
+  for (int q = 0; q < n_queries; ++q) {
+    order.clear();
+    for (int l = 0; l < n_lists; ++l)
+      for (int j = 0; j < list_len; ++j) {
+        const int64_t src = ((int64_t)l * n_queries + q) * list_len + j;
+        if (!in_rows || in_rows[src] >= 0) order.push_back(src);
+      }
+    const int take = std::min<int>(k_out, (int)order.size());
+    std::partial_sort(order.begin(), order.begin() + take, order.end(), [&](int64_t a, int64_t b) {
+      const uint32_t ka = f32_ordered(in_scores[a]), kb = f32_ordered(in_scores[b]);
+      if (ka != kb) return ka > kb;
+      if (in_rows && in_rows[a] != in_rows[b]) return in_rows[a] < in_rows[b];
+      return a < b;                                        // list order, then position
+    });
+    for (int j = 0; j < k_out; ++j) {
+      out_scores[(size_t)q * k_out + j] = j < take ? in_scores[order[j]] : -INFINITY;
+      if (in_rows) out_rows[(size_t)q * k_out + j] = j < take ? in_rows[order[j]] : -1;
+    }
+  }
   return DHR_OK;
 }
 

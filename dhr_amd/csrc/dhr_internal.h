@@ -186,6 +186,8 @@ hipError_t launch_count_ge(const uint64_t* topk_keys, int kp, int k, const float
                            int32_t* out, hipStream_t s);
 hipError_t launch_merge_topk(int n_queries, int n_in, const float* in_scores, const int64_t* in_rows, int k_out,
                              float* out_scores, int64_t* out_rows, hipStream_t s);
+hipError_t launch_merge_lists(int n_queries, int n_lists, int list_len, const float* in_scores, const int64_t* in_rows, int k_out,
+                              float* out_scores, int64_t* out_rows, hipStream_t s);
 
 extern int g_gemm_variant;
 constexpr int RESCORE_CANDS_PER_WG = 32;

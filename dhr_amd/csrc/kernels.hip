@@ -1775,4 +1775,113 @@ hipError_t launch_merge_topk(int n_queries, int n_in, const float* in_scores, co
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ merge_lists
+// The same reduce for lists that arrive SORTED, in the layout an all-gather leaves them in: [n_lists, Q, L].
+// No sort: every entry finds its output rank = its own position + the number of entries of every other list
+// that come before it (searched in LDS).  Order: (score desc, row asc, list asc);
+// padding (row < 0) ranks behind everything.  rows == nullptr: scores only, ties keep list order.
+template <int NL>
+__global__ void __launch_bounds__(1024) merge_lists_kernel(int n_lists, int L, int n_queries, const float* __restrict__ in_scores,
+                                                          const int64_t* __restrict__ in_rows, int k_out,
+                                                          float* __restrict__ out_scores, int64_t* __restrict__ out_rows) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n_tot = n_lists * L;
+  int64_t* rw = (int64_t*)smem;                           // [n_tot] rows (only with in_rows)
+  int64_t* orow = rw + (in_rows ? n_tot : 0);             // [k_out] output rows, staged so that the HBM writes are coalesced
+  uint32_t* sk = (uint32_t*)(orow + (in_rows ? k_out : 0));
+  float* osc = (float*)(sk + n_tot);                      // [k_out] output scores
+  const int q = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  for (int j = tid; j < k_out; j += nthr) {
+    osc[j] = -INFINITY;
+    if (in_rows) orow[j] = -1;
+  }
+  for (int e = tid; e < n_tot; e += nthr) {
+    const int l = e / L, j = e - l * L;
+    const int64_t src = ((int64_t)l * n_queries + q) * L + j;
+    uint32_t key = f32_ordered(in_scores[src]);
+    if (in_rows) {
+      const int64_t row = in_rows[src];
+      if (row < 0) key = 0u;
+      rw[e] = row < 0 ? INT64_MAX : row;
+    }
+    sk[e] = key;
+  }
+  __syncthreads();
+  // A thread owns a run of consecutive entries of ONE list.  Its first entry finds its place in every other list by
+  // binary search; the next entries only advance from there (the places are monotone along a sorted run: ~2 probes
+  // per list instead of log2 L).  The kernel is bound by instruction issue, not by LDS latency or bandwidth.
+  const int tpl = nthr / n_lists;                         // threads per list
+  const int run = (L + tpl - 1) / tpl;
+  const int l = tid / tpl;
+  if (l < n_lists) {
+    const int j0 = (tid - l * tpl) * run, j1 = min(L, j0 + run);
+    int pos[NL];
+#pragma unroll
+    for (int m = 0; m < NL; ++m) pos[m] = 0;
+    for (int j = j0; j < j1; ++j) {
+      const int e = l * L + j;
+      const uint32_t key = sk[e];
+      const int64_t row = in_rows ? rw[e] : 0;
+      auto before = [&](int m, int i) -> bool {            // entry i of list m sorts before e: (score desc, row asc, list asc)
+        const uint32_t km = sk[m * L + i];
+        if (km != key) return km > key;
+        if (!in_rows) return m < l;
+        const int64_t rm = rw[m * L + i];
+        return rm < row || (rm == row && m < l);
+      };
+      int rank = j;
+#pragma unroll
+      for (int m = 0; m < NL; ++m) {
+        if (m < n_lists && m != l) {
+          int p = pos[m];
+          if (j == j0) {
+            int hi = L;
+            while (p < hi) {
+              const int mid = (p + hi) >> 1;
+              if (before(m, mid)) p = mid + 1; else hi = mid;
+            }
+          } else {
+            while (p < L && before(m, p)) ++p;
+          }
+          pos[m] = p;
+          rank += p;
+        }
+      }
+      if (rank >= k_out) break;                            // ranks only grow along the run
+      if (in_rows && row == INT64_MAX) continue;           // padding: the slot keeps (-inf, -1)
+      osc[rank] = ordered_f32(key);
+      if (in_rows) orow[rank] = row;
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < k_out; j += nthr) {
+    out_scores[(int64_t)q * k_out + j] = osc[j];
+    if (out_rows) out_rows[(int64_t)q * k_out + j] = orow[j];
+  }
+}
+hipError_t launch_merge_lists(int n_queries, int n_lists, int list_len, const float* in_scores, const int64_t* in_rows, int k_out,
+                              float* out_scores, int64_t* out_rows, hipStream_t s) {
+  if (n_queries <= 0) return hipSuccess;
+  const size_t bytes = ((size_t)n_lists * list_len + (size_t)k_out) * (in_rows ? 12 : 4);
+  if (bytes > 160 * 1024 || n_lists > 64) return hipErrorInvalidValue;
+  static const int env_threads = getenv("DHR_MERGE_THREADS") ? atoi(getenv("DHR_MERGE_THREADS")) : 0;
+  const int threads = env_threads ? env_threads : 512;     // measured best of 256 / 512 / 1024 on every shard-reduce shape
+  auto go = [&](auto kernel, size_t& attr_bytes) -> hipError_t {
+    if (bytes > attr_bytes) {
+      hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e != hipSuccess) return e;
+      attr_bytes = bytes;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)n_queries), dim3(threads), bytes, s, n_lists, list_len, n_queries, in_scores, in_rows,
+                       k_out, out_scores, out_rows);
+    return hipGetLastError();
+  };
+  static size_t a2 = 0, a4 = 0, a8 = 0, a16 = 0, a64 = 0;
+  if (n_lists <= 2) return go(merge_lists_kernel<2>, a2);
+  if (n_lists <= 4) return go(merge_lists_kernel<4>, a4);
+  if (n_lists <= 8) return go(merge_lists_kernel<8>, a8);
+  if (n_lists <= 16) return go(merge_lists_kernel<16>, a16);
+  return go(merge_lists_kernel<64>, a64);
+}
+
 }  // namespace dhr

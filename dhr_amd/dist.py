@@ -41,9 +41,38 @@ def merge_topk(scores, rows, k: int):
     return out_s, out_r
 
 
+def merge_sorted_lists(scores, rows, k: int):
+    """scores/rows: [n_lists, Q, L] tensors, every list sorted (score desc, row asc), padding (row < 0) at
+    its tail -- the layout all_gather_into_tensor leaves the per-shard results in.  -> ([Q,k], [Q,k]).
+    rows may be None (scores only; returns (scores, None)).  No sort, no transpose copy: dhr_merge_topk_lists."""
+    import torch
+    lib = _lib.load()
+    n_lists, q, ll = (int(x) for x in scores.shape)
+    scores = scores.contiguous()
+    rows = rows.contiguous() if rows is not None else None
+    if n_lists > 64 or (n_lists * ll + k) * (12 if rows is not None else 4) > 160 * 1024:   # beyond the LDS: general reduce
+        cs = scores.permute(1, 0, 2).reshape(q, n_lists * ll)
+        cr = rows.permute(1, 0, 2).reshape(q, n_lists * ll) if rows is not None else \
+            torch.arange(n_lists * ll, device=scores.device, dtype=torch.int64).expand(q, -1).contiguous()
+        out = merge_topk(cs, cr, k)
+        return out if rows is not None else (out[0], None)
+    out_s = torch.empty((q, k), dtype=torch.float32, device=scores.device)
+    out_r = torch.empty((q, k), dtype=torch.int64, device=scores.device) if rows is not None else None
+    pr = rows.data_ptr() if rows is not None else None
+    po = out_r.data_ptr() if rows is not None else None
+    if scores.is_cuda:
+        stream = torch.cuda.current_stream(scores.device).cuda_stream
+        _lib.check(lib.dhr_merge_topk_lists(scores.device.index, q, n_lists, ll, scores.data_ptr(), pr, k,
+                                            out_s.data_ptr(), po, stream), "dhr_merge_topk_lists")
+    else:
+        _lib.check(lib.dhr_merge_topk_lists_host(q, n_lists, ll, scores.data_ptr(), pr, k, out_s.data_ptr(), po),
+                   "dhr_merge_topk_lists_host")
+    return out_s, out_r
+
+
 def allgather_merge(local_scores, local_rows, k: int, group=None):
-    """local_* : [Q, k_local] tensors of this rank's shard (global rows).  Returns the merged
-    [Q, k] lists, identical on every rank."""
+    """local_* : [Q, k_local] tensors of this rank's shard (global rows, sorted best first as the search
+    returns them).  Returns the merged [Q, k] lists, identical on every rank."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -54,18 +83,15 @@ def allgather_merge(local_scores, local_rows, k: int, group=None):
     gr = torch.empty((world * q, kl), dtype=torch.int64, device=local_rows.device)
     dist.all_gather_into_tensor(gs, local_scores.contiguous(), group=group)
     dist.all_gather_into_tensor(gr, local_rows.contiguous(), group=group)
-    # [world, Q, kl] -> [Q, world*kl], shards in rank order (ascending row ranges)
-    cs = gs.view(world, q, kl).permute(1, 0, 2).reshape(q, world * kl)
-    cr = gr.view(world, q, kl).permute(1, 0, 2).reshape(q, world * kl)
-    return merge_topk(cs, cr, k)
+    # [world, Q, kl], shards in rank order (ascending row ranges): reduced in place, no transpose
+    return merge_sorted_lists(gs.view(world, q, kl), gr.view(world, q, kl), k)
 
 
 def common_threshold(sample_scores_all, r: int):
-    """[world, Q, r] best sample scores of every shard -> [Q] the r-th best of the union per query."""
-    import torch
-    world, q, _ = sample_scores_all.shape
-    cat = sample_scores_all.permute(1, 0, 2).reshape(q, world * r)
-    return torch.topk(cat, r, dim=1).values[:, r - 1].contiguous()
+    """[world, Q, r] best sample scores of every shard (each list sorted, best first) -> [Q] the r-th best
+    of the union per query."""
+    merged, _ = merge_sorted_lists(sample_scores_all, None, r)
+    return merged[:, r - 1].contiguous()
 
 
 def sharded_search(index, q_value, q_index, k: int, group=None):
@@ -84,24 +110,25 @@ def sharded_search(index, q_value, q_index, k: int, group=None):
         return merge_topk(scores, rows, k)
     r = index.sample_rank(k)
     dev = getattr(index, "torch_device", None) or torch.device("cuda", index.device)
-    rr = torch.tensor([r], dtype=torch.int32, device=dev)
-    dist.all_reduce(rr, op=dist.ReduceOp.MIN, group=group)            # shards of different size may disagree
-    if int(rr.item()) != r or r == 0:
-        rmax = torch.tensor([r], dtype=torch.int32, device=rr.device)
-        dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=group)
-        if int(rr.item()) != int(rmax.item()) or r == 0:              # not uniformly samplable: local thresholds
-            scores, rows = index.search(q_value, q_index, k, out_device=True)
-            return allgather_merge(scores, rows, k, group)
+    rr = torch.tensor([r, -r], dtype=torch.int32, device=dev)
+    dist.all_reduce(rr, op=dist.ReduceOp.MIN, group=group)            # (min r, -max r): shards of different size may disagree
+    rr = rr.tolist()
+    if r == 0 or rr[0] != r or -rr[1] != r:                           # not uniformly samplable: local thresholds
+        scores, rows = index.search(q_value, q_index, k, out_device=True)
+        return allgather_merge(scores, rows, k, group)
     sample = index.search_begin(q_value, q_index, k)
     nq = sample.shape[0]
     gathered = torch.empty((world * nq, r), dtype=torch.float32, device=sample.device)
     dist.all_gather_into_tensor(gathered, sample, group=group)
     tau = common_threshold(gathered.view(world, nq, r), r)
     scores, rows, count = index.search_finish(tau)
-    bad = (count < 0).to(torch.int32)
-    tot = torch.stack([count.clamp(min=0), bad]).to(torch.int32)
-    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
-    failed = torch.nonzero((tot[0] < k) | (tot[1] > 0)).flatten()
+    # one small all-gather of the per-query counts serves the completeness check AND the useful list length
+    counts = torch.empty((world * nq,), dtype=torch.int32, device=count.device)
+    dist.all_gather_into_tensor(counts, count.to(torch.int32).contiguous(), group=group)
+    counts = counts.view(world, nq)
+    fail_mask = (counts.clamp(min=0).sum(0) < k) | (counts < 0).any(0)
+    n_failed, cmax = torch.stack([fail_mask.sum(), counts.max()]).tolist()      # one host read for both
+    failed = torch.nonzero(fail_mask).flatten() if n_failed else fail_mask[:0]
     if failed.numel() > 0:                                             # identical on every rank
         ids = failed.cpu().numpy()
         sub_v = q_value[ids] if not hasattr(q_value, "index_select") else q_value.index_select(0, failed.to(q_value.device))
@@ -113,7 +140,5 @@ def sharded_search(index, q_value, q_index, k: int, group=None):
         rows[failed] = fr
         return allgather_merge(scores, rows, k, group)
     # every global top-k row reaches tau, and a shard holds `count` of those: the tails of the lists are dead
-    cmax = count.max().to(torch.int32).reshape(1)
-    dist.all_reduce(cmax, op=dist.ReduceOp.MAX, group=group)
-    kk = min(k, (int(cmax.item()) + 63) // 64 * 64)
+    kk = min(k, (int(cmax) + 63) // 64 * 64)
     return allgather_merge(scores[:, :kk].contiguous(), rows[:, :kk].contiguous(), k, group)

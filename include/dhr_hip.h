@@ -99,7 +99,7 @@ typedef enum dhr_param {
   DHR_PARAM_OVERLAP_AUX = 11,  /* 1 (default): refine / rescoring / select of chunk i run beside the GEMM of chunk i+1; 0: one after the other */
   DHR_PARAM_PROGRESSIVE_THR = 8, /* 1 (default): later main-pass chunks filter with the running exact k-th best, not only the sampled threshold */
   DHR_PARAM_GEMM_VARIANT = 6, /* reserved: only 3 (the built kernel) is accepted */
-  DHR_PARAM_SAMPLE_PERIOD = 5 /* every S-th corpus tile seeds the thresholds (default 16; 0 = plain streaming) */
+  DHR_PARAM_SAMPLE_PERIOD = 5 /* every S-th corpus tile seeds the thresholds (default 32; 0 = plain streaming) */
 } dhr_param;
 
 int dhr_version(void);
@@ -183,6 +183,18 @@ int dhr_merge_topk(int32_t device, int32_t n_queries, int32_t n_in, const float*
 int dhr_merge_topk_host(int32_t n_queries, int32_t n_in, const float* in_scores, const int64_t* in_rows,
                         int32_t k_out, float* out_scores, int64_t* out_rows);
 
+/* The same reduce for lists that are already SORTED, in the layout an all-gather of the per-shard results
+ * leaves them in: in_scores / in_rows are [n_lists, n_queries, list_len]; every list is in output order
+ * (score desc, row asc) with its padding (row < 0) at the tail -- what dhr_search / dhr_search_finish write.
+ * No sort is run: every entry finds its output rank by binary searches in the other lists.  in_rows may be
+ * NULL (scores only, e.g. the shards' sample scores of dhr_search_begin; ties keep list order; out_rows is
+ * ignored).  (n_lists*list_len + k_out)*12 B (4 B without rows) must fit 160 KiB, n_lists <= 64.  DEVICE pointers
+ * on `device`. */
+int dhr_merge_topk_lists(int32_t device, int32_t n_queries, int32_t n_lists, int32_t list_len, const float* in_scores,
+                         const int64_t* in_rows, int32_t k_out, float* out_scores, int64_t* out_rows, void* stream);
+/* Host twin (no sortedness needed: it sorts). */
+int dhr_merge_topk_lists_host(int32_t n_queries, int32_t n_lists, int32_t list_len, const float* in_scores,
+                              const int64_t* in_rows, int32_t k_out, float* out_scores, int64_t* out_rows);
 /* Fused densify, the step immediately upstream of the index (tevatron/DHR/utils.py:5-22 and the
  * casts of tevatron/driver/encode.py:155-158,180-183).  lexical is [batch, vocab] (value_dtype DHR_VAL_F32 or DHR_VAL_F16,
  * row stride ld); the columns [remove_dims, vocab) are viewed as [n_groups, dims] and

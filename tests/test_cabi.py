@@ -83,6 +83,28 @@ def test_host_merge_matches_oracle():
         assert np.all(hr2[i, valid[i]:] == -1) and np.all(np.isneginf(hs2[i, valid[i]:]))
 
 
+def test_host_merge_lists_matches_oracle():
+    from dhr_amd import _lib
+    from oracle import gip_oracle as O
+    lib = _lib.load()
+    from tests.util import sorted_lists
+    rng = np.random.default_rng(5)
+    n_lists, q, ll, k = 5, 9, 60, 100
+    s, r = sorted_lists(rng, n_lists, q, ll)
+    es, er = O.merge_topk(list(s), list(r), k)
+    hs, hr = np.empty((q, k), np.float32), np.empty((q, k), np.int64)
+    assert lib.dhr_merge_topk_lists_host(q, n_lists, ll, s.ctypes.data, r.ctypes.data, k, hs.ctypes.data, hr.ctypes.data) == 0
+    np.testing.assert_array_equal(hs, es)
+    np.testing.assert_array_equal(hr, er)
+    # scores only: the k best scores of the union
+    hs2 = np.empty((q, 7), np.float32)
+    full = np.where(r >= 0, s, -np.inf)
+    assert lib.dhr_merge_topk_lists_host(q, n_lists, ll, full.ctypes.data, None, 7, hs2.ctypes.data, None) == 0
+    want = -np.sort(-full.transpose(1, 0, 2).reshape(q, -1), axis=1)[:, :7]
+    np.testing.assert_array_equal(hs2, want)
+    assert lib.dhr_merge_topk_lists_host(0, 1, 1, None, None, 1, None, None) == -1
+
+
 def test_file_info_struct_and_bad_files(tmp_path):
     """dhr_file_info layout matches the header; a file that is not a device-ready index is rejected without a GPU."""
     import ctypes as C

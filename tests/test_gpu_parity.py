@@ -233,6 +233,49 @@ def test_merge_topk_device_matches_host_and_oracle(G):
     np.testing.assert_array_equal(os_.cpu().numpy(), es); np.testing.assert_array_equal(or_.cpu().numpy(), er)
 
 
+@pytest.mark.parametrize("n_lists,q,ll,k", [(8, 37, 192, 1000), (3, 5, 1000, 1000), (2, 4, 64, 10), (8, 3, 1024, 1000), (1, 3, 50, 80)])
+def test_merge_sorted_lists_device(G, n_lists, q, ll, k):
+    """dhr_merge_topk_lists (rank merge of sorted per-shard lists in all-gather layout) == host twin == oracle."""
+    import torch
+    from dhr_amd import _lib, dist as D
+    from tests.util import sorted_lists
+    lib = _lib.load()
+    rng = np.random.default_rng(100 * n_lists + ll)
+    s, r = sorted_lists(rng, n_lists, q, ll)
+    es, er = O.merge_topk(list(s), list(r), k)
+    ds, dr = torch.from_numpy(s).cuda(), torch.from_numpy(r).cuda()
+    ms, mr = D.merge_sorted_lists(ds, dr, k)                       # wrapper (long lists go to the general reduce)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(ms.cpu().numpy(), es)
+    np.testing.assert_array_equal(mr.cpu().numpy(), er)
+    ks, kr = torch.empty((q, k), dtype=torch.float32, device="cuda"), torch.empty((q, k), dtype=torch.int64, device="cuda")
+    _lib.check(lib.dhr_merge_topk_lists(0, q, n_lists, ll, ds.data_ptr(), dr.data_ptr(), k, ks.data_ptr(), kr.data_ptr(), 0),
+               "dhr_merge_topk_lists")                             # the rank-merge kernel itself, any shape that fits the LDS
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(ks.cpu().numpy(), es)
+    np.testing.assert_array_equal(kr.cpu().numpy(), er)
+    hs, hr = D.merge_sorted_lists(torch.from_numpy(s), torch.from_numpy(r), k)       # host twin through the same wrapper
+    np.testing.assert_array_equal(hs.numpy(), es)
+    np.testing.assert_array_equal(hr.numpy(), er)
+    # scores only (the shards' sample scores): the r-th best of the union
+    full = np.where(r >= 0, s, -np.inf).astype(np.float32)
+    rr = min(ll, 58)
+    tau = D.common_threshold(torch.from_numpy(np.ascontiguousarray(full[:, :, :rr])).cuda(), rr).cpu().numpy()
+    want = -np.sort(-full[:, :, :rr].transpose(1, 0, 2).reshape(q, -1), axis=1)[:, rr - 1]
+    np.testing.assert_array_equal(tau, want)
+
+
+def test_merge_sorted_lists_beyond_lds_falls_back_to_general_reduce(G):
+    import torch
+    from dhr_amd import dist as D
+    from tests.util import sorted_lists
+    s, r = sorted_lists(np.random.default_rng(9), 8, 2, 2000, ragged=False)          # 8*2000*12 B > 160 KiB
+    es, er = O.merge_topk(list(s), list(r), 1000)
+    ms, mr = D.merge_sorted_lists(torch.from_numpy(s).cuda(), torch.from_numpy(r).cuda(), 1000)
+    np.testing.assert_array_equal(ms.cpu().numpy(), es)
+    np.testing.assert_array_equal(mr.cpu().numpy(), er)
+
+
 def test_sharded_equals_unsharded(G):
     """Row shards (gip_retrieval.py:292-306 arithmetic) + the shard reduce == one index."""
     from dhr_amd import synth, _lib
@@ -340,7 +383,7 @@ def test_sampled_threshold_fallbacks(G, boosted_mod):
     n = 300_000
     cv, qv = _structured_corpus(n, boosted_mod)
     _, _, st = _search_check(G, cv, None, qv.astype(np.float32), None, 1000,
-                             params=[(_lib.PARAM_CAND_CAP, 4096)])
+                             params=[(_lib.PARAM_CAND_CAP, 4096), (_lib.PARAM_SAMPLE_PERIOD, 16)])   # the corpus is built for period 16
     print(boosted_mod, st)
     if boosted_mod == 0:
         assert st["sample_fallback_queries"] == 10      # all 5 fail at depth 0 and again at depth 1 (16x capacity), then stream
@@ -491,6 +534,7 @@ def test_staged_sharded_search_common_threshold(G, kind):
 def test_staged_sharded_search_failure_path(G):
     """All high-scoring rows sit in sample tiles of shard 0: the common threshold is too high for the
     union to reach k rows, the count check must catch it and the local fallback must repair it."""
+    from dhr_amd import _lib
     n, k, ns = 400_000, 1000, 2
     cv, qv = _structured_corpus(n, 0)
     q32 = qv.astype(np.float32)
@@ -501,6 +545,7 @@ def test_staged_sharded_search_failure_path(G):
     for sh in range(ns):
         lo, hi = G.shard_bounds(n, ns, sh)
         shards.append(G.GipIndex(cv[lo:hi], None, row_offset=lo))
+        shards[-1].set_param(_lib.PARAM_SAMPLE_PERIOD, 16)         # the period the corpus is structured for
     ms, mr, n_failed, tot = _fake_world_search(G, shards, q32, None, k)
     for s in shards:
         s.close()

@@ -53,3 +53,17 @@ def parse_trec(text):
         qid, _, docid, rank, score, _run = line.split(" ")
         out.setdefault(qid, []).append((docid, int(rank), float(score)))
     return out
+
+
+def sorted_lists(rng, n_lists, q, ll, ragged=True):
+    """[n_lists, q, ll] per-shard result lists as the search writes them: (score desc, row asc), (-inf, -1) tails."""
+    s = np.round(rng.standard_normal((n_lists, q, ll)).astype(np.float32), 1) + np.float32(0)   # many exact ties; no -0.0
+    r = rng.permutation(10_000_000)[: n_lists * q * ll].reshape(n_lists, q, ll).astype(np.int64)
+    for l in range(n_lists):
+        for i in range(q):
+            order = np.lexsort((r[l, i], -s[l, i].astype(np.float64)))
+            s[l, i], r[l, i] = s[l, i][order], r[l, i][order]
+            if ragged:
+                fill = int(rng.integers(0, ll + 1))
+                s[l, i, fill:], r[l, i, fill:] = -np.inf, -1
+    return s, r

@@ -53,18 +53,22 @@ def main():
         for ix in shards:
             torch.cuda.synchronize(); t = time.perf_counter()
             samples.append(ix.search_begin(qv, qi, k)); torch.cuda.synchronize(); tb.append(time.perf_counter() - t)
+        st_begin = shards[0].stats()
         t = time.perf_counter(); tau = D.common_threshold(torch.stack(samples), rnk); torch.cuda.synchronize(); tt = time.perf_counter() - t
         for ix in shards:
             torch.cuda.synchronize(); t = time.perf_counter()
             outs.append(ix.search_finish(tau)); torch.cuda.synchronize(); tf.append(time.perf_counter() - t)
         t = time.perf_counter()
         cnts = torch.stack([o[2] for o in outs]); kk = min(k, (int(cnts.max()) + 63) // 64 * 64)
-        ms, mr = D.merge_topk(torch.cat([o[0][:, :kk] for o in outs], 1), torch.cat([o[1][:, :kk] for o in outs], 1), k); torch.cuda.synchronize(); tm = time.perf_counter() - t
+        gs = torch.stack([o[0][:, :kk] for o in outs]); gr = torch.stack([o[1][:, :kk] for o in outs])     # what the all-gather leaves
+        torch.cuda.synchronize(); t = time.perf_counter()
+        ms, mr = D.merge_sorted_lists(gs, gr, k); torch.cuda.synchronize(); tm = time.perf_counter() - t
         tot = torch.stack([o[2] for o in outs]).clamp(min=0).sum(0)
         failed = int(((tot < k) | (torch.stack([o[2] for o in outs]) < 0).any(0)).sum())
     st = shards[0].stats()
     print("shards %d rank r=%d : begin max %.1f ms  finish max %.1f ms  tau %.2f ms  merge %.2f ms  -> est. step %.1f ms (+ all-gather)  failed queries %d"
           % (a.shards, rnk, max(tb) * 1e3, max(tf) * 1e3, tt * 1e3, tm * 1e3, (max(tb) + max(tf) + tt + tm) * 1e3, failed))
+    print("shard0 stats after begin:", {k_: (round(v, 2) if isinstance(v, float) else v) for k_, v in st_begin.items()})
     print("shard0 stats:", {k_: (round(v, 2) if isinstance(v, float) else v) for k_, v in st.items()})
 
 
