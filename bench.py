@@ -219,11 +219,11 @@ def main():
                          "achieved": round(ach_tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach_tf / MFMA_PEAK_TFLOPS, 4),
                          # fabric-side (Infinity Cache + HBM) read bytes per launch: PMC passes cannot run inside this process,
-                         # so this is the per-corpus-row figure of profiles/r01f_gemm_pmc.txt (FETCH_SIZE x2, rocprofv3 --pmc on
+                         # so this is the per-corpus-row figure of profiles/r01h_gemm_pmc.txt (FETCH_SIZE x2, rocprofv3 --pmc on
                          # the same kernel, 6 980 queries) x the average rows per launch; only quoted for that configuration
-                         "traffic": (round(34.6e3 * stats_acc.get("gemm_rows", 0) / max(launches, 1), 0)
+                         "traffic": (round(35.3e3 * stats_acc.get("gemm_rows", 0) / max(launches, 1), 0)
                                      if d_dlr == 768 and d_cls == 768 and nq == 6980 and args.idx_buckets in (0, 2) and world == 1 else None),
-                         "traffic_unit": "bytes per launch (FETCH_SIZE, gfx950-corrected; profiles/r01f_gemm_pmc.txt)",
+                         "traffic_unit": "bytes per launch (FETCH_SIZE, gfx950-corrected; profiles/r01h_gemm_pmc.txt)",
                          "launches": launches, "avg_launch_ms": round(gemm_ms / max(launches, 1), 3),
                          "alg_flops_per_step": gemm_flops_alg / args.steps},
             "whole_job_frac_of_gemm_roofline": round(qps * 2.0 * n * K / (MFMA_PEAK_TFLOPS * 1e12 * world), 4),
