@@ -822,3 +822,14 @@ def test_random_configurations(G, monkeypatch):
     import stress
     monkeypatch.setattr(sys, "argv", ["stress.py", "80", "11"])
     stress.main()
+
+
+def test_random_controller_configurations(G, monkeypatch):
+    """A slice of tools/stress_sampled.py: corpora large enough for the sampled thresholds, random sample period / list capacity /
+    chunk count / head size, benign and adversarial row orders, single index and the staged sharded search -- each checked
+    against the oracle's float64 scores."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import stress_sampled
+    monkeypatch.setattr(sys, "argv", ["stress_sampled.py", "14", "5"])
+    stress_sampled.main()
