@@ -675,7 +675,10 @@ __device__ __forceinline__ void expand_bucket_columns(const uint32_t (&r)[4], ui
       : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
 }
 
-template <bool DUMP, int ABL = 0>   // ABL (timing experiments only, wrong results): 1 no in-loop DMA, 2 no fragment reads, 3 no matrix instructions, 4 no epilogue, 5 = 1 + 2
+// ABL (timing experiments only, wrong results unless noted): 1 no in-loop DMA, 2 no fragment reads, 3 no matrix instructions, 4 no epilogue,
+// 5 = 1 + 2, 7 no query-side DMA, 8 = 7 + no query fragment reads, 9 no corpus-side DMA, 11 both operands always from L2-hot tiles,
+// 12 producers never wait for the DMA, 13 register-staged producers (global_load -> VGPR -> ds_write; CORRECT results, slower)
+template <bool DUMP, int ABL = 0>
 __global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int64_t b = blockIdx.x;
@@ -694,8 +697,8 @@ __global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ts = p.ts, tsq = p.ts_q, td = p.td, nst = tsq + td;
-  const char* a_src = (const char*)p.a_tiles + dt * ((int64_t)ts * SP_STAGE_A + (int64_t)td * SP_DENSE);
-  const char* b_src = (const char*)p.b_tiles + (int64_t)qt * ((int64_t)tsq * SP_STAGE_B + (int64_t)td * SP_DENSE);
+  const char* a_src = (const char*)p.a_tiles + (ABL == 11 ? (dt & 3) : dt) * ((int64_t)ts * SP_STAGE_A + (int64_t)td * SP_DENSE);
+  const char* b_src = (const char*)p.b_tiles + (int64_t)(ABL == 11 ? (qt & 1) : qt) * ((int64_t)tsq * SP_STAGE_B + (int64_t)td * SP_DENSE);
 
   floatx16 acc[4][2];
   const int wm = (wave >> 2) & 1;
@@ -730,6 +733,52 @@ __global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(
         __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g + j * 1024 + lane_off), LDS_PTR(lds + j * 1024), 16, 0, 0);
       if (is_a && sp) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g + 8192 + lane_off), LDS_PTR(lds + 8192), 16, 0, 0);
     };
+    if (ABL == 13) {
+      // Register-staged producers (correct results): global_load_dwordx4 -> VGPRs (three stages in flight in the
+      // producer's otherwise idle registers) -> ds_write_b128 into the slot one stage ahead of the consumers.
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 rb0[9], rb1[9], rb2[9];
+      auto src_of = [&](int u, int& l) __attribute__((always_inline)) -> const char* {
+        const bool sp = u < tsq;
+        if (is_a) { l = sp ? hf * 9216 : hf * 8192;
+                    return sp ? a_src + (int64_t)(u < ts ? u : u - ts) * SP_STAGE_A + hf * 9216 : a_dense + (int64_t)(u - tsq) * SP_DENSE + hf * 8192; }
+        l = SP_STAGE_A + hf * 8192;
+        return (sp ? b_src + (int64_t)u * SP_STAGE_B : b_dense + (int64_t)(u - tsq) * SP_DENSE) + hf * 8192;
+      };
+      auto ld = [&](int u, u32x4 (&rb)[9]) __attribute__((always_inline)) {
+        int l; const char* g = src_of(u, l) + lane_off;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rb[j] = *(const u32x4*)(g + j * 1024);
+        if (is_a && u < tsq) rb[8] = *(const u32x4*)(g + 8192);
+      };
+      auto st = [&](int u, const u32x4 (&rb)[9]) __attribute__((always_inline)) {
+        int l; (void)src_of(u, l);
+        char* lds = smem + (u & (GEMM_PC_SLOTS - 1)) * SP_SLOT + l + lane_off;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *(u32x4*)(lds + j * 1024) = rb[j];
+        if (is_a && u < tsq) *(u32x4*)(lds + 8192) = rb[8];
+      };
+      ld(0, rb0);
+      if (nst > 1) ld(1, rb1);
+      if (nst > 2) ld(2, rb2);
+      st(0, rb0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                   // stage 0 is in its slot
+      // iteration u: fetch stage u+3 into the buffer stage u left, put stage u+1 into its slot, end stage u
+      auto step = [&](int u, u32x4 (&rb_new)[9], const u32x4 (&rb_next)[9]) __attribute__((always_inline)) {
+        if (u >= nst) return;
+        if (u + 3 < nst) ld(u + 3, rb_new);
+        if (u + 1 < nst) st(u + 1, rb_next);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      };
+#pragma unroll 1
+      for (int u = 0; u < nst; u += 3) {
+        step(u, rb0, rb1);
+        step(u + 1, rb1, rb2);
+        step(u + 2, rb2, rb0);
+      }
+    } else {
     issue(0);
     if (nst > 1) issue(1);
     if (nst > 2) issue(2);
@@ -741,14 +790,16 @@ __global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(
 #pragma unroll 1
     for (int u = 0; u < nst; ++u) {
       // slot (u+3)&3 was read during stage u-1; every consumer passed the barrier that ended it
-      if (u + 3 < nst && ABL != 1 && ABL != 5) issue(u + 3);
+      if (u + 3 < nst && ABL != 1 && ABL != 5 && !((ABL == 7 || ABL == 8) && !is_a) && !(ABL == 9 && is_a)) issue(u + 3);
       // stage u+1 must have landed before the barrier; the stages after it stay in flight
       const int after = (nst - 1 < u + 3 ? nst - 1 : u + 3) - (u + 1);
-      if (ABL == 1 || ABL == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (ABL == 12) { /* timing only: never wait for the DMA inside the loop */ }
+      else if (ABL == 1 || ABL == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if (after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+    }
     }
   } else {
     // ------------------------------------------------------------------ consumers
@@ -772,7 +823,7 @@ __global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(
     const int q_c0 = q_row + ((fhalf ^ swz4) << 4), q_c1 = q_row + (((2 + fhalf) ^ swz4) << 4);
     const int p_off = SP_A_BYTES + ((wm * 8 + fhalf) * 32 + frow) * 4; // position words, + mi*256
     half8 abl_f;
-    if (ABL == 2 || ABL == 5) { for (int e = 0; e < 8; ++e) abl_f[e] = (_Float16)(0.001f * (float)(lane + e)); asm volatile("" : "+v"(abl_f)); }
+    if (ABL == 2 || ABL == 5 || ABL == 8) { for (int e = 0; e < 8; ++e) abl_f[e] = (_Float16)(0.001f * (float)(lane + e)); asm volatile("" : "+v"(abl_f)); }
     __builtin_amdgcn_s_barrier();
     // ---- gated columns: sparse matrix cores
 #pragma unroll 1
@@ -788,7 +839,7 @@ __global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(
         half8 af[4];
         union { half8 h; uint32_t w[4]; } raw[2];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) raw[ni].h = (ABL == 2 || ABL == 5) ? abl_f : *(const half8*)(sl + (kb ? q_c1 : q_c0) + ni * 2048);
+        for (int ni = 0; ni < 2; ++ni) raw[ni].h = (ABL == 2 || ABL == 5 || ABL == 8) ? abl_f : *(const half8*)(sl + (kb ? q_c1 : q_c0) + ni * 2048);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) af[mi] = (ABL == 2 || ABL == 5) ? abl_f : *(const half8*)(sl + (kb ? a_c1 : a_c0) + mi * 2048);
 #pragma unroll
@@ -815,7 +866,7 @@ __global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(
       for (int kk = 0; kk < 2; ++kk) {
         half8 bf[2];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) bf[ni] = (ABL == 2 || ABL == 5) ? abl_f : *(const half8*)(sl + (kk ? q_c1 : q_c0) + ni * 2048);
+        for (int ni = 0; ni < 2; ++ni) bf[ni] = (ABL == 2 || ABL == 5 || ABL == 8) ? abl_f : *(const half8*)(sl + (kk ? q_c1 : q_c0) + ni * 2048);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
           const half8 af = (ABL == 2 || ABL == 5) ? abl_f : *(const half8*)(sl + (kk ? a_c1 : a_c0) + mi * 2048);
@@ -865,10 +916,12 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
   if (a.ts > 0) {
     if (a.dump)
       hipLaunchKernelGGL(gemm_filter_sparse_kernel<true>, grid, dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a);
-    else if (g_gemm_ablate >= 1 && g_gemm_ablate <= 5) {
+    else if (g_gemm_ablate >= 1) {
 #define SP_ABL(N) { (void)hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_PC_LDS); \
       hipLaunchKernelGGL((gemm_filter_sparse_kernel<false, N>), grid, dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a); }
-      if (g_gemm_ablate == 1) SP_ABL(1) else if (g_gemm_ablate == 2) SP_ABL(2) else if (g_gemm_ablate == 3) SP_ABL(3) else if (g_gemm_ablate == 4) SP_ABL(4) else SP_ABL(5)
+      if (g_gemm_ablate == 1) SP_ABL(1) else if (g_gemm_ablate == 2) SP_ABL(2) else if (g_gemm_ablate == 3) SP_ABL(3) else if (g_gemm_ablate == 4) SP_ABL(4)
+      else if (g_gemm_ablate == 7) SP_ABL(7) else if (g_gemm_ablate == 8) SP_ABL(8) else if (g_gemm_ablate == 9) SP_ABL(9) else if (g_gemm_ablate == 11) SP_ABL(11)
+      else if (g_gemm_ablate == 12) SP_ABL(12) else if (g_gemm_ablate == 13) SP_ABL(13) else SP_ABL(5)
 #undef SP_ABL
     } else
       hipLaunchKernelGGL(gemm_filter_sparse_kernel<false>, grid, dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a);
