@@ -199,6 +199,37 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     qps = nq * args.steps / elapsed
 
+    # ---- N > 1: size-independent checks of the sharded result, outside the timed region (the oracle cannot hold the
+    # corpus): sorted lists of distinct rows; every returned score is the exact score of its row on the rank that holds
+    # the row (dhr_score_rows, an independent code path); no sampled row of any shard outside a list beats its k-th score
+    dist_check = None
+    if world > 1:
+        import torch.distributed as dist
+        gs, gr = step()
+        torch.cuda.synchronize()
+        ds = gs[:, 1:] - gs[:, :-1]
+        ok_sorted = bool((ds <= 0).all()) and bool((gr[:, 1:][ds == 0] > gr[:, :-1][ds == 0]).all())
+        ok_distinct = int(torch.sort(gr, dim=1).values.diff(dim=1).eq(0).sum()) == 0
+        sub = torch.arange(0, nq, max(1, nq // 32), device=device)
+        qs = qv[sub].cpu().numpy().astype(np.float32)
+        qis = None if qi is None else qi[sub].cpu().numpy()
+        rows = gr[sub].cpu().numpy()
+        mine = torch.from_numpy(index.score_rows(qs, qis, rows)).to(device)     # -inf for the rows of other shards
+        dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+        ok_scores = bool(torch.equal(mine, gs[sub]))
+        g = torch.Generator(device="cpu").manual_seed(7 + rank)
+        rnd = (torch.randint(0, hi - lo, (len(sub), 50_000), generator=g) + lo).numpy().astype(np.int64)
+        rs = index.score_rows(qs, qis, rnd)
+        kth = gs[sub, k - 1].cpu().numpy()[:, None]
+        inlist = np.stack([np.isin(rnd[i], rows[i]) for i in range(len(sub))])
+        beat = torch.tensor([int(np.count_nonzero((rs > kth) & ~inlist))], dtype=torch.int64, device=device)
+        dist.all_reduce(beat, op=dist.ReduceOp.SUM)
+        dist_check = {"queries": int(len(sub)), "sorted": ok_sorted, "distinct_rows": ok_distinct,
+                      "scores_equal_exact_rescoring": ok_scores, "sampled_rows_per_rank": 50_000,
+                      "rows_beating_kth_outside_list": int(beat.item())}
+        if not (ok_sorted and ok_distinct and ok_scores and int(beat.item()) == 0):
+            raise SystemExit("sharded result failed its property check: %s" % dist_check)
+
     out = None
     if rank == 0:
         ach_tf = gemm_flops_alg / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -256,6 +287,8 @@ def main():
                 except AssertionError:
                     bad += 1
             out["parity_check"] = {"queries": int(sqv.shape[0]), "rows": int(scv.shape[0]), "failed": bad}
+        if dist_check is not None:
+            out["parity_check"] = dist_check
         print(json.dumps(out), flush=True)
     index.close()
     if world > 1:

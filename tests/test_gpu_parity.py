@@ -833,3 +833,23 @@ def test_random_controller_configurations(G, monkeypatch):
     import stress_sampled
     monkeypatch.setattr(sys, "argv", ["stress_sampled.py", "14", "5"])
     stress_sampled.main()
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """bench.py's N>1 path end to end (torch.distributed.run, staged sharded search, collectives, JSON line) with two
+    ranks on ONE GPU over gloo (DHR_BENCH_SINGLE_DEVICE=1, testing mode); the line must carry the contract's fields
+    and bench.py's own oracle check of a corpus slice must have passed (it raises otherwise)."""
+    import json, os, subprocess, sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = dict(os.environ, DHR_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--dist-backend", "gloo",
+           "--n-docs", "700000", "--n-queries", "512"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0 and j["unit"] == "queries/s"
+    assert j["config"]["parallelism"] == "rowshard2+allgather"
+    pc = j["parity_check"]                               # the sharded result's property check ran on both ranks
+    assert pc["sorted"] and pc["distinct_rows"] and pc["scores_equal_exact_rescoring"] and pc["rows_beating_kth_outside_list"] == 0
