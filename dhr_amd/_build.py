@@ -7,8 +7,8 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdhr_hip.so")
-SOURCES = ["kernels.hip", "api.hip"]
-HEADERS = ["dhr_internal.h", os.path.join("..", "..", "include", "dhr_hip.h")]
+SOURCES = ["kernels.hip", "gemm_w4.hip", "api.hip"]
+HEADERS = ["dhr_internal.h", "gemm_common.h", os.path.join("..", "..", "include", "dhr_hip.h")]
 
 
 def _stale() -> bool:

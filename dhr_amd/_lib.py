@@ -15,7 +15,7 @@ VAL_F16, VAL_F32 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 PARAM_CAND_CAP, PARAM_FIRST_ROWS, PARAM_PROFILE, PARAM_MAX_GROWTH, PARAM_SAMPLE_PERIOD, PARAM_GEMM_VARIANT, PARAM_MAIN_CHUNKS, PARAM_PROGRESSIVE_THR, PARAM_AUX_CUS, PARAM_GEMM_EXCLUSIVE, PARAM_OVERLAP_AUX = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 
-EXPORTS = ["dhr_version", "dhr_last_error", "dhr_index_create", "dhr_index_destroy", "dhr_index_set_param",
+EXPORTS = ["dhr_version", "dhr_abi_sizes", "dhr_last_error", "dhr_index_create", "dhr_index_destroy", "dhr_index_set_param",
            "dhr_index_device_bytes", "dhr_search", "dhr_score_rows", "dhr_merge_topk", "dhr_merge_topk_host", "dhr_merge_topk_lists", "dhr_merge_topk_lists_host",
            "dhr_get_stats", "dhr_debug_bound_scores", "dhr_debug_gemm_time", "dhr_search_sample_rank", "dhr_search_begin",
            "dhr_search_finish", "dhr_search_rerank", "dhr_index_save", "dhr_index_file_info", "dhr_index_load", "dhr_densify", "dhr_pq_train", "dhr_pq_encode", "dhr_pq_decode"]
@@ -73,13 +73,23 @@ def load():
     # to the copy that is already mapped (same SONAME) and torch tensors and our kernels share it.
     import torch  # noqa: F401
     path = _build.LIB
-    if not os.path.exists(path):
+    import shutil
+    have_hipcc = shutil.which("hipcc") is not None or os.path.exists("/opt/rocm/bin/hipcc")
+    if not os.path.exists(path) or (have_hipcc and _build._stale()):
+        # a library older than its sources would be loaded silently -- and a changed struct layout corrupts memory through
+        # ctypes -- so rebuild whenever a compiler is at hand (build() is a no-op when nothing is stale)
         try:
             _build.build()
         except Exception as e:  # noqa: BLE001
-            raise DhrError(f"libdhr_hip.so is not built and hipcc failed: {e}") from e
+            raise DhrError(f"libdhr_hip.so is missing or older than its sources and hipcc failed: {e}") from e
     lib = C.CDLL(path)
     lib.dhr_version.restype = C.c_int
+    lib.dhr_abi_sizes.argtypes = [C.POINTER(C.c_int32)]
+    sizes = (C.c_int32 * 4)()
+    lib.dhr_abi_sizes(sizes)
+    want = [C.sizeof(IndexDesc), C.sizeof(QueryBatch), C.sizeof(SearchStats), C.sizeof(FileInfo)]
+    if list(sizes) != want:
+        raise DhrError(f"libdhr_hip.so struct sizes {list(sizes)} differ from the binding's {want}: stale library, rebuild it")
     lib.dhr_last_error.restype = C.c_char_p
     lib.dhr_index_create.argtypes = [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]
     lib.dhr_index_destroy.argtypes = [C.c_void_p]

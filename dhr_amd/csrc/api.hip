@@ -125,6 +125,10 @@ static void free_ws(Workspace& w) {
 }
 
 extern "C" int dhr_version(void) { return DHR_VERSION; }
+extern "C" void dhr_abi_sizes(int32_t out[4]) {
+  out[0] = (int32_t)sizeof(dhr_index_desc); out[1] = (int32_t)sizeof(dhr_query_batch);
+  out[2] = (int32_t)sizeof(dhr_search_stats); out[3] = (int32_t)sizeof(dhr_file_info);
+}
 extern "C" const char* dhr_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" void dhr_index_destroy(dhr_index* ix) {
@@ -162,7 +166,7 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
     case DHR_PARAM_GEMM_EXCLUSIVE: ix->gemm_exclusive = value != 0; return DHR_OK;
     case DHR_PARAM_OVERLAP_AUX: ix->overlap_aux = value != 0; return DHR_OK;
     case DHR_PARAM_GEMM_VARIANT:
-      if (value != 3) return set_error(DHR_ERR_INVALID, "gemm_variant: only 3 is built (the other variants measured no better and were removed)");
+      if (value != 3 && value != 4) return set_error(DHR_ERR_INVALID, "gemm_variant: 3 (12-wave producer / consumer kernel) or 4 (4-wave kernel, 128 x 128 wave tiles)");
       dhr::g_gemm_variant = (int)value; return DHR_OK;
     case DHR_PARAM_MAX_GROWTH:
       if (value < 1 || value > 1024) return set_error(DHR_ERR_INVALID, "max_growth must be in [1,1024] sixteenths");

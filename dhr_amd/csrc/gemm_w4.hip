@@ -1,0 +1,317 @@
+// Bound GEMM + filter, 4-wave variant (one wave per SIMD, 128 x 128 wave tiles) -- see the comment below.
+#include "gemm_common.h"
+#include <type_traits>
+
+namespace dhr {
+
+// ------------------------------------------------------------------------------------------ 4-wave bound GEMM (variant 4)
+// Same operand images, same 256 x 256 tile, but FOUR waves per workgroup -- one per SIMD, each with the SIMD's whole
+// 512-entry register file: a 128 x 128 wave tile (256 fp32 accumulators) and two sets of fragment registers.  What it
+// buys over the 12-wave producer / consumer kernel above: a third less LDS fragment traffic per multiply-add (the wave
+// tile is square), no parked producer registers, and one workgroup barrier per PAIR of 32-column stages (64 matrix
+// instructions per wave between barriers instead of 16).  The stage ring is the same 4 x 34 KiB; stages are handed over
+// in pairs (ring halves), the LDS-DMA of pair g+1 is issued by the four waves with fixed roles (wave w: stage w>>1 of the
+// pair, corpus image for even w, query image for odd w) right after the barrier that frees its ring half, and lands while
+// pair g is computed.  The barrier of pair g sits before the pair's last 16 matrix instructions, and the first fragments of
+// pair g+1 are read under them.
+constexpr int GEMM_W4_THREADS = 256;
+template <int NI>
+__device__ __forceinline__ void gemm_dump_tile_w(const GemmArgs& p, floatx16 (&acc)[4][NI], int64_t dt, int qt, int wm, int wn, int lane) {
+  const int fhalf = lane >> 5;
+  const int64_t row_base = dt * TILE_ROWS + wm * 128;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int q = qt * TILE_ROWS + wn * (32 * NI) + ni * 32 + (lane & 31);
+    if (q < p.n_queries) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t row = row_base + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+          if (row < p.n_rows && row >= p.dump_row0 && row - p.dump_row0 < p.dump_ld)
+            p.dump[(int64_t)q * p.dump_ld + (row - p.dump_row0)] = acc[mi][ni][e];
+        }
+    }
+  }
+}
+// Filter epilogue, same scheme as gemm_epilogue (private hit stacks in the idle ring, one global atomic per thread and
+// query), for NT consumer threads holding 4 x NI blocks each.
+template <int NI, int NT>
+__device__ __forceinline__ void gemm_epilogue_w(const GemmArgs& p, floatx16 (&acc)[4][NI], int64_t dt, int qt, int wm, int wn,
+                                                int tid, int lane, char* smem) {
+  __syncthreads();                       // every wave is done with the staging ring
+  const int fhalf = lane >> 5;
+  const int64_t row0 = dt * TILE_ROWS;
+  const int rows_valid = (int)(p.n_rows - row0 < TILE_ROWS ? p.n_rows - row0 : TILE_ROWS);
+  uint2* stack = (uint2*)smem + tid;                       // slot j at stack[j * NT]
+  uint32_t j = 0, jn[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int q = qt * TILE_ROWS + wn * (32 * NI) + ni * 32 + (lane & 31);
+    const float t = p.thr[q];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const floatx16& a = acc[mi][ni];
+      const float m0 = __builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), a[2]), m1 = __builtin_fmaxf(__builtin_fmaxf(a[3], a[4]), a[5]);
+      const float m2 = __builtin_fmaxf(__builtin_fmaxf(a[6], a[7]), a[8]), m3 = __builtin_fmaxf(__builtin_fmaxf(a[9], a[10]), a[11]);
+      const float m4 = __builtin_fmaxf(__builtin_fmaxf(a[12], a[13]), a[14]);
+      const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(m2, m3)), __builtin_fmaxf(m4, a[15]));
+      if (mx >= t) {
+        asm volatile("");
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = a[e];
+          if (v >= t) {
+            asm volatile("");
+            const int rl = wm * 128 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+            if (rl < rows_valid) {
+              if (j < EPI_STACK) stack[j * NT] = make_uint2((uint32_t)rl, __float_as_uint(v));
+              else {
+                const uint32_t slot = atomicAdd(p.cnt + q, 1u);
+                if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(row0 + rl), __float_as_uint(v));
+              }
+              ++j;
+            }
+          }
+        }
+      }
+    }
+    jn[ni] = j < EPI_STACK ? j : EPI_STACK;
+  }
+  if (j == 0) return;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const uint32_t lo = ni ? jn[ni - 1] : 0u, hi = jn[ni];
+    if (hi > lo) {
+      const int q = qt * TILE_ROWS + wn * (32 * NI) + ni * 32 + (lane & 31);
+      const uint32_t base = atomicAdd(p.cnt + q, hi - lo);
+      for (uint32_t i = lo; i < hi; ++i) {
+        const uint2 en = stack[i * NT];
+        const uint32_t slot = base + (i - lo);
+        if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)row0 + en.x, en.y);
+      }
+    }
+  }
+}
+
+// Matrix instructions as inline asm with the accumulator pinned to the AGPR half of the register file: with all 256 AGPRs
+// holding accumulators the compiler's own allocation of the builtins splits tuples into VGPRs and spills around the loops.
+// Hazards the compiler cannot see through the asm: VALU write -> matrix read (expand_bucket_columns ends with s_nop 1),
+// matrix write -> VALU read of the accumulators (s_nop padding before the epilogue).
+__device__ __forceinline__ void smfmac_kb0(floatx16& c, const half8& a, const half16& b, uint32_t idx) {
+  asm("v_smfmac_f32_32x32x32_f16 %0, %1, %2, %3" : "+a"(c) : "v"(a), "v"(b), "v"(idx));
+}
+__device__ __forceinline__ void smfmac_kb1(floatx16& c, const half8& a, const half16& b, uint32_t idx) {
+  asm("v_smfmac_f32_32x32x32_f16 %0, %1, %2, %3 abid:1" : "+a"(c) : "v"(a), "v"(b), "v"(idx));
+}
+__device__ __forceinline__ void mfma_f16(floatx16& c, const half8& a, const half8& b) {
+  asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+struct W4Frag {            // fragments of one 16-deep block: 4 corpus row blocks, 4 query blocks (compressed in sparse stages)
+  half8 a[4];
+  union { half8 h; uint32_t w[4]; } b[4];
+};
+
+template <bool DUMP>
+__global__ void __launch_bounds__(GEMM_W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) gemm_filter_w4_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int64_t b = blockIdx.x;
+  const int xcd = (int)(b & 7);
+  const int64_t i = b >> 3;
+  const int per_group = DOC_GROUP * p.n_qtiles;
+  const int64_t g_local = i / per_group;
+  const int r = (int)(i - g_local * per_group);
+  const int qt = r / DOC_GROUP;
+  const int dl = r - qt * DOC_GROUP;
+  const int64_t seq = p.seq_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
+  if (seq >= p.seq_hi) return;
+  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head);
+  if (dt >= p.n_tiles) return;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ts = p.ts, tsq = p.ts_q, td = p.td, nst = tsq + td;
+  const char* a_src = (const char*)p.a_tiles + dt * ((int64_t)ts * SP_STAGE_A + (int64_t)td * SP_DENSE);
+  const char* b_src = (const char*)p.b_tiles + (int64_t)qt * ((int64_t)tsq * SP_STAGE_B + (int64_t)td * SP_DENSE);
+  const char* a_dense = a_src + (int64_t)ts * SP_STAGE_A;
+  const char* b_dense = b_src + (int64_t)tsq * SP_STAGE_B;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int npairs_ = nst >> 1;
+
+  // ---- LDS-DMA, fixed roles: this wave streams image (wave & 1 ? query : corpus) of stage 2*g + (wave >> 1) of pair g
+  const bool dma_b = (wave & 1) != 0;
+  const int dma_s = wave >> 1;
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  // dma_setup(g) fixes this wave's source / destination of pair g; dma_piece(j) issues the j-th KiB (three instructions:
+  // address add, M0, the load).  The pieces are spread over the matrix instructions of three blocks (6 + 6 + 6): a burst
+  // of 18 DMA instructions would hold the wave's only instruction stream -- and with it the SIMD's matrix pipe.
+  const char* dma_gp = nullptr;
+  uint32_t dma_lds = 0;
+  int dma_n = 0;
+  const char* nx_gp = nullptr;        // the state of the NEXT pair to go out is computed ahead of the barrier that frees its ring half
+  uint32_t nx_lds = 0;
+  int nx_n = 0;
+  const char* const role_src = (dma_b ? b_src : a_src) + lane_off;
+  const int64_t role_sp = dma_b ? SP_STAGE_B : SP_STAGE_A;
+  const int64_t role_dense0 = dma_b ? (int64_t)tsq * SP_STAGE_B : (int64_t)ts * SP_STAGE_A;
+  const uint32_t smem_u = (uint32_t)(uintptr_t)LDS_PTR(smem);
+  auto dma_prepare = [&](int g) __attribute__((always_inline)) {
+    const int u = 2 * g + dma_s;
+    const bool sp = u < tsq;
+    const int us = (!dma_b && u >= ts) ? u - ts : u;          // an ungated batch runs the corpus's sparse stages twice
+    const int64_t off = sp ? (int64_t)us * role_sp : role_dense0 + (int64_t)(u - tsq) * SP_DENSE;
+    nx_gp = role_src + off;
+    nx_lds = smem_u + (uint32_t)((u & 3) * SP_SLOT + (dma_b ? SP_STAGE_A : 0));
+    nx_n = g < npairs_ ? ((!dma_b && sp) ? 18 : 16) : 0;
+  };
+  auto dma_commit = [&]() __attribute__((always_inline)) { dma_gp = nx_gp; dma_lds = nx_lds; dma_n = nx_n; };
+  auto dma_setup = [&](int g) __attribute__((always_inline)) { dma_prepare(g); dma_commit(); };
+  auto dma_piece = [&](int j) __attribute__((always_inline)) {
+    if (j < dma_n) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(dma_gp + j * 1024), (__attribute__((address_space(3))) void*)(uintptr_t)(dma_lds + (uint32_t)j * 1024u), 16, 0, 0);
+  };
+  auto issue_pair = [&](int g) {
+    dma_setup(g);
+#pragma unroll
+    for (int j = 0; j < 18; ++j) dma_piece(j);
+  };
+
+  floatx16 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+  const int swz4 = (frow >> 2) & 3;
+  const int a_row = (wm * 128 + frow) * 64;                         // + mi*2048
+  const int q_row = SP_STAGE_A + (wn * 128 + frow) * 64;            // + ni*2048
+  const int c0 = (fhalf ^ swz4) << 4, c1 = ((2 + fhalf) ^ swz4) << 4;
+  const int p_off = SP_A_BYTES + ((wm * 8 + fhalf) * 32 + frow) * 4; // position words, + mi*256
+
+  // block t of the tile = (stage t >> 1, 16-deep half t & 1)
+  auto load_frag = [&](W4Frag& f, int t) __attribute__((always_inline)) {
+    const char* sl = smem + ((t >> 1) & 3) * SP_SLOT;
+    const int c = (t & 1) ? c1 : c0;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) f.b[ni].h = *(const half8*)(sl + q_row + c + ni * 2048);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) f.a[mi] = *(const half8*)(sl + a_row + c + mi * 2048);
+  };
+  uint32_t pwd[4];
+  auto load_pwd = [&](int u) __attribute__((always_inline)) {
+    const char* sl = smem + (u & 3) * SP_SLOT;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) pwd[mi] = *(const uint32_t*)(sl + p_off + mi * 256);
+  };
+  // DMA0: pieces [DMA0, DMA0 + 6) of the pending pair go out behind the first three query blocks of this 16-instruction block
+  auto mma_sparse = [&](const W4Frag& f, auto kb_c, auto dma_c) __attribute__((always_inline)) {
+    constexpr int KB = decltype(kb_c)::value;
+    constexpr int DMA0 = decltype(dma_c)::value;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      union { half16 h; uint32_t w[8]; } bf;
+      expand_bucket_columns(f.b[ni].w, bf.w);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        if constexpr (KB == 0) smfmac_kb0(acc[mi][ni], f.a[mi], bf.h, pwd[mi]); else smfmac_kb1(acc[mi][ni], f.a[mi], bf.h, pwd[mi]);
+      if constexpr (DMA0 >= 0) if (ni < 3) { dma_piece(DMA0 + 2 * ni); dma_piece(DMA0 + 2 * ni + 1); }
+    }
+  };
+  auto mma_dense = [&](const W4Frag& f, auto dma_c) __attribute__((always_inline)) {
+    constexpr int DMA0 = decltype(dma_c)::value;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        mfma_f16(acc[mi][ni], f.a[mi], f.b[ni].h);
+      if constexpr (DMA0 >= 0) if (ni < 3) { dma_piece(DMA0 + 2 * ni); dma_piece(DMA0 + 2 * ni + 1); }
+    }
+  };
+  // Pairs are homogeneous (the launcher only selects this kernel when tsq and td are even): a loop over the sparse
+  // pairs, then one over the dense pairs, both straight-line in the accumulators.
+  const int npairs = nst >> 1, nsp = tsq >> 1;
+  issue_pair(0);
+  if (npairs > 1) { issue_pair(1); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }   // pair 0 landed; pair 1 (16 or 18 pieces per wave) in flight
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  W4Frag f0, f1;
+  if (nsp > 0) load_pwd(0);
+  load_frag(f0, 0);
+  constexpr std::integral_constant<int, 0> KB0{};
+  constexpr std::integral_constant<int, 1> KB1{};
+  constexpr std::integral_constant<int, -1> NODMA{};
+  constexpr std::integral_constant<int, 0> DMA_A{};
+  constexpr std::integral_constant<int, 6> DMA_B{};
+  constexpr std::integral_constant<int, 12> DMA_C{};
+  dma_n = 0;             // nothing pending during pair 0's first two blocks (pairs 0 and 1 went out in the prologue)
+  // Schedule of the DMA of pair g+2 (ring half of pair g): block 3 of pair g (behind the barrier that frees the half)
+  // carries pieces 0-5, blocks 0 and 1 of pair g+1 pieces 6-11 and 12-17; the barrier of pair g+1 waits for them.
+#pragma unroll 1
+  for (int g = 0; g < nsp; ++g) {
+    const int t0 = 4 * g;
+    load_frag(f1, t0 + 1);
+    mma_sparse(f0, KB0, DMA_B);
+    load_frag(f0, t0 + 2);
+    mma_sparse(f1, KB1, DMA_C);
+    load_pwd(2 * g + 1);
+    load_frag(f1, t0 + 3);
+    mma_sparse(f0, KB0, NODMA);
+    // every read of this pair's ring half has been issued; the next pair must have landed before anybody reads it
+    dma_prepare(g + 2);
+    __builtin_amdgcn_sched_barrier(0);                    // the matrix asm is not volatile: without this the compiler sinks block 2 below the wait
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    dma_commit();                                     // into the ring half this pair just left
+    uint32_t nx[4] = {0u, 0u, 0u, 0u};
+    if (g + 1 < nsp) {
+      const char* sl = smem + ((2 * (g + 1)) & 3) * SP_SLOT;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) nx[mi] = *(const uint32_t*)(sl + p_off + mi * 256);
+    }
+    if (g + 1 < npairs) load_frag(f0, t0 + 4);
+    mma_sparse(f1, KB1, DMA_A);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) pwd[mi] = nx[mi];
+  }
+#pragma unroll 1
+  for (int g = nsp; g < npairs; ++g) {
+    const int t0 = 4 * g;
+    load_frag(f1, t0 + 1);
+    mma_dense(f0, DMA_B);
+    load_frag(f0, t0 + 2);
+    mma_dense(f1, DMA_C);
+    load_frag(f1, t0 + 3);
+    mma_dense(f0, NODMA);
+    dma_prepare(g + 2);
+    __builtin_amdgcn_sched_barrier(0);                    // the matrix asm is not volatile: without this the compiler sinks block 2 below the wait
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    dma_commit();
+    if (g + 1 < npairs) load_frag(f0, t0 + 4);
+    mma_dense(f1, DMA_A);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // the last matrix results are in the accumulators
+  if (DUMP) { gemm_dump_tile_w<4>(p, acc, dt, qt, wm, wn, lane); return; }
+  gemm_epilogue_w<4, GEMM_W4_THREADS>(p, acc, dt, qt, wm, wn, (int)threadIdx.x, lane, smem);
+}
+
+
+hipError_t launch_gemm_w4(const GemmArgs& a, dim3 grid, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_filter_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_RING_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)gemm_filter_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_RING_LDS);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (a.dump) hipLaunchKernelGGL(gemm_filter_w4_kernel<true>, grid, dim3(GEMM_W4_THREADS), GEMM_RING_LDS, s, a);
+  else hipLaunchKernelGGL(gemm_filter_w4_kernel<false>, grid, dim3(GEMM_W4_THREADS), GEMM_RING_LDS, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace dhr

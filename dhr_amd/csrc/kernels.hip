@@ -14,15 +14,12 @@
 #include <cstdlib>
 
 #include "dhr_internal.h"
+#include "gemm_common.h"
 #include <type_traits>
 
 namespace dhr {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef short short8 __attribute__((ext_vector_type(8)));
-#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
-#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -464,7 +461,6 @@ __device__ __forceinline__ void gemm_dump_tile(const GemmArgs& p, floatx16 (&acc
 // reserves room in the global list with ONE atomic per (thread, query) -- a hot query's 24 hits per tile cost one
 // atomic -- and copies its own stack out.  Only hits beyond the stack (a thread with more than 32 of its 128
 // accumulators passing) fall back to one-by-one appends.
-constexpr int EPI_STACK = 32;
 template <bool DUMP, int NTHREADS = 512>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, floatx16 (&acc)[4][2], int64_t dt, int qt, int wm, int wn,
                                               int lane, char* smem, bool has_acc = true) {
@@ -656,25 +652,6 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_v3_kernel(GemmArg
 constexpr int GEMM_PC_THREADS = 768;
 constexpr int GEMM_PC_SLOTS = 4;
 constexpr int GEMM_PC_LDS = GEMM_PC_SLOTS * SP_SLOT + 64;      // 136 KiB ring (the filter epilogue's hit queue reuses it, + its counter word)
-typedef _Float16 half16 __attribute__((ext_vector_type(16)));
-
-// Compressed query fragment -> smfmac B operand: each fp16 slice value v (bucket in the sign bit) becomes its two
-// bucket columns (max(v,0), max(-v,0)), one v_pk_max_f16 per output register.  One asm block, so that the two
-// wait states a matrix instruction needs after a VALU write of its operand (the compiler cannot see through
-// inline asm) are inside it.
-__device__ __forceinline__ void expand_bucket_columns(const uint32_t (&r)[4], uint32_t (&o)[8]) {
-  asm("v_pk_max_f16 %0, %8, 0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
-      "v_pk_max_f16 %1, %8, 0 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
-      "v_pk_max_f16 %2, %9, 0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
-      "v_pk_max_f16 %3, %9, 0 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
-      "v_pk_max_f16 %4, %10, 0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
-      "v_pk_max_f16 %5, %10, 0 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
-      "v_pk_max_f16 %6, %11, 0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
-      "v_pk_max_f16 %7, %11, 0 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
-      "s_nop 1"
-      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
-      : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
-}
 
 // ABL (timing experiments only, wrong results unless noted): 1 no in-loop DMA, 2 no fragment reads, 3 no matrix instructions, 4 no epilogue,
 // 5 = 1 + 2, 7 no query-side DMA, 8 = 7 + no query fragment reads, 9 no corpus-side DMA, 11 both operands always from L2-hot tiles,
@@ -898,6 +875,7 @@ __global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(
   gemm_epilogue<DUMP, GEMM_PC_THREADS>(p, acc, dt, qt, wm, wn, lane, smem, wave < 8);
 }
 
+
 int g_gemm_ablate = 0;    // tuning only (DHR_GEMM_ABLATE environment variable): timing ablations of the 2:4 kernel, wrong results
 int g_gemm_variant = 3;   // kept for the C ABI's DHR_PARAM_GEMM_VARIANT; only variant 3 is built (the others measured no better and were removed)
 
@@ -907,6 +885,7 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
   static bool env_read = false;
   if (!env_read) {
     if (const char* e = getenv("DHR_GEMM_ABLATE")) g_gemm_ablate = atoi(e);
+    if (const char* e = getenv("DHR_GEMM_VARIANT")) g_gemm_variant = atoi(e);     // tuning only (the torch-free PMC driver)
     env_read = true;
   }
   const int64_t n_tiles = a.seq_hi - a.seq_lo;
@@ -927,6 +906,7 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const dim3 grid((unsigned)blocks);
+  if (a.ts > 0 && g_gemm_variant == 4 && g_gemm_ablate == 0 && !(a.ts_q & 1) && !(a.td & 1)) return launch_gemm_w4(a, grid, s);   // pairs of stages
   if (a.ts > 0) {
     if (a.dump)
       hipLaunchKernelGGL(gemm_filter_sparse_kernel<true>, grid, dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a);

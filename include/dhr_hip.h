@@ -98,11 +98,15 @@ typedef enum dhr_param {
   DHR_PARAM_GEMM_EXCLUSIVE = 10, /* with AUX_CUS: 1 = run the bound GEMM on the other CUs only */
   DHR_PARAM_OVERLAP_AUX = 11,  /* 1 (default): refine / rescoring / select of chunk i run beside the GEMM of chunk i+1; 0: one after the other */
   DHR_PARAM_PROGRESSIVE_THR = 8, /* 1 (default): later main-pass chunks filter with the running exact k-th best, not only the sampled threshold */
-  DHR_PARAM_GEMM_VARIANT = 6, /* reserved: only 3 (the built kernel) is accepted */
+  DHR_PARAM_GEMM_VARIANT = 6, /* bound-GEMM kernel of the 2:4 layout: 3 = 12-wave producer / consumer, 4 = 4-wave with 128 x 128 wave tiles */
   DHR_PARAM_SAMPLE_PERIOD = 5 /* every S-th corpus tile seeds the thresholds (default 32; 0 = plain streaming) */
 } dhr_param;
 
 int dhr_version(void);
+/* sizeof of the four public structs as this library was compiled: { dhr_index_desc, dhr_query_batch, dhr_search_stats,
+ * dhr_file_info }.  A binding compares them with its own declarations at load time (a stale library whose struct layout
+ * differs would otherwise corrupt memory silently). */
+void dhr_abi_sizes(int32_t out[4]);
 /* Message of the last failure on the calling thread ("" if none). */
 const char* dhr_last_error(void);
 

@@ -272,3 +272,54 @@ def check_topk(rows, scores, exact_f64: np.ndarray, k: int, *, eps_rel: float = 
     if ref_scores is not None:
         assert np.all(np.abs(np.sort(scores) - np.sort(np.asarray(ref_scores, np.float64))) <= atol)
     return {"boundary": len(may) - len(must)}
+
+
+# --------------------------------------------------------------------------- two-stage parity rule
+def stage1_scores_f64(q_val, q_idx, c_val, c_idx, theta: float, ip: bool) -> np.ndarray:
+    """Float64 stage-1 score of the theta>0 modes (gip_retrieval.py:128-139): the gated inner product restricted to the
+    query dimensions with q > theta, or the plain inner product over all columns with --IP.  q_idx / c_idx unpadded."""
+    qv = np.asarray(q_val, np.float64)
+    cv = np.asarray(c_val, np.float64)
+    if ip:
+        return cv @ qv
+    d = q_idx.shape[-1]
+    keep = qv > theta
+    gate = (c_idx[:, :d] == q_idx[None, :d]) & keep[None, :d]
+    s = (gate * cv[:, :d]) @ qv[:d]
+    if cv.shape[1] > d:
+        s = s + cv[:, d:] @ (qv[d:] * keep[d:])
+    return s
+
+
+def check_two_stage(rows, scores, stage1_f64: np.ndarray, exact_f64: np.ndarray, k1: int, k: int, *,
+                    eps_rel: float = 1e-5, atol: float = 1e-3):
+    """Parity rule of `--rerank` (gip_retrieval.py:141-153): the result is the exact-score top-k of SOME stage-1 set C1
+    with |C1| = k1 that holds every row strictly above the k1-th best stage-1 score and nothing strictly below it.  A
+    returned list may differ from the reference's only by rows inside the float64 tie band of the stage-1 boundary
+    (1e-5 relative at the k1-th stage-1 score) or of the stage-2 boundary (1e-5 relative at the k-th exact score)."""
+    rows = np.asarray(rows, np.int64)
+    scores = np.asarray(scores, np.float64)
+    n = exact_f64.shape[0]
+    k1 = min(k1, n)
+    kk = min(k, k1)
+    assert len(rows) == kk and len(set(rows.tolist())) == kk
+    assert np.all(np.abs(scores - exact_f64[rows]) <= atol)
+    assert np.all(np.diff(scores) <= 1e-6 * np.maximum(1.0, np.abs(scores[:-1]))), "not sorted best-first"
+    s1k = np.sort(stage1_f64)[::-1][k1 - 1]
+    e1 = eps_rel * max(abs(s1k), 1e-30) + 1e-12
+    must1 = stage1_f64 > s1k + e1
+    may1 = stage1_f64 >= s1k - e1
+    assert np.all(may1[rows]), "a returned row is strictly below the stage-1 boundary"
+    # stage 2: k-th returned exact score; every CERTAIN stage-1 row strictly above it must be present
+    sk = exact_f64[rows].min()
+    e2 = eps_rel * max(abs(sk), 1e-30) + 1e-12
+    got = np.zeros(n, bool)
+    got[rows] = True
+    missing = must1 & ~got & (exact_f64 > sk + e2)
+    assert not missing.any(), f"{int(missing.sum())} certain stage-1 rows beat the k-th returned score but are missing"
+    # ... and the list cannot be better than any admissible C1 allows: with C1 >= must1 the k-th best of C1 is at
+    # least the k-th best exact score inside must1
+    if int(must1.sum()) >= kk:
+        lower = np.sort(exact_f64[must1])[::-1][kk - 1]
+        assert sk >= lower - e2
+    return {"band1": int(may1.sum() - must1.sum())}

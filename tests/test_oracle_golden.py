@@ -207,3 +207,37 @@ def test_pq_oracle_self_consistency():
         d = ((sub[:, None, :] - cb[m][None]) ** 2).sum(2)
         assert (np.abs(d[np.arange(50), codes[:50, m]] - d.min(1)) < 1e-5).all()
     np.testing.assert_allclose(PO.adc_scores(q, codes, cb), q.astype(np.float64) @ xr.T.astype(np.float64), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["F6_hyb_theta03_rerank", "F6_hyb_theta03_norerank", "F6_hyb_ip_rerank", "F6_hyb_ip_norerank"])
+def test_two_stage_rule_admits_the_reference(golden, case):
+    """The float64 tie-band rule the GPU tests apply to the theta>0 modes (oracle.check_two_stage / check_topk on the
+    stage-1 score) accepts the reference's own recorded lists, and rejects a list with ONE wrong row."""
+    info, ref_rows, ref_scores = golden.case(case)
+    d, q, qi, c, ci = _prepared(golden, info)
+    for i in range(q.shape[0]):
+        s1 = O.stage1_scores_f64(q[i], qi[i], c, ci, info["theta"], info.get("IP", False))
+        ex = O.gip_scores_f64(q[i], qi[i], c, ci)
+        rows = np.asarray(ref_rows[i])
+        if info.get("rerank", False):
+            rr = rows[np.argsort(-ex[rows], kind="stable")]
+            O.check_two_stage(rr, ex[rr], s1, ex, info["agip_topk"], info["topk"])
+            # one genuinely wrong row: swap the best row for the best row that is NOT in the list and far below the k-th score
+            bad = rr.copy()
+            outside = np.setdiff1d(np.nonzero(s1 >= np.sort(s1)[::-1][info["agip_topk"] - 1])[0], rr)
+            cand = outside[ex[outside] < ex[rr].min() - 1e-3]
+            if len(cand):
+                bad[0] = cand[0]
+                bad = bad[np.argsort(-ex[bad], kind="stable")]
+                with pytest.raises(AssertionError):
+                    O.check_two_stage(bad, ex[bad], s1, ex, info["agip_topk"], info["topk"])
+        else:
+            rr = rows[np.argsort(-s1[rows], kind="stable")]
+            np.testing.assert_allclose(np.sort(s1[rr]), np.sort(ref_scores[i].astype(np.float64)), rtol=3e-6, atol=3e-6)
+            O.check_topk(rr, s1[rr], s1, info["topk"])
+            bad = rr.copy()
+            far = np.nonzero(s1 < s1[rr].min() - 1e-3)[0]
+            bad[0] = far[0]
+            bad = bad[np.argsort(-s1[bad], kind="stable")]
+            with pytest.raises(AssertionError):
+                O.check_topk(bad, s1[bad], s1, info["topk"])

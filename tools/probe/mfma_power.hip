@@ -1,0 +1,169 @@
+// Sustained matrix-core rate under the package power cap, as a function of instruction shape and OPERAND DATA
+// (register operands only, no LDS / memory traffic in the loop).  Every wave holds 4 A fragments and 2 B fragments
+// (the bound GEMM's 128 x 64 wave tile) loaded from a host-generated buffer, so successive matrix instructions see
+// different operand bits, as in the real kernel.  Prints TFLOP/s and the effective shader clock (s_memtime / wall).
+// Build: hipcc --offload-arch=gfx950 -O2 -o _bin/mfma_power mfma_power.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <chrono>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef int intx16 __attribute__((ext_vector_type(16)));
+typedef int intx4 __attribute__((ext_vector_type(4)));
+union Frag { uint32_t w[4]; half8 h; bf8 b; intx4 i; };
+
+// KIND 0 f16 32x32x16, 1 bf16 32x32x16, 2 f16 16x16x32, 3 smfmac f16 32x32x32, 4 i8 32x32x32.  ORDER 0: A-major (B alternates),
+// 1: B-major (A alternates every instruction).
+template <int KIND, int ORDER>
+__global__ void __launch_bounds__(256) k(const uint32_t* __restrict__ data, float* out, int iters, long long* cyc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t* src = data + ((size_t)(blockIdx.x * 4 + wave) * 64 + lane) * 40;   // 10 x 16 bytes per lane
+  Frag a[4], b[2], b2[2];
+  for (int i = 0; i < 4; ++i) for (int e = 0; e < 4; ++e) a[i].w[e] = src[i * 4 + e];
+  for (int i = 0; i < 2; ++i) for (int e = 0; e < 4; ++e) { b[i].w[e] = src[16 + i * 4 + e]; b2[i].w[e] = src[24 + i * 4 + e]; }
+  const long long t0 = clock64();
+  float s = 0.f;
+  if constexpr (KIND == 2) {
+    floatx4 c[4][2];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 4; ++e) c[i][j][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)       // 4 x 8 instructions of 8192 MACs = the MACs of 8 x 32x32x16... (2 reps)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i].h, b[j].h, c[i][j], 0, 0, 0);
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 4; ++e) s += c[i][j][e];
+  } else if constexpr (KIND == 4) {
+    intx16 c[4][2];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) c[i][j][e] = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i].i, b[j].i, c[i][j], 0, 0, 0);
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) s += (float)c[i][j][e];
+  } else {
+    floatx16 c[4][2];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) c[i][j][e] = 0.f;
+    union { half16 h; uint32_t w[8]; } bb[2];
+    for (int j = 0; j < 2; ++j) for (int e = 0; e < 4; ++e) { bb[j].w[e] = b[j].w[e]; bb[j].w[4 + e] = b2[j].w[e]; }
+    for (int it = 0; it < iters; ++it) {
+      if constexpr (ORDER == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if constexpr (KIND == 0) c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i].h, b[j].h, c[i][j], 0, 0, 0);
+            if constexpr (KIND == 1) c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].b, b[j].b, c[i][j], 0, 0, 0);
+            if constexpr (KIND == 3) c[i][j] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(a[i].h, bb[j].h, c[i][j], 0x44444444, 0, 0);
+          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if constexpr (KIND == 0) c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i].h, b[j].h, c[i][j], 0, 0, 0);
+            if constexpr (KIND == 1) c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].b, b[j].b, c[i][j], 0, 0, 0);
+            if constexpr (KIND == 3) c[i][j] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(a[i].h, bb[j].h, c[i][j], 0x44444444, 0, 0);
+          }
+      }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) s += c[i][j][e];
+  }
+  const long long t1 = clock64();
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *cyc = t1 - t0;
+}
+
+static uint64_t rs = 0x9E3779B97F4A7C15ull;
+static inline uint64_t rnd() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; }
+static inline double unif() { return (double)(rnd() >> 11) / 9007199254740992.0; }
+static inline double gauss() { return std::sqrt(-2.0 * std::log(unif() + 1e-300)) * std::cos(6.283185307179586 * unif()); }
+static uint16_t f2h(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+
+// pattern: 0 zeros, 1 N(0,.1) f16, 2/3/4 the same with the low 3/5/7 mantissa bits cleared, 5 DLR-like non-negative,
+// 6 N(0,.1) bf16, 7 random bytes, 8 constant 0.1 f16, 9 N(0,.1) f16 low 5 bits cleared on the A fragments only
+static void fill(std::vector<uint16_t>& v, int pattern) {
+  const size_t per_lane = 80;      // 16-bit values per lane: 32 A, 16 B, 16 B2, 16 pad
+  for (size_t i = 0; i < v.size(); ++i) {
+    const size_t e = i % per_lane;
+    uint16_t x = 0;
+    switch (pattern) {
+      case 0: x = 0; break;
+      case 1: x = f2h((float)(0.1 * gauss())); break;
+      case 2: x = f2h((float)(0.1 * gauss())) & 0xfff8; break;
+      case 3: x = f2h((float)(0.1 * gauss())) & 0xffe0; break;
+      case 4: x = f2h((float)(0.1 * gauss())) & 0xff80; break;
+      case 5: x = f2h((float)(unif() < 0.1 ? 0.1 + 2.9 * unif() : 0.02 * unif())); break;
+      case 6: x = f2bf((float)(0.1 * gauss())); break;
+      case 7: x = (uint16_t)rnd(); break;
+      case 8: x = f2h(0.1f); break;
+      case 9: x = f2h((float)(0.1 * gauss())); if (e < 32) x &= 0xffe0; break;
+    }
+    v[i] = x;
+  }
+}
+
+template <int KIND, int ORDER>
+static void run(const char* name, int pattern, double macs_per_inst, int inst_per_iter, double seconds) {
+  const int blocks = 512;           // 2 workgroups of 4 waves per CU: two waves per SIMD
+  const size_t n16 = (size_t)blocks * 256 * 80;
+  std::vector<uint16_t> h(n16);
+  fill(h, pattern);
+  uint32_t* d; float* out; long long* cyc;
+  hipMalloc(&d, n16 * 2); hipMalloc(&out, (size_t)blocks * 256 * 4); hipMalloc(&cyc, 8);
+  hipMemcpy(d, h.data(), n16 * 2, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  int iters = 20000;
+  float ms = 0;
+  for (int rep = 0; rep < 3; ++rep) {      // rep 0 calibrates, rep 1 warms into the power-capped state, rep 2 is measured
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<KIND, ORDER>), dim3(blocks), dim3(256), 0, 0, d, out, iters, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    if (rep == 0) iters = (int)(iters * (seconds * 1e3 / ms));
+  }
+  long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+  const double n_inst = (double)blocks * 4 * iters * inst_per_iter;
+  const double tf = n_inst * macs_per_inst * 2.0 / ms / 1e9;
+  const auto now = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+  printf("%-34s pattern %d: %8.1f ms  %7.1f TFLOP/s  s_memtime %.3f GHz-equivalent  [t=%.1f]\n", name, pattern, ms, tf, (double)c / ms / 1e6, now);
+  fflush(stdout);
+  hipFree(d); hipFree(out); hipFree(cyc);
+}
+
+int main(int argc, char** argv) {
+  const double sec = argc > 1 ? atof(argv[1]) : 1.2;
+  const double M32 = 32.0 * 32 * 16;
+  run<0, 0>("f16 32x32x16 A-major", 1, M32, 8, sec);      // warm up the box
+  run<0, 0>("f16 32x32x16 A-major", 0, M32, 8, sec);
+  run<0, 0>("f16 32x32x16 A-major", 8, M32, 8, sec);
+  run<0, 0>("f16 32x32x16 A-major", 1, M32, 8, sec);
+  run<0, 1>("f16 32x32x16 B-major", 1, M32, 8, sec);
+  run<0, 0>("f16 32x32x16 A-major", 2, M32, 8, sec);
+  run<0, 0>("f16 32x32x16 A-major", 3, M32, 8, sec);
+  run<0, 0>("f16 32x32x16 A-major", 4, M32, 8, sec);
+  run<0, 0>("f16 32x32x16 A-major", 9, M32, 8, sec);
+  run<0, 0>("f16 32x32x16 A-major", 5, M32, 8, sec);
+  run<1, 0>("bf16 32x32x16 A-major", 6, M32, 8, sec);
+  run<1, 0>("bf16 32x32x16 A-major", 0, M32, 8, sec);
+  run<2, 0>("f16 16x16x32", 1, 16.0 * 16 * 32, 32, sec);
+  run<3, 0>("smfmac f16 32x32x32 A-major", 1, 32.0 * 32 * 32, 8, sec);
+  run<3, 1>("smfmac f16 32x32x32 B-major", 1, 32.0 * 32 * 32, 8, sec);
+  run<3, 0>("smfmac f16 32x32x32 A-major", 5, 32.0 * 32 * 32, 8, sec);
+  run<4, 0>("i8 32x32x32", 7, 32.0 * 32 * 32, 8, sec);
+  run<0, 0>("f16 32x32x16 A-major", 1, M32, 8, sec);
+  return 0;
+}
