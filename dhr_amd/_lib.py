@@ -72,10 +72,10 @@ def load():
     # share the device.  Import torch FIRST so that the loader resolves our NEEDED libamdhip64.so.7
     # to the copy that is already mapped (same SONAME) and torch tensors and our kernels share it.
     import torch  # noqa: F401
-    path = _build.LIB
+    path = os.environ.get("DHR_HIP_LIB") or _build.LIB      # the override is a tuning aid (alternative builds side by side)
     import shutil
     have_hipcc = shutil.which("hipcc") is not None or os.path.exists("/opt/rocm/bin/hipcc")
-    if not os.path.exists(path) or (have_hipcc and _build._stale()):
+    if not os.path.exists(path) or (path == _build.LIB and have_hipcc and _build._stale()):
         # a library older than its sources would be loaded silently -- and a changed struct layout corrupts memory through
         # ctypes -- so rebuild whenever a compiler is at hand (build() is a no-op when nothing is stale)
         try:

@@ -108,6 +108,27 @@ __device__ __forceinline__ void mfma_f16(floatx16& c, const half8& a, const half
   asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
+#ifndef W4_DMA_PER_BLOCK
+#define W4_DMA_PER_BLOCK 9      // DMA pieces (of <= 18 per wave and stage pair) issued inside one 16-instruction block ...
+#define W4_DMA_PER_NI 3         // ... behind each of its query blocks
+#endif
+// Issue group of a sparse block: the two expansion instructions of one register of the NEXT query block's compressed fragment
+// (value v, bucket in the sign bit -> the two bucket columns (max(v,0), max(-v,0))), then one matrix instruction of the current
+// one.  (In a __device__ function: the host pass of the compiler rejects the constraints inside the kernel body itself.)
+template <int KB>
+__device__ __forceinline__ void sm_unit(floatx16& c, uint32_t& o_lo, uint32_t& o_hi, const half8& a, const half16& b, uint32_t idx, uint32_t raw) {
+  if constexpr (KB == 0)
+    asm("v_pk_max_f16 %1, %6, 0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
+        "v_pk_max_f16 %2, %6, 0 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
+        "v_smfmac_f32_32x32x32_f16 %0, %3, %4, %5"
+        : "+a"(c), "=&v"(o_lo), "=&v"(o_hi) : "v"(a), "v"(b), "v"(idx), "v"(raw));
+  else
+    asm("v_pk_max_f16 %1, %6, 0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
+        "v_pk_max_f16 %2, %6, 0 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
+        "v_smfmac_f32_32x32x32_f16 %0, %3, %4, %5 abid:1"
+        : "+a"(c), "=&v"(o_lo), "=&v"(o_hi) : "v"(a), "v"(b), "v"(idx), "v"(raw));
+}
+
 struct W4Frag {            // fragments of one 16-deep block: 4 corpus row blocks, 4 query blocks (compressed in sparse stages)
   half8 a[4];
   union { half8 h; uint32_t w[4]; } b[4];
@@ -201,36 +222,55 @@ __global__ void __launch_bounds__(GEMM_W4_THREADS) __attribute__((amdgpu_waves_p
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) f.a[mi] = *(const half8*)(sl + a_row + c + mi * 2048);
   };
-  uint32_t pwd[4];
-  auto load_pwd = [&](int u) __attribute__((always_inline)) {
+  // Position words of a sparse stage (one u32 per 32-row block: low half = 16-slice block 0, high half = block 1), two sets:
+  // even / odd stage of a pair.
+  uint32_t pwx[4] = {0u, 0u, 0u, 0u}, pwy[4] = {0u, 0u, 0u, 0u};
+  auto load_pw = [&](uint32_t (&pw)[4], int u) __attribute__((always_inline)) {
     const char* sl = smem + (u & 3) * SP_SLOT;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) pwd[mi] = *(const uint32_t*)(sl + p_off + mi * 256);
+    for (int mi = 0; mi < 4; ++mi) pw[mi] = *(const uint32_t*)(sl + p_off + mi * 256);
   };
-  // DMA0: pieces [DMA0, DMA0 + 6) of the pending pair go out behind the first three query blocks of this 16-instruction block
-  auto mma_sparse = [&](const W4Frag& f, auto kb_c, auto dma_c) __attribute__((always_inline)) {
+  // One 16-instruction block, written as 16 issue groups "fragment read | 2 expansion VALU | matrix instruction | DMA piece":
+  // the wave is the SIMD's only instruction stream, so whatever sits between two matrix instructions beyond the ~32 cycles the
+  // first one executes leaves the matrix pipe idle (measured on the first version of this kernel: 8 expansions + 2 DMA pieces
+  // in a row between groups of 4 matrix instructions cost a third of the pipe's time).  Per group: the g-th of the 8 fragment
+  // reads of the NEXT block (groups 0-7), the two v_pk_max_f16 that expand one register of the next query block's compressed
+  // fragment (sparse stages), one matrix instruction, and in groups 8-13 one DMA piece of the pair that is going out.
+  union BF { half16 h; uint32_t w[8]; };
+  BF bfa, bfb;       // expanded query block: bfa holds the CURRENT block's ni = 0 expansion on entry of a sparse block
+  auto blk_sparse = [&](const W4Frag& fc, W4Frag& fn, int tn, bool do_load, auto kb_c, auto dma_c, const uint32_t (&pw)[4]) __attribute__((always_inline)) {
     constexpr int KB = decltype(kb_c)::value;
     constexpr int DMA0 = decltype(dma_c)::value;
+    const char* sl = smem + ((tn >> 1) & 3) * SP_SLOT + ((tn & 1) ? c1 : c0);
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      union { half16 h; uint32_t w[8]; } bf;
-      expand_bucket_columns(f.b[ni].w, bf.w);
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-        if constexpr (KB == 0) smfmac_kb0(acc[mi][ni], f.a[mi], bf.h, pwd[mi]); else smfmac_kb1(acc[mi][ni], f.a[mi], bf.h, pwd[mi]);
-      if constexpr (DMA0 >= 0) if (ni < 3) { dma_piece(DMA0 + 2 * ni); dma_piece(DMA0 + 2 * ni + 1); }
+    for (int g = 0; g < 16; ++g) {
+      const int ni = g >> 2, mi = g & 3;
+      if (do_load) {
+        if (g < 4) fn.b[g].h = *(const half8*)(sl + q_row + g * 2048);
+        else if (g < 8) fn.a[g - 4] = *(const half8*)(sl + a_row + (g - 4) * 2048);
+      }
+      BF& cur = (ni & 1) ? bfb : bfa;
+      BF& oth = (ni & 1) ? bfa : bfb;
+      const uint32_t rw = ni < 3 ? fc.b[ni + 1].w[mi] : fn.b[0].w[mi];
+      sm_unit<KB>(acc[mi][ni], oth.w[2 * mi], oth.w[2 * mi + 1], fc.a[mi], cur.h, pw[mi], rw);
+      if constexpr (DMA0 >= 0) if (g >= 8 && g < 14) dma_piece(DMA0 + g - 8);
     }
   };
-  auto mma_dense = [&](const W4Frag& f, auto dma_c) __attribute__((always_inline)) {
+  auto blk_dense = [&](const W4Frag& fc, W4Frag& fn, int tn, bool do_load, auto dma_c) __attribute__((always_inline)) {
     constexpr int DMA0 = decltype(dma_c)::value;
+    const char* sl = smem + ((tn >> 1) & 3) * SP_SLOT + ((tn & 1) ? c1 : c0);
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-        mfma_f16(acc[mi][ni], f.a[mi], f.b[ni].h);
-      if constexpr (DMA0 >= 0) if (ni < 3) { dma_piece(DMA0 + 2 * ni); dma_piece(DMA0 + 2 * ni + 1); }
+    for (int g = 0; g < 16; ++g) {
+      const int ni = g >> 2, mi = g & 3;
+      if (do_load) {
+        if (g < 4) fn.b[g].h = *(const half8*)(sl + q_row + g * 2048);
+        else if (g < 8) fn.a[g - 4] = *(const half8*)(sl + a_row + (g - 4) * 2048);
+      }
+      mfma_f16(acc[mi][ni], fc.a[mi], fc.b[ni].h);
+      if constexpr (DMA0 >= 0) if (g >= 8 && g < 14) dma_piece(DMA0 + g - 8);
     }
   };
+
   // Pairs are homogeneous (the launcher only selects this kernel when tsq and td are even): a loop over the sparse
   // pairs, then one over the dense pairs, both straight-line in the accumulators.
   const int npairs = nst >> 1, nsp = tsq >> 1;
@@ -239,8 +279,9 @@ __global__ void __launch_bounds__(GEMM_W4_THREADS) __attribute__((amdgpu_waves_p
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   W4Frag f0, f1;
-  if (nsp > 0) load_pwd(0);
+  if (nsp > 0) load_pw(pwx, 0);
   load_frag(f0, 0);
+  if (nsp > 0) expand_bucket_columns(f0.b[0].w, bfa.w);
   constexpr std::integral_constant<int, 0> KB0{};
   constexpr std::integral_constant<int, 1> KB1{};
   constexpr std::integral_constant<int, -1> NODMA{};
@@ -253,46 +294,31 @@ __global__ void __launch_bounds__(GEMM_W4_THREADS) __attribute__((amdgpu_waves_p
 #pragma unroll 1
   for (int g = 0; g < nsp; ++g) {
     const int t0 = 4 * g;
-    load_frag(f1, t0 + 1);
-    mma_sparse(f0, KB0, DMA_B);
-    load_frag(f0, t0 + 2);
-    mma_sparse(f1, KB1, DMA_C);
-    load_pwd(2 * g + 1);
-    load_frag(f1, t0 + 3);
-    mma_sparse(f0, KB0, NODMA);
+    blk_sparse(f0, f1, t0 + 1, true, KB0, DMA_B, pwx);
+    blk_sparse(f1, f0, t0 + 2, true, KB1, DMA_C, pwx);
+    load_pw(pwy, 2 * g + 1);
+    blk_sparse(f0, f1, t0 + 3, true, KB0, NODMA, pwy);
     // every read of this pair's ring half has been issued; the next pair must have landed before anybody reads it
     dma_prepare(g + 2);
     __builtin_amdgcn_sched_barrier(0);                    // the matrix asm is not volatile: without this the compiler sinks block 2 below the wait
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    dma_commit();                                     // into the ring half this pair just left
-    uint32_t nx[4] = {0u, 0u, 0u, 0u};
-    if (g + 1 < nsp) {
-      const char* sl = smem + ((2 * (g + 1)) & 3) * SP_SLOT;
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) nx[mi] = *(const uint32_t*)(sl + p_off + mi * 256);
-    }
-    if (g + 1 < npairs) load_frag(f0, t0 + 4);
-    mma_sparse(f1, KB1, DMA_A);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) pwd[mi] = nx[mi];
+    dma_commit();
+    if (g + 1 < nsp) load_pw(pwx, 2 * (g + 1));
+    blk_sparse(f1, f0, t0 + 4, g + 1 < npairs, KB1, DMA_A, pwy);
   }
 #pragma unroll 1
   for (int g = nsp; g < npairs; ++g) {
     const int t0 = 4 * g;
-    load_frag(f1, t0 + 1);
-    mma_dense(f0, DMA_B);
-    load_frag(f0, t0 + 2);
-    mma_dense(f1, DMA_C);
-    load_frag(f1, t0 + 3);
-    mma_dense(f0, NODMA);
+    blk_dense(f0, f1, t0 + 1, true, DMA_B);
+    blk_dense(f1, f0, t0 + 2, true, DMA_C);
+    blk_dense(f0, f1, t0 + 3, true, NODMA);
     dma_prepare(g + 2);
-    __builtin_amdgcn_sched_barrier(0);                    // the matrix asm is not volatile: without this the compiler sinks block 2 below the wait
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     dma_commit();
-    if (g + 1 < npairs) load_frag(f0, t0 + 4);
-    mma_dense(f1, DMA_A);
+    blk_dense(f1, f0, t0 + 4, g + 1 < npairs, DMA_A);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // the last matrix results are in the accumulators
   if (DUMP) { gemm_dump_tile_w<4>(p, acc, dt, qt, wm, wn, lane); return; }
