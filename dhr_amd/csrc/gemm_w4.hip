@@ -108,10 +108,40 @@ __device__ __forceinline__ void mfma_f16(floatx16& c, const half8& a, const half
   asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
-#ifndef W4_DMA_PER_BLOCK
-#define W4_DMA_PER_BLOCK 9      // DMA pieces (of <= 18 per wave and stage pair) issued inside one 16-instruction block ...
-#define W4_DMA_PER_NI 3         // ... behind each of its query blocks
+// timing ablations (wrong results): W4_ABL 1 = no pair barrier, 2 = no DMA wait before it, 3 = neither, 4 = no DMA pieces in the loop
+#ifndef W4_ABL
+#define W4_ABL 0
 #endif
+#if W4_ABL == 1
+#define W4_PAIR_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#elif W4_ABL == 2
+#define W4_PAIR_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#elif W4_ABL == 3
+#define W4_PAIR_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define W4_PAIR_SYNC() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#endif
+#define W4_PREP(g) do { if constexpr (W4_DMA_MODE == 3) { nx_off = role_goff((g) + 3, nx_18); } else dma_prepare((g) + 2); } while (0)
+#define W4_COMMIT(g) do { if constexpr (W4_DMA_MODE == 3) { \
+    wr_on = (g) + 2 < npairs; wr_off = (uint32_t)(((2 * ((g) + 2) + dma_s) & 3) * SP_SLOT + (dma_b ? SP_STAGE_A : 0)) + lane_off; \
+    wr_18 = wr_on && ld_18; ld_gp = role_src + nx_off; ld_18 = nx_18; } else dma_commit(); } while (0)
+#ifndef W4_BUFFER_DMA
+#define W4_BUFFER_DMA 1
+#endif
+#ifndef W4_DMA_MODE
+#define W4_DMA_MODE 0
+#endif
+// DMA piece issued behind matrix instruction g (0..15) of the block with phase PH (0: the block right behind the pair barrier,
+// 1 / 2: the next pair's first two blocks), or -1.  Mode 0: 6 + 6 + 6 in groups 8-13; mode 1: 16 in phase 0 (one per group), 2 in phase 1.
+__host__ __device__ constexpr int w4_dma_piece(int ph, int g) {
+#if W4_DMA_MODE >= 2
+  return -1;    // staggered schedule: see w4_dma_gap below
+#elif W4_DMA_MODE == 0
+  return (g >= 8 && g < 14) ? ph * 6 + g - 8 : -1;
+#else
+  return ph == 0 ? g : (ph == 1 && g >= 8 && g < 10 ? 16 + g - 8 : -1);
+#endif
+}
 // Issue group of a sparse block: the two expansion instructions of one register of the NEXT query block's compressed fragment
 // (value v, bucket in the sign bit -> the two bucket columns (max(v,0), max(-v,0))), then one matrix instruction of the current
 // one.  (In a __device__ function: the host pass of the compiler rejects the constraints inside the kernel body itself.)
@@ -173,6 +203,7 @@ __global__ void __launch_bounds__(GEMM_W4_THREADS) __attribute__((amdgpu_waves_p
   const char* nx_gp = nullptr;        // the state of the NEXT pair to go out is computed ahead of the barrier that frees its ring half
   uint32_t nx_lds = 0;
   int nx_n = 0;
+  int dma_soff = 0, nx_soff = 0;
   const char* const role_src = (dma_b ? b_src : a_src) + lane_off;
   const int64_t role_sp = dma_b ? SP_STAGE_B : SP_STAGE_A;
   const int64_t role_dense0 = dma_b ? (int64_t)tsq * SP_STAGE_B : (int64_t)ts * SP_STAGE_A;
@@ -183,18 +214,74 @@ __global__ void __launch_bounds__(GEMM_W4_THREADS) __attribute__((amdgpu_waves_p
     const int us = (!dma_b && u >= ts) ? u - ts : u;          // an ungated batch runs the corpus's sparse stages twice
     const int64_t off = sp ? (int64_t)us * role_sp : role_dense0 + (int64_t)(u - tsq) * SP_DENSE;
     nx_gp = role_src + off;
+    nx_soff = (int)off;
     nx_lds = smem_u + (uint32_t)((u & 3) * SP_SLOT + (dma_b ? SP_STAGE_A : 0));
     nx_n = g < npairs_ ? ((!dma_b && sp) ? 18 : 16) : 0;
   };
-  auto dma_commit = [&]() __attribute__((always_inline)) { dma_gp = nx_gp; dma_lds = nx_lds; dma_n = nx_n; };
+  int dma_res = -1;
+  auto dma_commit = [&]() __attribute__((always_inline)) { dma_gp = nx_gp; dma_soff = nx_soff; dma_lds = nx_lds; dma_n = W4_ABL == 4 ? 0 : nx_n; dma_res = dma_n > 0 ? wave % 3 : -1; };
   auto dma_setup = [&](int g) __attribute__((always_inline)) { dma_prepare(g); dma_commit(); };
+  // buffer form of the LDS-DMA: scalar base (resource) + scalar pair offset + constant lane offset register + immediate --
+  // no per-piece vector address arithmetic, one address register per lane instead of two
+  const __amdgpu_buffer_rsrc_t role_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(dma_b ? b_src : a_src), (short)0, 0x7fffffff, 0x00020000);
   auto dma_piece = [&](int j) __attribute__((always_inline)) {
+#if W4_BUFFER_DMA
+    if (j < dma_n) {
+      // the instruction's immediate offset is added to the global AND to the LDS address (M0 + offset + 16 * lane)
+      __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(uintptr_t)(dma_lds + (uint32_t)(j >> 2) * 4096u);
+      const int so = dma_soff + (j >> 2) * 4096;
+      switch (j & 3) {      // the immediate must be a literal
+        case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(role_rsrc, l, 16, (int)lane_off, so, 0, 0); break;
+        case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(role_rsrc, l, 16, (int)lane_off, so, 1024, 0); break;
+        case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(role_rsrc, l, 16, (int)lane_off, so, 2048, 0); break;
+        default: __builtin_amdgcn_raw_ptr_buffer_load_lds(role_rsrc, l, 16, (int)lane_off, so, 3072, 0); break;
+      }
+    }
+#else
     if (j < dma_n) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(dma_gp + j * 1024), (__attribute__((address_space(3))) void*)(uintptr_t)(dma_lds + (uint32_t)j * 1024u), 16, 0, 0);
+#endif
   };
   auto issue_pair = [&](int g) {
     dma_setup(g);
 #pragma unroll
     for (int j = 0; j < 18; ++j) dma_piece(j);
+  };
+
+  // ---- mode 3: register-staged operand stream.  An LDS-DMA instruction holds the issuing wave ~60-80 cycles (measured: with
+  // all of them removed from the loop the kernel runs in 23.8 instead of 38.5 ms), which a wave that is its SIMD's only
+  // matrix-instruction stream cannot hide.  A plain global_load_dwordx4 retires from the issue port at once and a
+  // ds_write_b128 in ~13 cycles, so the stream goes global -> 18 x 4 staging registers -> LDS: the loads of pair g+3 are
+  // issued during pair g+1 (behind the stores that free their registers), the stores of pair g+2 behind the barrier of pair g.
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 stg[18];
+  const char* ld_gp = role_src;       // source of the pair being loaded into the staging registers
+  bool ld_18 = false;
+  uint32_t wr_off = 0;                // LDS byte offset (from smem) of the pair being stored, this lane
+  bool wr_on = false, wr_18 = false;
+  int64_t nx_off = 0;
+  bool nx_18 = false;
+  auto role_goff = [&](int g, bool& is18) __attribute__((always_inline)) -> int64_t {
+    int u = 2 * g + dma_s;
+    if (u > nst - 1) u = nst - 2 + dma_s;                       // past the end: a valid address (the data is never stored)
+    const bool sp = u < tsq;
+    const int us = (!dma_b && u >= ts) ? u - ts : u;
+    is18 = !dma_b && sp;
+    return sp ? (int64_t)us * role_sp : role_dense0 + (int64_t)(u - tsq) * SP_DENSE;
+  };
+  auto stg_load = [&](int j) __attribute__((always_inline)) {
+    // roles with 16 pieces re-read a valid address for the last two (unconditional loads: a branch around a load costs a full drain)
+    stg[j] = *(const u32x4*)(ld_gp + ((j >= 16 && !ld_18) ? 15 : j) * 1024);
+  };
+  auto stg_store = [&](int j) __attribute__((always_inline)) {
+    if (j < 16) { if (wr_on) *(u32x4*)(smem + wr_off + j * 1024) = stg[j]; }
+    else if (wr_18) *(u32x4*)(smem + wr_off + j * 1024) = stg[j];
+  };
+  // phase PH (0: the block behind the pair barrier, 1-3: the next pair's blocks), matrix instruction g -> staging work
+  auto xfer = [&](auto ph_c, int g) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph_c)::value;
+    if constexpr (PH == 0) { if (g & 1) stg_store(g >> 1); }                       // stores 0-7
+    else if constexpr (PH == 1) { if (g < 10) stg_store(8 + g); if (g >= 8) stg_load(g - 8); }   // stores 8-17, loads 0-7
+    else if constexpr (PH == 2) { if (g < 10) stg_load(8 + g); }                  // loads 8-17
   };
 
   floatx16 acc[4][4];
@@ -253,7 +340,15 @@ __global__ void __launch_bounds__(GEMM_W4_THREADS) __attribute__((amdgpu_waves_p
       BF& oth = (ni & 1) ? bfa : bfb;
       const uint32_t rw = ni < 3 ? fc.b[ni + 1].w[mi] : fn.b[0].w[mi];
       sm_unit<KB>(acc[mi][ni], oth.w[2 * mi], oth.w[2 * mi + 1], fc.a[mi], cur.h, pw[mi], rw);
-      if constexpr (DMA0 >= 0) if (g >= 8 && g < 14) dma_piece(DMA0 + g - 8);
+      if constexpr (DMA0 >= 0) if (w4_dma_piece(DMA0, g) >= 0) dma_piece(w4_dma_piece(DMA0, g));
+      if constexpr (W4_DMA_MODE == 3 && DMA0 >= 0) xfer(dma_c, g);
+      if constexpr (W4_DMA_MODE == 2 && DMA0 >= 0) {
+        // staggered: the four waves share one address path (64 B / clk: a KiB piece holds it ~16 cycles); in lockstep they all issue
+        // at once and each piece waits for the others'.  Gap G = 16 * phase + g of the 64 behind the pair barrier carries piece G / 3 of
+        // the wave with wave % 3 == G % 3 (pieces 0-17 in gaps 0-53).
+        const int G = 16 * DMA0 + g;
+        if (G < 54 && (G % 3) == dma_res) dma_piece(G / 3);
+      }
     }
   };
   auto blk_dense = [&](const W4Frag& fc, W4Frag& fn, int tn, bool do_load, auto dma_c) __attribute__((always_inline)) {
@@ -267,7 +362,15 @@ __global__ void __launch_bounds__(GEMM_W4_THREADS) __attribute__((amdgpu_waves_p
         else if (g < 8) fn.a[g - 4] = *(const half8*)(sl + a_row + (g - 4) * 2048);
       }
       mfma_f16(acc[mi][ni], fc.a[mi], fc.b[ni].h);
-      if constexpr (DMA0 >= 0) if (g >= 8 && g < 14) dma_piece(DMA0 + g - 8);
+      if constexpr (DMA0 >= 0) if (w4_dma_piece(DMA0, g) >= 0) dma_piece(w4_dma_piece(DMA0, g));
+      if constexpr (W4_DMA_MODE == 3 && DMA0 >= 0) xfer(dma_c, g);
+      if constexpr (W4_DMA_MODE == 2 && DMA0 >= 0) {
+        // staggered: the four waves share one address path (64 B / clk: a KiB piece holds it ~16 cycles); in lockstep they all issue
+        // at once and each piece waits for the others'.  Gap G = 16 * phase + g of the 64 behind the pair barrier carries piece G / 3 of
+        // the wave with wave % 3 == G % 3 (pieces 0-17 in gaps 0-53).
+        const int G = 16 * DMA0 + g;
+        if (G < 54 && (G % 3) == dma_res) dma_piece(G / 3);
+      }
     }
   };
 
@@ -278,6 +381,7 @@ __global__ void __launch_bounds__(GEMM_W4_THREADS) __attribute__((amdgpu_waves_p
   if (npairs > 1) { issue_pair(1); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }   // pair 0 landed; pair 1 (16 or 18 pieces per wave) in flight
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if constexpr (W4_DMA_MODE == 3) { nx_off = role_goff(2, nx_18); ld_gp = role_src + nx_off; ld_18 = nx_18; }   // pair 2 is staged during pair 0
   W4Frag f0, f1;
   if (nsp > 0) load_pw(pwx, 0);
   load_frag(f0, 0);
@@ -286,9 +390,10 @@ __global__ void __launch_bounds__(GEMM_W4_THREADS) __attribute__((amdgpu_waves_p
   constexpr std::integral_constant<int, 1> KB1{};
   constexpr std::integral_constant<int, -1> NODMA{};
   constexpr std::integral_constant<int, 0> DMA_A{};
-  constexpr std::integral_constant<int, 6> DMA_B{};
-  constexpr std::integral_constant<int, 12> DMA_C{};
-  dma_n = 0;             // nothing pending during pair 0's first two blocks (pairs 0 and 1 went out in the prologue)
+  constexpr std::integral_constant<int, 1> DMA_B{};
+  constexpr std::integral_constant<int, 2> DMA_C{};
+  constexpr std::integral_constant<int, (W4_DMA_MODE >= 2 ? 3 : -1)> DMA_D{};
+  dma_n = 0; dma_res = -1;   // nothing pending during pair 0's first two blocks (pairs 0 and 1 went out in the prologue)
   // Schedule of the DMA of pair g+2 (ring half of pair g): block 3 of pair g (behind the barrier that frees the half)
   // carries pieces 0-5, blocks 0 and 1 of pair g+1 pieces 6-11 and 12-17; the barrier of pair g+1 waits for them.
 #pragma unroll 1
@@ -297,13 +402,12 @@ __global__ void __launch_bounds__(GEMM_W4_THREADS) __attribute__((amdgpu_waves_p
     blk_sparse(f0, f1, t0 + 1, true, KB0, DMA_B, pwx);
     blk_sparse(f1, f0, t0 + 2, true, KB1, DMA_C, pwx);
     load_pw(pwy, 2 * g + 1);
-    blk_sparse(f0, f1, t0 + 3, true, KB0, NODMA, pwy);
+    blk_sparse(f0, f1, t0 + 3, true, KB0, DMA_D, pwy);
     // every read of this pair's ring half has been issued; the next pair must have landed before anybody reads it
-    dma_prepare(g + 2);
+    W4_PREP(g);
     __builtin_amdgcn_sched_barrier(0);                    // the matrix asm is not volatile: without this the compiler sinks block 2 below the wait
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    dma_commit();
+    W4_PAIR_SYNC();
+    W4_COMMIT(g);
     if (g + 1 < nsp) load_pw(pwx, 2 * (g + 1));
     blk_sparse(f1, f0, t0 + 4, g + 1 < npairs, KB1, DMA_A, pwy);
   }
@@ -312,12 +416,11 @@ __global__ void __launch_bounds__(GEMM_W4_THREADS) __attribute__((amdgpu_waves_p
     const int t0 = 4 * g;
     blk_dense(f0, f1, t0 + 1, true, DMA_B);
     blk_dense(f1, f0, t0 + 2, true, DMA_C);
-    blk_dense(f0, f1, t0 + 3, true, NODMA);
-    dma_prepare(g + 2);
+    blk_dense(f0, f1, t0 + 3, true, DMA_D);
+    W4_PREP(g);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    dma_commit();
+    W4_PAIR_SYNC();
+    W4_COMMIT(g);
     blk_dense(f1, f0, t0 + 4, g + 1 < npairs, DMA_A);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // the last matrix results are in the accumulators
