@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--aux-cus", type=int, default=-1, help="tuning: CUs the refine/rescoring stream is confined to (0 = no mask)")
     ap.add_argument("--gemm-exclusive", type=int, default=-1)
     ap.add_argument("--overlap-aux", type=int, default=-1)
+    ap.add_argument("--gemm-variant", type=int, default=-1, help="tuning: bound-GEMM kernel of the 2:4 layout (3 = 12-wave producer / consumer, 4 = 4-wave)")
     ap.add_argument("--no-progressive-thr", action="store_true", help="A/B: keep the sampled thresholds frozen over the main pass")
     ap.add_argument("--first-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -144,6 +145,8 @@ def main():
         index.set_param(_lib.PARAM_AUX_CUS, args.aux_cus)
     if args.overlap_aux >= 0:
         index.set_param(_lib.PARAM_OVERLAP_AUX, args.overlap_aux)
+    if args.gemm_variant >= 0:
+        index.set_param(_lib.PARAM_GEMM_VARIANT, args.gemm_variant)
     if args.gemm_exclusive >= 0:
         index.set_param(_lib.PARAM_GEMM_EXCLUSIVE, args.gemm_exclusive)
     if args.no_progressive_thr:

@@ -32,6 +32,6 @@ __device__ __forceinline__ void expand_bucket_columns(const uint32_t (&r)[4], ui
 }
 
 
-hipError_t launch_gemm_w4(const GemmArgs& a, dim3 grid, hipStream_t s);
+hipError_t launch_gemm_wx(const GemmArgs& a, dim3 grid, int variant, hipStream_t s);   // variant 4 (4 waves) or 5 (8 waves)
 
 }  // namespace dhr

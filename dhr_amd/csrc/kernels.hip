@@ -906,7 +906,7 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const dim3 grid((unsigned)blocks);
-  if (a.ts > 0 && g_gemm_variant == 4 && g_gemm_ablate == 0 && !(a.ts_q & 1) && !(a.td & 1)) return launch_gemm_w4(a, grid, s);   // pairs of stages
+  if (a.ts > 0 && (g_gemm_variant == 4 || g_gemm_variant == 5) && g_gemm_ablate == 0 && !(a.ts_q & 1) && !(a.td & 1)) return launch_gemm_wx(a, grid, g_gemm_variant, s);   // pairs of stages
   if (a.ts > 0) {
     if (a.dump)
       hipLaunchKernelGGL(gemm_filter_sparse_kernel<true>, grid, dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a);

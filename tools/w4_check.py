@@ -26,12 +26,13 @@ def main():
         ix = GipIndex(cv, ci, idx_buckets=2)
         q32 = qv.astype(np.float32)
         u3 = bound(ix, q32, qi, n, 3)
-        u4 = bound(ix, q32, qi, n, 4)
-        u4i = bound(ix, q32, None, n, 4)          # ungated batch: 2 * ts sparse stages on the query side
         u3i = bound(ix, q32, None, n, 3)
+        for v in (4, 5):
+            u4 = bound(ix, q32, qi, n, v)
+            u4i = bound(ix, q32, None, n, v)          # ungated batch: 2 * ts sparse stages on the query side
+            print("n %d q %d d_cls %d: variant %d gated max|v-v3| %.3g  ungated %.3g  (|u| max %.3f)" % (n, q, d_cls, v, np.abs(u4 - u3).max(), np.abs(u4i - u3i).max(), np.abs(u3).max()))
+            assert np.array_equal(u4, u3) and np.array_equal(u4i, u3i)
         ix.close()
-        print("n %d q %d d_cls %d: gated max|v4-v3| %.3g  ungated %.3g  (|u| max %.3f)" % (n, q, d_cls, np.abs(u4 - u3).max(), np.abs(u4i - u3i).max(), np.abs(u3).max()))
-        assert np.array_equal(u4, u3) and np.array_equal(u4i, u3i)
     rows = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
     import bench
     dev = torch.device("cuda", 0)
@@ -41,7 +42,7 @@ def main():
     del cv
     qb, keep = _lib.make_query_batch(qv, qi)
     for rep in range(2):
-        for variant in (3, 4):
+        for variant in (3, 4, 5):
             ix.set_param(_lib.PARAM_GEMM_VARIANT, variant)
             ms, fl = C.c_double(), C.c_double()
             _lib.check(ix._lib.dhr_debug_gemm_time(ix._h, C.byref(qb), 8, C.byref(ms), C.byref(fl), None), "gemm_time")
@@ -49,11 +50,12 @@ def main():
             print("variant %d: %.3f ms per %d rows, algorithmic %.1f TFLOP/s (frac %.3f)" % (variant, ms.value, rows, alg / ms.value / 1e9, alg / ms.value / 1e9 / 2500))
     # a search with each variant: identical results
     res = []
-    for variant in (3, 4):
+    for variant in (3, 4, 5):
         ix.set_param(_lib.PARAM_GEMM_VARIANT, variant)
         s, r = ix.search(qv, qi, 1000, out_device=True)
         res.append((s.cpu(), r.cpu()))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for o in res[1:]:
+        assert torch.equal(res[0][0], o[0]) and torch.equal(res[0][1], o[1])
     print("search results identical")
     ix.close()
 
