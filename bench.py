@@ -31,43 +31,72 @@ if ROOT not in sys.path:
 N_MSMARCO = 8_841_823
 Q_DEV = 6_980
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md chip table
+GEN_CHUNK = 1 << 18            # the synthetic corpus is seeded per GLOBAL chunk of this many rows: a shard of any world size is a slice of the same corpus
+
+# BASELINE.json config 5: the 13 public BEIR corpora (documents, test queries), sizes from the public BEIR table
+BEIR = [("trec-covid", 171_332, 50), ("nfcorpus", 3_633, 323), ("nq", 2_681_468, 3_452), ("hotpotqa", 5_233_329, 7_405),
+        ("fiqa", 57_638, 648), ("arguana", 8_674, 1_406), ("webis-touche2020", 382_545, 49), ("quora", 522_931, 10_000),
+        ("dbpedia-entity", 4_635_922, 400), ("scidocs", 25_657, 1_000), ("fever", 5_416_568, 6_666),
+        ("climate-fever", 5_416_593, 1_535), ("scifact", 5_183, 300)]
 
 
-def gen_shard(torch, synth, device, seed, n_rows, d_dlr, d_cls, lmin, lmax, uniform_idx, chunk=1 << 18):
-    """Synthetic rows on the GPU, SURVEY.md section 8(d) recipe.  -> (value fp16 [n,K], index u8 [n,d_dlr]|None)"""
-    gen = torch.Generator(device=device).manual_seed(seed)
+def gen_rows(torch, synth, device, seed, row_lo, row_hi, d_dlr, d_cls, lmin, lmax, uniform_idx):
+    """Rows [row_lo, row_hi) of the synthetic matrix with this seed, on the GPU (SURVEY.md section 8(d) recipe).  Every global
+    GEN_CHUNK-row chunk has its own generator seed, so the rows do not depend on how the corpus is sharded.
+    -> (value fp16 [n,K], index u8 [n,d_dlr]|None)"""
+    n_rows = row_hi - row_lo
     k = d_dlr + d_cls
     value = torch.empty((n_rows, k), dtype=torch.float16, device=device)
     index = torch.empty((n_rows, d_dlr), dtype=torch.uint8, device=device) if d_dlr else None
-    for lo in range(0, n_rows, chunk):
-        hi = min(n_rows, lo + chunk)
+    for c in range(row_lo // GEN_CHUNK, (row_hi + GEN_CHUNK - 1) // GEN_CHUNK):
+        c_lo = c * GEN_CHUNK
+        a, b = max(row_lo, c_lo), min(row_hi, c_lo + GEN_CHUNK)
+        gen = torch.Generator(device=device).manual_seed(seed * 1_000_003 + c)
         if d_dlr:
-            v, i = synth.torch_make_dlr(gen, hi - lo, d_dlr, lmin, lmax, device, uniform_idx=uniform_idx)
-            value[lo:hi, :d_dlr] = v
-            index[lo:hi] = i
+            v, i = synth.torch_make_dlr(gen, GEN_CHUNK, d_dlr, lmin, lmax, device, uniform_idx=uniform_idx)
+            value[a - row_lo:b - row_lo, :d_dlr] = v[a - c_lo:b - c_lo]
+            index[a - row_lo:b - row_lo] = i[a - c_lo:b - c_lo]
+            del v, i
         if d_cls:
-            value[lo:hi, d_dlr:] = (torch.randn((hi - lo, d_cls), generator=gen, device=device) * 0.1).to(torch.float16)
+            d = (torch.randn((GEN_CHUNK, d_cls), generator=gen, device=device) * 0.1).to(torch.float16)
+            value[a - row_lo:b - row_lo, d_dlr:] = d[a - c_lo:b - c_lo]
+            del d
     return value, index
 
 
-def cpu_baseline(O, cv, ci, qv, qi, k, n_full):
-    """The oracle's restatement of the reference's per-query loop (mask*corpus -> einsum -> topk,
-    gip_retrieval.py:119-125), fp32, ONE thread (the reference sets torch.set_num_threads(1) for
-    --batch 1, :255-259), on a bounded sample; linear extrapolation in the row count."""
-    c32 = cv.astype(np.float32)
-    q32 = qv.astype(np.float32)
-    if ci is not None:
-        cls_dim = c32.shape[1] - ci.shape[1]
-        cip = O.pad_idx(ci, cls_dim)
-        qip = O.pad_idx(qi, cls_dim)
-    t0 = time.perf_counter()
-    rows = []
-    for i in range(q32.shape[0]):
-        s = O.gip_scores_f32(q32[i], qip[i], c32, cip) if ci is not None else O.ip_scores_f32(q32[i], c32)
-        rows.append(O.topk_desc(s, k))
-    dt = time.perf_counter() - t0
-    s_per_query = dt / q32.shape[0]
-    return s_per_query, s_per_query * (n_full / c32.shape[0]), rows
+def gen_shard(torch, synth, device, seed, n_rows, d_dlr, d_cls, lmin, lmax, uniform_idx, chunk=GEN_CHUNK):
+    """Rows [0, n_rows) (kept for the tools that build one stand-alone shard)."""
+    return gen_rows(torch, synth, device, seed, 0, n_rows, d_dlr, d_cls, lmin, lmax, uniform_idx)
+
+
+def result_checksum(torch, scores, rows):
+    """Order-sensitive checksum of a [Q, k] result (device tensors): any N must print the same pair for the same corpus."""
+    q, k = rows.shape
+    w = (torch.arange(k, device=rows.device, dtype=torch.int64) + 1)[None, :] * (torch.arange(q, device=rows.device, dtype=torch.int64) % 1021 + 1)[:, None]
+    r = int(((rows.to(torch.int64) + 1) * w).sum().item() & ((1 << 62) - 1))
+    sbits = int((scores.contiguous().view(torch.int32).to(torch.int64) * w).sum().item() & ((1 << 62) - 1))
+    return {"rows": r, "score_bits": sbits}
+
+
+def cpu_baseline_legs(sample, k, n_full, q_one, q_all):
+    """The reference's per-query loop restated with its own torch ops (oracle/gip_oracle_torch.py, checked against the numpy
+    oracle), timed on the host: (i) ONE thread -- the reference's setting for --batch 1, gip_retrieval.py:255-259 -- and
+    (ii) all cores, on a bounded slice of the same corpus; linear extrapolation in the row count."""
+    from oracle import gip_oracle_torch as OT
+    scv, sci, sqv, sqi = sample
+    c32, q32 = scv.astype(np.float32), sqv.astype(np.float32)          # the reference's astype(float32) copies (:268-313), outside its timer too
+    cores = os.cpu_count() or 1
+    s1, _ = OT.gip_loop(q32[:q_one], None if sqi is None else sqi[:q_one], c32, sci, k, 1)
+    sa, _ = OT.gip_loop(q32[:q_all], None if sqi is None else sqi[:q_all], c32, sci, k, cores)
+    scale = n_full / c32.shape[0]
+    what = "torch-CPU restatement of gip_retrieval.py:115-126 (mask * corpus -> einsum -> topk, one query at a time, fp32)"
+    return {"value": round(1.0 / (s1 * scale), 5), "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": "%d queries x %d-row slice of the same synthetic corpus, %s, 1 thread (the reference's --batch 1 setting); "
+                      "%.3f s/query measured, x%.2f linear extrapolation to %d rows" % (q_one, c32.shape[0], what, s1, scale, n_full),
+            "all_cores": {"value": round(1.0 / (sa * scale), 5), "unit": "queries/s", "cores": cores,
+                          "sample": "%d queries x %d rows, same loop with torch.set_num_threads(%d); %.3f s/query measured, x%.2f"
+                                    % (q_all, c32.shape[0], cores, sa, scale)},
+            "host_cpus": cores}
 
 
 def main():
@@ -75,11 +104,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="hybrid", choices=["hybrid", "dense"],
-                    help="hybrid = config 3 (768 DLR + 768 dense); dense = config 2 (768 dense, no index array)")
-    ap.add_argument("--n-docs", type=int, default=N_MSMARCO)
-    ap.add_argument("--n-queries", type=int, default=Q_DEV)
+    ap.add_argument("--workload", default="hybrid", choices=["hybrid", "dense", "bm25", "beir"],
+                    help="hybrid = config 3 / 4 (768 DLR + 768 dense, 8.84 M rows); dense = config 2 (768 dense, no index array); "
+                         "bm25 = config 1 (100 k rows, DLR only, int16 whole-word slice index); beir = config 5 sweep (13 corpus sizes, "
+                         "768 DLR + 128 dense), one JSON line per corpus")
+    ap.add_argument("--n-docs", type=int, default=0, help="override the workload's corpus size")
+    ap.add_argument("--n-queries", type=int, default=0, help="override the workload's query count")
     ap.add_argument("--topk", type=int, default=1000)
+    ap.add_argument("--pq", action="store_true", help="beir: product-quantised first stage (--PQIP: ADC scan to agip_topk candidates, exact GIP rerank) instead of the exact search")
+    ap.add_argument("--agip-topk", type=int, default=10000)
     ap.add_argument("--uniform-idx", action="store_true", help="adversarial variant: uniform slice indices")
     ap.add_argument("--cand-cap", type=int, default=0)
     ap.add_argument("--idx-buckets", type=int, default=0)
@@ -89,19 +122,21 @@ def main():
     ap.add_argument("--aux-cus", type=int, default=-1, help="tuning: CUs the refine/rescoring stream is confined to (0 = no mask)")
     ap.add_argument("--gemm-exclusive", type=int, default=-1)
     ap.add_argument("--overlap-aux", type=int, default=-1)
-    ap.add_argument("--gemm-variant", type=int, default=-1, help="tuning: bound-GEMM kernel of the 2:4 layout (3 = 12-wave producer / consumer, 4 = 4-wave)")
+    ap.add_argument("--gemm-variant", type=int, default=-1, help="tuning: bound-GEMM kernel of the 2:4 layout (3 = 12-wave producer / consumer, 4 = 4 waves, 5 = 8 waves)")
     ap.add_argument("--no-progressive-thr", action="store_true", help="A/B: keep the sampled thresholds frozen over the main pass")
     ap.add_argument("--first-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=200_000)
-    ap.add_argument("--cpu-queries", type=int, default=40)
+    ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline slice (SURVEY.md section 8d: 1 M)")
+    ap.add_argument("--cpu-queries", type=int, default=32, help="queries of the all-cores CPU leg (section 8d: 32)")
+    ap.add_argument("--cpu-queries-1t", type=int, default=12, help="queries of the one-thread CPU leg (bounded: ~1.2 s per query and M rows)")
+    ap.add_argument("--parity-rows", type=int, default=200_000)
+    ap.add_argument("--parity-queries", type=int, default=24)
     ap.add_argument("--seed", type=int, default=1237)
     ap.add_argument("--dist-backend", default="nccl", help="testing only: 'gloo' lets several ranks share ONE GPU (with DHR_BENCH_SINGLE_DEVICE=1)")
     args = ap.parse_args()
 
     import torch
     from dhr_amd import _lib, dist as D, synth
-    from dhr_amd.retrieval.gip_retrieval import GipIndex
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -119,15 +154,52 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
-    d_dlr, d_cls = (768, 768) if args.workload == "hybrid" else (0, 768)
+    ctx = dict(torch=torch, _lib=_lib, D=D, synth=synth, world=world, rank=rank, local_rank=local_rank, device=device)
+    if args.workload == "beir":
+        for name, n_docs, n_q in BEIR:
+            spec = dict(name="beir/" + name, n=args.n_docs or n_docs, nq=args.n_queries or n_q, d_dlr=768, d_cls=128, kind="encoder",
+                        baseline_config="config 5: DeLADE-CLS-P on BEIR-13 (%s)" % name, seed=args.seed + 5 + (hash(name) % 997))
+            out = run_workload(args, spec, ctx)
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+    else:
+        spec = {"hybrid": dict(name="hybrid", n=N_MSMARCO, nq=Q_DEV, d_dlr=768, d_cls=768, kind="encoder",
+                               baseline_config="config 3: DeLADE-CLS 768+768 dense-hybrid" if world == 1 else "config 4: 768+768 dense-hybrid, corpus row-sharded across %d GPUs" % world),
+                "dense": dict(name="dense", n=N_MSMARCO, nq=Q_DEV, d_dlr=0, d_cls=768, kind="dense", baseline_config="config 2: Aggretriever 768-d dense-only"),
+                "bm25": dict(name="bm25", n=100_000, nq=Q_DEV, d_dlr=768, d_cls=0, kind="bm25",
+                             baseline_config="config 1: BM25 densified (DLR only), 100k-passage toy corpus")}[args.workload]
+        spec["n"] = args.n_docs or spec["n"]
+        spec["nq"] = args.n_queries or spec["nq"]
+        spec["seed"] = args.seed
+        out = run_workload(args, spec, ctx)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def run_workload(args, spec, ctx):
+    torch, _lib, D, synth = ctx["torch"], ctx["_lib"], ctx["D"], ctx["synth"]
+    world, rank, local_rank, device = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["device"]
+    from dhr_amd.retrieval.gip_retrieval import GipIndex
+    d_dlr, d_cls, n, nq, k = spec["d_dlr"], spec["d_cls"], spec["n"], spec["nq"], args.topk
     K = d_dlr + d_cls
-    n, nq, k = args.n_docs, args.n_queries, args.topk
     lo, hi = D.shard_bounds(n, world, rank)
+    seed = spec["seed"]
 
     # ---------------- data (outside the timed region)
     t_gen = time.perf_counter()
-    cv, ci = gen_shard(torch, synth, device, args.seed + 1000 * rank, hi - lo, d_dlr, d_cls, 30, 90, args.uniform_idx)
-    qv, qi = gen_shard(torch, synth, device, args.seed + 999_983, nq, d_dlr, d_cls, 4, 12, args.uniform_idx)
+    if spec["kind"] == "bm25":
+        # config 1: whole-word vocabulary (2.6 M terms -> int16 slice index < 3400), no background, integer query weights;
+        # generated on the host (the numpy generator covers int16 indices), rows [lo, hi) of the SAME matrix on every rank
+        cvh, cih, qvh, qih = synth.make_pair(seed, n, nq, d_dlr, 0, kind="bm25")
+        cv, ci = torch.from_numpy(cvh[lo:hi]).to(device), torch.from_numpy(cih[lo:hi]).to(device)
+        qv, qi = torch.from_numpy(qvh).to(device), torch.from_numpy(qih).to(device)
+        del cvh, cih, qvh, qih
+    else:
+        cv, ci = gen_rows(torch, synth, device, seed, lo, hi, d_dlr, d_cls, 30, 90, args.uniform_idx)
+        qv, qi = gen_rows(torch, synth, device, seed + 999_983, 0, nq, d_dlr, d_cls, 4, 12, args.uniform_idx)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
     t_build = time.perf_counter()
@@ -135,40 +207,37 @@ def main():
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
     index.set_param(_lib.PARAM_PROFILE, 1)
-    if args.cand_cap:
-        index.set_param(_lib.PARAM_CAND_CAP, args.cand_cap)
-    if args.sample_period >= 0:
-        index.set_param(_lib.PARAM_SAMPLE_PERIOD, args.sample_period)
-    if args.max_growth:
-        index.set_param(_lib.PARAM_MAX_GROWTH, args.max_growth)
-    if args.aux_cus >= 0:
-        index.set_param(_lib.PARAM_AUX_CUS, args.aux_cus)
-    if args.overlap_aux >= 0:
-        index.set_param(_lib.PARAM_OVERLAP_AUX, args.overlap_aux)
-    if args.gemm_variant >= 0:
-        index.set_param(_lib.PARAM_GEMM_VARIANT, args.gemm_variant)
-    if args.gemm_exclusive >= 0:
-        index.set_param(_lib.PARAM_GEMM_EXCLUSIVE, args.gemm_exclusive)
+    for flag, prm in ((args.cand_cap, _lib.PARAM_CAND_CAP), (args.max_growth, _lib.PARAM_MAX_GROWTH), (args.main_chunks, _lib.PARAM_MAIN_CHUNKS),
+                      (args.first_rows, _lib.PARAM_FIRST_ROWS)):
+        if flag:
+            index.set_param(prm, flag)
+    for flag, prm in ((args.sample_period, _lib.PARAM_SAMPLE_PERIOD), (args.aux_cus, _lib.PARAM_AUX_CUS), (args.overlap_aux, _lib.PARAM_OVERLAP_AUX),
+                      (args.gemm_variant, _lib.PARAM_GEMM_VARIANT), (args.gemm_exclusive, _lib.PARAM_GEMM_EXCLUSIVE)):
+        if flag >= 0:
+            index.set_param(prm, flag)
     if args.no_progressive_thr:
         index.set_param(_lib.PARAM_PROGRESSIVE_THR, 0)
-    if args.main_chunks:
-        index.set_param(_lib.PARAM_MAIN_CHUNKS, args.main_chunks)
-    if args.first_rows:
-        index.set_param(_lib.PARAM_FIRST_ROWS, args.first_rows)
 
-    # host sample for the CPU baseline + an in-bench parity check (rank 0, N=1 only)
-    sample = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        m, mq = min(args.cpu_rows, hi - lo), min(args.cpu_queries, nq)
-        sample = (cv[:m].cpu().numpy(), None if ci is None else ci[:m].cpu().numpy(),
-                  qv[:mq].cpu().numpy(), None if qi is None else qi[:mq].cpu().numpy())
+    # host samples for the CPU baseline and the in-bench parity check (rank 0, N=1 only; BEFORE the corpus tensors are dropped)
+    cpu_sample = par_sample = None
+    if rank == 0 and world == 1:
+        def host_slice(m, mq):
+            m, mq = min(m, hi - lo), min(mq, nq)
+            return (cv[:m].cpu().numpy(), None if ci is None else ci[:m].cpu().numpy(), qv[:mq].cpu().numpy(), None if qi is None else qi[:mq].cpu().numpy())
+        if not args.no_cpu_baseline:
+            cpu_sample = host_slice(args.cpu_rows, max(args.cpu_queries, args.cpu_queries_1t))
+        par_sample = host_slice(args.parity_rows, args.parity_queries)
     del cv, ci
     torch.cuda.empty_cache()
+
+    pq = None
+    if args.pq:
+        raise SystemExit("--pq: wired in with the ADC scan (see dhr_amd/retrieval/quantize_index.py)")
 
     def step():
         if world > 1:
             return D.sharded_search(index, qv, qi, k)        # common thresholds + one all-gather of the shard lists
-        return index.search(qv, qi, k, out_device=True)
+        return index.search(qv, qi, min(k, n), out_device=True)
 
     def barrier():
         if world > 1:
@@ -202,14 +271,28 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     qps = nq * args.steps / elapsed
 
+    # the same K steps with the result copied to (pinned) host memory inside the timed region: what the reference's timer
+    # (gip_retrieval.py:107,161-163: query loop incl. top-k and the D2H of the lists) covers; `value` stays the device-resident rate
+    kk = min(k, n)
+    host_s = torch.empty((nq, kk), dtype=torch.float32).pin_memory()
+    host_r = torch.empty((nq, kk), dtype=torch.int64).pin_memory()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        gs, gr = step()
+        if rank == 0:
+            host_s.copy_(gs[:, :kk], non_blocking=True)
+            host_r.copy_(gr[:, :kk], non_blocking=True)
+    barrier()
+    ms_incl_d2h = (time.perf_counter() - t1) * 1e3 / args.steps
+    checksum = result_checksum(torch, gs[:, :kk], gr[:, :kk])
+
     # ---- N > 1: size-independent checks of the sharded result, outside the timed region (the oracle cannot hold the
     # corpus): sorted lists of distinct rows; every returned score is the exact score of its row on the rank that holds
     # the row (dhr_score_rows, an independent code path); no sampled row of any shard outside a list beats its k-th score
     dist_check = None
     if world > 1:
         import torch.distributed as dist
-        gs, gr = step()
-        torch.cuda.synchronize()
         ds = gs[:, 1:] - gs[:, :-1]
         ok_sorted = bool((ds <= 0).all()) and bool((gr[:, 1:][ds == 0] > gr[:, :-1][ds == 0]).all())
         ok_distinct = int(torch.sort(gr, dim=1).values.diff(dim=1).eq(0).sum()) == 0
@@ -236,31 +319,41 @@ def main():
     out = None
     if rank == 0:
         ach_tf = gemm_flops_alg / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        sparse_layout = d_dlr > 0 and args.idx_buckets in (0, 2)
+        variant = args.gemm_variant if args.gemm_variant >= 0 else 5
+        kernel = ("gemm_filter_wx_kernel<NI=%d> (bound GEMM on the 2:4 sparse matrix cores + fused threshold filter, %d waves)" % ((4, 4) if variant == 4 else (2, 8))
+                  if sparse_layout and variant in (4, 5) else
+                  "gemm_filter_sparse_kernel (bound GEMM on the 2:4 sparse matrix cores + fused threshold filter)" if sparse_layout else
+                  "gemm_filter_v3_kernel (bound GEMM + fused threshold filter)")
+        # fabric-side (Infinity Cache + HBM) read bytes: PMC passes cannot run inside this process (a torch process hangs under
+        # --pmc), so `traffic` is the per-corpus-row figure of the committed rocprofv3 FETCH_SIZE pass over the SAME kernel
+        # (tools/prof.sh -> profiles/r02_gemm_pmc.txt; torch-free driver, 6 980 queries) x the average rows per launch
+        traffic_per_row = TRAFFIC_BYTES_PER_ROW.get((d_dlr, d_cls, nq, variant)) if sparse_layout and world == 1 else None
+        rows_per_launch = stats_acc.get("gemm_rows", 0) / max(launches, 1)
+        alg_bytes_per_row = 2 * K + d_dlr * (2 if spec["kind"] == "bm25" else 1)
         out = {
             "metric": "queries/sec (exact top-%d, brute-force dense-hybrid GIP retrieval)" % k,
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f16 (fp16 x fp16 -> fp32 on the matrix cores for the bound; fp64-accumulated exact rescoring)", "data": "synthetic",
-            "config": {"workload": ("MS MARCO-sized corpus %d x (%d DLR + %d dense) fp16%s, %d queries, top-%d, %s"
-                                    % (n, d_dlr, d_cls, " + uint8 slice index" if d_dlr else "", nq, k,
-                                       "uniform slice index (adversarial)" if args.uniform_idx else "densify-rule slice index")),
-                       "baseline_config": "config 3: DeLADE-CLS 768+768 dense-hybrid" if d_dlr else "config 2: Aggretriever 768-d dense-only",
+            "config": {"workload": ("%s: %d rows x (%d DLR + %d dense) fp16%s, %d queries, top-%d, %s"
+                                    % (spec["name"], n, d_dlr, d_cls,
+                                       (" + int16 slice index" if spec["kind"] == "bm25" else " + uint8 slice index") if d_dlr else "", nq, k,
+                                       "uniform slice index (adversarial)" if args.uniform_idx else
+                                       "whole-word vocabulary, no background" if spec["kind"] == "bm25" else "densify-rule slice index")),
+                       "baseline_config": spec["baseline_config"],
                        "parallelism": "rowshard%d+allgather" % world if world > 1 else "1gpu"},
-            "roofline": {"bound": "mfma",
-                         "kernel": ("gemm_filter_sparse_kernel (bound GEMM on the 2:4 sparse matrix cores + fused threshold filter)"
-                                    if d_dlr and args.idx_buckets in (0, 2) else
-                                    "gemm_filter_v3_kernel (bound GEMM + fused threshold filter)"),
+            "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": round(ach_tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach_tf / MFMA_PEAK_TFLOPS, 4),
-                         # fabric-side (Infinity Cache + HBM) read bytes per launch: PMC passes cannot run inside this process,
-                         # so this is the per-corpus-row figure of profiles/r01h_gemm_pmc.txt (FETCH_SIZE x2, rocprofv3 --pmc on
-                         # the same kernel, 6 980 queries) x the average rows per launch; only quoted for that configuration
-                         "traffic": (round(35.3e3 * stats_acc.get("gemm_rows", 0) / max(launches, 1), 0)
-                                     if d_dlr == 768 and d_cls == 768 and nq == 6980 and args.idx_buckets in (0, 2) and world == 1 else None),
-                         "traffic_unit": "bytes per launch (FETCH_SIZE, gfx950-corrected; profiles/r01h_gemm_pmc.txt)",
+                         "traffic": None if traffic_per_row is None else round(traffic_per_row * rows_per_launch, 0),
+                         "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE, gfx950-corrected; profiles/r02_gemm_pmc.txt)",
+                         "algorithmic_bytes_per_launch": round(alg_bytes_per_row * rows_per_launch, 0),
                          "launches": launches, "avg_launch_ms": round(gemm_ms / max(launches, 1), 3),
                          "alg_flops_per_step": gemm_flops_alg / args.steps},
             "whole_job_frac_of_gemm_roofline": round(qps * 2.0 * n * K / (MFMA_PEAK_TFLOPS * 1e12 * world), 4),
+            "ms_per_step_incl_d2h": round(ms_incl_d2h, 3),
+            "result_checksum": checksum,
             "phase_ms_per_step": {key: round(v / args.steps, 3) for key, v in stats_acc.items() if key.endswith("_ms")}
                                  | {"gemm_ms": round(gemm_ms / args.steps, 3)},
             "candidates_per_query": {"bound": round(stats_acc["candidates_bound"] / args.steps / nq, 1),
@@ -269,34 +362,35 @@ def main():
             "setup_s": {"generate": round(t_gen, 2), "index_build": round(t_build, 2)},
             "index_device_gb": round(index.device_bytes() / 1e9, 2),
         }
-        if sample is not None:
+        if cpu_sample is not None:
+            out["cpu_baseline"] = cpu_baseline_legs(cpu_sample, k, n, min(args.cpu_queries_1t, nq), min(args.cpu_queries, nq))
+        if par_sample is not None:
+            # parity of the HIP path on a slice of the same corpus against the oracle (outside the timed region)
             from oracle import gip_oracle as O
-            scv, sci, sqv, sqi = sample
-            s_q, s_q_full, cpu_rows = cpu_baseline(O, scv, sci, sqv, sqi, k, n)
-            out["cpu_baseline"] = {"value": round(1.0 / s_q_full, 5), "unit": "queries/s", "cores": 1, "kind": "port",
-                                   "sample": "%d queries x %d-row slice of the same synthetic corpus, fp32 numpy restatement of "
-                                             "gip_retrieval.py:119-125, 1 thread; %.3f s/query measured, x%.1f linear extrapolation "
-                                             "to %d rows" % (sqv.shape[0], scv.shape[0], s_q, n / scv.shape[0], n),
-                                   "host_cpus": os.cpu_count()}
-            # parity of the HIP path on the same sample (outside the timed region)
+            scv, sci, sqv, sqi = par_sample
             six = GipIndex(scv, sci, device=local_rank)
-            gs, gr = six.search(sqv.astype(np.float32), sqi, k)
+            kp = min(k, scv.shape[0])
+            gs2, gr2 = six.search(sqv.astype(np.float32), sqi, kp)
             six.close()
             bad = 0
+            c32 = scv.astype(np.float32)
             for i in range(sqv.shape[0]):
-                ex = O.gip_scores_f64(sqv[i].astype(np.float32), None if sqi is None else sqi[i], scv.astype(np.float32), sci)
+                ex = O.gip_scores_f64(sqv[i].astype(np.float32), None if sqi is None else sqi[i], c32, sci)
                 try:
-                    O.check_topk(gr[i], gs[i], ex, k)
+                    O.check_topk(gr2[i], gs2[i], ex, kp)
                 except AssertionError:
                     bad += 1
             out["parity_check"] = {"queries": int(sqv.shape[0]), "rows": int(scv.shape[0]), "failed": bad}
         if dist_check is not None:
             out["parity_check"] = dist_check
-        print(json.dumps(out), flush=True)
     index.close()
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    del index, qv, qi
+    torch.cuda.empty_cache()
+    return out
+
+
+# fabric-side read bytes per corpus row of the bound GEMM, from the committed PMC pass (d_dlr, d_cls, queries, kernel variant)
+TRAFFIC_BYTES_PER_ROW = {}
 
 
 if __name__ == "__main__":

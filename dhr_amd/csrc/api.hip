@@ -102,7 +102,7 @@ struct dhr_index {
   int main_chunks = 2;
   int progressive_thr = 1;
   int n_cu = 256;
-  int overlap_aux = 1;                     // 0: refine / rescoring / select run on the GEMM's stream (every kernel gets the whole chip)
+  int overlap_aux = 0;                     // 0 (default): refine / rescoring / select run on the GEMM's stream (every kernel gets the whole chip); 1: beside the next chunk's GEMM on a CU-masked stream -- the same step time on one GPU (192.7 vs 193.0 ms), but the GEMM launches then run 7 % longer
   int aux_cus = 128, gemm_exclusive = 0;   // CU-masked streams of the main pass (0 = off)
   int aux_cus_made = -1, gemm_excl_made = -1;
   hipStream_t s_gemm = nullptr;         // main-pass GEMM stream when CU masks are in use

@@ -210,9 +210,14 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
   };
   auto dma_commit = [&]() __attribute__((always_inline)) { dma_soff = nx_soff; dma_lds = nx_lds; dma_n = nx_n; };
   auto dma_piece = [&](int j) __attribute__((always_inline)) {
+#if W4_ABL == 5      // timing only: the same bytes as plain loads into registers that nobody reads (no LDS write)
+    if (j < dma_n) { typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(role_rsrc, (int)lane_off + (j & 3) * 1024, dma_soff + (j >> 2) * 4096, 0); asm volatile("" :: "v"(x)); }
+    return;
+#endif
     if (j < dma_n) {
       __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(uintptr_t)(dma_lds + (uint32_t)(j >> 2) * 4096u);
-      const int so = dma_soff + (j >> 2) * 4096;
+      const int so = W4_ABL == 6 ? 0 : dma_soff + (j >> 2) * 4096;      // 6 (timing only): always the tile's first 4 KiB, L1-resident
       switch (j & 3) {      // the immediate must be a literal
         case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(role_rsrc, l, 16, (int)lane_off, so, 0, 0); break;
         case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(role_rsrc, l, 16, (int)lane_off, so, 1024, 0); break;

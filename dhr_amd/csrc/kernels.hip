@@ -877,7 +877,7 @@ __global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(
 
 
 int g_gemm_ablate = 0;    // tuning only (DHR_GEMM_ABLATE environment variable): timing ablations of the 2:4 kernel, wrong results
-int g_gemm_variant = 3;   // kept for the C ABI's DHR_PARAM_GEMM_VARIANT; only variant 3 is built (the others measured no better and were removed)
+int g_gemm_variant = 5;   // DHR_PARAM_GEMM_VARIANT: 2:4 layout kernels 3 (12 waves, producer / consumer), 4 (4 waves), 5 (8 waves; default: 2 % faster in the bench)
 
 // The bound GEMM + filter over the tiles [seq_lo, seq_hi) of the sequence: gemm_filter_sparse_kernel for the 2:4 layout
 // (a.ts > 0), gemm_filter_v3_kernel for the K-step tile layout (dense-only indexes, other bucket counts).

@@ -241,3 +241,21 @@ def test_two_stage_rule_admits_the_reference(golden, case):
             bad = bad[np.argsort(-s1[bad], kind="stable")]
             with pytest.raises(AssertionError):
                 O.check_topk(bad, s1[bad], s1, info["topk"])
+
+
+def test_torch_restatement_equals_numpy_oracle():
+    """oracle/gip_oracle_torch.py (the timed cpu_baseline legs of bench.py) returns the numpy oracle's top-k sets."""
+    from dhr_amd import synth
+    from oracle import gip_oracle_torch as OT
+    cv, ci, qv, qi = synth.make_pair(31, 3000, 5, 768, 64)
+    c32, q32 = cv.astype(np.float32), qv.astype(np.float32)
+    for threads in (1, 2):
+        _, rows = OT.gip_loop(q32, qi, c32, ci, 50, threads)
+        for i in range(5):
+            ex = O.gip_scores_f64(q32[i], qi[i], c32, ci)
+            O.check_topk(rows[i][np.argsort(-ex[rows[i]], kind="stable")], np.sort(ex[rows[i]])[::-1], ex, 50)
+    dv, _, dq, _ = synth.make_pair(32, 2000, 3, 0, 768, kind="dense")
+    _, rows = OT.gip_loop(dq.astype(np.float32), None, dv.astype(np.float32), None, 20, 1)
+    for i in range(3):
+        ex = O.gip_scores_f64(dq[i].astype(np.float32), None, dv.astype(np.float32), None)
+        O.check_topk(rows[i][np.argsort(-ex[rows[i]], kind="stable")], np.sort(ex[rows[i]])[::-1], ex, 20)

@@ -26,12 +26,12 @@ def main():
     dev = torch.device("cuda", 0)
     d_dlr, d_cls = (768, 768) if a.workload == "hybrid" else (0, 768)
     k = 1000
-    qv, qi = bench.gen_shard(torch, synth, dev, 1237 + 999_983, a.n_queries, d_dlr, d_cls, 4, 12, False)
+    qv, qi = bench.gen_rows(torch, synth, dev, 1237 + 999_983, 0, a.n_queries, d_dlr, d_cls, 4, 12, False)
     # per-shard: begin; keep sample; destroy? the finish needs the handle -> keep all shards resident (fits: ~13 GB each)
     shards = []
     for r in range(a.only or a.shards):
         lo, hi = D.shard_bounds(a.n_docs, a.shards, r)
-        cv, ci = bench.gen_shard(torch, synth, dev, 1237 + 1000 * r, hi - lo, d_dlr, d_cls, 30, 90, False)
+        cv, ci = bench.gen_rows(torch, synth, dev, 1237, lo, hi, d_dlr, d_cls, 30, 90, False)
         ix = GipIndex(cv, ci, row_offset=lo)
         ix.set_param(_lib.PARAM_PROFILE, 1)
         if a.cand_cap:
