@@ -127,8 +127,8 @@ def main():
     ap.add_argument("--first-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline slice (SURVEY.md section 8d: 1 M)")
-    ap.add_argument("--cpu-queries", type=int, default=32, help="queries of the all-cores CPU leg (section 8d: 32)")
-    ap.add_argument("--cpu-queries-1t", type=int, default=12, help="queries of the one-thread CPU leg (bounded: ~1.2 s per query and M rows)")
+    ap.add_argument("--cpu-queries", type=int, default=8, help="queries of the all-cores CPU leg (~3.3 s per query and M rows on the 256-thread host; section 8d's 32 with --cpu-queries 32)")
+    ap.add_argument("--cpu-queries-1t", type=int, default=4, help="queries of the one-thread CPU leg (~3.5 s per query and M rows)")
     ap.add_argument("--parity-rows", type=int, default=200_000)
     ap.add_argument("--parity-queries", type=int, default=24)
     ap.add_argument("--seed", type=int, default=1237)
@@ -390,7 +390,7 @@ def run_workload(args, spec, ctx):
 
 
 # fabric-side read bytes per corpus row of the bound GEMM, from the committed PMC pass (d_dlr, d_cls, queries, kernel variant)
-TRAFFIC_BYTES_PER_ROW = {}
+TRAFFIC_BYTES_PER_ROW = {(768, 768, 6980, 5): 34.6e3}      # profiles/r02_gemm_pmc.txt: 17.31 GB per 500 000-row launch
 
 
 if __name__ == "__main__":

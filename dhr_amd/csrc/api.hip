@@ -102,7 +102,7 @@ struct dhr_index {
   int main_chunks = 2;
   int progressive_thr = 1;
   int n_cu = 256;
-  int overlap_aux = 0;                     // 0 (default): refine / rescoring / select run on the GEMM's stream (every kernel gets the whole chip); 1: beside the next chunk's GEMM on a CU-masked stream -- the same step time on one GPU (192.7 vs 193.0 ms), but the GEMM launches then run 7 % longer
+  int overlap_aux = -1;                    // 0: refine / rescoring / select run on the GEMM's stream (every kernel gets the whole chip); 1: beside the next chunk's GEMM on a CU-masked stream; -1 (default) = 1 for dense-only indexes (110.4 -> 101.7 ms per step at config 2), 0 for gated ones (the same step time, 192.7 vs 193.0 ms, but the overlapped GEMM launches run 7 % longer)
   int aux_cus = 128, gemm_exclusive = 0;   // CU-masked streams of the main pass (0 = off)
   int aux_cus_made = -1, gemm_excl_made = -1;
   hipStream_t s_gemm = nullptr;         // main-pass GEMM stream when CU masks are in use
@@ -164,7 +164,7 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
       if (value < 0 || value > 192 || value % 8) return set_error(DHR_ERR_INVALID, "aux_cus must be a multiple of 8 in [0,192]");
       ix->aux_cus = (int)value; return DHR_OK;
     case DHR_PARAM_GEMM_EXCLUSIVE: ix->gemm_exclusive = value != 0; return DHR_OK;
-    case DHR_PARAM_OVERLAP_AUX: ix->overlap_aux = value != 0; return DHR_OK;
+    case DHR_PARAM_OVERLAP_AUX: ix->overlap_aux = value < 0 ? -1 : value != 0; return DHR_OK;
     case DHR_PARAM_GEMM_VARIANT:
       if (value < 3 || value > 5) return set_error(DHR_ERR_INVALID, "gemm_variant: 3 (12-wave producer / consumer kernel), 4 (4 waves, 128 x 128 wave tiles) or 5 (8 waves, 128 x 64 wave tiles)");
       dhr::g_gemm_variant = (int)value; return DHR_OK;
@@ -860,7 +860,8 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       ix->aux_cus_made = ix->aux_cus; ix->gemm_excl_made = ix->gemm_exclusive;
     }
     hipStream_t sg = ix->s_gemm ? ix->s_gemm : s;
-    hipStream_t sb = ix->overlap_aux ? ix->s_aux : sg;
+    const bool overlap = ix->overlap_aux < 0 ? ix->d_dlr == 0 : ix->overlap_aux != 0;
+    hipStream_t sb = overlap ? ix->s_aux : sg;
     hipEvent_t ev_enter = nullptr;
     if (sg != s) {
       HIP_TRY(hipEventCreateWithFlags(&ev_enter, hipEventDisableTiming));

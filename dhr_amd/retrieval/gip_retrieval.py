@@ -220,6 +220,21 @@ def _to_dicts(qids, rows, scores, offset=0):
     return all_results, all_scores
 
 
+QUERY_CHUNK = 8192      # queries per library call: the search workspace grows linearly with the batch (the reference loops per query and takes any number)
+
+
+def _by_chunks(n_queries, call):
+    """call(lo, hi) -> (scores, rows) numpy arrays of queries [lo, hi); the whole query set in slices of QUERY_CHUNK."""
+    if n_queries <= QUERY_CHUNK:
+        return call(0, n_queries)
+    parts = [call(lo, min(n_queries, lo + QUERY_CHUNK)) for lo in range(0, n_queries, QUERY_CHUNK)]
+    return np.concatenate([p[0] for p in parts], axis=0), np.concatenate([p[1] for p in parts], axis=0)
+
+
+def _sl(a, lo, hi):
+    return None if a is None else a[lo:hi]
+
+
 def _corpus_index(corpus_embs, corpus_arg_idxs, args):
     if isinstance(corpus_embs, GipIndex):
         return corpus_embs, False
@@ -232,7 +247,7 @@ def IP_retrieval(qids, query_embs, corpus_embs, args):
     corpus_embs: array/tensor [N,K] or a prebuilt GipIndex (dense-only)."""
     index, owned = _corpus_index(corpus_embs, None, args)
     start_time = time.time()
-    scores, rows = index.search(query_embs, None, args.topk)
+    scores, rows = _by_chunks(len(qids), lambda lo, hi: index.search(query_embs[lo:hi], None, args.topk))
     res = _to_dicts(qids, rows, scores, index.row_offset)
     time_per_query = (time.time() - start_time) / len(qids)
     print('Retrieving {} queries ({:0.3f} s/query), average number of index use {}'.format(len(qids), time_per_query, 0.0))
@@ -256,7 +271,7 @@ def GIP_retrieval(qids, query_embs, query_arg_idxs, corpus_embs, corpus_arg_idxs
             if args.topk > n and not getattr(args, "allow_short", False):
                 raise RuntimeError("selected index k out of range")          # torch.topk, :123
             total_num_idx = args.emb_dim * len(qids)
-            scores, rows = index.search(query_embs, query_arg_idxs, args.topk)
+            scores, rows = _by_chunks(len(qids), lambda lo, hi: index.search(query_embs[lo:hi], _sl(query_arg_idxs, lo, hi), args.topk))
         else:
             q = _np(query_embs).astype(np.float32)
             qi = _np(query_arg_idxs)
@@ -267,16 +282,11 @@ def GIP_retrieval(qids, query_embs, query_arg_idxs, corpus_embs, corpus_arg_idxs
                 q1, qi1 = np.where(q > theta, q, np.float32(0)), qi           # restrict to the important columns
             else:
                 q1, qi1 = q, None                                             # ungated inner product
-            if args.rerank and k1 <= 16384:
-                scores, rows = index.search_rerank(q1, qi1, q, qi, k1, min(args.topk, k1))   # both stages on the device
-            elif args.rerank:
-                s1, r1 = index.search(q1, qi1, k1)
-                s2 = index.score_rows(q, qi, r1)
-                order = np.lexsort((r1, -s2.astype(np.float64)), axis=1)[:, : args.topk]
-                rows = np.take_along_axis(r1, order, axis=1)
-                scores = np.take_along_axis(s2, order, axis=1)
-            else:
-                scores, rows = index.search(q1, qi1, k1)
+            def two_stage(lo, hi):
+                if args.rerank:
+                    return index.search_rerank(q1[lo:hi], _sl(qi1, lo, hi), q[lo:hi], qi[lo:hi], k1, min(args.topk, k1))   # both stages on the device
+                return index.search(q1[lo:hi], _sl(qi1, lo, hi), k1)
+            scores, rows = _by_chunks(len(qids), two_stage)
         res = _to_dicts(qids, rows, scores, index.row_offset)
     finally:
         if owned:
@@ -309,14 +319,16 @@ def PQ_IP_retrieval(qids, query_embs, query_arg_idxs, corpus_embs, corpus_arg_id
     try:
         q = _np(query_embs).astype(np.float32)
         k1 = min(args.agip_topk, index.n_rows)
-        s1, r1 = pq_index.search(q, None, k1)
-        if args.rerank:
-            s2 = index.score_rows(q, _np(query_arg_idxs), r1)
+        qi_np = _np(query_arg_idxs)
+
+        def pq_stage(lo, hi):
+            s1, r1 = pq_index.search(q[lo:hi], None, k1)
+            if not args.rerank:
+                return s1[:, : args.topk], r1[:, : args.topk]
+            s2 = index.score_rows(q[lo:hi], qi_np[lo:hi], r1)
             order = np.lexsort((r1, -s2.astype(np.float64)), axis=1)[:, : args.topk]
-            rows = np.take_along_axis(r1, order, axis=1)
-            scores = np.take_along_axis(s2, order, axis=1)
-        else:
-            scores, rows = s1[:, : args.topk], r1[:, : args.topk]
+            return np.take_along_axis(s2, order, axis=1), np.take_along_axis(r1, order, axis=1)
+        scores, rows = _by_chunks(len(qids), pq_stage)
         res = _to_dicts(qids, rows, scores, index.row_offset)
     finally:
         pq_index.close()

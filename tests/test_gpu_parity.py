@@ -895,3 +895,98 @@ def test_bench_two_ranks_share_one_gpu():
     assert j["config"]["parallelism"] == "rowshard2+allgather"
     pc = j["parity_check"]                               # the sharded result's property check ran on both ranks
     assert pc["sorted"] and pc["distinct_rows"] and pc["scores_equal_exact_rescoring"] and pc["rows_beating_kth_outside_list"] == 0
+
+
+def test_config1_bm25_full_query_set(G):
+    """BASELINE config 1 at its full query count: 100 k DLR-only BM25-like passages (int16 whole-word slice index), Q = 6 980,
+    top-1000; the whole batch is searched, a spread sample of the queries is checked against the oracle's float64 scores."""
+    from dhr_amd import synth
+    cv, ci, qv, qi = synth.make_pair(1234 + 1, 100_000, 6980, 768, 0, kind="bm25")
+    q32 = qv.astype(np.float32)
+    ix = G.GipIndex(cv, ci)
+    scores, rows = ix.search(q32, qi, 1000)
+    st = ix.stats()
+    ix.close()
+    assert scores.shape == (6980, 1000) and np.all(rows >= 0)
+    assert np.all(np.diff(scores, axis=1) <= 0)
+    c32 = cv.astype(np.float32)
+    for i in range(0, 6980, 349):                      # 20 queries over the whole batch
+        ex = O.gip_scores_f64(q32[i], qi[i], c32, ci)
+        O.check_topk(rows[i], scores[i], ex, 1000)
+    print({k: st[k] for k in ("phases", "candidates_bound", "candidates_exact", "total_ms")})
+
+
+def _fake_world_search_any(G, shards, q, qi, k):
+    """dhr_amd.dist.sharded_search with the collectives replaced by in-process tensor ops (one GPU, S shards), INCLUDING its
+    fallback for shards that cannot be sampled uniformly (tiny or unequal shards: local thresholds, k > rows of a shard)."""
+    import torch
+    from dhr_amd import dist as D
+    rs = [s.sample_rank(k) for s in shards]
+    if rs[0] == 0 or any(r != rs[0] for r in rs):
+        outs = [s.search(q, qi, k, out_device=True) for s in shards]
+        ms, mr = D.merge_topk(torch.cat([o[0] for o in outs], 1), torch.cat([o[1] for o in outs], 1), k)
+        return ms.cpu().numpy(), mr.cpu().numpy(), "local"
+    ms, mr, n_failed, _ = _fake_world_search(G, shards, q, qi, k)
+    return ms, mr, "common-threshold (%d failed)" % n_failed
+
+
+def test_config5_beir_sizes_sharded_8(G):
+    """BASELINE config 5's corpus sizes (the 13 public BEIR corpora, 3.6 k ... 5.4 M documents; hybrid 768 + 128) through the
+    8-shard path on one GPU: the merged result must be bit-identical to the unsharded search of the same corpus, for every
+    size -- including the corpora where a shard holds fewer rows than k (nfcorpus: 454 rows per shard, k = 1000; the reference's
+    torch.topk raises there, gip_retrieval.py:123, the build pads).  The small corpora are also checked against the oracle, the
+    large ones through size-independent properties (exact rescoring of every returned row, no sampled outsider beats the k-th)."""
+    import torch
+    import bench
+    from dhr_amd import synth
+    dev = torch.device("cuda", 0)
+    k, nq, ns = 1000, 16, 8
+    for name, n, _ in bench.BEIR:
+        cv, ci = bench.gen_rows(torch, synth, dev, 4300 + (n % 97), 0, n, 768, 128, 30, 90, False)
+        qv, qi = bench.gen_rows(torch, synth, dev, 99, 0, nq, 768, 128, 4, 12, False)
+        full = G.GipIndex(cv, ci)
+        kk = min(k, n)
+        fs, fr = full.search(qv, qi, kk, out_device=True)
+        shards = []
+        for sh in range(ns):
+            lo, hi = G.shard_bounds(n, ns, sh)
+            shards.append(G.GipIndex(cv[lo:hi], ci[lo:hi], row_offset=lo))
+        ms, mr, how = _fake_world_search_any(G, shards, qv, qi, kk)
+        for s in shards:
+            s.close()
+        fs_h, fr_h = fs.cpu().numpy(), fr.cpu().numpy()
+        np.testing.assert_array_equal(mr, fr_h, err_msg=name)
+        np.testing.assert_array_equal(ms, fs_h, err_msg=name)
+        q32 = qv.cpu().numpy().astype(np.float32)
+        qih = qi.cpu().numpy()
+        if n <= 60_000:
+            c32, cih = cv.cpu().numpy().astype(np.float32), ci.cpu().numpy()
+            for i in range(nq):
+                O.check_topk(fr_h[i], fs_h[i], O.gip_scores_f64(q32[i], qih[i], c32, cih), kk)
+        else:
+            assert np.all(np.diff(fs_h, axis=1) <= 0) and all(len(set(r.tolist())) == kk for r in fr_h)
+            np.testing.assert_array_equal(full.score_rows(q32, qih, fr_h), fs_h)         # an independent code path (dhr_score_rows)
+            rnd = np.random.default_rng(n).integers(0, n, (nq, 20_000)).astype(np.int64)
+            outsider = full.score_rows(q32, qih, rnd)
+            for i in range(nq):
+                assert not np.any((outsider[i] > fs_h[i, -1]) & ~np.isin(rnd[i], fr_h[i])), name
+        full.close()
+        del cv, ci
+        torch.cuda.empty_cache()
+        print(name, n, how)
+
+
+def test_query_chunking_same_result(G, golden, monkeypatch):
+    """The host mirror hands the library the query set in slices (QUERY_CHUNK; the reference loops per query and takes any number):
+    results must not depend on the slice size, in the brute-force, two-stage and dense-only entry points."""
+    info, _, _ = golden.case("F3_hyb_brute_k100")
+    d = golden.inputs("hyb")
+    q, qi = O.prepare_queries(d["qv"], d["qi"], 768, 1.0)
+    qids = list(d["qids"])
+    args2 = case_args(dict(topk=50, theta=0.3, rerank=True, agip_topk=300))
+    ref = (G.GIP_retrieval(qids, q, qi, d["cv"], d["ci"], case_args(info)), G.GIP_retrieval(qids, q, qi, d["cv"], d["ci"], args2),
+           G.IP_retrieval(qids, q, d["cv"], case_args(dict(topk=20))))
+    monkeypatch.setattr(G, "QUERY_CHUNK", 5)
+    got = (G.GIP_retrieval(qids, q, qi, d["cv"], d["ci"], case_args(info)), G.GIP_retrieval(qids, q, qi, d["cv"], d["ci"], args2),
+           G.IP_retrieval(qids, q, d["cv"], case_args(dict(topk=20))))
+    assert ref == got

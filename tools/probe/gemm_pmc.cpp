@@ -13,9 +13,9 @@ static inline uint32_t next() { rng = rng * 1664525u + 1013904223u; return rng >
 int main(int argc, char** argv) {
   const int64_t n = argc > 1 ? atoll(argv[1]) : 500000;
   const int q = argc > 2 ? atoi(argv[2]) : 6980;
-  const int d_dlr = 768, d_cls = 768, k = d_dlr + d_cls;
+  const int d_dlr = argc > 3 ? atoi(argv[3]) : 768, d_cls = 768, k = d_dlr + d_cls;      // d_dlr = 0: dense-only index (gemm_filter_v3_kernel)
   std::vector<__half> cv((size_t)n * k), qv((size_t)q * k);
-  std::vector<uint8_t> ci((size_t)n * d_dlr), qi((size_t)q * d_dlr);
+  std::vector<uint8_t> ci((size_t)n * d_dlr + 1), qi((size_t)q * d_dlr + 1);
   auto fill = [&](std::vector<__half>& v, std::vector<uint8_t>& idx, int64_t rows) {
     for (int64_t r = 0; r < rows; ++r) {
       for (int j = 0; j < d_dlr; ++j) {
@@ -29,11 +29,11 @@ int main(int argc, char** argv) {
   };
   fill(cv, ci, n); fill(qv, qi, q);
   dhr_index_desc d{}; d.device = 0; d.mem_kind = DHR_MEM_HOST; d.n_rows = n; d.d_dlr = d_dlr; d.d_cls = d_cls;
-  d.value = cv.data(); d.ld_value = k; d.index = ci.data(); d.index_dtype = DHR_IDX_U8; d.idx_buckets = 0; d.ld_index = d_dlr;
+  d.value = cv.data(); d.ld_value = k; d.index = d_dlr ? ci.data() : nullptr; d.index_dtype = d_dlr ? DHR_IDX_U8 : DHR_IDX_NONE; d.idx_buckets = 0; d.ld_index = d_dlr;
   dhr_index* ix = nullptr;
   if (dhr_index_create(&d, &ix)) { printf("create: %s\n", dhr_last_error()); return 1; }
   dhr_query_batch qb{}; qb.n_queries = q; qb.mem_kind = DHR_MEM_HOST; qb.value = qv.data(); qb.value_dtype = DHR_VAL_F16;
-  qb.index_dtype = DHR_IDX_U8; qb.ld_value = k; qb.index = qi.data(); qb.ld_index = d_dlr;
+  qb.index_dtype = d_dlr ? DHR_IDX_U8 : DHR_IDX_NONE; qb.ld_value = k; qb.index = d_dlr ? qi.data() : nullptr; qb.ld_index = d_dlr;
   double ms = 0, fl = 0;
   if (dhr_debug_gemm_time(ix, &qb, 2, &ms, &fl, nullptr)) { printf("gemm: %s\n", dhr_last_error()); return 1; }
   const double tile_bytes = 24 * 34816.0 + 24 * 32768.0;

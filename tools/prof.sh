@@ -1,19 +1,29 @@
 #!/bin/bash
-# Round profiles: bench JSON lines (hybrid, dense, uniform idx), rocprofv3 kernel trace of the default bench, and separate
-# PMC passes (FETCH_SIZE; TCC hit/miss) over the bound GEMM alone through the torch-free driver (a torch process hangs under
-# --pmc).  Every step has its own timeout.  Outputs under gpurun_out/; copy what should be judged into profiles/.
+# Round profiles: bench JSON lines (hybrid, dense, uniform idx, bm25), rocprofv3 kernel trace of the default bench, and separate
+# PMC passes over the bound GEMM alone through the torch-free driver (a torch process hangs under --pmc): FETCH_SIZE; TCC hit /
+# miss; SQ busy / wait counters -- for the 2:4 kernel (hybrid) and for the dense-only kernel.  Every step has its own timeout.
+# Outputs under gpurun_out/; copy what should be judged into profiles/.   usage: bash tools/prof.sh r02
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r01}
-mkdir -p $R/gpurun_out
+TAG=${1:-r02}
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
 cd $R
-timeout 400 python bench.py > gpurun_out/bench_${TAG}_hybrid.json 2> gpurun_out/bench_${TAG}_hybrid.err
-timeout 400 python bench.py --workload dense > gpurun_out/bench_${TAG}_dense.json 2> gpurun_out/bench_${TAG}_dense.err
-timeout 400 python bench.py --uniform-idx --no-cpu-baseline > gpurun_out/bench_${TAG}_hybrid_uniform_idx.json 2> gpurun_out/bench_${TAG}_uniform.err
+timeout 400 python bench.py > $O/bench_${TAG}_hybrid.json 2> $O/bench_hybrid.err
+timeout 400 python bench.py --workload dense --no-cpu-baseline > $O/bench_${TAG}_dense.json 2> $O/bench_dense.err
+timeout 400 python bench.py --uniform-idx --no-cpu-baseline > $O/bench_${TAG}_hybrid_uniform_idx.json 2> $O/bench_uniform.err
+timeout 300 python bench.py --workload bm25 --no-cpu-baseline > $O/bench_${TAG}_bm25.json 2> $O/bench_bm25.err
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG} -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_${TAG}_bench.log 2>&1
-timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_f -- $R/tools/probe/_bin/gemm_pmc 500000 6980 > $R/gpurun_out/pmc_${TAG}_f.log 2>&1
-timeout 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_t -- $R/tools/probe/_bin/gemm_pmc 500000 6980 > $R/gpurun_out/pmc_${TAG}_t.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/trace_bench.log 2>&1
+SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
+for cfg in "hyb 768" "dense 0"; do
+  set -- $cfg
+  timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_$1_f -- $R/tools/probe/_bin/gemm_pmc 500000 6980 $2 > $O/pmc_$1_f.log 2>&1
+  timeout 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $O/pmc_$1_t -- $R/tools/probe/_bin/gemm_pmc 500000 6980 $2 > $O/pmc_$1_t.log 2>&1
+  timeout 200 rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $O/pmc_$1_s -- $R/tools/probe/_bin/gemm_pmc 500000 6980 $2 > $O/pmc_$1_s.log 2>&1
+done
 cd $R
-DB=$(ls gpurun_out/prof_${TAG}/*/*_results.db | head -1)
-python tools/rocpd_summary.py $DB gpurun_out/${TAG}_kernel_stats.txt | head -12
-tail -1 gpurun_out/pmc_${TAG}_f.log
+DB=$(ls $O/trace/*/*_results.db 2>/dev/null | head -1)
+[ -n "$DB" ] && python tools/rocpd_summary.py $DB $O/${TAG}_kernel_stats.txt | head -14
+python3 tools/pmc_summary.py $O > $O/${TAG}_gemm_pmc_raw.txt
+cat $O/${TAG}_gemm_pmc_raw.txt
+tail -1 $O/pmc_hyb_f.log; tail -1 $O/pmc_dense_f.log
