@@ -7,7 +7,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdhr_hip.so")
-SOURCES = ["kernels.hip", "gemm_w4.hip", "api.hip"]
+SOURCES = ["kernels.hip", "gemm_w4.hip", "api.hip", "sharded.hip"]
 HEADERS = ["dhr_internal.h", "gemm_common.h", os.path.join("..", "..", "include", "dhr_hip.h")]
 
 
@@ -23,7 +23,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-unused-result",
-           "-o", LIB] + SOURCES
+           "-o", LIB] + SOURCES + ["-L/opt/rocm/lib", "-lrccl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, cwd=CSRC, check=True)

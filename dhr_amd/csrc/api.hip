@@ -130,6 +130,7 @@ extern "C" void dhr_abi_sizes(int32_t out[4]) {
   out[2] = (int32_t)sizeof(dhr_search_stats); out[3] = (int32_t)sizeof(dhr_file_info);
 }
 extern "C" const char* dhr_last_error(void) { return g_last_error.c_str(); }
+extern "C" int dhr_set_error_message(int code, const char* msg) { return set_error(code, msg ? msg : ""); }
 
 extern "C" void dhr_index_destroy(dhr_index* ix) {
   if (!ix) return;
@@ -175,6 +176,7 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
   return set_error(DHR_ERR_INVALID, "unknown parameter");
 }
 
+extern "C" int dhr_index_device(const dhr_index* ix) { return ix ? ix->device : -1; }
 extern "C" int64_t dhr_index_device_bytes(const dhr_index* ix) { return ix ? ix->index_bytes + ix->ws.bytes + ix->ws_fb[0].bytes + ix->ws_fb[1].bytes : 0; }
 extern "C" int dhr_get_stats(const dhr_index* ix, dhr_search_stats* out) {
   if (!ix || !out) return set_error(DHR_ERR_INVALID, "null argument");

@@ -7,6 +7,10 @@
 
 #include "../../include/dhr_hip.h"
 
+// library-internal helpers with C linkage (api.hip), used by the other translation units
+extern "C" int dhr_set_error_message(int code, const char* msg);   // records the calling thread's last error, returns code
+extern "C" int dhr_index_device(const dhr_index* ix);
+
 namespace dhr {
 
 // ---------------------------------------------------------------------------------------------

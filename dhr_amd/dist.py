@@ -1,9 +1,14 @@
 """Row-sharded retrieval across the GPUs of one node: one process per GPU, the corpus split exactly
 like the reference's --total_shrad/--shrad (retrieval/gip_retrieval.py:292-306), queries replicated,
-ONE all-gather of the per-shard top-k (RCCL over xGMI; `nccl` backend) and a per-query k-way reduce
-on every rank -- the semantics of retrieval/merge.result.py:22-42 without the text-file round trip.
+all-gathers of the per-shard results over RCCL (xGMI) and a per-query reduce on every rank -- the
+semantics of retrieval/merge.result.py:22-42 without the text-file round trip.
 
-Payload per rank at Q=6980, k=1000: 6980*1000*(4+8) B = 84 MB."""
+The product path is the C ABI: `ShardComm` (dhr_comm_*: an RCCL communicator the library creates itself
+from a 128-byte id; the id travels over whatever torch.distributed group is up) and
+`sharded_search` -> dhr_search_sharded (sample all-gather, common thresholds, count all-gather, list
+all-gather, rank merge: dhr_amd/csrc/sharded.hip).  The same control flow written with torch.distributed
+collectives (`sharded_search_torch`) is kept as the CPU test shim: it runs under gloo, where RCCL cannot
+(tests/test_dist_gloo.py), and is what `sharded_search` uses when the process group's backend is gloo."""
 from __future__ import annotations
 
 import ctypes as C
@@ -94,7 +99,91 @@ def common_threshold(sample_scores_all, r: int):
     return merged[:, r - 1].contiguous()
 
 
+class ShardComm:
+    """dhr_comm: the library's own RCCL communicator for this rank.  Collective constructor: rank 0 draws the id
+    (dhr_comm_unique_id), it is broadcast over the torch.distributed group, every rank calls dhr_comm_create."""
+
+    def __init__(self, device: int, group=None):
+        import torch
+        import torch.distributed as dist
+        self._lib = _lib.load()
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = int(device)
+        uid = (C.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(self._lib.dhr_comm_unique_id(uid, 128), "dhr_comm_unique_id")
+        if self.world > 1:
+            backend = dist.get_backend(group)
+            t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
+            if backend == "nccl":
+                t = t.to(torch.device("cuda", self.device))
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+        h = C.c_void_p()
+        _lib.check(self._lib.dhr_comm_create(uid, self.world, self.rank, self.device, C.byref(h)), "dhr_comm_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dhr_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+_COMMS = {}
+
+
+def _comm_for(index, group):
+    key = (index.device, id(group))
+    if key not in _COMMS:
+        _COMMS[key] = ShardComm(index.device, group)
+    return _COMMS[key]
+
+
+def search_sharded_local(shards, q_value, q_index, k: int):
+    """One process, several shard handles (dhr_search_sharded_local): -> (scores, rows) torch cuda tensors [Q, k]."""
+    import torch
+    lib = _lib.load()
+    qb, keep = _lib.make_query_batch(q_value, q_index)
+    dev = torch.device("cuda", shards[0].device)
+    scores = torch.empty((qb.n_queries, k), dtype=torch.float32, device=dev)
+    rows = torch.empty((qb.n_queries, k), dtype=torch.int64, device=dev)
+    arr = (C.c_void_p * len(shards))(*[s._h for s in shards])
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.dhr_search_sharded_local(arr, len(shards), C.byref(qb), int(k), scores.data_ptr(), rows.data_ptr(), _lib.MEM_DEVICE, stream),
+                   "dhr_search_sharded_local")
+    return scores, rows
+
+
 def sharded_search(index, q_value, q_index, k: int, group=None):
+    """index: this rank's GipIndex (rows shard_bounds(N, world, rank), row_offset=lo).  Returns the global [Q,k] (scores, rows)
+    torch cuda tensors on every rank.  RCCL process groups (and single processes) run dhr_search_sharded; a gloo group runs the
+    torch.distributed restatement of the same steps (testing)."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size(group) > 1 and dist.get_backend(group) != "nccl":
+        return sharded_search_torch(index, q_value, q_index, k, group)
+    comm = _comm_for(index, group)
+    lib = _lib.load()
+    qb, keep = _lib.make_query_batch(q_value, q_index)
+    dev = torch.device("cuda", index.device)
+    scores = torch.empty((qb.n_queries, k), dtype=torch.float32, device=dev)
+    rows = torch.empty((qb.n_queries, k), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.dhr_search_sharded(index._h, comm._h, C.byref(qb), int(k), scores.data_ptr(), rows.data_ptr(), _lib.MEM_DEVICE, stream),
+                   "dhr_search_sharded")
+    return scores, rows
+
+
+def sharded_search_torch(index, q_value, q_index, k: int, group=None):
     """index: this rank's GipIndex (rows shard_bounds(N, world, rank), row_offset=lo).  Returns the global
     [Q,k] (scores, rows) on every rank.
 

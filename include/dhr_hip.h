@@ -241,6 +241,32 @@ int dhr_debug_bound_scores(dhr_index* index, const dhr_query_batch* queries, int
 int dhr_debug_gemm_time(dhr_index* index, const dhr_query_batch* queries, int32_t iters, double* ms_out,
                         double* flops_out, void* stream);
 
+/* ---- Row-sharded search: replaces the reference's --total_shrad / --shrad runs plus
+ * retrieval/merge.result.py:22-42.  The corpus rows are split like gip_retrieval.py:292-306 (per = N // S, the last shard takes
+ * the remainder; dhr_index_desc.row_offset = the shard's first global row), queries are replicated, and the result is the global
+ * [n_queries, k] (scores, rows) -- bit-identical to the unsharded dhr_search of the whole corpus -- on EVERY rank.
+ *
+ * dhr_comm: an RCCL communicator (librccl is linked directly; all-gathers run on the caller's stream over xGMI).
+ *   dhr_comm_unique_id   rank 0: a 128-byte id to hand to every rank (any out-of-band channel)
+ *   dhr_comm_create      every rank: ncclCommInitRank on `device` (collective over the ranks)
+ *   dhr_comm_wrap        adopt an existing ncclComm_t (not destroyed by dhr_comm_destroy)
+ * dhr_search_sharded: one process per GPU; collective -- every rank calls it with the same batch and k.  Sequence: sampled
+ *   pass -> all-gather of [Q, r] sample scores -> common per-query thresholds -> main pass -> all-gather of the per-query
+ *   counts -> all-gather of the list prefixes [Q, kk] -> rank merge of the sorted lists; one host read at the end (number of
+ *   queries whose lists were incomplete; those are redone with local thresholds).
+ * dhr_search_sharded_local: one process, several shard handles (on one or more devices), no communicator -- the same control
+ *   flow with the gathers done by device copies.  A device-resident query batch must be readable from every shard's device
+ *   (same device, or peer access); host batches always work. */
+typedef struct dhr_comm dhr_comm; /* opaque */
+int dhr_comm_unique_id(void* out128, int32_t out_bytes);
+int dhr_comm_create(const void* unique_id128, int32_t world, int32_t rank, int32_t device, dhr_comm** out);
+int dhr_comm_wrap(void* nccl_comm, int32_t world, int32_t rank, int32_t device, dhr_comm** out);
+void dhr_comm_destroy(dhr_comm* comm);
+int dhr_search_sharded(dhr_index* shard, dhr_comm* comm, const dhr_query_batch* queries, int32_t k, float* out_scores,
+                       int64_t* out_rows, int32_t out_mem_kind, void* stream);
+int dhr_search_sharded_local(dhr_index** shards, int32_t n_shards, const dhr_query_batch* queries, int32_t k, float* out_scores,
+                             int64_t* out_rows, int32_t out_mem_kind, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

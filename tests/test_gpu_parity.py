@@ -952,6 +952,10 @@ def test_config5_beir_sizes_sharded_8(G):
             lo, hi = G.shard_bounds(n, ns, sh)
             shards.append(G.GipIndex(cv[lo:hi], ci[lo:hi], row_offset=lo))
         ms, mr, how = _fake_world_search_any(G, shards, qv, qi, kk)
+        from dhr_amd import dist as D
+        cs, cr = D.search_sharded_local(shards, qv, qi, kk)            # the product path: dhr_search_sharded_local (C ABI)
+        np.testing.assert_array_equal(cr.cpu().numpy(), mr, err_msg=name)
+        np.testing.assert_array_equal(cs.cpu().numpy(), ms, err_msg=name)
         for s in shards:
             s.close()
         fs_h, fr_h = fs.cpu().numpy(), fr.cpu().numpy()
@@ -990,3 +994,69 @@ def test_query_chunking_same_result(G, golden, monkeypatch):
     got = (G.GIP_retrieval(qids, q, qi, d["cv"], d["ci"], case_args(info)), G.GIP_retrieval(qids, q, qi, d["cv"], d["ci"], args2),
            G.IP_retrieval(qids, q, d["cv"], case_args(dict(topk=20))))
     assert ref == got
+
+
+@pytest.mark.parametrize("kind", ["hybrid", "dense", "structured", "tiny"])
+def test_search_sharded_local_c_abi(G, kind):
+    """dhr_search_sharded_local (one process, S shard handles; the same sharded_core as the RCCL entry point, gathers by device
+    copies) == the unsharded search, bit for bit: common-threshold path (hybrid, dense), its failure repair (structured: every
+    high-scoring row sits in sample tiles of shard 0), and the local-threshold path (tiny shards, k > rows of a shard)."""
+    from dhr_amd import synth, _lib, dist as D
+    k = 1000
+    period = 4
+    if kind == "hybrid":
+        n, ns = 400_000, 4
+        cv, ci, qv, qi = synth.make_pair(22, n, 12, 768, 64)
+    elif kind == "dense":
+        n, ns = 400_000, 4
+        cv, ci, qv, qi = synth.make_pair(23, n, 12, 0, 256, kind="dense")
+    elif kind == "structured":
+        n, ns, period = 400_000, 2, 16
+        cv, qv = _structured_corpus(n, 0)
+        ci = qi = None
+    else:
+        n, ns, k = 3_000, 8, 500
+        cv, ci, qv, qi = synth.make_pair(24, n, 9, 768, 128)
+    q32 = qv.astype(np.float32)
+    full = G.GipIndex(cv, ci)
+    fs, fr = full.search(q32, qi, k)
+    full.close()
+    shards = []
+    for sh in range(ns):
+        lo, hi = G.shard_bounds(n, ns, sh)
+        shards.append(G.GipIndex(cv[lo:hi], None if ci is None else ci[lo:hi], row_offset=lo))
+        shards[-1].set_param(_lib.PARAM_SAMPLE_PERIOD, period)
+    try:
+        for q_in, qi_in in ((q32, qi), (qv, qi)):                      # fp32 host batch, fp16 host batch
+            ss, sr = D.search_sharded_local(shards, q_in, qi_in, k)
+            np.testing.assert_array_equal(sr.cpu().numpy(), fr)
+            np.testing.assert_array_equal(ss.cpu().numpy(), fs)
+        import torch
+        qd = torch.from_numpy(q32).cuda()
+        qid = None if qi is None else torch.from_numpy(qi).cuda()
+        ss, sr = D.search_sharded_local(shards, qd, qid, k)             # device-resident batch (the failure repair gathers on the device)
+        np.testing.assert_array_equal(sr.cpu().numpy(), fr)
+        np.testing.assert_array_equal(ss.cpu().numpy(), fs)
+    finally:
+        for s in shards:
+            s.close()
+
+
+def test_search_sharded_rccl_single_rank(G):
+    """dhr_comm_* + dhr_search_sharded through a real RCCL communicator of world size 1 (all this one-GPU box can hold): the
+    collective entry point, its scratch arena and the result delivery; equals dhr_search."""
+    from dhr_amd import synth, dist as D
+    cv, ci, qv, qi = synth.make_pair(25, 120_000, 10, 768, 64)
+    q32 = qv.astype(np.float32)
+    ix = G.GipIndex(cv, ci)
+    try:
+        fs, fr = ix.search(q32, qi, 1000)
+        comm = D.ShardComm(0)
+        assert comm.world == 1 and comm.rank == 0
+        comm.close()
+        for _ in range(2):                                             # second call reuses the grown arena
+            ss, sr = D.sharded_search(ix, q32, qi, 1000)
+            np.testing.assert_array_equal(sr.cpu().numpy(), fr)
+            np.testing.assert_array_equal(ss.cpu().numpy(), fs)
+    finally:
+        ix.close()
