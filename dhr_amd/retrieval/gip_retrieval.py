@@ -299,10 +299,10 @@ def GIP_retrieval(qids, query_embs, query_arg_idxs, corpus_embs, corpus_arg_idxs
 
 def PQ_IP_retrieval(qids, query_embs, query_arg_idxs, corpus_embs, corpus_arg_idxs, args):
     """gip_retrieval.py:167-231: first stage = product-quantised inner product over the WHOLE vector (no gate), agip_topk
-    candidates; --rerank: exact GIP of those candidates, top-k (:205-215); otherwise the first topk PQ results (:218-221).
-    The PQ index is the library's own (retrieval/quantize_index.py mirror; faiss files are not readable here): the codes are
-    decoded once on the device and searched with the dense bound GEMM -- an exact inner product on the decoded vectors is
-    the ADC score.  Parity with faiss unpinned."""
+    candidates (faiss IndexPQ.search, :202); --rerank: exact GIP of those candidates, top-k (:205-215); otherwise the first topk
+    PQ results (:218-221).  `--faiss_pq_index_path` is a faiss IndexPQ file (retrieval/quantize_index.py, the reference's or this
+    build's).  The codes stay resident at one byte per sub-quantiser and row and are searched by the ADC scan (dhr_pq_search);
+    the candidates are rescored exactly by dhr_score_rows.  Parity with faiss unpinned (faiss is not part of the reference tree)."""
     from . import quantize_index as QI
     assert args.faiss_pq_index_path is not None, 'you do not spesify your PQ index through --faiss_pq_index_path'
     print('Load PQ index ...')
@@ -310,11 +310,7 @@ def PQ_IP_retrieval(qids, query_embs, query_arg_idxs, corpus_embs, corpus_arg_id
     index, owned = _corpus_index(corpus_embs, corpus_arg_idxs, args)
     if pq["codes"].shape[0] != index.n_rows or pq["d"] != index.k:
         raise ValueError("the PQ index does not describe the same corpus as --index_path")
-    import torch
-    dev = torch.device("cuda", getattr(args, "device", 0))
-    decoded = QI.decode(torch.from_numpy(pq["codebooks"]).to(dev), torch.from_numpy(pq["codes"]).to(dev), device=dev.index or 0)
-    pq_index = GipIndex(decoded, None, device=dev.index or 0, row_offset=index.row_offset)
-    del decoded
+    pq_index = QI.PqIndex(pq["codebooks"], pq["codes"], nbits=pq["nbits"], device=getattr(args, "device", 0), row_offset=index.row_offset)
     start_time = time.time()
     try:
         q = _np(query_embs).astype(np.float32)
@@ -322,7 +318,7 @@ def PQ_IP_retrieval(qids, query_embs, query_arg_idxs, corpus_embs, corpus_arg_id
         qi_np = _np(query_arg_idxs)
 
         def pq_stage(lo, hi):
-            s1, r1 = pq_index.search(q[lo:hi], None, k1)
+            s1, r1 = pq_index.search(q[lo:hi], k1)
             if not args.rerank:
                 return s1[:, : args.topk], r1[:, : args.topk]
             s2 = index.score_rows(q[lo:hi], qi_np[lo:hi], r1)

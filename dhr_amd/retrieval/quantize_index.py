@@ -1,11 +1,15 @@
 """Drop-in for castorini/dhr's retrieval/quantize_index.py (:9-42): build the product-quantised first-stage index
-of `--PQIP`.  Same flags (including the reference's spelling `--qauntized_dim`).  The reference trains and writes a
-faiss `IndexPQ(d, M, nbits, METRIC_INNER_PRODUCT)`; faiss is not available to this build, so the quantiser is the
-library's own restatement of that algorithm (dhr_pq_train / dhr_pq_encode, HIP) and the file is a pickle
+of `--PQIP`.  Same flags (including the reference's spelling `--qauntized_dim`).  The reference trains a faiss
+`IndexPQ(d, M, nbits, METRIC_INNER_PRODUCT)` and writes it with `faiss.write_index`; faiss is not available to this build, so
+the quantiser is the library's own restatement of the algorithm (dhr_pq_train / dhr_pq_encode, HIP).
 
-    {"format": "dhr-pq", "version": 1, "d", "M", "nbits", "codebooks": float32 [M,256,d/M], "codes": uint8 [N,M]}
-
--- NOT a faiss file.  Parity with faiss is unpinned; tests check recall against the exact search."""
+File format: the output IS a faiss IndexPQ file -- the byte layout faiss' index_write.cpp produces for an IndexPQ
+("IxPq" fourcc, index header, ProductQuantizer, codes, search parameters; `write_faiss_indexpq` / `read_faiss_indexpq` below,
+restated from the published faiss 1.7 serialisation code) -- so `--faiss_pq_index_path` accepts an index built by the reference's
+own quantize_index.py and the reference can read ours.  The layout is restated from the public source, not validated against a
+faiss binary here (faiss absent): PARITY WITH FAISS IS UNPINNED -- codebooks differ from faiss' k-means,
+tests check the ADC arithmetic exactly against the restated oracle and recall against the exact search.  The earlier pickle
+format ({"format": "dhr-pq", ...}) is still read."""
 from __future__ import annotations
 
 import argparse
@@ -60,19 +64,174 @@ def decode(codebooks, codes, device: int = 0):
     return out
 
 
-def save_pq(path, codebooks, codes):
+FAISS_FOURCC_IXPQ = int.from_bytes(b"IxPq", "little")
+METRIC_INNER_PRODUCT, METRIC_L2 = 0, 1
+
+
+def pack_codes(codes: np.ndarray, nbits: int) -> np.ndarray:
+    """[N, M] one code per byte -> faiss' packed code bytes [N, ceil(M * nbits / 8)] (PQEncoderGeneric: LSB first, contiguous)."""
+    n, m = codes.shape
+    if nbits == 8:
+        return np.ascontiguousarray(codes, np.uint8)
+    bits = ((codes[:, :, None].astype(np.uint16) >> np.arange(nbits, dtype=np.uint16)) & 1).astype(np.uint8).reshape(n, m * nbits)
+    return np.packbits(bits, axis=1, bitorder="little")
+
+
+def unpack_codes(packed: np.ndarray, m: int, nbits: int) -> np.ndarray:
+    if nbits == 8:
+        return np.ascontiguousarray(packed[:, :m], np.uint8)
+    bits = np.unpackbits(packed, axis=1, bitorder="little")[:, : m * nbits].reshape(packed.shape[0], m, nbits)
+    return (bits.astype(np.uint16) << np.arange(nbits, dtype=np.uint16)).sum(2).astype(np.uint8)
+
+
+def write_faiss_indexpq(path, codebooks, codes, nbits: int = 8, metric: int = METRIC_INNER_PRODUCT):
+    """faiss.write_index(IndexPQ) byte layout (faiss/impl/index_write.cpp, 1.7.x):
+       u32 fourcc "IxPq" | header: i32 d, i64 ntotal, i64 dummy (1<<20), i64 dummy, u8 is_trained, i32 metric_type
+       [, f32 metric_arg if metric_type > 1] | ProductQuantizer: u64 d, u64 M, u64 nbits, vector<float> centroids
+       (u64 count, data [M][ksub][dsub]) | vector<u8> codes (u64 count, ntotal * code_size bytes) | i32 search_type (0 = ST_PQ),
+       u8 encode_signs, i32 polysemous_ht."""
+    cb = np.ascontiguousarray(np.asarray(codebooks), "<f4")
+    m, ksub, dsub = cb.shape
+    assert ksub == 1 << nbits
+    packed = pack_codes(np.asarray(codes, np.uint8), nbits)
+    n = packed.shape[0]
+    with open(path, "wb") as f:
+        f.write(np.uint32(FAISS_FOURCC_IXPQ).tobytes())
+        f.write(np.int32(m * dsub).tobytes() + np.int64(n).tobytes() + np.int64(1 << 20).tobytes() + np.int64(1 << 20).tobytes())
+        f.write(np.uint8(1).tobytes() + np.int32(metric).tobytes())
+        f.write(np.uint64(m * dsub).tobytes() + np.uint64(m).tobytes() + np.uint64(nbits).tobytes())
+        f.write(np.uint64(cb.size).tobytes())
+        f.write(cb.tobytes())
+        f.write(np.uint64(packed.size).tobytes())
+        f.write(packed.tobytes())
+        f.write(np.int32(0).tobytes() + np.uint8(0).tobytes() + np.int32(0).tobytes())
+
+
+def read_faiss_indexpq(path):
+    """-> {"d", "M", "nbits", "metric", "codebooks": float32 [M, 2^nbits, d/M], "codes": uint8 [N, M] (one code per byte)}."""
+    with open(path, "rb") as f:
+        buf = memoryview(f.read())
+    pos = 0
+
+    def take(dtype, count=1):
+        nonlocal pos
+        dt = np.dtype(dtype)
+        if pos + dt.itemsize * count > len(buf):
+            raise ValueError(f"{path}: truncated faiss IndexPQ file")
+        a = np.frombuffer(buf, dt, count, pos)
+        pos += dt.itemsize * count
+        return a
+    if int(take("<u4")[0]) != FAISS_FOURCC_IXPQ:
+        raise ValueError(f"{path}: not a faiss IndexPQ file (fourcc 'IxPq' expected; other faiss index types are not supported)")
+    d, ntotal = int(take("<i4")[0]), int(take("<i8")[0])
+    take("<i8", 2)
+    _trained, metric = int(take("u1")[0]), int(take("<i4")[0])
+    if metric > 1:
+        take("<f4")
+    pd, m, nbits = (int(x) for x in take("<u8", 3))
+    if pd != d or m <= 0 or d % m or not 1 <= nbits <= 8:
+        raise ValueError(f"{path}: unsupported ProductQuantizer (d {pd}/{d}, M {m}, nbits {nbits}; nbits <= 8 only)")
+    n_cent = int(take("<u8")[0])
+    ksub, dsub = 1 << nbits, d // m
+    if n_cent != m * ksub * dsub:
+        raise ValueError(f"{path}: centroid table of {n_cent} floats, expected {m * ksub * dsub}")
+    cb = take("<f4", n_cent).reshape(m, ksub, dsub).copy()
+    n_codes = int(take("<u8")[0])
+    code_size = (m * nbits + 7) // 8
+    if n_codes != ntotal * code_size:
+        raise ValueError(f"{path}: {n_codes} code bytes for {ntotal} vectors of {code_size} bytes")
+    packed = take("u1", n_codes).reshape(ntotal, code_size)
+    if metric != METRIC_INNER_PRODUCT:
+        raise ValueError(f"{path}: metric_type {metric}; the reference builds METRIC_INNER_PRODUCT (quantize_index.py:29)")
+    return {"format": "faiss-IxPq", "d": d, "M": m, "nbits": nbits, "metric": metric, "codebooks": cb, "codes": unpack_codes(packed, m, nbits)}
+
+
+class PqIndex:
+    """Device-resident PQ index (dhr_pq_*): codes (one byte per sub-quantiser and row) + codebooks; .search = the ADC scan."""
+
+    def __init__(self, codebooks, codes, nbits: int = 8, device: int = 0, row_offset: int = 0):
+        self._lib = _lib.load()
+        cb = np.ascontiguousarray(np.asarray(codebooks), np.float32) if isinstance(codebooks, np.ndarray) or not hasattr(codebooks, "data_ptr") else codebooks
+        self.M, self.ksub, self.dsub = int(cb.shape[0]), int(cb.shape[1]), int(cb.shape[2])
+        self.d, self.n, self.device, self.row_offset = self.M * self.dsub, int(codes.shape[0]), int(device), int(row_offset)
+        if isinstance(codes, np.ndarray):
+            codes = np.ascontiguousarray(codes, np.uint8)
+            cb = np.ascontiguousarray(np.asarray(cb), np.float32)
+            kind, pc, pb = _lib.MEM_HOST, codes.ctypes.data, cb.ctypes.data
+        else:
+            codes, cb = codes.contiguous(), cb.contiguous()
+            kind, pc, pb = _lib.MEM_DEVICE, codes.data_ptr(), cb.data_ptr()
+        h = C.c_void_p()
+        _lib.check(self._lib.dhr_pq_create(self.device, kind, self.n, self.d, self.M, int(nbits), pb, pc, self.row_offset, C.byref(h)), "dhr_pq_create")
+        self._h = h
+
+    def search(self, q_value, k: int, out_device: bool = False):
+        qb, keep = _lib.make_query_batch(q_value, None)
+        if out_device:
+            import torch
+            dev = torch.device("cuda", self.device)
+            s = torch.empty((qb.n_queries, k), dtype=torch.float32, device=dev)
+            r = torch.empty((qb.n_queries, k), dtype=torch.int64, device=dev)
+            _lib.check(self._lib.dhr_pq_search(self._h, C.byref(qb), int(k), s.data_ptr(), r.data_ptr(), _lib.MEM_DEVICE, None), "dhr_pq_search")
+            return s, r
+        s = np.empty((qb.n_queries, k), np.float32)
+        r = np.empty((qb.n_queries, k), np.int64)
+        _lib.check(self._lib.dhr_pq_search(self._h, C.byref(qb), int(k), s.ctypes.data, r.ctypes.data, _lib.MEM_HOST, None), "dhr_pq_search")
+        return s, r
+
+    def adc_scores(self, q_value, row_lo: int = 0, row_hi: int | None = None):
+        import torch
+        row_hi = self.n if row_hi is None else row_hi
+        qb, keep = _lib.make_query_batch(q_value, None)
+        out = torch.empty((qb.n_queries, row_hi - row_lo), dtype=torch.float32, device=torch.device("cuda", self.device))
+        _lib.check(self._lib.dhr_pq_adc_scores(self._h, C.byref(qb), int(row_lo), int(row_hi), out.data_ptr(), None), "dhr_pq_adc_scores")
+        return out
+
+    def device_bytes(self) -> int:
+        return int(self._lib.dhr_pq_device_bytes(self._h))
+
+    def last_scan(self):
+        ms, by = C.c_double(), C.c_double()
+        _lib.check(self._lib.dhr_pq_last_scan(self._h, C.byref(ms), C.byref(by)), "dhr_pq_last_scan")
+        return ms.value, by.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dhr_pq_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def save_pq_pickle(path, codebooks, codes):
     M, _, dsub = codebooks.shape
     with open(path, 'wb') as f:
         pickle.dump({"format": PQ_FORMAT, "version": 1, "d": int(M * dsub), "M": int(M), "nbits": 8,
                      "codebooks": np.asarray(codebooks, np.float32), "codes": np.asarray(codes, np.uint8)}, f, protocol=4)
 
 
+def save_pq(path, codebooks, codes, nbits: int = 8):
+    """What `--output_index_path` receives: a faiss IndexPQ file (see the module docstring)."""
+    write_faiss_indexpq(path, np.asarray(codebooks, np.float32), np.asarray(codes, np.uint8), nbits)
+
+
 def load_pq(path):
+    """`--faiss_pq_index_path`: a faiss IndexPQ file (the reference's quantize_index.py output, or ours), or the earlier pickle."""
     with open(path, 'rb') as f:
-        obj = pickle.load(f)
+        head = f.read(4)
+    if head == b"IxPq":
+        return read_faiss_indexpq(path)
+    try:
+        with open(path, 'rb') as f:
+            obj = pickle.load(f)
+    except Exception as e:  # noqa: BLE001
+        raise ValueError(f"{path} is neither a faiss IndexPQ file ('IxPq') nor a {PQ_FORMAT} pickle: {e}") from e
     if not isinstance(obj, dict) or obj.get("format") != PQ_FORMAT:
-        raise ValueError(f"{path} is not a {PQ_FORMAT} file (faiss index files are not readable without faiss; rebuild it with "
-                         "python -m retrieval.quantize_index)")
+        raise ValueError(f"{path} is neither a faiss IndexPQ file ('IxPq') nor a {PQ_FORMAT} pickle")
     return obj
 
 

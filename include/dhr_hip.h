@@ -241,6 +241,28 @@ int dhr_debug_bound_scores(dhr_index* index, const dhr_query_batch* queries, int
 int dhr_debug_gemm_time(dhr_index* index, const dhr_query_batch* queries, int32_t iters, double* ms_out,
                         double* flops_out, void* stream);
 
+/* ---- Product-quantised first stage of --PQIP as an ADC scan.  Replaces
+ * faiss.read_index(...) + IndexPQ.search(queries, agip_topk) (retrieval/gip_retrieval.py:170,202; built by
+ * retrieval/quantize_index.py:27-37 as IndexPQ(d, M, nbits, METRIC_INNER_PRODUCT)).  faiss is not part of the reference tree: the
+ * algorithm is restated from its publication, PARITY WITH FAISS IS UNPINNED.  The handle keeps the codes (ONE BYTE per
+ * sub-quantiser and row: 64 B per row at M = 64) and the codebooks ([M][2^nbits][d/M] fp32, faiss' centroid order) on the
+ * device; a search builds per-query lookup tables <q_m, c_m[j]> and scans the codes (HBM / LDS-gather bound), fused with the
+ * running top-k threshold filter.  score(q, x) = sum_m LUT[q][m][code_m(x)] in fp32, m ascending.
+ *   codes     [n][M] uint8, one code per byte (unpack files with nbits < 8 first)
+ *   queries   values only ([n_queries][d], fp16 or fp32; index arrays are ignored: the first stage is ungated)
+ *   dhr_pq_search    -> [n_queries][k] (score desc, row asc on exact ties; global rows; (-inf, -1) beyond the corpus), k <= 16384
+ *   dhr_pq_adc_scores-> raw scores of rows [row_lo, row_hi), device memory [n_queries][row_hi - row_lo] (tests)
+ *   dhr_pq_last_scan -> duration (ms, hipEvents) and code bytes read by the scan kernel launches of the last search */
+typedef struct dhr_pq dhr_pq; /* opaque */
+int dhr_pq_create(int32_t device, int32_t mem_kind, int64_t n, int32_t d, int32_t M, int32_t nbits, const float* codebooks,
+                  const uint8_t* codes, int64_t row_offset, dhr_pq** out);
+void dhr_pq_destroy(dhr_pq* pq);
+int64_t dhr_pq_device_bytes(const dhr_pq* pq);
+int dhr_pq_search(dhr_pq* pq, const dhr_query_batch* queries, int32_t k, float* out_scores, int64_t* out_rows, int32_t out_mem_kind,
+                  void* stream);
+int dhr_pq_adc_scores(dhr_pq* pq, const dhr_query_batch* queries, int64_t row_lo, int64_t row_hi, float* out_dev, void* stream);
+int dhr_pq_last_scan(const dhr_pq* pq, double* ms, double* code_bytes);
+
 /* ---- Row-sharded search: replaces the reference's --total_shrad / --shrad runs plus
  * retrieval/merge.result.py:22-42.  The corpus rows are split like gip_retrieval.py:292-306 (per = N // S, the last shard takes
  * the remainder; dhr_index_desc.row_offset = the shard's first global row), queries are replicated, and the result is the global

@@ -741,16 +741,24 @@ def test_pq_first_stage(G, tmp_path, monkeypatch):
     # decode == oracle decode (rounded to fp16)
     dec = QI.decode(cb, codes)
     np.testing.assert_array_equal(dec, PO.decode(codes, cb).astype(np.float16))
-    # ADC search: exact inner product on the decoded vectors == table-based ADC scores of the oracle (fp16 rounding of the
-    # reconstruction is the only difference)
-    pix = G.GipIndex(dec, None)
+    # ADC scan (dhr_pq_*): the codes stay resident at 64 B per row; raw scores == the oracle's table-based ADC scores to 1e-5
+    # (fp32 tables and sums; no fp16 rounding of a reconstruction), the search == the exact top-k of those scores
+    pix = QI.PqIndex(cb, codes)
     ix = G.GipIndex(cv, ci)
     try:
-        s1, r1 = pix.search(q, None, 500)
         adc = PO.adc_scores(q, codes, cb)
+        raw = pix.adc_scores(q).cpu().numpy()
+        np.testing.assert_allclose(raw, adc, rtol=0, atol=1e-5 * max(1.0, float(np.abs(adc).max())))
+        assert pix.device_bytes() - 64 * 256 * 14 * 4 >= 20000 * 64
+        s1, r1 = pix.search(q, 500)
+        assert pix.device_bytes() < 20000 * 64 + 64 * 256 * 14 * 4 + (1 << 30)       # codes + codebooks + the (bounded) search workspace
         for i in range(16):
-            top = np.sort(adc[i])[::-1][:500]
-            np.testing.assert_allclose(s1[i], top, rtol=2e-3, atol=2e-3)
+            O.check_topk(r1[i], s1[i], adc[i], 500, atol=1e-4)
+        s1d, r1d = pix.search(__import__("torch").from_numpy(qv).cuda(), 500, out_device=True)      # fp16 device batch
+        np.testing.assert_array_equal(r1d.cpu().numpy(), r1)
+        sk, rk = pix.search(q[:3], 16384)                                             # k at the limit, > the first scan block
+        for i in range(3):
+            O.check_topk(rk[i], sk[i], adc[i], 16384, atol=1e-4)
         # recall of the PQ first stage and of the reranked result against the exact search
         se, re_ = ix.search(q, qi, 100)
         sip, rip = ix.search(q, None, 100)

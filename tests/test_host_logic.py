@@ -6,6 +6,7 @@ import pickle
 import tempfile
 
 import numpy as np
+import pytest
 
 from oracle import gip_oracle as O
 from tests.util import dump_pickle
@@ -93,3 +94,37 @@ def test_key_encoding_roundtrip_is_order_preserving():
     vals = np.array([-np.inf, -3.5, -1e-30, -0.0, 0.0, 1e-30, 2.0, 65504.0, np.inf], np.float32)
     keys = [int(f32_ordered(v)) for v in vals]
     assert keys == sorted(keys) and len(set(keys[:3])) == 3
+
+
+def test_faiss_indexpq_file_round_trip(tmp_path):
+    """retrieval/quantize_index.py writes a faiss IndexPQ file (byte layout of faiss' index_write.cpp, restated): header fields at
+    the documented offsets, codes packed LSB-first for nbits < 8, and read back bit-identically; other files are refused."""
+    import struct
+    from dhr_amd.retrieval import quantize_index as QI
+    rng = np.random.default_rng(3)
+    for nbits, m, dsub, n in ((8, 64, 14, 300), (6, 8, 4, 77), (4, 16, 2, 50)):
+        cb = rng.standard_normal((m, 1 << nbits, dsub)).astype(np.float32)
+        codes = rng.integers(0, 1 << nbits, (n, m)).astype(np.uint8)
+        path = str(tmp_path / f"pq{nbits}")
+        QI.write_faiss_indexpq(path, cb, codes, nbits)
+        raw = open(path, "rb").read()
+        assert raw[:4] == b"IxPq"
+        d, ntotal, dummy1, dummy2, trained, metric = struct.unpack_from("<iqqqBi", raw, 4)
+        assert (d, ntotal, dummy1, dummy2, trained, metric) == (m * dsub, n, 1 << 20, 1 << 20, 1, 0)
+        pd, pm, pnb, ncent = struct.unpack_from("<QQQQ", raw, 4 + 4 + 8 + 8 + 8 + 1 + 4)
+        assert (pd, pm, pnb, ncent) == (m * dsub, m, nbits, m * (1 << nbits) * dsub)
+        code_size = (m * nbits + 7) // 8
+        assert len(raw) == 37 + 32 + 4 * ncent + 8 + n * code_size + 9
+        back = QI.load_pq(path)
+        assert (back["d"], back["M"], back["nbits"]) == (m * dsub, m, nbits)
+        np.testing.assert_array_equal(back["codebooks"], cb)
+        np.testing.assert_array_equal(back["codes"], codes)
+    np.testing.assert_array_equal(QI.pack_codes(np.array([[1, 2, 3, 0]], np.uint8), 4), np.array([[0x21, 0x03]], np.uint8))   # LSB first
+    bad = tmp_path / "bad"
+    bad.write_bytes(b"IxFlxxxxxxxxxxxxxxxx")
+    with pytest.raises(ValueError):
+        QI.load_pq(str(bad))
+    trunc = tmp_path / "trunc"
+    trunc.write_bytes(open(str(tmp_path / "pq8"), "rb").read()[:500])
+    with pytest.raises(ValueError):
+        QI.load_pq(str(trunc))
