@@ -285,7 +285,8 @@ extern "C" int dhr_pq_search(dhr_pq* pq, const dhr_query_batch* qb, int32_t k, f
         (void)hipEventRecord(e0, s);
         if ((rc = scan(pq, nq, lo, hi, true, nullptr, 0, s))) return done(rc);
         (void)hipEventRecord(e1, s);
-        if (launch_max_u32(pq->cnt, nq, pq->d_max, nullptr, s) != hipSuccess) return done(dhr_set_error_message(DHR_ERR_HIP, "max launch failed"));
+        if (hipMemsetAsync(pq->d_max, 0, 16, s) != hipSuccess || launch_max_u32(pq->cnt, nq, pq->d_max, (unsigned long long*)(pq->d_max + 2), s) != hipSuccess)
+          return done(dhr_set_error_message(DHR_ERR_HIP, "max launch failed"));
         uint32_t mx = 0;
         if (hipMemcpyAsync(&mx, pq->d_max, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
           return done(dhr_set_error_message(DHR_ERR_HIP, "count read-back failed"));
