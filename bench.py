@@ -227,14 +227,28 @@ def run_workload(args, spec, ctx):
         if not args.no_cpu_baseline:
             cpu_sample = host_slice(args.cpu_rows, max(args.cpu_queries, args.cpu_queries_1t))
         par_sample = host_slice(args.parity_rows, args.parity_queries)
+    pq = None
+    t_pq = 0.0
+    if args.pq:
+        # --PQIP (gip_retrieval.py:167-231): product-quantised first stage over the whole vector (M = 64 sub-quantisers, 8 bits:
+        # quantize_index.py:29) -> agip_topk candidates -> exact GIP rerank.  Codebooks: the library's own k-means (parity with faiss unpinned).
+        from dhr_amd.retrieval import quantize_index as QI
+        t_pq = time.perf_counter()
+        cb, codes, _ = QI.train_and_encode(cv, 64, 8, iters=10, device=local_rank)
+        pq = QI.PqIndex(cb, codes, nbits=8, device=local_rank, row_offset=lo)
+        del cb, codes
+        torch.cuda.synchronize()
+        t_pq = time.perf_counter() - t_pq
     del cv, ci
     torch.cuda.empty_cache()
-
-    pq = None
-    if args.pq:
-        raise SystemExit("--pq: wired in with the ADC scan (see dhr_amd/retrieval/quantize_index.py)")
+    k1 = min(args.agip_topk, hi - lo)
 
     def step():
+        if pq is not None:
+            s1, r1 = pq.search(qv, k1, out_device=True)                       # ADC scan: top-agip_topk by the quantised inner product
+            s2 = index.score_rows_device(qv, qi, r1)                          # exact gated inner product of the candidates (:205-215)
+            top = torch.topk(s2, min(k, k1), dim=1)
+            return top.values, torch.gather(r1, 1, top.indices)
         if world > 1:
             return D.sharded_search(index, qv, qi, k)        # common thresholds + one all-gather of the shard lists
         return index.search(qv, qi, min(k, n), out_device=True)
@@ -254,7 +268,12 @@ def run_workload(args, spec, ctx):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        st = index.stats()
+        st = index.stats() if pq is None else dict.fromkeys(("gemm_ms", "phases", "gemm_flops_alg", "refine_ms", "rescore_ms", "select_ms", "prep_ms", "total_ms",
+                                                              "candidates_bound", "candidates_exact", "overflow_retries", "gemm_rows", "sample_fallback_queries"), 0)
+        if pq is not None:
+            ms_scan, by_scan = pq.last_scan()
+            stats_acc["adc_scan_ms"] = stats_acc.get("adc_scan_ms", 0) + ms_scan
+            stats_acc["adc_code_bytes"] = stats_acc.get("adc_code_bytes", 0) + by_scan
         gemm_ms += st["gemm_ms"]
         launches += st["phases"]
         gemm_flops_alg += st["gemm_flops_alg"]                  # algorithmic: real Q and K of every launch
@@ -362,6 +381,17 @@ def run_workload(args, spec, ctx):
             "setup_s": {"generate": round(t_gen, 2), "index_build": round(t_build, 2)},
             "index_device_gb": round(index.device_bytes() / 1e9, 2),
         }
+        if pq is not None:
+            # the dominant kernel of this mode is the ADC scan: HBM / LDS-gather bound integer-index work (roofline on HBM bytes)
+            scan_s = stats_acc["adc_scan_ms"] * 1e-3
+            gbs = stats_acc["adc_code_bytes"] / scan_s / 1e9 if scan_s > 0 else 0.0
+            out["roofline"] = {"bound": "hbm", "kernel": "adc_scan_kernel (product-quantised inner product: 64 B of codes per row, fp32 lookup tables of a query pair in LDS, fused threshold filter)",
+                               "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None,
+                               "algorithmic_bytes_per_step": stats_acc["adc_code_bytes"] / args.steps,
+                               "note": "code bytes the scan launches read (rows x 64 B x query pairs) / their hipEvent time; the tables of a pair are re-read from L2 per row block"}
+            out["config"]["first_stage"] = "PQ M=64 nbits=8 ADC scan, agip_topk %d, exact GIP rerank of the candidates" % k1
+            out["pq"] = {"index_device_mb": round(pq.device_bytes() / 1e6, 1), "train_encode_s": round(t_pq, 2), "adc_scan_ms_per_step": round(stats_acc["adc_scan_ms"] / args.steps, 3)}
+            pq.close()
         if cpu_sample is not None:
             out["cpu_baseline"] = cpu_baseline_legs(cpu_sample, k, n, min(args.cpu_queries_1t, nq), min(args.cpu_queries, nq))
         if par_sample is not None:

@@ -185,6 +185,16 @@ class GipIndex:
         del keep
         return out
 
+    def score_rows_device(self, q_value, q_index, rows):
+        """score_rows for a torch cuda int64 tensor of rows [Q, m]: -> torch cuda fp32 [Q, m] (no host round trip)."""
+        import torch
+        qb, keep = _lib.make_query_batch(q_value, q_index)
+        rows = rows.contiguous()
+        out = torch.empty(rows.shape, dtype=torch.float32, device=rows.device)
+        _lib.check(self._lib.dhr_score_rows(self._h, C.byref(qb), int(rows.shape[1]), rows.data_ptr(), out.data_ptr(), _lib.MEM_DEVICE, 0), "dhr_score_rows")
+        del keep
+        return out
+
 
 def _as_f16(a):
     """Corpus values are fp16 on disk; the reference widens them to fp32 on its CPU path
