@@ -102,6 +102,7 @@ struct dhr_index {
   int main_chunks = 2;
   int progressive_thr = 1;
   int n_cu = 256;
+  int gemm_variant = 0;                    // 2:4 layout kernel of THIS handle (0 = library default)
   int overlap_aux = -1;                    // 0: refine / rescoring / select run on the GEMM's stream (every kernel gets the whole chip); 1: beside the next chunk's GEMM on a CU-masked stream; -1 (default) = 1 for dense-only indexes (110.4 -> 101.7 ms per step at config 2), 0 for gated ones (the same step time, 192.7 vs 193.0 ms, but the overlapped GEMM launches run 7 % longer)
   int aux_cus = 128, gemm_exclusive = 0;   // CU-masked streams of the main pass (0 = off)
   int aux_cus_made = -1, gemm_excl_made = -1;
@@ -168,7 +169,7 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
     case DHR_PARAM_OVERLAP_AUX: ix->overlap_aux = value < 0 ? -1 : value != 0; return DHR_OK;
     case DHR_PARAM_GEMM_VARIANT:
       if (value < 3 || value > 5) return set_error(DHR_ERR_INVALID, "gemm_variant: 3 (12-wave producer / consumer kernel), 4 (4 waves, 128 x 128 wave tiles) or 5 (8 waves, 128 x 64 wave tiles)");
-      dhr::g_gemm_variant = (int)value; return DHR_OK;
+      ix->gemm_variant = (int)value; return DHR_OK;
     case DHR_PARAM_MAX_GROWTH:
       if (value < 1 || value > 1024) return set_error(DHR_ERR_INVALID, "max_growth must be in [1,1024] sixteenths");
       ix->max_growth16 = (int)value; return DHR_OK;
@@ -508,6 +509,10 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   const bool refine = ix->heavy_key != nullptr;
   // default list depth: 262144 (refine) / 65536, but never more than ~32 GiB for the two bound-list sets of a big batch
   int64_t base_cap = refine ? 262144 : 65536;
+  // ... sized by the SHARD: a list cannot hold more rows than the shard has, and the chunk planner of the main pass cuts the pass
+  // so that the fullest list fits, so a 1/8 shard gets 1/8 of the depth (floor: 32768 / 16384) instead of the full-corpus workspace
+  const int64_t by_rows = std::max<int64_t>(ix->n_rows / (refine ? 32 : 128), refine ? 32768 : 16384);
+  while (base_cap / 2 >= by_rows) base_cap >>= 1;
   while (base_cap > 4096 && (int64_t)q_pad * base_cap * 16 > ((int64_t)32 << 30)) base_cap >>= 1;
   if (ix->cand_cap > 0) base_cap = ix->cand_cap;
   // fallback depths serve a handful of queries: 16x deeper lists there cost little memory
@@ -634,7 +639,7 @@ static RescoreArgs base_rescore_args(const dhr_index* ix, const Workspace& w, in
 static int gemm_phase(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi, int map_mode, int period, int64_t head,
                       Timer& tm, dhr_search_stats& st, hipStream_t s, uint32_t* maxc, unsigned long long* sumc) {
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant;
   g.seq_lo = lo; g.seq_hi = hi; g.map_mode = map_mode; g.period = period; g.head = head; g.n_tiles = ix->n_tiles;
   g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt;
   g.cap = (uint32_t)w.cap; g.n_queries = Q;
@@ -900,7 +905,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       const int64_t lo = bound[i], hi = bound[i + 1];
       if (i >= 2) HIP_TRY(hipStreamWaitEvent(sg, ev_done[i - 2], 0));      // list set is free again
       GemmArgs g{};
-      g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q;
+      g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant;
       g.seq_lo = lo; g.seq_hi = hi; g.map_mode = 2; g.period = S; g.head = head; g.n_tiles = ix->n_tiles;
       g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr_hat; g.cand = cand; g.cnt = cnt;
       g.cap = (uint32_t)w.cap; g.n_queries = Q;
@@ -1414,7 +1419,7 @@ extern "C" int dhr_debug_bound_scores(dhr_index* ix, const dhr_query_batch* qb, 
   if ((rc = ensure_ws(ix, w, qb->n_queries, 1, 0)) != DHR_OK) return rc;
   if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.seq_lo = row_lo / TILE_ROWS;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.seq_lo = row_lo / TILE_ROWS;
   g.seq_hi = (row_hi + TILE_ROWS - 1) / TILE_ROWS; g.map_mode = 0; g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
   g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
   g.dump = out_dev; g.dump_ld = row_hi - row_lo; g.dump_row0 = row_lo;
@@ -1446,7 +1451,7 @@ extern "C" int dhr_debug_gemm_time(dhr_index* ix, const dhr_query_batch* qb, int
   }
   HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.seq_lo = 0; g.seq_hi = ix->n_tiles; g.map_mode = 0;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.seq_lo = 0; g.seq_hi = ix->n_tiles; g.map_mode = 0;
   g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
   g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
   HIP_TRY(launch_gemm_filter(g, s));                      // warm-up

@@ -85,6 +85,7 @@ struct GemmArgs {
   int64_t dump_ld;
   int64_t dump_row0;
   int n_queries;
+  int variant;                // 2:4 layout kernel (3 / 4 / 5), 0 = the library default (g_gemm_variant)
 };
 
 struct RescoreArgs {

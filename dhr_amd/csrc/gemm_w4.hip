@@ -1,6 +1,7 @@
 // Bound GEMM + filter of the 2:4 layout without producer waves: variant 4 (four waves, one per SIMD, 128 x 128 wave tiles)
 // and variant 5 (eight waves, two per SIMD, 128 x 64 wave tiles) -- one templated kernel, see the comment below.
 #include "gemm_common.h"
+#include <mutex>
 #include <type_traits>
 
 namespace dhr {
@@ -347,7 +348,12 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
 }
 
 hipError_t launch_gemm_wx(const GemmArgs& a, dim3 grid, int variant, hipStream_t s) {
-  static bool attr_set = false;
+  static std::mutex attr_mu;                       // per-device, under a lock (handles on different devices / host threads)
+  static bool attr_set_dev[64] = {};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  std::lock_guard<std::mutex> attr_lock(attr_mu);
+  bool& attr_set = attr_set_dev[dev_ & 63];
   if (!attr_set) {
     const void* fns[4] = {(const void*)gemm_filter_wx_kernel<false, 4>, (const void*)gemm_filter_wx_kernel<true, 4>,
                           (const void*)gemm_filter_wx_kernel<false, 2>, (const void*)gemm_filter_wx_kernel<true, 2>};

@@ -12,6 +12,7 @@
 // :74-75 (plain IP + argsort), retrieval/merge.result.py:22-42 (shard reduce).
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "dhr_internal.h"
 #include "gemm_common.h"
@@ -20,6 +21,19 @@
 namespace dhr {
 
 typedef short short8 __attribute__((ext_vector_type(8)));
+
+// hipFuncAttributeMaxDynamicSharedMemorySize caches: per device and under a lock -- handles on different devices may be used
+// concurrently from different host threads (dhr_hip.h)
+static hipError_t ensure_lds_attr(const void* fn, int bytes, int (&have)[64]) {
+  static std::mutex mu;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (bytes <= have[dev & 63]) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) have[dev & 63] = bytes;
+  return e;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -893,7 +907,13 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
   const int64_t groups = (n_tiles + DOC_GROUP - 1) / DOC_GROUP;
   const int64_t groups_per_xcd = (groups + 7) / 8;
   const int64_t blocks = groups_per_xcd * 8 * DOC_GROUP * a.n_qtiles;
-  static bool attr_set = false;
+  // per-device, under a lock: handles on different devices may be used from different host threads (dhr_hip.h)
+  static std::mutex attr_mu;
+  static bool attr_set_dev[64] = {};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  std::lock_guard<std::mutex> attr_lock(attr_mu);
+  bool& attr_set = attr_set_dev[dev_ & 63];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
@@ -906,7 +926,8 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const dim3 grid((unsigned)blocks);
-  if (a.ts > 0 && (g_gemm_variant == 4 || g_gemm_variant == 5) && g_gemm_ablate == 0 && !(a.ts_q & 1) && !(a.td & 1)) return launch_gemm_wx(a, grid, g_gemm_variant, s);   // pairs of stages
+  const int variant = a.variant ? a.variant : g_gemm_variant;        // per handle (dhr_index_set_param), else the library default
+  if (a.ts > 0 && (variant == 4 || variant == 5) && g_gemm_ablate == 0 && !(a.ts_q & 1) && !(a.td & 1)) return launch_gemm_wx(a, grid, variant, s);   // pairs of stages
   if (a.ts > 0) {
     if (a.dump)
       hipLaunchKernelGGL(gemm_filter_sparse_kernel<true>, grid, dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a);
@@ -1377,22 +1398,14 @@ __global__ void __launch_bounds__(SELECT_THREADS) select_big_kernel(SelectArgs p
 hipError_t launch_select(const SelectArgs& a, hipStream_t s) {
   if (a.kp > 4096) {
     const int bytes = (a.kp + SELECT_BIG_BATCH) * 8 + 16;
-    static int big_bytes = 0;
-    if (bytes > big_bytes) {
-      hipError_t e = hipFuncSetAttribute((const void*)select_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-      if (e != hipSuccess) return e;
-      big_bytes = bytes;
-    }
+    static int big_bytes[64] = {};
+    if (hipError_t e = ensure_lds_attr((const void*)select_big_kernel, bytes, big_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(select_big_kernel, dim3((unsigned)a.n_queries), dim3(SELECT_THREADS), bytes, s, a);
     return hipGetLastError();
   }
-  static int attr_bytes = 0;
+  static int attr_bytes[64] = {};
   const int bytes = a.sort_n * 8 + 16;
-  if (bytes > attr_bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return e;
-    attr_bytes = bytes;
-  }
+  if (hipError_t e = ensure_lds_attr((const void*)select_kernel, bytes, attr_bytes); e != hipSuccess) return e;
   hipLaunchKernelGGL(select_kernel, dim3((unsigned)a.n_queries), dim3(SELECT_SM_THREADS), bytes, s, a);
   return hipGetLastError();
 }
@@ -1812,12 +1825,8 @@ hipError_t launch_merge_topk(int n_queries, int n_in, const float* in_scores, co
   while (n_pad < n_in) n_pad <<= 1;
   const int bytes = n_pad * 8;
   if (bytes > 160 * 1024) return hipErrorInvalidValue;
-  static int attr_bytes = 0;
-  if (bytes > attr_bytes) {
-    hipError_t e = hipFuncSetAttribute((const void*)merge_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return e;
-    attr_bytes = bytes;
-  }
+  static int attr_bytes[64] = {};
+  if (hipError_t e = ensure_lds_attr((const void*)merge_topk_kernel, bytes, attr_bytes); e != hipSuccess) return e;
   hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)n_queries), dim3(1024), bytes, s, n_in, n_pad, in_scores, in_rows,
                      k_out, out_scores, out_rows);
   return hipGetLastError();

@@ -150,7 +150,7 @@ def search_sharded_local(shards, q_value, q_index, k: int):
     """One process, several shard handles (dhr_search_sharded_local): -> (scores, rows) torch cuda tensors [Q, k]."""
     import torch
     lib = _lib.load()
-    qb, keep = _lib.make_query_batch(q_value, q_index)
+    qb, keep = shards[0]._qb(q_value, q_index)
     dev = torch.device("cuda", shards[0].device)
     scores = torch.empty((qb.n_queries, k), dtype=torch.float32, device=dev)
     rows = torch.empty((qb.n_queries, k), dtype=torch.int64, device=dev)
@@ -172,7 +172,7 @@ def sharded_search(index, q_value, q_index, k: int, group=None):
         return sharded_search_torch(index, q_value, q_index, k, group)
     comm = _comm_for(index, group)
     lib = _lib.load()
-    qb, keep = _lib.make_query_batch(q_value, q_index)
+    qb, keep = index._qb(q_value, q_index)
     dev = torch.device("cuda", index.device)
     scores = torch.empty((qb.n_queries, k), dtype=torch.float32, device=dev)
     rows = torch.empty((qb.n_queries, k), dtype=torch.int64, device=dev)

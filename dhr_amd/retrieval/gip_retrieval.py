@@ -36,6 +36,14 @@ class GipIndex:
         d_dlr = 0 if index is None else int(index.shape[1])
         if index is not None and emb_dim is not None and emb_dim != d_dlr:
             raise ValueError(f"--emb_dim {emb_dim} does not match the index array width {d_dlr}")
+        # the kernels take gated widths that are a multiple of 8 (16-byte operand chunks); other --emb_dim values (the reference has
+        # no such limit) are zero-padded here: [dlr | 0-pad | dense] with index value 0 on both sides -- a padded slice contributes
+        # 0 * 0 to every score, so results are unchanged
+        self._dlr_pad = 0
+        if index is not None and d_dlr % 8:
+            self._dlr_pad = 8 - d_dlr % 8
+            value, index = _pad_dlr(value, index, d_dlr, self._dlr_pad)
+            k, d_dlr = k + self._dlr_pad, d_dlr + self._dlr_pad
         desc = _lib.IndexDesc()
         desc.device = device
         desc.n_rows = n
@@ -53,7 +61,15 @@ class GipIndex:
         h = C.c_void_p()
         _lib.check(lib.dhr_index_create(C.byref(desc), C.byref(h)), "dhr_index_create")
         self._h, self._lib = h, lib
-        self.n_rows, self.k, self.d_dlr, self.device, self.row_offset = n, k, d_dlr, device, row_offset
+        self.n_rows, self.k, self.d_dlr, self.device, self.row_offset = n, k - self._dlr_pad, d_dlr - self._dlr_pad, device, row_offset
+
+    def _qb(self, q_value, q_index):
+        """Query batch for the library (padded like the corpus when --emb_dim is not a multiple of 8)."""
+        if getattr(self, "_dlr_pad", 0) and q_index is not None:
+            q_value, q_index = _pad_dlr(q_value, q_index, self.d_dlr, self._dlr_pad)
+        elif getattr(self, "_dlr_pad", 0):
+            q_value, _ = _pad_dlr(q_value, None, self.d_dlr, self._dlr_pad)
+        return _lib.make_query_batch(q_value, q_index)
 
     # ---- device-ready index file (dhr_index_save / dhr_index_load; SURVEY section 8f row 2)
     def save(self, path: str, docids=None):
@@ -110,7 +126,7 @@ class GipIndex:
     def search(self, q_value, q_index, k: int, *, out_device: bool = False, stream: int = 0):
         """-> (scores fp32 [Q,k], rows int64 [Q,k]); rows are global (row_offset added), best first,
         (-inf, -1) padding when k > n_rows.  numpy outputs unless out_device (then torch cuda tensors)."""
-        qb, keep = _lib.make_query_batch(q_value, q_index)
+        qb, keep = self._qb(q_value, q_index)
         nq = qb.n_queries
         if out_device:
             import torch
@@ -129,8 +145,8 @@ class GipIndex:
     def search_rerank(self, q1_value, q1_index, q_value, q_index, k1: int, k: int, *, stream: int = 0):
         """Two-stage search on the device (dhr_search_rerank): top-k1 of the stage-1 batch, exact GIP of the full
         batch on those rows, top-k of that.  -> (scores fp32 [Q,k], rows int64 [Q,k]) numpy."""
-        qb1, keep1 = _lib.make_query_batch(q1_value, q1_index)
-        qb2, keep2 = _lib.make_query_batch(q_value, q_index)
+        qb1, keep1 = self._qb(q1_value, q1_index)
+        qb2, keep2 = self._qb(q_value, q_index)
         nq = qb1.n_queries
         scores = np.empty((nq, k), np.float32)
         rows = np.empty((nq, k), np.int64)
@@ -147,7 +163,7 @@ class GipIndex:
         """Runs the sampled part; -> torch cuda tensor [Q, r] with this shard's r best sample scores
         (None when the shard is too small to sample: then the whole search already ran)."""
         import torch
-        qb, keep = _lib.make_query_batch(q_value, q_index)
+        qb, keep = self._qb(q_value, q_index)
         r = self.sample_rank(k)
         out = None
         if r > 0:
@@ -177,7 +193,7 @@ class GipIndex:
 
     def score_rows(self, q_value, q_index, rows):
         """Exact gated inner product of each query against its own list of (global) rows [Q, m]."""
-        qb, keep = _lib.make_query_batch(q_value, q_index)
+        qb, keep = self._qb(q_value, q_index)
         rows = np.ascontiguousarray(rows, np.int64)
         out = np.empty(rows.shape, np.float32)
         _lib.check(self._lib.dhr_score_rows(self._h, C.byref(qb), int(rows.shape[1]), rows.ctypes.data, out.ctypes.data,
@@ -188,12 +204,24 @@ class GipIndex:
     def score_rows_device(self, q_value, q_index, rows):
         """score_rows for a torch cuda int64 tensor of rows [Q, m]: -> torch cuda fp32 [Q, m] (no host round trip)."""
         import torch
-        qb, keep = _lib.make_query_batch(q_value, q_index)
+        qb, keep = self._qb(q_value, q_index)
         rows = rows.contiguous()
         out = torch.empty(rows.shape, dtype=torch.float32, device=rows.device)
         _lib.check(self._lib.dhr_score_rows(self._h, C.byref(qb), int(rows.shape[1]), rows.data_ptr(), out.data_ptr(), _lib.MEM_DEVICE, 0), "dhr_score_rows")
         del keep
         return out
+
+
+def _pad_dlr(value, index, d_dlr, pad):
+    """[dlr | dense] -> [dlr | pad zeros | dense] (numpy or torch), index -> [index | pad zeros]."""
+    if isinstance(value, np.ndarray):
+        v = np.concatenate([value[:, :d_dlr], np.zeros((value.shape[0], pad), value.dtype), value[:, d_dlr:]], axis=1)
+        i = None if index is None else np.concatenate([index, np.zeros((index.shape[0], pad), index.dtype)], axis=1)
+        return np.ascontiguousarray(v), None if i is None else np.ascontiguousarray(i)
+    import torch
+    v = torch.cat([value[:, :d_dlr], torch.zeros((value.shape[0], pad), dtype=value.dtype, device=value.device), value[:, d_dlr:]], dim=1)
+    i = None if index is None else torch.cat([index, torch.zeros((index.shape[0], pad), dtype=index.dtype, device=index.device)], dim=1)
+    return v.contiguous(), None if i is None else i.contiguous()
 
 
 def _as_f16(a):

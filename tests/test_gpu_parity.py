@@ -807,13 +807,29 @@ def test_odd_shapes(G, n, q, d_dlr, d_cls, k):
     _search_check(G, cv, ci, qv.astype(np.float32), qi, k)
 
 
-def test_unsupported_width_is_refused_loudly(G):
-    """--emb_dim that is not a multiple of 8 is outside what the kernels cover: explicit DHR_ERR_UNSUPPORTED, no silent fallback."""
-    from dhr_amd import _lib
-    cv = np.zeros((64, 100 + 28), np.float16)
-    ci = np.zeros((64, 100), np.uint8)
-    with pytest.raises(_lib.DhrError, match="multiple of 8"):
-        G.GipIndex(cv, ci)
+def test_emb_dim_not_a_multiple_of_8(G):
+    """--emb_dim that is not a multiple of 8 (the reference takes any width): the C ABI refuses it explicitly (DHR_ERR_UNSUPPORTED,
+    no silent fallback), the host mirror zero-pads the gated half on both sides and the results equal the oracle's."""
+    import ctypes as C
+    from dhr_amd import _lib, synth
+    cv, ci, qv, qi = synth.make_pair(51, 3000, 6, 100, 28)
+    lib = _lib.load()
+    desc = _lib.IndexDesc()
+    desc.device, desc.n_rows, desc.d_dlr, desc.d_cls = 0, 3000, 100, 28
+    desc.value, desc.ld_value, desc.mem_kind = _lib._ptr_ld(cv)
+    desc.index, desc.ld_index, _ = _lib._ptr_ld(ci)
+    desc.index_dtype = _lib.IDX_U8
+    h = C.c_void_p()
+    assert lib.dhr_index_create(C.byref(desc), C.byref(h)) == -2 and b"multiple of 8" in lib.dhr_last_error()
+    _search_check(G, cv, ci, qv.astype(np.float32), qi, 50)
+    ix = G.GipIndex(cv, ci)
+    assert (ix.k, ix.d_dlr) == (128, 100)
+    s2, r2 = ix.search_rerank(np.where(qv > 0.3, qv, 0).astype(np.float32), qi, qv.astype(np.float32), qi, 300, 20)
+    rows = np.arange(3000, dtype=np.int64)[None, :].repeat(6, 0)
+    ex = ix.score_rows(qv.astype(np.float32), qi, rows)
+    ix.close()
+    for i in range(6):
+        np.testing.assert_allclose(ex[i], O.gip_scores_f64(qv[i].astype(np.float32), qi[i], cv.astype(np.float32), ci), rtol=0, atol=1e-5)
 
 
 @pytest.mark.parametrize("kind", ["hybrid", "dense"])
