@@ -213,7 +213,7 @@ static int ingest(dhr_index* ix, const dhr_index_desc* d, uint32_t* d_flags /* {
 // Pass 2: the bound-GEMM operand tiles from the device copy (needs the bucket map and abs_mode).
 static int build_tiles(dhr_index* ix, hipStream_t s) {
   const int64_t n = ix->n_rows, fill = ix->n_tiles * TILE_ROWS;
-  if (ix->ts > 0)
+  if (ix->ts + ix->td > 0)       // stage layout (2:4 sparse stages and / or 32-column dense stages)
     HIP_TRY(launch_tile_rows_sparse(ix->vals_rm, ix->k_rm, 0, n, fill, ix->d_dlr, ix->d_cls, ix->ts, ix->td, ix->c_idx, ix->idx_dtype,
                                     ix->bucket_map, ix->abs_mode, (char*)ix->tiles, s));
   else
@@ -281,6 +281,13 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
     ix->ts = d->d_dlr / 32;
     ix->td = (d->d_cls + 31) / 32;                     // ungated columns in 32-column stages
     ix->kt = ix->ts * TILE_K + ix->td * 32;            // logical operand columns (two bucket columns per gated slice)
+  } else if (!has_idx && d->idx_buckets == 0) {
+    // dense-only index: the same 32-column stage images (ts = 0), so that it runs on the 8-wave kernel of the 2:4 layout
+    // (idx_buckets = 1 keeps the K-step tile layout and gemm_filter_v3_kernel)
+    ix->n_buckets = 1;
+    ix->ts = 0;
+    ix->td = (d->d_cls + 31) / 32;
+    ix->kt = ix->td * 32;
   } else {
     ix->n_buckets = has_idx ? (d->idx_buckets > 0 ? d->idx_buckets : 3) : 1;
     ix->kt = (int)round_up((int64_t)ix->n_buckets * ix->d_dlr + ix->d_cls, TILE_K);
@@ -295,7 +302,7 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
   int rc = DHR_OK;
   auto fail = [&](int code) { hipFree(stage); hipFree(d_flags); hipFree(d_hist); dhr_index_destroy(ix); return code; };
 
-  const size_t tile_bytes = ix->ts > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * SP_STAGE_A + (size_t)ix->td * SP_DENSE)
+  const size_t tile_bytes = ix->ts + ix->td > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * SP_STAGE_A + (size_t)ix->td * SP_DENSE)
                                        : (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2;
   if (hipMalloc((void**)&ix->tiles, tile_bytes) != hipSuccess)
     return fail(set_error(DHR_ERR_HIP, "hipMalloc of " + std::to_string(tile_bytes) + " bytes for the corpus tiles failed"));

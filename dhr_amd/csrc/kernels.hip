@@ -352,8 +352,8 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
       q_pack[(int64_t)q * d_dlr + j] = ((uint32_t)cv.u << 16) | (bk << 12) | ((uint32_t)iv & 0xFFFu);
     }
   }
-  if (ts > 0) {
-    // 2:4 layout.  A sparse stage holds the row's 32 slice values once, the bucket in the sign bit (the bound
+  if (ts + td > 0) {
+    // stage layout (2:4).  A sparse stage holds the row's 32 slice values once, the bucket in the sign bit (the bound
     // operand is >= 0): the GEMM expands a value v into its two bucket columns (max(v,0), max(-v,0)) in
     // registers.  Order inside a 16-slice block: [0-3, 8-11 | 4-7, 12-15], the two 16-byte chunks the two
     // lane halves of the smfmac B operand read.  An ungated batch (plain inner product over a gated index)
@@ -927,8 +927,8 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
   }
   const dim3 grid((unsigned)blocks);
   const int variant = a.variant ? a.variant : g_gemm_variant;        // per handle (dhr_index_set_param), else the library default
-  if (a.ts > 0 && (variant == 4 || variant == 5) && g_gemm_ablate == 0 && !(a.ts_q & 1) && !(a.td & 1)) return launch_gemm_wx(a, grid, variant, s);   // pairs of stages
-  if (a.ts > 0) {
+  if (a.ts + a.td > 0 && (variant == 4 || variant == 5) && g_gemm_ablate == 0 && !(a.ts_q & 1) && !(a.td & 1)) return launch_gemm_wx(a, grid, variant, s);   // pairs of stages
+  if (a.ts + a.td > 0) {
     if (a.dump)
       hipLaunchKernelGGL(gemm_filter_sparse_kernel<true>, grid, dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a);
     else if (g_gemm_ablate >= 1) {
