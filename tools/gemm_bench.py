@@ -15,7 +15,7 @@ def main():
     ap.add_argument("--k", type=int, default=1536)
     ap.add_argument("--queries", type=int, default=6980)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--variant", type=int, default=3)
+    ap.add_argument("--variant", type=int, default=5)
     ap.add_argument("--dlr", type=int, default=0, help="gated columns (with a random uint8 slice index); the rest of --k is dense")
     ap.add_argument("--idx-buckets", type=int, default=0)
     ap.add_argument("--synth", action="store_true", help="the bench's synthetic hybrid data instead of uniform random operands")
@@ -43,7 +43,8 @@ def main():
         os.environ["DHR_GEMM_TIME_OPEN"] = "1"
         ix.search(qv, qi, 1000, out_device=True)
     del cv
-    ix.set_param(_lib.PARAM_GEMM_VARIANT, a.variant)
+    if a.variant != 3:
+        ix.set_param(_lib.PARAM_GEMM_VARIANT, a.variant)
     qb, keep = _lib.make_query_batch(qv, qi)
     ms, fl = C.c_double(), C.c_double()
     _lib.check(ix._lib.dhr_debug_gemm_time(ix._h, C.byref(qb), a.iters, C.byref(ms), C.byref(fl), None), "gemm_time")
