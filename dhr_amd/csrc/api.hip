@@ -352,7 +352,7 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
   }
   // pass 2: operand tiles
   if ((rc = build_tiles(ix, s)) != DHR_OK) return fail(rc);
-  if (has_idx && d->d_dlr <= 1024) {
+  if (has_idx && d->d_dlr <= 4096) {
     const size_t hkb = (size_t)d->n_rows * HEAVY * 4, hvb = (size_t)d->n_rows * HEAVY * 2;
     if (hipMalloc((void**)&ix->heavy_key, hkb) != hipSuccess || hipMalloc((void**)&ix->heavy_val, hvb) != hipSuccess)
       return fail(set_error(DHR_ERR_HIP, "hipMalloc of the refine lists failed"));

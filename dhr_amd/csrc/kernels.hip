@@ -991,6 +991,7 @@ __device__ __forceinline__ bool flat_block(const uint32_t* __restrict__ offs, in
 // Build (once per index): per row the HEAVY largest-magnitude gated entries, as
 //   key = slice << 20 | bucket << 16 | index value (16 bits),  val = the fp16 value;  unused slots key = ~0.
 // One wave per row, HEAVY rounds of wave-wide arg-max over a register copy of the row (d_dlr <= 1024).
+template <int SL>      // key registers per lane: 16 (d_dlr <= 1024) or 64 (<= 4096)
 __global__ void __launch_bounds__(256) heavy_build_kernel(const __half* __restrict__ vals_rm, int k_rm,
                                                           const void* __restrict__ idx, int idx_dtype, int64_t n_rows,
                                                           int d_dlr, const uint8_t* __restrict__ map, int n_buckets,
@@ -999,35 +1000,36 @@ __global__ void __launch_bounds__(256) heavy_build_kernel(const __half* __restri
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   for (int64_t row = wave0; row < n_rows; row += nwaves) {
-    uint32_t key[16];        // (|fp16| bits << 16) | (1023 - slice): larger value first, lower slice on ties
+    constexpr int MAXJ = 64 * SL - 1;
+    uint32_t key[SL];        // (|fp16| bits << 16) | (MAXJ - slice): larger value first, lower slice on ties
 #pragma unroll
-    for (int sl = 0; sl < 16; ++sl) {
+    for (int sl = 0; sl < SL; ++sl) {
       const int j = lane + 64 * sl;
       key[sl] = 0u;
       if (j < d_dlr) {
         union { _Float16 h; uint16_t u; } cv; cv.h = (_Float16)__half2float(vals_rm[row * k_rm + j]);
         const uint32_t mag = cv.u & 0x7FFFu;
-        if (mag) key[sl] = (mag << 16) | (uint32_t)(1023 - j);
+        if (mag) key[sl] = (mag << 16) | (uint32_t)(MAXJ - j);
       }
     }
     for (int r = 0; r < HEAVY; ++r) {
       uint32_t best = 0u;
 #pragma unroll
-      for (int sl = 0; sl < 16; ++sl) best = key[sl] > best ? key[sl] : best;
+      for (int sl = 0; sl < SL; ++sl) best = key[sl] > best ? key[sl] : best;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { const uint32_t ob = __shfl_xor(best, o, 64); best = ob > best ? ob : best; }
       if (best == 0u) {                       // fewer than HEAVY non-zero entries: pad
         if (lane == 0) for (int rr = r; rr < HEAVY; ++rr) { heavy_key[row * HEAVY + rr] = 0xFFFFFFFFu; heavy_val[row * HEAVY + rr] = __float2half(0.f); }
         break;
       }
-      const int j = 1023 - (int)(best & 0xFFFFu);
+      const int j = MAXJ - (int)(best & 0xFFFFu);
       if ((j & 63) == lane) {                 // owner lane writes the entry and retires it
         const int iv = load_idx(idx, idx_dtype, row * d_dlr + j);
         const uint32_t bk = n_buckets > 1 ? (uint32_t)bucket_of(iv, j, map, n_buckets) : 0u;
         heavy_key[row * HEAVY + r] = ((uint32_t)j << 20) | (bk << 16) | ((uint32_t)iv & 0xFFFFu);
         heavy_val[row * HEAVY + r] = vals_rm[row * k_rm + j];
 #pragma unroll
-        for (int sl = 0; sl < 16; ++sl) if (sl == (j >> 6)) key[sl] = 0u;
+        for (int sl = 0; sl < SL; ++sl) if (sl == (j >> 6)) key[sl] = 0u;
       }
     }
   }
@@ -1036,8 +1038,12 @@ hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, 
                               const uint8_t* map, int n_buckets, uint32_t* heavy_key, __half* heavy_val, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
   const int64_t blocks = (n_rows + 3) / 4;
-  hipLaunchKernelGGL(heavy_build_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, vals_rm, k_rm,
-                     idx, idx_dtype, n_rows, d_dlr, map, n_buckets, heavy_key, heavy_val);
+  if (d_dlr <= 1024)
+    hipLaunchKernelGGL(heavy_build_kernel<16>, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, vals_rm, k_rm,
+                       idx, idx_dtype, n_rows, d_dlr, map, n_buckets, heavy_key, heavy_val);
+  else
+    hipLaunchKernelGGL(heavy_build_kernel<64>, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, vals_rm, k_rm,
+                       idx, idx_dtype, n_rows, d_dlr, map, n_buckets, heavy_key, heavy_val);
   return hipGetLastError();
 }
 
@@ -1048,7 +1054,7 @@ hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, 
 // bits, an alias there only makes the bound looser).  8 lanes per candidate, 8 heavy entries per lane.
 constexpr int REFINE_PER_WG = 256;       // candidates of ONE query per workgroup (its operand words are staged in LDS once)
 __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
-  __shared__ uint32_t qw[1024];
+  extern __shared__ uint32_t qw[];             // [d_dlr] query words (up to 4096 slices: the slice id has 12 bits in a heavy-list key)
   int q = blockIdx.y;
   uint32_t blk = blockIdx.x;
   if (p.blk_off && !flat_block(p.blk_off, p.n_queries, blockIdx.x, q, blk)) return;
@@ -1100,9 +1106,9 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
 hipError_t launch_refine(const RefineArgs& a, hipStream_t s) {
   if (a.max_count == 0 || a.n_queries <= 0) return hipSuccess;
   if (a.blk_off) {
-    if (a.flat_blocks) hipLaunchKernelGGL(refine_kernel, dim3(a.flat_blocks), dim3(256), 0, s, a);
+    if (a.flat_blocks) hipLaunchKernelGGL(refine_kernel, dim3(a.flat_blocks), dim3(256), (size_t)a.d_dlr * 4, s, a);
   } else
-    hipLaunchKernelGGL(refine_kernel, dim3((a.max_count + REFINE_PER_WG - 1) / REFINE_PER_WG, (unsigned)a.n_queries), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(refine_kernel, dim3((a.max_count + REFINE_PER_WG - 1) / REFINE_PER_WG, (unsigned)a.n_queries), dim3(256), (size_t)a.d_dlr * 4, s, a);
   return hipGetLastError();
 }
 

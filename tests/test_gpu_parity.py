@@ -793,7 +793,8 @@ def test_pq_first_stage(G, tmp_path, monkeypatch):
 
 
 @pytest.mark.parametrize("n,q,d_dlr,d_cls,k", [(300, 3, 96, 32, 10), (257, 1, 768, 0, 5), (5000, 7, 64, 8, 100), (1000, 2, 104, 24, 50),
-                                               (70, 5, 32, 96, 70), (4097, 9, 768, 8, 33), (900, 4, 104, 27, 20), (900, 4, 8, 3, 20)])
+                                               (70, 5, 32, 96, 70), (4097, 9, 768, 8, 33), (900, 4, 104, 27, 20), (900, 4, 8, 3, 20),
+                                               (6000, 5, 2048, 64, 100), (3000, 3, 4096, 0, 40)])     # gated halves wider than 1024: refine lists up to 4096 slices
 def test_odd_shapes(G, n, q, d_dlr, d_cls, k):
     """Small / ragged / unusual widths: fewer rows than a tile, no dense tail, widths that are not multiples of 32 or 64
     (d_dlr % 32 != 0 takes the dense bucket-split layout), k == n."""
