@@ -159,8 +159,15 @@ union WExp { half16 h; uint32_t w[8]; };   // one expanded query block
 // behind the pair barrier, 1 / 2: the next pair's first two blocks, 3: its third), or -1.
 //   NI = 4 (16 instructions per block, <= 18 pieces per wave): 6 + 6 + 6 behind instructions 8-13 (0-7 carry the fragment reads);
 //   NI = 2 ( 8 instructions per block, <=  9 pieces per wave): 3 + 3 + 3 behind instructions 2, 4, 6.
-template <int NI>
+#ifndef W5_PARTNER_SHIFT
+#define W5_PARTNER_SHIFT 0
+#endif
+// SH (NI = 2 only, experiment W5_PARTNER_SHIFT): the two waves of a SIMD (waves w and w + 4) issue their pieces in different blocks
+// -- SH 0: 5 behind the pair barrier (phase 0) + 4 in phase 1; SH 1: 4 late in phase 1 + 5 in phase 2.
+template <int NI, int SH = -1>
 __host__ __device__ constexpr int wx_dma_piece(int ph, int g) {
+  if (NI == 2 && SH == 0) return ph == 0 ? (g >= 1 && g <= 5 ? g - 1 : -1) : ph == 1 ? (g <= 3 ? 5 + g : -1) : -1;
+  if (NI == 2 && SH == 1) return ph == 1 ? (g >= 4 ? g - 4 : -1) : ph == 2 ? (g <= 4 ? 4 + g : -1) : -1;
   if (ph > 2) return -1;
   if (NI == 4) return (g >= 8 && g < 14) ? ph * 6 + g - 8 : -1;
   return (g == 2 || g == 4 || g == 6) ? ph * 3 + (g >> 1) - 1 : -1;
@@ -283,7 +290,8 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
     else if (g < NI + 4) f.a[g - NI] = *(const half8*)(sl + a_row + (g - NI) * 2048);
   };
   WExp bfa, bfb;       // expanded query block: bfa holds the CURRENT block's ni = 0 expansion on entry of a sparse block
-  auto blk_sparse = [&](const WFrag<NI>& fc, WFrag<NI>& fn, int tn, bool do_load, auto kb_c, auto ph_c, const uint32_t (&pw)[4]) __attribute__((always_inline)) {
+  auto blk_sparse = [&](const WFrag<NI>& fc, WFrag<NI>& fn, int tn, bool do_load, auto kb_c, auto ph_c, const uint32_t (&pw)[4], auto sh_c) __attribute__((always_inline)) {
+    constexpr int SH = decltype(sh_c)::value;
     constexpr int KB = decltype(kb_c)::value;
     constexpr int PH = decltype(ph_c)::value;
     const char* sl = smem + ((tn >> 1) & 3) * SP_SLOT + ((tn & 1) ? c1 : c0);
@@ -295,10 +303,11 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
       WExp& oth = (ni & 1) ? bfa : bfb;
       const uint32_t rw = ni < NI - 1 ? fc.b[ni < NI - 1 ? ni + 1 : 0].w[mi] : fn.b[0].w[mi];
       sm_unit<KB>(acc[mi][ni], oth.w[2 * mi], oth.w[2 * mi + 1], fc.a[mi], cur.h, pw[mi], rw);
-      if (wx_dma_piece<NI>(PH, g) >= 0) dma_piece(wx_dma_piece<NI>(PH, g));
+      if (wx_dma_piece<NI, SH>(PH, g) >= 0) dma_piece(wx_dma_piece<NI, SH>(PH, g));
     }
   };
-  auto blk_dense = [&](const WFrag<NI>& fc, WFrag<NI>& fn, int tn, bool do_load, auto ph_c) __attribute__((always_inline)) {
+  auto blk_dense = [&](const WFrag<NI>& fc, WFrag<NI>& fn, int tn, bool do_load, auto ph_c, auto sh_c) __attribute__((always_inline)) {
+    constexpr int SH = decltype(sh_c)::value;
     constexpr int PH = decltype(ph_c)::value;
     const char* sl = smem + ((tn >> 1) & 3) * SP_SLOT + ((tn & 1) ? c1 : c0);
 #pragma unroll
@@ -306,7 +315,7 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
       const int ni = g >> 2, mi = g & 3;
       if (do_load) frag_read(fn, sl, g);
       mfma_f16(acc[mi][ni], fc.a[mi], fc.b[ni].h);
-      if (wx_dma_piece<NI>(PH, g) >= 0) dma_piece(wx_dma_piece<NI>(PH, g));
+      if (wx_dma_piece<NI, SH>(PH, g) >= 0) dma_piece(wx_dma_piece<NI, SH>(PH, g));
     }
   };
 
@@ -331,33 +340,38 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
   constexpr std::integral_constant<int, 2> PH2{};
   constexpr std::integral_constant<int, 3> PH3{};
   dma_n = 0;             // nothing pending during pair 0's first blocks (pairs 0 and 1 went out above)
+  auto run_loops = [&](auto sh_c) __attribute__((always_inline)) {
 #pragma unroll 1
   for (int g = 0; g < nsp; ++g) {
     const int t0 = 4 * g;
-    blk_sparse(f0, f1, t0 + 1, true, KB0, PH1, pwx);
-    blk_sparse(f1, f0, t0 + 2, true, KB1, PH2, pwx);
+    blk_sparse(f0, f1, t0 + 1, true, KB0, PH1, pwx, sh_c);
+    blk_sparse(f1, f0, t0 + 2, true, KB1, PH2, pwx, sh_c);
     load_pw(pwy, 2 * g + 1);
-    blk_sparse(f0, f1, t0 + 3, true, KB0, PH3, pwy);
+    blk_sparse(f0, f1, t0 + 3, true, KB0, PH3, pwy, sh_c);
     // every read of this pair's ring half has been issued; the next pair must have landed before anybody reads it
     dma_prepare(g + 2);
     __builtin_amdgcn_sched_barrier(0);                    // the matrix asm is not volatile: without this the compiler sinks the block above below the wait
     W4_PAIR_SYNC();
     dma_commit();                                         // pair g+2 goes into the ring half this pair just left
     if (g + 1 < nsp) load_pw(pwx, 2 * (g + 1));
-    blk_sparse(f1, f0, t0 + 4, g + 1 < npairs, KB1, PH0, pwy);
+    blk_sparse(f1, f0, t0 + 4, g + 1 < npairs, KB1, PH0, pwy, sh_c);
   }
 #pragma unroll 1
   for (int g = nsp; g < npairs; ++g) {
     const int t0 = 4 * g;
-    blk_dense(f0, f1, t0 + 1, true, PH1);
-    blk_dense(f1, f0, t0 + 2, true, PH2);
-    blk_dense(f0, f1, t0 + 3, true, PH3);
+    blk_dense(f0, f1, t0 + 1, true, PH1, sh_c);
+    blk_dense(f1, f0, t0 + 2, true, PH2, sh_c);
+    blk_dense(f0, f1, t0 + 3, true, PH3, sh_c);
     dma_prepare(g + 2);
     __builtin_amdgcn_sched_barrier(0);
     W4_PAIR_SYNC();
     dma_commit();
-    blk_dense(f1, f0, t0 + 4, g + 1 < npairs, PH0);
+    blk_dense(f1, f0, t0 + 4, g + 1 < npairs, PH0, sh_c);
   }
+  };
+  if constexpr (NI == 2 && W5_PARTNER_SHIFT) {
+    if (wave < 4) run_loops(std::integral_constant<int, 0>{}); else run_loops(std::integral_constant<int, 1>{});
+  } else run_loops(std::integral_constant<int, -1>{});
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // the last matrix results are in the accumulators
   if (DUMP) { gemm_dump_tile_w<NI>(p, acc, dt, qt, wm, wn, lane); return; }
   gemm_epilogue_w<NI, NT>(p, acc, dt, qt, wm, wn, (int)threadIdx.x, lane, smem, thr_r);
