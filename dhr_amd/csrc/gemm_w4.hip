@@ -120,8 +120,16 @@ __device__ __forceinline__ void mfma_f16(floatx16& c, const half8& a, const half
 }
 // Issue group of a sparse block: the two expansion instructions of one register of the NEXT query block's compressed fragment
 // (value v, bucket in the sign bit -> the two bucket columns (max(v,0), max(-v,0))), then one matrix instruction of the current one.
+#ifndef W4_ABL
+#define W4_ABL 0
+#endif
 template <int KB>
 __device__ __forceinline__ void sm_unit(floatx16& c, uint32_t& o_lo, uint32_t& o_hi, const half8& a, const half16& b, uint32_t idx, uint32_t raw) {
+#if W4_ABL == 7 || W4_ABL == 9      // timing only: no expansion instructions (the expanded blocks keep their prologue contents)
+  if constexpr (KB == 0) asm("v_smfmac_f32_32x32x32_f16 %0, %1, %2, %3" : "+a"(c) : "v"(a), "v"(b), "v"(idx));
+  else asm("v_smfmac_f32_32x32x32_f16 %0, %1, %2, %3 abid:1" : "+a"(c) : "v"(a), "v"(b), "v"(idx));
+  return;
+#endif
   if constexpr (KB == 0)
     asm("v_pk_max_f16 %1, %6, 0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
         "v_pk_max_f16 %2, %6, 0 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
@@ -134,10 +142,8 @@ __device__ __forceinline__ void sm_unit(floatx16& c, uint32_t& o_lo, uint32_t& o
         : "+a"(c), "=&v"(o_lo), "=&v"(o_hi) : "v"(a), "v"(b), "v"(idx), "v"(raw));
 }
 
-// timing ablations (wrong results): W4_ABL 1 = no pair barrier, 2 = no DMA wait before it, 3 = neither, 4 = no DMA pieces in the loop
-#ifndef W4_ABL
-#define W4_ABL 0
-#endif
+// timing ablations (wrong results): W4_ABL 1 = no pair barrier, 2 = no DMA wait before it, 3 = neither, 4 = no DMA pieces in the loop,
+// 7 = 4 + no expansion instructions, 8 = 4 + no fragment reads in the loop, 9 = 4 + 7 + 8
 #if W4_ABL == 1
 #define W4_PAIR_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #elif W4_ABL == 2
@@ -224,7 +230,7 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
     nx_soff = (sp ? us * role_sp : role_dense0 + (u - tsq) * SP_DENSE) + half_bytes;
     nx_lds = smem_u + (uint32_t)((u & 3) * SP_SLOT + (dma_b ? SP_STAGE_A : 0) + half_bytes);
     nx_n = g < npairs ? ((!dma_b && sp) ? MAXP : MAXP - MAXP / 9) : 0;    // 18 / 16 or 9 / 8 KiB
-    if (W4_ABL == 4 && g >= 2) nx_n = 0;
+    if ((W4_ABL == 4 || W4_ABL >= 7) && g >= 2) nx_n = 0;
   };
   auto dma_commit = [&]() __attribute__((always_inline)) { dma_soff = nx_soff; dma_lds = nx_lds; dma_n = nx_n; };
   auto dma_piece = [&](int j) __attribute__((always_inline)) {
@@ -298,7 +304,7 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int ni = g >> 2, mi = g & 3;
-      if (do_load) frag_read(fn, sl, g);
+      if (do_load && W4_ABL != 8 && W4_ABL != 9) frag_read(fn, sl, g);
       WExp& cur = (ni & 1) ? bfb : bfa;
       WExp& oth = (ni & 1) ? bfa : bfb;
       const uint32_t rw = ni < NI - 1 ? fc.b[ni < NI - 1 ? ni + 1 : 0].w[mi] : fn.b[0].w[mi];
@@ -313,7 +319,7 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int ni = g >> 2, mi = g & 3;
-      if (do_load) frag_read(fn, sl, g);
+      if (do_load && W4_ABL != 8 && W4_ABL != 9) frag_read(fn, sl, g);
       mfma_f16(acc[mi][ni], fc.a[mi], fc.b[ni].h);
       if (wx_dma_piece<NI, SH>(PH, g) >= 0) dma_piece(wx_dma_piece<NI, SH>(PH, g));
     }
@@ -333,6 +339,7 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
     for (int g = 0; g < NI + 4; ++g) frag_read(f0, sl, g);
   }
   if (nsp > 0) expand_bucket_columns(f0.b[0].w, bfa.w);
+  if (W4_ABL >= 7) { if (nsp > 0) expand_bucket_columns(f0.b[1].w, bfb.w); f1 = f0; }     // the ablations reuse these registers for the whole tile
   constexpr std::integral_constant<int, 0> KB0{};
   constexpr std::integral_constant<int, 1> KB1{};
   constexpr std::integral_constant<int, 0> PH0{};
