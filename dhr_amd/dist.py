@@ -168,8 +168,9 @@ def sharded_search(index, q_value, q_index, k: int, group=None):
     torch.distributed restatement of the same steps (testing)."""
     import torch
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size(group) > 1 and dist.get_backend(group) != "nccl":
-        return sharded_search_torch(index, q_value, q_index, k, group)
+    import os
+    if dist.is_initialized() and dist.get_world_size(group) > 1 and (dist.get_backend(group) != "nccl" or os.environ.get("DHR_SHARDED_IMPL") == "torch"):
+        return sharded_search_torch(index, q_value, q_index, k, group)      # gloo (CPU tests), or forced for A/B debugging on RCCL
     comm = _comm_for(index, group)
     lib = _lib.load()
     qb, keep = index._qb(q_value, q_index)
