@@ -520,7 +520,7 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   // so that the fullest list fits, so a 1/8 shard gets 1/8 of the depth (floor: 32768 / 16384) instead of the full-corpus workspace
   // (measured at config 3: depth 262 144 / 131 072 / 65 536 = 195.2 / 196.5 / 196.2 ms per step, 100.2 / 85.2 / 77.7 GB)
   const int64_t by_rows = std::max<int64_t>(ix->n_rows / 128, refine ? 32768 : 16384);
-  while (base_cap / 2 >= by_rows) base_cap >>= 1;
+  while (base_cap > by_rows && base_cap > 4096) base_cap >>= 1;          // power-of-two floor of n_rows / 128 (65 536 at 8.84 M rows)
   while (base_cap > 4096 && (int64_t)q_pad * base_cap * 16 > ((int64_t)32 << 30)) base_cap >>= 1;
   if (ix->cand_cap > 0) base_cap = ix->cand_cap;
   // fallback depths serve a handful of queries: 16x deeper lists there cost little memory
@@ -993,7 +993,7 @@ extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, f
   int rc = check_queries(ix, qb);
   if (rc) return rc;
   if (k <= 0) return set_error(DHR_ERR_INVALID, "k must be > 0");
-  if (k > 16384) return set_error(DHR_ERR_UNSUPPORTED, "k > 16384 is not supported by the LDS top-k merge");
+  if (k > (1 << 20)) return set_error(DHR_ERR_UNSUPPORTED, "k > 1048576 is not supported");      // k > 16384: global-memory merge (select_global.hip)
   if (!out_scores || !out_rows) return set_error(DHR_ERR_INVALID, "null output pointer");
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = (hipStream_t)stream;
@@ -1045,7 +1045,7 @@ extern "C" int dhr_search_rerank(dhr_index* ix, const dhr_query_batch* qb1, cons
   if ((rc = check_queries(ix, qb2)) != DHR_OK) return rc;
   if (qb1->n_queries != qb2->n_queries) return set_error(DHR_ERR_INVALID, "the two query batches differ in n_queries");
   if (k <= 0 || k1 < k) return set_error(DHR_ERR_INVALID, "need 0 < k <= k1");
-  if (k1 > 16384) return set_error(DHR_ERR_UNSUPPORTED, "k1 > 16384 is not supported by the LDS top-k merge");
+  if (k1 > (1 << 20)) return set_error(DHR_ERR_UNSUPPORTED, "k1 > 1048576 is not supported");
   if (!out_scores || !out_rows) return set_error(DHR_ERR_INVALID, "null output pointer");
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = (hipStream_t)stream;

@@ -162,6 +162,7 @@ struct RefineArgs {
 hipError_t launch_refine(const RefineArgs& a, hipStream_t s);
 hipError_t launch_rescore(const RescoreArgs& a, hipStream_t s);
 hipError_t launch_select(const SelectArgs& a, hipStream_t s);
+hipError_t launch_select_global(const SelectArgs& a, hipStream_t s);    // k > 16384 (select_global.hip)
 hipError_t launch_emit(const uint64_t* topk_keys, int kp, int n_queries, int k, int64_t row_offset, float* out_scores,
                        int64_t* out_rows, hipStream_t s);
 hipError_t launch_keys_to_rows(const uint64_t* topk_keys, int kp, int n_queries, int k, uint32_t* rows, hipStream_t s);

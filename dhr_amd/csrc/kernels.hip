@@ -1402,6 +1402,7 @@ __global__ void __launch_bounds__(SELECT_THREADS) select_big_kernel(SelectArgs p
 }
 
 hipError_t launch_select(const SelectArgs& a, hipStream_t s) {
+  if (a.kp > 16384) return launch_select_global(a, s);       // beyond the LDS: concatenate + segmented sort (select_global.hip)
   if (a.kp > 4096) {
     const int bytes = (a.kp + SELECT_BIG_BATCH) * 8 + 16;
     static int big_bytes[64] = {};

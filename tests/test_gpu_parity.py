@@ -450,9 +450,10 @@ def test_sampling_on_off_same_result(G):
     print([o[2]["candidates_exact"] for o in out], [o[2]["phases"] for o in out])
 
 
-@pytest.mark.parametrize("k", [4097, 10000, 16384])
+@pytest.mark.parametrize("k", [4097, 10000, 16384, 16385, 30000])
 def test_large_k(G, k):
-    """k beyond the single-pass LDS merge (the documented --agip_topk default is 10000)."""
+    """k beyond the single-pass LDS merge (the documented --agip_topk default is 10000) and beyond the LDS altogether
+    (k > 16384: global-memory merge, select_global.hip; the reference's torch.topk takes any k)."""
     from dhr_amd import synth
     cv, ci, qv, qi = synth.make_pair(17, 40_000, 6, 768, 64)
     _search_check(G, cv, ci, qv.astype(np.float32), qi, k, queries=[0, 5])
@@ -1085,3 +1086,16 @@ def test_search_sharded_rccl_single_rank(G):
             np.testing.assert_array_equal(ss.cpu().numpy(), fs)
     finally:
         ix.close()
+
+
+def test_two_stage_agip_topk_beyond_16384(G):
+    """--theta 0.3 --rerank --agip_topk 20000 (stage-1 list beyond the LDS merge) against the oracle, two-stage tie-band rule."""
+    from dhr_amd import synth
+    cv, ci, qv, qi = synth.make_pair(61, 30_000, 3, 768, 128)
+    q32 = qv.astype(np.float32)
+    info = dict(topk=200, theta=0.3, rerank=True, agip_topk=20000)
+    qids = ["a", "b", "c"]
+    res, sc = G.GIP_retrieval(qids, q32, qi, cv, ci, case_args(info))
+    c32 = cv.astype(np.float32)
+    for i, qid in enumerate(qids):
+        _check_theta_mode(info, q32[i], qi[i], c32, ci, res[qid], sc[qid])
