@@ -52,6 +52,7 @@ struct Workspace {
   uint8_t* q_idx8 = nullptr;
   uint32_t* q_inexact = nullptr;
   float *margin = nullptr, *tau = nullptr, *thr = nullptr;
+  float* i8_mul = nullptr;               // dense_i8 indexes: per-query factor (corpus scale x query scale) of the int8 stages
   uint32_t* cnt = nullptr;
   uint2* cand = nullptr;
   uint64_t *rs_keys = nullptr, *topk_keys = nullptr;
@@ -94,6 +95,10 @@ struct dhr_index {
   __half* heavy_val = nullptr;
   bool abs_mode = false;
   float dmax = 0.f;
+  // dense_i8: the ungated stages of the bound operands are int8 images (64 columns per stage) -- scale of the corpus image, corpus-wide
+  // maxima of ||d - scale*d8|| and ||scale*d8|| over the ungated part of a row (the filter margin pays for them, query_prep_kernel)
+  bool dense_i8 = false;
+  float i8_scale = 0.f, i8_ec = 0.f, i8_nc = 0.f;
   int64_t index_bytes = 0;
   // params
   int64_t cand_cap = 0, first_rows = 0;   // 0 = default (262144 with refine lists, else 65536)
@@ -115,7 +120,7 @@ struct dhr_index {
 };
 
 static void free_ws(Workspace& w) {
-  hipFree(w.q_tiles); hipFree(w.q32); hipFree(w.q_idx); hipFree(w.q16); hipFree(w.q_idx8); hipFree(w.q_inexact); hipFree(w.margin); hipFree(w.tau); hipFree(w.thr);
+  hipFree(w.q_tiles); hipFree(w.q32); hipFree(w.q_idx); hipFree(w.q16); hipFree(w.q_idx8); hipFree(w.q_inexact); hipFree(w.margin); hipFree(w.i8_mul); hipFree(w.tau); hipFree(w.thr);
   hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2); hipFree(w.q_pack); hipFree(w.cand_r); hipFree(w.cnt_r); hipFree(w.blk_off);
   if (w.h_pinned) hipHostFree(w.h_pinned);
   if (w.h_pinned2) hipHostFree(w.h_pinned2);
@@ -143,6 +148,25 @@ extern "C" void dhr_index_destroy(dhr_index* ix) {
   if (ix->s_gemm) hipStreamDestroy(ix->s_gemm);
   hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map); hipFree(ix->heavy_key); hipFree(ix->heavy_val);
   delete ix;
+}
+
+static int g_opt_dense_i8 = -1;      // -1: gated indexes with ungated columns only; 0: never; 1: dense-only indexes too
+extern "C" int dhr_set_option(int32_t option, int64_t value) {
+  if (option == DHR_OPT_DENSE_I8) { g_opt_dense_i8 = value < 0 ? -1 : (value != 0); return DHR_OK; }
+  return set_error(DHR_ERR_INVALID, "unknown option");
+}
+extern "C" int dhr_index_get_info(const dhr_index* ix, int32_t what, double* out) {
+  if (!ix || !out) return set_error(DHR_ERR_INVALID, "null argument");
+  switch (what) {
+    case DHR_INFO_DENSE_I8: *out = ix->dense_i8 ? 1.0 : 0.0; return DHR_OK;
+    case DHR_INFO_I8_SCALE: *out = ix->i8_scale; return DHR_OK;
+    case DHR_INFO_I8_ROW_ERR: *out = ix->i8_ec; return DHR_OK;
+    case DHR_INFO_I8_ROW_NORM: *out = ix->i8_nc; return DHR_OK;
+    case DHR_INFO_ROW_NORM_MAX: *out = ix->dmax; return DHR_OK;
+    case DHR_INFO_TILE_BYTES: *out = (double)(ix->ts + ix->td > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * SP_STAGE_A + (size_t)ix->td * SP_DENSE)
+                                                                      : (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2); return DHR_OK;
+  }
+  return set_error(DHR_ERR_INVALID, "unknown info id");
 }
 
 extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) {
@@ -215,7 +239,7 @@ static int build_tiles(dhr_index* ix, hipStream_t s) {
   const int64_t n = ix->n_rows, fill = ix->n_tiles * TILE_ROWS;
   if (ix->ts + ix->td > 0)       // stage layout (2:4 sparse stages and / or 32-column dense stages)
     HIP_TRY(launch_tile_rows_sparse(ix->vals_rm, ix->k_rm, 0, n, fill, ix->d_dlr, ix->d_cls, ix->ts, ix->td, ix->c_idx, ix->idx_dtype,
-                                    ix->bucket_map, ix->abs_mode, (char*)ix->tiles, s));
+                                    ix->bucket_map, ix->abs_mode, (char*)ix->tiles, ix->dense_i8 ? 1.f / ix->i8_scale : 0.f, s));
   else
     HIP_TRY(launch_tile_rows(ix->vals_rm, ix->k_rm, 0, n, fill, ix->d_dlr, ix->d_cls, ix->n_buckets, ix->kt, ix->c_idx, ix->idx_dtype,
                              ix->bucket_map, ix->abs_mode, ix->tiles, s));
@@ -276,17 +300,23 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
   // default for gated indexes: two buckets on the sparse matrix cores (needs 32-slice stages);
   // idx_buckets = 1,3,4,... selects the dense bucket-split operands instead
   const bool sparse_ok = has_idx && (d->d_dlr % 32 == 0);
+  // int8 image of the ungated columns (process-wide option / DHR_DENSE_I8; default: gated indexes only, where the gated part
+  // dominates the spread of the scores and the int8 margin costs few extra candidates -- DESIGN.md section 6b)
+  int want_i8 = g_opt_dense_i8;
+  if (const char* e = getenv("DHR_DENSE_I8")) want_i8 = atoi(e);
   if (sparse_ok && (d->idx_buckets == 0 || d->idx_buckets == 2)) {
     ix->n_buckets = 2;
     ix->ts = d->d_dlr / 32;
-    ix->td = (d->d_cls + 31) / 32;                     // ungated columns in 32-column stages
-    ix->kt = ix->ts * TILE_K + ix->td * 32;            // logical operand columns (two bucket columns per gated slice)
+    ix->dense_i8 = d->d_cls > 0 && !(ix->ts & 1) && (want_i8 < 0 || want_i8 > 0);   // stage pairs: the int8 stages run on the 8 / 4-wave kernels only
+    ix->td = ix->dense_i8 ? 2 * ((d->d_cls + 127) / 128) : (d->d_cls + 31) / 32;     // ungated columns in 32-column fp16 stages or PAIRS of 64-column int8 stages
+    ix->kt = ix->ts * TILE_K + ix->td * 32;            // operand bytes / 2 per row (fp16: logical columns, two bucket columns per gated slice)
   } else if (!has_idx && d->idx_buckets == 0) {
     // dense-only index: the same 32-column stage images (ts = 0), so that it runs on the 8-wave kernel of the 2:4 layout
     // (idx_buckets = 1 keeps the K-step tile layout and gemm_filter_v3_kernel)
     ix->n_buckets = 1;
     ix->ts = 0;
-    ix->td = (d->d_cls + 31) / 32;
+    ix->dense_i8 = want_i8 > 0;
+    ix->td = ix->dense_i8 ? 2 * ((d->d_cls + 127) / 128) : (d->d_cls + 31) / 32;
     ix->kt = ix->td * 32;
   } else {
     ix->n_buckets = has_idx ? (d->idx_buckets > 0 ? d->idx_buckets : 3) : 1;
@@ -329,12 +359,27 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
       hipMalloc(&stage, (size_t)std::min<int64_t>(block_rows, d->n_rows) * ix->k * 2) != hipSuccess)
     return fail(set_error(DHR_ERR_HIP, "hipMalloc of the staging buffer failed"));
   if ((rc = ingest(ix, d, d_flags, stage, block_rows, s)) != DHR_OK) return fail(rc);
-  uint32_t flags[2] = {0, 0};
-  if (hipMemcpy(flags, d_flags, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMemcpy failed"));
+  uint32_t flags[4] = {0, 0, 0, 0};
+  if (hipMemcpy(flags, d_flags, 16, hipMemcpyDeviceToHost) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMemcpy failed"));
   float max_sq;
   memcpy(&max_sq, &flags[0], 4);
   ix->dmax = std::sqrt(max_sq) * 1.0005f + 1e-30f;
   ix->abs_mode = flags[1] != 0;     // negative gated values: the bound needs |q|.|d| on the gated half
+  if (ix->dense_i8) {
+    float amax;
+    memcpy(&amax, &flags[2], 4);
+    float gmax;
+    memcpy(&gmax, &flags[3], 4);
+    ix->i8_scale = std::max(amax > 0.f ? amax / 127.f : 1.f, gmax / 60000.f);      // gated values must fit fp16 in units of the scale
+    if (hipMemsetAsync(d_flags, 0, 16, s) != hipSuccess ||
+        launch_i8_row_err(ix->vals_rm, ix->k_rm, ix->n_rows, ix->d_dlr, ix->d_cls, ix->i8_scale, 1.f / ix->i8_scale, d_flags, s) != hipSuccess ||
+        hipMemcpy(flags, d_flags, 8, hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(set_error(DHR_ERR_HIP, "int8 row-error pass failed"));
+    float e2, n2;
+    memcpy(&e2, &flags[0], 4); memcpy(&n2, &flags[1], 4);
+    ix->i8_ec = std::sqrt(e2) * 1.001f;
+    ix->i8_nc = std::sqrt(n2) * 1.001f;
+  }
   // bucket maps from the value mass per (slice, index value)
   if (has_idx && ix->n_buckets > 1 && idx_esize(d->index_dtype) == 1) {
     const size_t hb = (size_t)d->d_dlr * 256 * 4;
@@ -537,6 +582,7 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.q_idx8, (size_t)q_pad * std::max(ix->d_dlr, 8), tot));
   HIP_TRY(re_malloc(w.q_inexact, 16, tot));
   HIP_TRY(re_malloc(w.margin, (size_t)q_pad * 4, tot));
+  HIP_TRY(re_malloc(w.i8_mul, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.tau, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.thr, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.cnt, (size_t)q_pad * 4, tot));
@@ -613,7 +659,8 @@ static int prep_queries(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, 
   HIP_TRY(launch_query_prep(v, qb->value_dtype == DHR_VAL_F32, ldv, (ix->d_dlr > 0 && qb->index) ? qi : nullptr, qb->index_dtype, ldi,
                             qb->n_queries, w.q_pad, ix->d_dlr, ix->d_cls, ix->k_rm, ix->n_buckets, ix->kt, ix->bucket_map,
                             ix->abs_mode, ix->dmax, w.q_tiles, w.q32,
-                            w.q_idx, w.margin, w.tau, w.thr, ix->ts, ix->td, w.q_pack, w.q16, w.q_idx8, w.q_inexact, ix->idx_dtype, s));
+                            w.q_idx, w.margin, w.tau, w.thr, ix->ts, ix->td, w.q_pack, w.q16, w.q_idx8, w.q_inexact, ix->idx_dtype,
+                            ix->dense_i8 ? ix->i8_scale : 0.f, ix->i8_ec, ix->i8_nc, w.i8_mul, s));
   return DHR_OK;
 }
 
@@ -647,7 +694,7 @@ static RescoreArgs base_rescore_args(const dhr_index* ix, const Workspace& w, in
 static int gemm_phase(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi, int map_mode, int period, int64_t head,
                       Timer& tm, dhr_search_stats& st, hipStream_t s, uint32_t* maxc, unsigned long long* sumc) {
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = ix->dense_i8 ? w.i8_mul : nullptr;
   g.seq_lo = lo; g.seq_hi = hi; g.map_mode = map_mode; g.period = period; g.head = head; g.n_tiles = ix->n_tiles;
   g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt;
   g.cap = (uint32_t)w.cap; g.n_queries = Q;
@@ -913,7 +960,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       const int64_t lo = bound[i], hi = bound[i + 1];
       if (i >= 2) HIP_TRY(hipStreamWaitEvent(sg, ev_done[i - 2], 0));      // list set is free again
       GemmArgs g{};
-      g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant;
+      g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = ix->dense_i8 ? w.i8_mul : nullptr;
       g.seq_lo = lo; g.seq_hi = hi; g.map_mode = 2; g.period = S; g.head = head; g.n_tiles = ix->n_tiles;
       g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr_hat; g.cand = cand; g.cnt = cnt;
       g.cap = (uint32_t)w.cap; g.n_queries = Q;
@@ -1427,7 +1474,7 @@ extern "C" int dhr_debug_bound_scores(dhr_index* ix, const dhr_query_batch* qb, 
   if ((rc = ensure_ws(ix, w, qb->n_queries, 1, 0)) != DHR_OK) return rc;
   if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.seq_lo = row_lo / TILE_ROWS;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = ix->dense_i8 ? w.i8_mul : nullptr; g.seq_lo = row_lo / TILE_ROWS;
   g.seq_hi = (row_hi + TILE_ROWS - 1) / TILE_ROWS; g.map_mode = 0; g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
   g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
   g.dump = out_dev; g.dump_ld = row_hi - row_lo; g.dump_row0 = row_lo;
@@ -1459,7 +1506,7 @@ extern "C" int dhr_debug_gemm_time(dhr_index* ix, const dhr_query_batch* qb, int
   }
   HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.seq_lo = 0; g.seq_hi = ix->n_tiles; g.map_mode = 0;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = ix->dense_i8 ? w.i8_mul : nullptr; g.seq_lo = 0; g.seq_hi = ix->n_tiles; g.map_mode = 0;
   g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
   g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
   HIP_TRY(launch_gemm_filter(g, s));                      // warm-up

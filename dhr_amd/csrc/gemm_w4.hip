@@ -21,8 +21,10 @@ namespace dhr {
 // whatever sits between two matrix instructions beyond the ~32 cycles the first one executes idles the matrix pipe
 // (measured on the first cut of NI = 4: 8 expansions + 2 DMA pieces in a row between groups of 4 matrix instructions cost
 // a third of the pipe's time).
-template <int NI>
-__device__ __forceinline__ void gemm_dump_tile_w(const GemmArgs& p, floatx16 (&acc)[4][NI], int64_t dt, int qt, int wm, int wn, int lane) {
+constexpr float I8_MAGIC = 12582912.f;      // 2^23 + 2^22 = 0x4B400000: int32 adds of |sum| < 2^22 on these bits are exact fp32 adds
+template <int NI, bool I8>
+__device__ __forceinline__ void gemm_dump_tile_w(const GemmArgs& p, floatx16 (&acc)[4][NI], int64_t dt, int qt, int wm, int wn, int lane,
+                                                 const float (&mul_r)[NI]) {
   const int fhalf = lane >> 5;
   const int64_t row_base = dt * TILE_ROWS + wm * 128;
 #pragma unroll
@@ -35,16 +37,16 @@ __device__ __forceinline__ void gemm_dump_tile_w(const GemmArgs& p, floatx16 (&a
         for (int e = 0; e < 16; ++e) {
           const int64_t row = row_base + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
           if (row < p.n_rows && row >= p.dump_row0 && row - p.dump_row0 < p.dump_ld)
-            p.dump[(int64_t)q * p.dump_ld + (row - p.dump_row0)] = acc[mi][ni][e];
+            p.dump[(int64_t)q * p.dump_ld + (row - p.dump_row0)] = I8 ? (acc[mi][ni][e] - I8_MAGIC) * mul_r[ni] : acc[mi][ni][e];
         }
     }
   }
 }
 // Filter epilogue, same scheme as gemm_epilogue (private hit stacks in the idle ring, one global atomic per thread and
 // query), for NT consumer threads holding 4 x NI blocks each.
-template <int NI, int NT>
+template <int NI, int NT, bool I8>
 __device__ __forceinline__ void gemm_epilogue_w(const GemmArgs& p, floatx16 (&acc)[4][NI], int64_t dt, int qt, int wm, int wn,
-                                                int tid, int lane, char* smem, const float (&thr_r)[NI]) {
+                                                int tid, int lane, char* smem, const float (&thr_r)[NI], const float (&mul_r)[NI]) {
   __syncthreads();                       // every wave is done with the staging ring
   const int fhalf = lane >> 5;
   const int64_t row0 = dt * TILE_ROWS;
@@ -79,10 +81,11 @@ __device__ __forceinline__ void gemm_epilogue_w(const GemmArgs& p, floatx16 (&ac
                 asm volatile("");
                 const int rl = wm * 128 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
                 if (rl < rows_valid) {
-                  if (j < EPI_STACK) stack[j * NT] = make_uint2((uint32_t)rl, __float_as_uint(v));
+                  const float vs = I8 ? (v - I8_MAGIC) * mul_r[ni] : v;          // the candidate lists carry score units
+                  if (j < EPI_STACK) stack[j * NT] = make_uint2((uint32_t)rl, __float_as_uint(vs));
                   else {
                     const uint32_t slot = atomicAdd(p.cnt + q, 1u);
-                    if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(row0 + rl), __float_as_uint(v));
+                    if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(row0 + rl), __float_as_uint(vs));
                   }
                   ++j;
                 }
@@ -117,6 +120,11 @@ __device__ __forceinline__ void gemm_epilogue_w(const GemmArgs& p, floatx16 (&ac
 // does not read them; expand_bucket_columns ends with s_nop 1), matrix write -> VALU read (s_nop padding before the epilogue).
 __device__ __forceinline__ void mfma_f16(floatx16& c, const half8& a, const half8& b) {
   asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// int8 stages of a dense_i8 index: the same 16-byte fragments, 32 columns deep; the accumulator registers hold int32 sums until
+// the conversion between the dense and the gated stages
+__device__ __forceinline__ void mfma_i8(floatx16& c, const half8& a, const half8& b) {
+  asm("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 // Issue group of a sparse block: the two expansion instructions of one register of the NEXT query block's compressed fragment
 // (value v, bucket in the sign bit -> the two bucket columns (max(v,0), max(-v,0))), then one matrix instruction of the current one.
@@ -179,7 +187,10 @@ __host__ __device__ constexpr int wx_dma_piece(int ph, int g) {
   return (g == 2 || g == 4 || g == 6) ? ph * 3 + (g >> 1) - 1 : -1;
 }
 
-template <bool DUMP, int NI>
+// I8 (dense_i8 indexes): the td ungated stages are int8 images (64 columns per stage) and run FIRST, on v_mfma_i32_32x32x32_i8 at
+// twice the fp16 instruction's columns per issue; then every accumulator is converted once, fp32(sum) * i8_mul[query], and the
+// gated stages accumulate on top in fp32.  Stage unit u of the tile: u < td dense, else sparse stage u - td.
+template <bool DUMP, int NI, bool I8>
 __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(4 / NI, 4 / NI))) gemm_filter_wx_kernel(GemmArgs p) {
   constexpr int NWAVES = 16 / NI;            // 4 or 8
   constexpr int NT = 64 * NWAVES;
@@ -207,6 +218,8 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
   const char* b_src = (const char*)p.b_tiles + (int64_t)qt * ((int64_t)tsq * SP_STAGE_B + (int64_t)td * SP_DENSE);
   const int wm = wave / WN, wn = wave % WN;
   const int npairs = nst >> 1, nsp = tsq >> 1;     // pairs are homogeneous: the launcher selects this kernel only when tsq and td are even
+  const int u_sp0 = I8 ? td : 0;                   // first sparse stage unit; dense units are [tsq, nst) or, I8, [0, td)
+  const int sp_lo = u_sp0 >> 1, sp_hi = sp_lo + nsp, dn_lo = I8 ? 0 : nsp, dn_hi = I8 ? (td >> 1) : npairs;
 
   // ---- LDS-DMA, fixed roles.  NI = 4: wave w streams the whole image (w & 1 ? query : corpus) of stage 2g + (w >> 1);
   // NI = 2: wave w streams half (w & 1) of image ((w >> 1) & 1 ? query : corpus) of stage 2g + (w >> 2).  Buffer form of the
@@ -224,10 +237,11 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
   uint32_t dma_lds = 0, nx_lds = 0;
   auto dma_prepare = [&](int g) __attribute__((always_inline)) {      // this wave's source / destination / piece count of pair g
     const int u = 2 * g + dma_s;
-    const bool sp = u < tsq;
-    const int us = (!dma_b && u >= ts) ? u - ts : u;                   // an ungated batch runs the corpus's sparse stages twice
+    const bool sp = u >= u_sp0 && u < u_sp0 + tsq;
+    const int usp = u - u_sp0;
+    const int us = (!dma_b && usp >= ts) ? usp - ts : usp;             // an ungated batch runs the corpus's sparse stages twice
     const int half_bytes = NI == 4 ? 0 : dma_h * ((!dma_b && sp) ? SP_STAGE_A / 2 : 8192);
-    nx_soff = (sp ? us * role_sp : role_dense0 + (u - tsq) * SP_DENSE) + half_bytes;
+    nx_soff = (sp ? us * role_sp : role_dense0 + (I8 ? u : u - tsq) * SP_DENSE) + half_bytes;
     nx_lds = smem_u + (uint32_t)((u & 3) * SP_SLOT + (dma_b ? SP_STAGE_A : 0) + half_bytes);
     nx_n = g < npairs ? ((!dma_b && sp) ? MAXP : MAXP - MAXP / 9) : 0;    // 18 / 16 or 9 / 8 KiB
     if ((W4_ABL == 4 || W4_ABL >= 7) && g >= 2) nx_n = 0;
@@ -263,11 +277,20 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = I8 ? I8_MAGIC : 0.f;
   float thr_r[NI];                                // this lane's query thresholds for the filter epilogue, fetched now
+  float mul_r[NI];                                // I8: accumulator units -> score units of this lane's queries
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    thr_r[ni] = p.thr[qt * TILE_ROWS + wn * (32 * NI) + ni * 32 + (lane & 31)];
+    const int q = qt * TILE_ROWS + wn * (32 * NI) + ni * 32 + (lane & 31);
+    thr_r[ni] = p.thr[q];
+    if constexpr (I8) {
+      // the accumulators run in units of mul (corpus scale x query scale) above I8_MAGIC; the roundings here and in the fp32
+      // accumulation on top of the 2^23-sized offset are paid by the filter margin (query_prep_kernel)
+      mul_r[ni] = p.i8_mul[q];
+      thr_r[ni] = fmaf(thr_r[ni], 1.f / mul_r[ni], I8_MAGIC);
+      asm volatile("" : "+v"(mul_r[ni]));
+    } else mul_r[ni] = 1.f;
     asm volatile("" : "+v"(thr_r[ni]));
   }
 
@@ -320,7 +343,7 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
     for (int g = 0; g < NG; ++g) {
       const int ni = g >> 2, mi = g & 3;
       if (do_load && W4_ABL != 8 && W4_ABL != 9) frag_read(fn, sl, g);
-      mfma_f16(acc[mi][ni], fc.a[mi], fc.b[ni].h);
+      if constexpr (I8) mfma_i8(acc[mi][ni], fc.a[mi], fc.b[ni].h); else mfma_f16(acc[mi][ni], fc.a[mi], fc.b[ni].h);
       if (wx_dma_piece<NI, SH>(PH, g) >= 0) dma_piece(wx_dma_piece<NI, SH>(PH, g));
     }
   };
@@ -332,13 +355,13 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
   } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   WFrag<NI> f0, f1;
-  if (nsp > 0) load_pw(pwx, 0);
+  if (nsp > 0 && sp_lo == 0) load_pw(pwx, 0);
   {
     const char* sl = smem + c0;
 #pragma unroll
     for (int g = 0; g < NI + 4; ++g) frag_read(f0, sl, g);
   }
-  if (nsp > 0) expand_bucket_columns(f0.b[0].w, bfa.w);
+  if (nsp > 0 && sp_lo == 0) expand_bucket_columns(f0.b[0].w, bfa.w);
   if (W4_ABL >= 7) { if (nsp > 0) expand_bucket_columns(f0.b[1].w, bfb.w); f1 = f0; }     // the ablations reuse these registers for the whole tile
   constexpr std::integral_constant<int, 0> KB0{};
   constexpr std::integral_constant<int, 1> KB1{};
@@ -347,9 +370,9 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
   constexpr std::integral_constant<int, 2> PH2{};
   constexpr std::integral_constant<int, 3> PH3{};
   dma_n = 0;             // nothing pending during pair 0's first blocks (pairs 0 and 1 went out above)
-  auto run_loops = [&](auto sh_c) __attribute__((always_inline)) {
+  auto run_sparse = [&](auto sh_c) __attribute__((always_inline)) {
 #pragma unroll 1
-  for (int g = 0; g < nsp; ++g) {
+  for (int g = sp_lo; g < sp_hi; ++g) {
     const int t0 = 4 * g;
     blk_sparse(f0, f1, t0 + 1, true, KB0, PH1, pwx, sh_c);
     blk_sparse(f1, f0, t0 + 2, true, KB1, PH2, pwx, sh_c);
@@ -360,11 +383,13 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
     __builtin_amdgcn_sched_barrier(0);                    // the matrix asm is not volatile: without this the compiler sinks the block above below the wait
     W4_PAIR_SYNC();
     dma_commit();                                         // pair g+2 goes into the ring half this pair just left
-    if (g + 1 < nsp) load_pw(pwx, 2 * (g + 1));
+    if (g + 1 < sp_hi) load_pw(pwx, 2 * (g + 1));
     blk_sparse(f1, f0, t0 + 4, g + 1 < npairs, KB1, PH0, pwy, sh_c);
   }
+  };
+  auto run_dense = [&](auto sh_c) __attribute__((always_inline)) {
 #pragma unroll 1
-  for (int g = nsp; g < npairs; ++g) {
+  for (int g = dn_lo; g < dn_hi; ++g) {
     const int t0 = 4 * g;
     blk_dense(f0, f1, t0 + 1, true, PH1, sh_c);
     blk_dense(f1, f0, t0 + 2, true, PH2, sh_c);
@@ -376,12 +401,28 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
     blk_dense(f1, f0, t0 + 4, g + 1 < npairs, PH0, sh_c);
   }
   };
+  auto run_loops = [&](auto sh_c) __attribute__((always_inline)) {
+    if constexpr (I8) {
+      run_dense(sh_c);
+      // No conversion: the accumulators were started at the bit pattern of 2^23 + 2^22 (I8_MAGIC), and while |sum| < 2^22 an int32
+      // add on those bits IS the fp32 number I8_MAGIC + sum -- the gated stages go on accumulating in fp32 on the same registers.
+      // f0 already holds the first sparse block's fragments (read under the last dense block).
+      if (nsp > 0) {
+        load_pw(pwx, u_sp0);
+        expand_bucket_columns(f0.b[0].w, bfa.w);
+      }
+      run_sparse(sh_c);
+    } else {
+      run_sparse(sh_c);
+      run_dense(sh_c);
+    }
+  };
   if constexpr (NI == 2 && W5_PARTNER_SHIFT) {
     if (wave < 4) run_loops(std::integral_constant<int, 0>{}); else run_loops(std::integral_constant<int, 1>{});
   } else run_loops(std::integral_constant<int, -1>{});
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // the last matrix results are in the accumulators
-  if (DUMP) { gemm_dump_tile_w<NI>(p, acc, dt, qt, wm, wn, lane); return; }
-  gemm_epilogue_w<NI, NT>(p, acc, dt, qt, wm, wn, (int)threadIdx.x, lane, smem, thr_r);
+  if (DUMP) { gemm_dump_tile_w<NI, I8>(p, acc, dt, qt, wm, wn, lane, mul_r); return; }
+  gemm_epilogue_w<NI, NT, I8>(p, acc, dt, qt, wm, wn, (int)threadIdx.x, lane, smem, thr_r, mul_r);
 }
 
 hipError_t launch_gemm_wx(const GemmArgs& a, dim3 grid, int variant, hipStream_t s) {
@@ -392,21 +433,23 @@ hipError_t launch_gemm_wx(const GemmArgs& a, dim3 grid, int variant, hipStream_t
   std::lock_guard<std::mutex> attr_lock(attr_mu);
   bool& attr_set = attr_set_dev[dev_ & 63];
   if (!attr_set) {
-    const void* fns[4] = {(const void*)gemm_filter_wx_kernel<false, 4>, (const void*)gemm_filter_wx_kernel<true, 4>,
-                          (const void*)gemm_filter_wx_kernel<false, 2>, (const void*)gemm_filter_wx_kernel<true, 2>};
+    const void* fns[8] = {(const void*)gemm_filter_wx_kernel<false, 4, false>, (const void*)gemm_filter_wx_kernel<true, 4, false>,
+                          (const void*)gemm_filter_wx_kernel<false, 2, false>, (const void*)gemm_filter_wx_kernel<true, 2, false>,
+                          (const void*)gemm_filter_wx_kernel<false, 4, true>, (const void*)gemm_filter_wx_kernel<true, 4, true>,
+                          (const void*)gemm_filter_wx_kernel<false, 2, true>, (const void*)gemm_filter_wx_kernel<true, 2, true>};
     for (const void* f : fns) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_RING_LDS);
       if (e != hipSuccess) return e;
     }
     attr_set = true;
   }
-  if (variant == 4) {
-    if (a.dump) hipLaunchKernelGGL((gemm_filter_wx_kernel<true, 4>), grid, dim3(256), GEMM_RING_LDS, s, a);
-    else hipLaunchKernelGGL((gemm_filter_wx_kernel<false, 4>), grid, dim3(256), GEMM_RING_LDS, s, a);
-  } else {
-    if (a.dump) hipLaunchKernelGGL((gemm_filter_wx_kernel<true, 2>), grid, dim3(512), GEMM_RING_LDS, s, a);
-    else hipLaunchKernelGGL((gemm_filter_wx_kernel<false, 2>), grid, dim3(512), GEMM_RING_LDS, s, a);
-  }
+#define WX_LAUNCH(NI_, NT_) do { \
+    if (a.i8_mul) { if (a.dump) hipLaunchKernelGGL((gemm_filter_wx_kernel<true, NI_, true>), grid, dim3(NT_), GEMM_RING_LDS, s, a); \
+                    else hipLaunchKernelGGL((gemm_filter_wx_kernel<false, NI_, true>), grid, dim3(NT_), GEMM_RING_LDS, s, a); } \
+    else { if (a.dump) hipLaunchKernelGGL((gemm_filter_wx_kernel<true, NI_, false>), grid, dim3(NT_), GEMM_RING_LDS, s, a); \
+           else hipLaunchKernelGGL((gemm_filter_wx_kernel<false, NI_, false>), grid, dim3(NT_), GEMM_RING_LDS, s, a); } } while (0)
+  if (variant == 4) WX_LAUNCH(4, 256); else WX_LAUNCH(2, 512);
+#undef WX_LAUNCH
   return hipGetLastError();
 }
 

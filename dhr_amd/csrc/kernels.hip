@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) scan_rows_kernel(const __half* __restrict
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   const bool vec = ((k & 7) == 0) && ((ld & 7) == 0) && ((((uintptr_t)src) & 15) == 0);
-  float best = 0.f;
+  float best = 0.f, amax = 0.f, gmax = 0.f;
   bool neg = false;
   for (int64_t row = wave0; row < n_rows; row += nwaves) {
     const __half* r = src + row * ld;
@@ -68,6 +68,7 @@ __global__ void __launch_bounds__(256) scan_rows_kernel(const __half* __restrict
           const float f = (float)v[e];
           s += f * f;
           neg |= (c * 8 + e < d_dlr) && (f < 0.f);
+          if (fabsf(f) <= 65504.f) { if (c * 8 + e >= d_dlr) amax = fmaxf(amax, fabsf(f)); else gmax = fmaxf(gmax, fabsf(f)); }
         }
       }
     } else {
@@ -75,13 +76,53 @@ __global__ void __launch_bounds__(256) scan_rows_kernel(const __half* __restrict
         const float f = __half2float(r[j]);
         s += f * f;
         neg |= (j < d_dlr) && (f < 0.f);
+        if (fabsf(f) <= 65504.f) { if (j >= d_dlr) amax = fmaxf(amax, fabsf(f)); else gmax = fmaxf(gmax, fabsf(f)); }
       }
     }
     s = wave_sum(s);
     best = fmaxf(best, s);
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { amax = fmaxf(amax, __shfl_xor(amax, o, 64)); gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64)); }
   if (lane == 0 && best > 0.f) atomicMax(max_sq_bits, __float_as_uint(best));
+  if (lane == 0 && amax > 0.f) atomicMax(max_sq_bits + 2, __float_as_uint(amax));     // scale of the int8 image of the ungated columns
+  if (lane == 0 && gmax > 0.f) atomicMax(max_sq_bits + 3, __float_as_uint(gmax));     // largest finite |gated value|: it must fit fp16 in units of that scale
   if (__any(neg) && lane == 0) atomicOr(neg_flag, 1u);
+}
+
+// dense_i8 indexes: one wave per row over the ungated columns of the row-major copy.  The bound GEMM multiplies the int8
+// images; what it loses per row is  <q, d - scale*q8(d)>  <= ||q|| * ||d - scale*q8(d)||  and  <q - sq*q8(q), scale*q8(d)>
+// <= ||q - sq*q8(q)|| * ||scale*q8(d)||  (query_prep turns the two corpus-wide maxima into the filter margin).
+__global__ void __launch_bounds__(256) i8_row_err_kernel(const __half* __restrict__ vals_rm, int k_rm, int64_t n_rows, int d_dlr,
+                                                         int d_cls, float scale, float inv_scale, uint32_t* out_bits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  float be = 0.f, bn = 0.f;
+  for (int64_t row = wave0; row < n_rows; row += nwaves) {
+    const __half* r = vals_rm + row * k_rm + d_dlr;
+    float se = 0.f, sn = 0.f;
+    for (int j = lane; j < d_cls; j += 64) {
+      const float f = __half2float(r[j]);
+      const float back = scale * (float)quant_i8(f, inv_scale);
+      const float e = f - back;
+      se += e * e;
+      sn += back * back;
+    }
+    be = fmaxf(be, wave_sum(se));
+    bn = fmaxf(bn, wave_sum(sn));
+  }
+  if (lane == 0 && !(be >= 0.f)) be = INFINITY;      // a NaN / inf row: the margin becomes infinite, the filter passes everything (still exact)
+  if (lane == 0 && !(bn >= 0.f)) bn = INFINITY;
+  if (lane == 0) { atomicMax(out_bits, __float_as_uint(be)); atomicMax(out_bits + 1, __float_as_uint(bn)); }
+}
+hipError_t launch_i8_row_err(const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls, float scale, float inv_scale,
+                             uint32_t* out_bits, hipStream_t s) {
+  if (n_rows <= 0) return hipSuccess;
+  const int64_t blocks = (n_rows + 3) / 4;
+  hipLaunchKernelGGL(i8_row_err_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, vals_rm, k_rm, n_rows,
+                     d_dlr, d_cls, scale, inv_scale, out_bits);
+  return hipGetLastError();
 }
 
 hipError_t launch_scan_rows(const __half* src, int64_t ld, int64_t n_rows, int d_dlr, int k, uint32_t* max_sq_bits,
@@ -93,6 +134,12 @@ hipError_t launch_scan_rows(const __half* src, int64_t ld, int64_t n_rows, int d
   return hipGetLastError();
 }
 
+// x >= 0 scaled into the units of a dense_i8 index and rounded UP to fp16 (the gated operands stay an upper bound)
+__device__ __forceinline__ _Float16 half_up(float x) {
+  _Float16 h = (_Float16)x;
+  if ((float)h < x) { union { _Float16 h; uint16_t u; } v; v.h = h; v.u += 1; h = v.h; }     // x > 0 here: next representable value (inf past 65504)
+  return h;
+}
 // ------------------------------------------------------------------------------------------ tile_rows
 // Bucket of a slice index value: per-slice 256-entry table (8-bit index dtypes, balanced by corpus
 // frequency at build time) or value % n_buckets (int16 indices, whole-word BM25 vocabularies).
@@ -183,7 +230,7 @@ __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __r
                                                                int64_t n_rows_src, int64_t n_rows_fill, int d_dlr,
                                                                int d_cls, int ts, int td, const void* __restrict__ idx,
                                                                int idx_dtype, const uint8_t* __restrict__ map, int abs_dlr,
-                                                               char* __restrict__ tiles) {
+                                                               char* __restrict__ tiles, float i8_inv) {
   const int k = d_dlr + d_cls;
   const int sp_chunks = ts * 4, dn_chunks = td * 4;
   const int cpr = sp_chunks + dn_chunks;
@@ -207,6 +254,7 @@ __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __r
         if (rl < n_rows_src && j0 + e < d_dlr) {
           _Float16 x = (_Float16)__half2float(src[rl * ld + j0 + e]);
           if (abs_dlr && x < (_Float16)0.f) x = -x;
+          if (i8_inv > 0.f && x > (_Float16)0.f) x = half_up((float)x * i8_inv);     // dense_i8: accumulator units (1 / corpus scale on this side)
           v[e] = x;
           bucket = bucket_of(load_idx(idx, idx_dtype, row * d_dlr + j0 + e), j0 + e, map, 2);
         }
@@ -217,6 +265,15 @@ __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __r
       // position words: [32-row block][lane half][row in block] u32 = (block-1 bits << 16 | block-0 bits), so that the 32 lanes
       // of a half read 32 consecutive words (the row-major [row][half] order cost a 2-way bank conflict on every read)
       *(uint16_t*)(stg + SP_A_BYTES + ((((r >> 5) * 2 + (cc & 1)) * 32 + (r & 31)) * 4) + (cc >> 1) * 2) = (uint16_t)bits;
+    } else if (i8_inv > 0.f) {
+      // int8 stage: 64 columns per 64-byte row, chunk cc = columns 16*cc .. 16*cc+15 (a lane half of v_mfma_i32_32x32x32_i8
+      // takes 16 consecutive bytes; the order of the columns inside a 32-deep block is irrelevant as long as both operands agree)
+      const int dc = c - sp_chunks, st = dc >> 2, cc = dc & 3, j0 = d_dlr + dc * 16;
+      union { half8 h; int8_t b[16]; } o;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o.b[e] = (rl < n_rows_src && j0 + e < k) ? (int8_t)quant_i8(__half2float(src[rl * ld + j0 + e]), i8_inv) : (int8_t)0;
+      char* stg = tile + (int64_t)ts * SP_STAGE_A + (int64_t)st * SP_DENSE;
+      *(half8*)(stg + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = o.h;
     } else {
       const int dc = c - sp_chunks, st = dc >> 2, cc = dc & 3, j0 = d_dlr + dc * 8;
       if (rl < n_rows_src)
@@ -230,12 +287,12 @@ __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __r
 }
 hipError_t launch_tile_rows_sparse(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
                                    int d_dlr, int d_cls, int ts, int td, const void* idx, int idx_dtype, const uint8_t* map,
-                                   bool abs_dlr, char* tiles, hipStream_t s) {
+                                   bool abs_dlr, char* tiles, float i8_inv_scale, hipStream_t s) {
   if (n_rows_fill <= 0) return hipSuccess;
   const int64_t total = n_rows_fill * (ts * 4 + td * 4);
   const int64_t blocks = (total + 255) / 256;
   hipLaunchKernelGGL(tile_rows_sparse_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, src, ld,
-                     row_lo, n_rows_src, n_rows_fill, d_dlr, d_cls, ts, td, idx, idx_dtype, map, abs_dlr ? 1 : 0, tiles);
+                     row_lo, n_rows_src, n_rows_fill, d_dlr, d_cls, ts, td, idx, idx_dtype, map, abs_dlr ? 1 : 0, tiles, i8_inv_scale);
   return hipGetLastError();
 }
 
@@ -307,7 +364,8 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
                                                          float* __restrict__ thr, int ts, int td,
                                                          uint32_t* __restrict__ q_pack, __half* __restrict__ q16,
                                                          uint8_t* __restrict__ q_idx8, uint32_t* __restrict__ q_inexact,
-                                                         int c_idx_dtype) {
+                                                         int c_idx_dtype, float i8_scale, float i8_ec, float i8_nc,
+                                                         float* __restrict__ i8_mul) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= q_pad) return;
@@ -352,6 +410,40 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
       q_pack[(int64_t)q * d_dlr + j] = ((uint32_t)cv.u << 16) | (bk << 12) | ((uint32_t)iv & 0xFFFu);
     }
   }
+  // dense_i8 index.  The query's int8 scale sq: max |ungated value| / 127, coarsened (a) until the largest gated value fits fp16
+  // in units of sq and (b) until ||q8|| * max_r ||d8_r|| < 2^22 - the integer sums must stay inside the exact range of the
+  // accumulators' 2^23 + 2^22 offset (gemm_w4.hip).  Then the norm of the ungated part and of what the int8 image loses: the margin.
+  float i8_inv_q = 0.f, i8_sq = 0.f, i8_qn = 0.f, i8_qe = 0.f;
+  bool i8_zero = false;
+  if (i8_scale > 0.f) {
+    float am = 0.f, gm = 0.f;
+    for (int j = lane; j < k; j += 64) {
+      const float v = fabsf(qval(j));
+      if (v <= 3.0e38f) { if (j >= d_dlr) am = fmaxf(am, v); else gm = fmaxf(gm, v); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { am = fmaxf(am, __shfl_xor(am, o, 64)); gm = fmaxf(gm, __shfl_xor(gm, o, 64)); }
+    i8_sq = fmaxf(am > 0.f ? am / 127.f : 1.f, gm / 60000.f);
+    const float n8_cap = 4.0e6f / fmaxf(i8_nc / i8_scale, 1.f);         // ||q8|| must stay below this
+    for (int it = 0; it < 4; ++it) {
+      i8_inv_q = 1.f / i8_sq;
+      i8_zero = it == 3;              // last resort (never seen): an all-zero int8 image, the margin pays the whole ungated part
+      float sn = 0.f, se = 0.f, s8 = 0.f;
+      for (int j = d_dlr + lane; j < k; j += 64) {
+        const float v = qval(j);
+        const float q8 = i8_zero ? 0.f : (float)quant_i8(v, i8_inv_q);
+        const float e = v - i8_sq * q8;
+        sn += v * v;
+        se += e * e;
+        s8 += q8 * q8;
+      }
+      i8_qn = sqrtf(wave_sum(sn));
+      i8_qe = sqrtf(wave_sum(se));
+      const float n8 = sqrtf(wave_sum(s8));
+      if (n8 <= n8_cap) break;
+      if (it < 2) i8_sq *= 1.05f * n8 / n8_cap;
+    }
+  }
   if (ts + td > 0) {
     // stage layout (2:4).  A sparse stage holds the row's 32 slice values once, the bucket in the sign bit (the bound
     // operand is >= 0): the GEMM expands a value v into its two bucket columns (max(v,0), max(-v,0)) in
@@ -371,15 +463,22 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
         for (int e8 = 0; e8 < 8; ++e8) {
           float v = 0.f;
           const int j = cst * 32 + kb * 16 + 8 * (e8 >> 2) + 4 * hh + (e8 & 3);
+          bool neg_b = false;
           if (j < d_dlr) {
             v = qval(j);
             v = abs_dlr ? fabsf(v) : fmaxf(v, 0.f);
-            const int bucket = idx ? bucket_of(qidx(j), j, map, 2) : (st >= ts);
-            if (bucket) v = -v;
+            neg_b = (idx ? bucket_of(qidx(j), j, map, 2) : (st >= ts)) != 0;
           }
-          h8[e8] = (_Float16)v;
+          _Float16 hv = (i8_scale > 0.f && v > 0.f) ? half_up(v * i8_inv_q) : (_Float16)v;     // dense_i8: accumulator units, rounded up
+          h8[e8] = neg_b ? -hv : hv;
         }
         *(half8*)(tile + (int64_t)st * SP_STAGE_B + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = h8;
+      } else if (i8_scale > 0.f) {
+        const int dc = c - ts_q * 4, st = dc >> 2, cc = dc & 3;
+        union { half8 h; int8_t b[16]; } o;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o.b[e] = i8_zero ? (int8_t)0 : (int8_t)quant_i8(qval(d_dlr + dc * 16 + e), i8_inv_q);     // qval: 0 beyond the data
+        *(half8*)(tile + (int64_t)ts_q * SP_STAGE_B + (int64_t)st * SP_DENSE + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = o.h;
       } else {
         const int dc = c - ts_q * 4, st = dc >> 2, cc = dc & 3;
 #pragma unroll
@@ -411,7 +510,19 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
   s16 = wave_sum(s16);
   sr = wave_sum(sr);
   if (lane == 0) {
-    const float m = 1.05f * (float)(kt + 256) * 5.9604645e-8f * sqrtf(s16) * dmax + 1.0001f * sqrtf(sr) * dmax;
+    float m = 1.05f * (float)(kt + 256) * 5.9604645e-8f * sqrtf(s16) * dmax + 1.0001f * sqrtf(sr) * dmax;
+    if (i8_scale > 0.f) {
+      // int8 image of the ungated columns: <q,d> - mul * <q8,d8>  =  <q, d - sc*d8>  +  <q - sq*q8, sc*d8>  +  (sc*sq - mul) <q8,d8>
+      // with the corpus-wide maxima ec >= ||d - sc*d8||, nc >= ||sc*d8|| (Cauchy-Schwarz on the first two, fp32 rounding of the
+      // factor and of the converted sum on the third)
+      // The factor is rounded UP (the gated products up(q/sq) * up(d/sc) * mul must not fall below q*d, which the refine step takes
+      // off again), and the fp32 accumulation of the gated stages happens on top of the 2^23-sized offset: <= 1 unit (ulp of
+      // [2^23, 2^24), 2 above) per matrix instruction of the chain plus the threshold conversion in the kernel -> 4 * (chain + 8) units.
+      const float mul = __uint_as_float(__float_as_uint(i8_scale * i8_sq) + 8u);     // +2^-20: above every rounding of the scaled operands
+      m += 1.001f * (i8_qn * i8_ec + i8_qe * i8_nc) + 1.2e-6f * (i8_qn + i8_qe) * i8_nc + 4.f * (float)(2 * (idx ? ts : 2 * ts) + 8) * mul;
+      if (!(m >= 0.f)) m = INFINITY;                     // NaN somewhere: filter with -inf thresholds (everything is rescored exactly)
+      i8_mul[q] = real ? mul : 0.f;
+    }
     margin[q] = m;
     tau[q] = -INFINITY;
     thr[q] = real ? -INFINITY : INFINITY;              // padded queries never pass the filter
@@ -422,10 +533,11 @@ hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const 
                              int n_queries, int q_pad, int d_dlr, int d_cls, int k_rm, int n_buckets, int kt,
                              const uint8_t* map, bool abs_dlr, float dmax, __half* q_tiles, float* q32, int16_t* q_idx,
                              float* margin, float* tau, float* thr, int ts, int td, uint32_t* q_pack, __half* q16, uint8_t* q_idx8,
-                             uint32_t* q_inexact, int c_idx_dtype, hipStream_t s) {
+                             uint32_t* q_inexact, int c_idx_dtype, float i8_scale, float i8_ec, float i8_nc, float* i8_mul,
+                             hipStream_t s) {
   hipLaunchKernelGGL(query_prep_kernel, dim3((q_pad + 3) / 4), dim3(256), 0, s, src, src_is_f32, ld, idx, idx_dtype,
                      ld_idx, n_queries, q_pad, d_dlr, d_cls, k_rm, n_buckets, kt, map, abs_dlr ? 1 : 0, dmax, q_tiles, q32,
-                     q_idx, margin, tau, thr, ts, td, q_pack, q16, q_idx8, q_inexact, c_idx_dtype);
+                     q_idx, margin, tau, thr, ts, td, q_pack, q16, q_idx8, q_inexact, c_idx_dtype, i8_scale, i8_ec, i8_nc, i8_mul);
   return hipGetLastError();
 }
 
@@ -927,6 +1039,8 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
   }
   const dim3 grid((unsigned)blocks);
   const int variant = a.variant ? a.variant : g_gemm_variant;        // per handle (dhr_index_set_param), else the library default
+  if (a.i8_mul)      // int8 dense stages exist in the every-wave-computes kernels only (dhr_index_create enables them only where those run)
+    return (a.ts + a.td > 0 && !(a.ts_q & 1) && !(a.td & 1)) ? launch_gemm_wx(a, grid, variant == 4 ? 4 : 5, s) : hipErrorInvalidValue;
   if (a.ts + a.td > 0 && (variant == 4 || variant == 5) && g_gemm_ablate == 0 && !(a.ts_q & 1) && !(a.td & 1)) return launch_gemm_wx(a, grid, variant, s);   // pairs of stages
   if (a.ts + a.td > 0) {
     if (a.dump)

@@ -118,6 +118,12 @@ class GipIndex:
     def device_bytes(self) -> int:
         return int(self._lib.dhr_index_device_bytes(self._h))
 
+    def info(self, what: int) -> float:
+        """dhr_index_get_info: read-only facts about the built index (_lib.INFO_*)."""
+        out = C.c_double()
+        _lib.check(self._lib.dhr_index_get_info(self._h, what, C.byref(out)), "dhr_index_get_info")
+        return out.value
+
     def stats(self) -> dict:
         st = _lib.SearchStats()
         _lib.check(self._lib.dhr_get_stats(self._h, C.byref(st)), "dhr_get_stats")

@@ -102,6 +102,25 @@ typedef enum dhr_param {
   DHR_PARAM_SAMPLE_PERIOD = 5 /* every S-th corpus tile seeds the thresholds (default 32; 0 = plain streaming) */
 } dhr_param;
 
+/* Process-wide options read by dhr_index_create (dhr_set_option). */
+typedef enum dhr_option {
+  DHR_OPT_DENSE_I8 = 1  /* int8 image of the UNGATED columns in the bound GEMM (v_mfma_i32_32x32x32_i8, twice the fp16 instruction's
+                           columns per issue; the quantisation error is paid by the filter margin, results stay exact):
+                           -1 (default) = gated indexes that also carry ungated columns, 0 = never, 1 = dense-only indexes too.
+                           The environment variable DHR_DENSE_I8 overrides it. */
+} dhr_option;
+int dhr_set_option(int32_t option, int64_t value);
+/* Read-only facts about a built index (dhr_index_get_info). */
+typedef enum dhr_info {
+  DHR_INFO_DENSE_I8 = 1,      /* 1 if the ungated stages are int8 images */
+  DHR_INFO_I8_SCALE = 2,      /* corpus-side scale: max |ungated value| / 127 */
+  DHR_INFO_I8_ROW_ERR = 3,    /* max over rows of || d - scale * q8(d) ||   (ungated part) */
+  DHR_INFO_I8_ROW_NORM = 4,   /* max over rows of || scale * q8(d) || */
+  DHR_INFO_ROW_NORM_MAX = 5,  /* max over rows of || row || */
+  DHR_INFO_TILE_BYTES = 6     /* bytes of the bound-GEMM operand images */
+} dhr_info;
+int dhr_index_get_info(const dhr_index* index, int32_t what, double* out);
+
 int dhr_version(void);
 /* sizeof of the four public structs as this library was compiled: { dhr_index_desc, dhr_query_batch, dhr_search_stats,
  * dhr_file_info }.  A binding compares them with its own declarations at load time (a stale library whose struct layout

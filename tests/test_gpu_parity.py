@@ -41,6 +41,25 @@ def _search_check(G, cv, ci, qv32, qi, k, *, params=(), emb_dim=None, queries=No
     return scores, rows, st
 
 
+def _i8_quant(x, scale):
+    inv = np.float32(1.0) / np.float32(scale)
+    return np.clip(np.rint(x.astype(np.float32) * inv), -127, 127)
+
+
+def _i8_margin(ix, qv32, d_cls):
+    """Per-query bound of |<q,d> - mul <q8,d8>| over the ungated columns of a dense_i8 index, restated from query_prep_kernel
+    (kernels.hip): ||q|| * max_r ||d - sc d8|| + ||q - sq q8|| * max_r ||sc d8||."""
+    from dhr_amd import _lib
+    ec, nc = ix.info(_lib.INFO_I8_ROW_ERR), ix.info(_lib.INFO_I8_ROW_NORM)
+    qd = qv32[:, qv32.shape[1] - d_cls:].astype(np.float32)
+    qg = np.abs(qv32[:, :qv32.shape[1] - d_cls]).max(axis=1, initial=0.0)
+    am = np.abs(qd).max(axis=1)
+    sq = np.maximum(np.where(am > 0, am / np.float32(127), np.float32(1)), qg / np.float32(60000)).astype(np.float32)
+    q8 = np.stack([_i8_quant(qd[i], sq[i]) for i in range(len(qd))])
+    qe = np.linalg.norm(qd - sq[:, None] * q8, axis=1)
+    return 1.01 * (np.linalg.norm(qd, axis=1) * ec + qe * nc) + 1e-2
+
+
 def test_bound_gemm_layout(G, golden):
     """The MFMA bound GEMM (tile layout, swizzle, fragment mapping) == plain Q x D^T."""
     import ctypes as C
@@ -64,7 +83,9 @@ def test_bound_gemm_layout(G, golden):
         ix = G.GipIndex(cv, d["ci"][:1000], idx_buckets=nb)
         _lib.check(ix._lib.dhr_debug_bound_scores(ix._h, C.byref(qb), 0, 1000, out.data_ptr(), 0), "debug_bound")
         ub = out.cpu().numpy().astype(np.float64)
-        assert np.all(ub >= exact - 1e-3) and np.all(ub <= ref + 1e-3)
+        # an int8 image of the ungated columns (two-bucket layout, DHR_INFO_DENSE_I8) is off by at most what the filter margin pays
+        tol = 1e-3 + (_i8_margin(ix, qv, cv.shape[1] - d["ci"].shape[1]).max() if ix.info(_lib.INFO_DENSE_I8) else 0.0)
+        assert np.all(ub >= exact - tol) and np.all(ub <= ref + tol)
         slack.append(float((ub - exact).mean()))
         ix.close()
     assert slack[0] > slack[1] > slack[2] and slack[0] < float((ref - exact).mean())
@@ -1099,3 +1120,93 @@ def test_two_stage_agip_topk_beyond_16384(G):
     c32 = cv.astype(np.float32)
     for i, qid in enumerate(qids):
         _check_theta_mode(info, q32[i], qi[i], c32, ci, res[qid], sc[qid])
+
+
+def _i8_pair(G, cv, ci, qv32, qi, k, *, dense_only_opt=False, ungated=False):
+    """The same search with fp16 and with int8 ungated stages: identical rows, scores and both exact."""
+    from dhr_amd import _lib
+    lib = _lib.load()
+    out = []
+    try:
+        for opt in (0, 1):
+            _lib.check(lib.dhr_set_option(_lib.OPT_DENSE_I8, opt), "set_option")
+            ix = G.GipIndex(cv, ci)
+            assert int(ix.info(_lib.INFO_DENSE_I8)) == opt
+            ix.set_param(_lib.PARAM_PROFILE, 1)
+            s, r = ix.search(qv32, None if ungated else qi, k)
+            out.append((s, r, ix.stats(), ix.info(_lib.INFO_TILE_BYTES)))
+            ix.close()
+    finally:
+        _lib.check(lib.dhr_set_option(_lib.OPT_DENSE_I8, -1), "set_option")
+    (s0, r0, st0, b0), (s1, r1, st1, b1) = out
+    np.testing.assert_array_equal(r0, r1)
+    np.testing.assert_array_equal(s0, s1)
+    c32 = cv.astype(np.float32)
+    for i in range(min(4, qv32.shape[0])):
+        ex = O.gip_scores_f64(qv32[i], None if (ungated or qi is None) else qi[i], c32, None if ungated else ci)
+        O.check_topk(r1[i, :min(k, len(ex))], s1[i, :min(k, len(ex))], ex, k, atol=max(1e-3, 1e-6 * float(np.abs(ex).max())))
+    return st0, st1, b0, b1
+
+
+def test_dense_i8_equals_fp16_hybrid(G):
+    """int8 image of the ungated columns (v_mfma_i32_32x32x32_i8 stages, accumulators started at 2^23 + 2^22): the survivors are a
+    superset, the results identical; the operand images shrink by the ungated half."""
+    from dhr_amd import synth
+    cv, ci, qv, qi = synth.make_pair(21, 60_000, 40, 768, 768)
+    st0, st1, b0, b1 = _i8_pair(G, cv, ci, qv.astype(np.float32), qi, 1000)
+    assert b1 < b0 and st1["candidates_bound"] >= st0["candidates_bound"]
+    print("bound candidates fp16 / int8:", st0["candidates_bound"], st1["candidates_bound"], "exact:", st0["candidates_exact"], st1["candidates_exact"])
+    # ungated batch (--IP stage 1) over the gated int8 index, and a width that needs zero padding of the int8 stages
+    _i8_pair(G, cv[:20_000], ci[:20_000], qv[:9].astype(np.float32), qi[:9], 300, ungated=True)
+    cv2 = np.ascontiguousarray(np.concatenate([cv[:9000, :768], cv[:9000, 768:768 + 200]], axis=1))
+    qv2 = np.ascontiguousarray(np.concatenate([qv[:7, :768], qv[:7, 768:768 + 200]], axis=1))
+    _i8_pair(G, cv2, ci[:9000], qv2.astype(np.float32), qi[:7], 100)
+
+
+def test_dense_i8_dense_only_index(G):
+    from dhr_amd import synth
+    cv, _, qv, _ = synth.make_pair(22, 40_000, 30, 0, 768, kind="dense")
+    from dhr_amd import _lib
+    lib = _lib.load()
+    ix = G.GipIndex(cv, None)
+    assert int(ix.info(_lib.INFO_DENSE_I8)) == 0            # default: gated indexes only
+    ix.close()
+    _i8_pair(G, cv, None, qv.astype(np.float32), None, 100)
+
+
+@pytest.mark.parametrize("kind", ["spiky_rows", "huge_gated", "zero_dense", "tiny_dense", "one_hot_queries", "fp32_queries", "negative_gated"])
+def test_dense_i8_adversarial(G, kind):
+    """Inputs that stress the int8 image: rows / queries whose ungated part is one large entry (the query scale is coarsened until
+    the integer sums fit the accumulator offset), gated values near the fp16 limit (the scale is raised until they fit in scaled
+    units), an all-zero or tiny ungated part, queries that are not fp16-representable, negative gated values (abs mode)."""
+    rng = np.random.default_rng(hash(kind) % 1000)
+    n, q, d = 6000, 12, 128
+    cv = np.abs(rng.standard_normal((n, 2 * d)) * 0.3).astype(np.float16)
+    cv[:, d:] = (rng.standard_normal((n, d)) * 0.1).astype(np.float16)
+    qv = np.abs(rng.standard_normal((q, 2 * d)) * 0.3).astype(np.float32)
+    qv[:, d:] = (rng.standard_normal((q, d)) * 0.1).astype(np.float16)
+    ci = rng.integers(0, 6, (n, d)).astype(np.uint8)
+    qi = rng.integers(0, 6, (q, d)).astype(np.uint8)
+    if kind == "spiky_rows":
+        cv[:, d:] = 0
+        cv[np.arange(n), d + rng.integers(0, d, n)] = np.float16(40.0)
+        cv[::7, d:] = np.float16(40.0)                      # rows with the largest possible int8 norm
+        qv[:, d:] = np.float16(3.0)
+    elif kind == "huge_gated":
+        cv[::5, :d] = np.float16(900.0)
+        qv[::2, :d] = 50.0
+    elif kind == "zero_dense":
+        cv[:, d:] = 0
+        qv[3:, d:] = 0
+    elif kind == "tiny_dense":
+        cv[:, d:] = (rng.standard_normal((n, d)) * 1e-4).astype(np.float16)
+        qv[:, d:] = (rng.standard_normal((q, d)) * 1e-4).astype(np.float16)
+    elif kind == "one_hot_queries":
+        qv[:, d:] = 0
+        qv[np.arange(q), d + rng.integers(0, d, q)] = 2.0
+    elif kind == "fp32_queries":
+        qv = (qv * np.float32(1.0001) + np.float32(1e-5)).astype(np.float32)
+    elif kind == "negative_gated":
+        cv[::3, :d] *= np.float16(-1)
+        qv[::2, :d] *= -1
+    _i8_pair(G, cv, ci, qv, qi, 200)
