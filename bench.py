@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 N_MSMARCO = 8_841_823
 Q_DEV = 6_980
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md chip table
+MFMA_PEAK_I8_TOPS = 5000.0     # dense int8 MFMA peak (same table): the ungated columns of a dense_i8 index run on it
 GEN_CHUNK = 1 << 18            # the synthetic corpus is seeded per GLOBAL chunk of this many rows: a shard of any world size is a slice of the same corpus
 
 # BASELINE.json config 5: the 13 public BEIR corpora (documents, test queries), sizes from the public BEIR table
@@ -122,6 +123,7 @@ def main():
     ap.add_argument("--aux-cus", type=int, default=-1, help="tuning: CUs the refine/rescoring stream is confined to (0 = no mask)")
     ap.add_argument("--gemm-exclusive", type=int, default=-1)
     ap.add_argument("--overlap-aux", type=int, default=-1)
+    ap.add_argument("--dense-i8", type=int, default=-1, help="int8 image of the ungated columns in the bound GEMM (dhr_set_option DHR_OPT_DENSE_I8): -1 library default (gated indexes), 0 off, 1 on for dense-only indexes too")
     ap.add_argument("--gemm-variant", type=int, default=-1, help="tuning: bound-GEMM kernel of the 2:4 layout (3 = 12-wave producer / consumer, 4 = 4 waves, 5 = 8 waves)")
     ap.add_argument("--no-progressive-thr", action="store_true", help="A/B: keep the sampled thresholds frozen over the main pass")
     ap.add_argument("--first-rows", type=int, default=0)
@@ -203,7 +205,9 @@ def run_workload(args, spec, ctx):
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
     t_build = time.perf_counter()
+    _lib.check(_lib.load().dhr_set_option(_lib.OPT_DENSE_I8, args.dense_i8), "dhr_set_option")
     index = GipIndex(cv, ci, device=local_rank, row_offset=lo, idx_buckets=args.idx_buckets)
+    dense_i8 = bool(index.info(_lib.INFO_DENSE_I8))
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
     index.set_param(_lib.PARAM_PROFILE, 1)
@@ -347,14 +351,19 @@ def run_workload(args, spec, ctx):
         # fabric-side (Infinity Cache + HBM) read bytes: PMC passes cannot run inside this process (a torch process hangs under
         # --pmc), so `traffic` is the per-corpus-row figure of the committed rocprofv3 FETCH_SIZE pass over the SAME kernel
         # (tools/prof.sh -> profiles/r02_gemm_pmc.txt; torch-free driver, 6 980 queries) x the average rows per launch
-        traffic_per_row = TRAFFIC_BYTES_PER_ROW.get((d_dlr, d_cls, nq, variant)) if sparse_layout and world == 1 else None
+        traffic_per_row = TRAFFIC_BYTES_PER_ROW.get((d_dlr, d_cls, nq, variant, int(dense_i8))) if sparse_layout and world == 1 else None
+        # peak of the instruction mix: gated columns on the fp16 (2:4 sparse: two bucket columns per slice at twice the rate) matrix
+        # instructions, ungated columns on fp16 or, dense_i8, on the int8 instruction (twice the columns per issue)
+        peak = (d_dlr + d_cls) / (d_dlr / MFMA_PEAK_TFLOPS + d_cls / (MFMA_PEAK_I8_TOPS if dense_i8 else MFMA_PEAK_TFLOPS))
         rows_per_launch = stats_acc.get("gemm_rows", 0) / max(launches, 1)
         alg_bytes_per_row = 2 * K + d_dlr * (2 if spec["kind"] == "bm25" else 1)
         out = {
             "metric": "queries/sec (exact top-%d, brute-force dense-hybrid GIP retrieval)" % k,
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f16 (fp16 x fp16 -> fp32 on the matrix cores for the bound; fp64-accumulated exact rescoring)", "data": "synthetic",
+            "dtype": ("f16 + i8 (bound: gated columns fp16 x fp16 -> fp32, ungated columns int8 x int8 -> int32 on the matrix cores, the quantisation error paid by the filter margin; "
+                      "fp64-accumulated exact rescoring of the survivors in fp16 x fp32 -- results identical to the fp16 bound)" if dense_i8 else
+                      "f16 (fp16 x fp16 -> fp32 on the matrix cores for the bound; fp64-accumulated exact rescoring)"), "data": "synthetic",
             "config": {"workload": ("%s: %d rows x (%d DLR + %d dense) fp16%s, %d queries, top-%d, %s"
                                     % (spec["name"], n, d_dlr, d_cls,
                                        (" + int16 slice index" if spec["kind"] == "bm25" else " + uint8 slice index") if d_dlr else "", nq, k,
@@ -363,14 +372,17 @@ def run_workload(args, spec, ctx):
                        "baseline_config": spec["baseline_config"],
                        "parallelism": "rowshard%d+allgather" % world if world > 1 else "1gpu"},
             "roofline": {"bound": "mfma", "kernel": kernel,
-                         "achieved": round(ach_tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach_tf / MFMA_PEAK_TFLOPS, 4),
+                         "achieved": round(ach_tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(ach_tf / peak, 4),
+                         "peak_note": ("instruction mix: %d gated columns at the 2 500 TFLOP/s fp16 peak, %d ungated columns at the 5 000 TOP/s int8 peak" % (d_dlr, d_cls)
+                                       if dense_i8 else "dense fp16 matrix peak"),
+                         "frac_of_fp16_peak": round(ach_tf / MFMA_PEAK_TFLOPS, 4),
                          "traffic": None if traffic_per_row is None else round(traffic_per_row * rows_per_launch, 0),
                          "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE, gfx950-corrected; profiles/r02_gemm_pmc.txt)",
                          "algorithmic_bytes_per_launch": round(alg_bytes_per_row * rows_per_launch, 0),
                          "launches": launches, "avg_launch_ms": round(gemm_ms / max(launches, 1), 3),
                          "alg_flops_per_step": gemm_flops_alg / args.steps},
-            "whole_job_frac_of_gemm_roofline": round(qps * 2.0 * n * K / (MFMA_PEAK_TFLOPS * 1e12 * world), 4),
+            "whole_job_frac_of_gemm_roofline": round(qps * 2.0 * n * K / (peak * 1e12 * world), 4),
             "ms_per_step_incl_d2h": round(ms_incl_d2h, 3),
             "result_checksum": checksum,
             "phase_ms_per_step": {key: round(v / args.steps, 3) for key, v in stats_acc.items() if key.endswith("_ms")}
@@ -420,7 +432,9 @@ def run_workload(args, spec, ctx):
 
 
 # fabric-side read bytes per corpus row of the bound GEMM, from the committed PMC pass (d_dlr, d_cls, queries, kernel variant)
-TRAFFIC_BYTES_PER_ROW = {(768, 768, 6980, 5): 34.6e3}      # profiles/r02_gemm_pmc.txt: 17.31 GB per 500 000-row launch
+# (d_dlr, d_cls, queries, kernel variant, dense_i8) -> fabric-side read bytes per corpus row, profiles/r02_gemm_pmc.txt
+TRAFFIC_BYTES_PER_ROW = {(768, 768, 6980, 5, 0): 34.6e3,     # fp16 image of the ungated columns: 17.31 GB per 500 000-row launch
+                         (768, 768, 6980, 5, 1): 26.2e3}     # int8 image (default): 13.10 GB
 
 
 if __name__ == "__main__":

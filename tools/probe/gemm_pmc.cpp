@@ -36,10 +36,14 @@ int main(int argc, char** argv) {
   qb.index_dtype = d_dlr ? DHR_IDX_U8 : DHR_IDX_NONE; qb.ld_value = k; qb.index = d_dlr ? qi.data() : nullptr; qb.ld_index = d_dlr;
   double ms = 0, fl = 0;
   if (dhr_debug_gemm_time(ix, &qb, 2, &ms, &fl, nullptr)) { printf("gemm: %s\n", dhr_last_error()); return 1; }
-  const double tile_bytes = 24 * 34816.0 + 24 * 32768.0;
+  double i8 = 0;
+  dhr_index_get_info(ix, DHR_INFO_DENSE_I8, &i8);
+  const int ts = d_dlr / 32, td = i8 != 0 ? 2 * ((d_cls + 127) / 128) : (d_cls + 31) / 32;     // sparse stages (34 KiB corpus + query), dense stages (16 + 16 KiB)
+  const double tile_bytes = ts * 34816.0 + td * 32768.0;
   const double tiles = (double)((n + 255) / 256) * ((q + 255) / 256);
-  printf("rows %lld queries %d: %.3f ms per launch, %.1f TFLOP/s issued; operand bytes through LDS per launch %.2f GB; unique operand bytes %.3f GB\n",
-         (long long)n, q, ms, fl / ms / 1e9, tiles * tile_bytes / 1e9, ((double)((n + 255) / 256) * 835584.0 + (double)((q + 255) / 256) * 786432.0) / 1e9);
+  printf("rows %lld queries %d dense_i8 %d: %.3f ms per launch, %.1f TFLOP/s issued; operand bytes through LDS per launch %.2f GB; unique operand bytes %.3f GB\n",
+         (long long)n, q, (int)i8, ms, fl / ms / 1e9, tiles * tile_bytes / 1e9,
+         ((double)((n + 255) / 256) * (ts * 18432.0 + td * 16384.0) + (double)((q + 255) / 256) * (ts + td) * 16384.0) / 1e9);
   dhr_index_destroy(ix);
   return 0;
 }

@@ -11,19 +11,23 @@ cd $R
 timeout 400 python bench.py > $O/bench_${TAG}_hybrid.json 2> $O/bench_hybrid.err
 timeout 400 python bench.py --workload dense --no-cpu-baseline > $O/bench_${TAG}_dense.json 2> $O/bench_dense.err
 timeout 400 python bench.py --uniform-idx --no-cpu-baseline > $O/bench_${TAG}_hybrid_uniform_idx.json 2> $O/bench_uniform.err
+timeout 400 python bench.py --dense-i8 0 --no-cpu-baseline > $O/bench_${TAG}_hybrid_fp16_bound.json 2> $O/bench_hybrid_fp16.err
 timeout 300 python bench.py --workload bm25 --no-cpu-baseline > $O/bench_${TAG}_bm25.json 2> $O/bench_bm25.err
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/trace_bench.log 2>&1
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
-for cfg in "hyb 768" "dense 0"; do
+# hyb: the default hybrid index (int8 image of the ungated columns); hybf16: the same with DHR_DENSE_I8=0; dense: dense-only (fp16)
+for cfg in "hyb 768 -1" "hybf16 768 0" "dense 0 -1"; do
   set -- $cfg
+  export DHR_DENSE_I8=$3
   timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_$1_f -- $R/tools/probe/_bin/gemm_pmc 500000 6980 $2 > $O/pmc_$1_f.log 2>&1
   timeout 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $O/pmc_$1_t -- $R/tools/probe/_bin/gemm_pmc 500000 6980 $2 > $O/pmc_$1_t.log 2>&1
   timeout 200 rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $O/pmc_$1_s -- $R/tools/probe/_bin/gemm_pmc 500000 6980 $2 > $O/pmc_$1_s.log 2>&1
 done
+unset DHR_DENSE_I8
 cd $R
 DB=$(ls $O/trace/*/*_results.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB $O/${TAG}_kernel_stats.txt | head -14
 python3 tools/pmc_summary.py $O > $O/${TAG}_gemm_pmc_raw.txt
 cat $O/${TAG}_gemm_pmc_raw.txt
-tail -1 $O/pmc_hyb_f.log; tail -1 $O/pmc_dense_f.log
+tail -1 $O/pmc_hyb_f.log; tail -1 $O/pmc_hybf16_f.log; tail -1 $O/pmc_dense_f.log
