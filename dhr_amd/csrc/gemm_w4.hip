@@ -98,17 +98,23 @@ __device__ __forceinline__ void gemm_epilogue_w(const GemmArgs& p, floatx16 (&ac
     jn[ni] = j < EPI_STACK ? j : EPI_STACK;
   }
   if (j == 0) return;
+  // all of a lane's list reservations go out before the first one is waited for: one L2 round trip per tile, not NI
+  // (A/B on one box, open filter, 2 M rows: 31.58 vs 31.81 ms)
+  uint32_t base[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const uint32_t lo = ni ? jn[ni - 1] : 0u, hi = jn[ni];
-    if (hi > lo) {
-      const int q = qt * TILE_ROWS + wn * (32 * NI) + ni * 32 + (lane & 31);
-      const uint32_t base = atomicAdd(p.cnt + q, hi - lo);
-      for (uint32_t i = lo; i < hi; ++i) {
-        const uint2 en = stack[i * NT];
-        const uint32_t slot = base + (i - lo);
-        if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)row0 + en.x, en.y);
-      }
+    base[ni] = 0u;
+    if (hi > lo) base[ni] = atomicAdd(p.cnt + (qt * TILE_ROWS + wn * (32 * NI) + ni * 32 + (lane & 31)), hi - lo);
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const uint32_t lo = ni ? jn[ni - 1] : 0u, hi = jn[ni];
+    const int q = qt * TILE_ROWS + wn * (32 * NI) + ni * 32 + (lane & 31);
+    for (uint32_t i = lo; i < hi; ++i) {
+      const uint2 en = stack[i * NT];
+      const uint32_t slot = base[ni] + (i - lo);
+      if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)row0 + en.x, en.y);
     }
   }
 }
