@@ -1351,9 +1351,15 @@ struct Staged {
 
 extern "C" int dhr_pq_train(int32_t device, int32_t mem_kind, const void* values, int64_t ld, int64_t n, int32_t d, int32_t M, int32_t iters,
                             int64_t max_points, float* codebooks, double* out_error, void* stream) {
+  return dhr_pq_train_nbits(device, mem_kind, values, ld, n, d, M, 8, iters, max_points, codebooks, out_error, stream);
+}
+extern "C" int dhr_pq_train_nbits(int32_t device, int32_t mem_kind, const void* values, int64_t ld, int64_t n, int32_t d, int32_t M, int32_t nbits,
+                                  int32_t iters, int64_t max_points, float* codebooks, double* out_error, void* stream) {
   int rc = pq_check(values, codebooks, n, d, M, ld);
   if (rc) return rc;
-  if (n < 1 || iters < 0 || max_points < 256) return set_error(DHR_ERR_INVALID, "need n >= 1, iters >= 0, max_points >= 256");
+  if (nbits < 1 || nbits > 8) return set_error(DHR_ERR_UNSUPPORTED, "nbits must be in [1, 8] (one code byte per sub-quantiser on the device; faiss' bit-packed rows are a file format matter)");
+  const int ksub = 1 << nbits;
+  if (n < 1 || iters < 0 || max_points < ksub) return set_error(DHR_ERR_INVALID, "need n >= 1, iters >= 0, max_points >= 2^nbits");
   HIP_TRY(hipSetDevice(device));
   hipStream_t s = (hipStream_t)stream;
   const int dsub = d / M;
@@ -1370,24 +1376,24 @@ extern "C" int dhr_pq_train(int32_t device, int32_t mem_kind, const void* values
   } else {
     v.dev = const_cast<void*>(values);
   }
-  const size_t cb_bytes = (size_t)M * 256 * dsub * 4;
+  const size_t cb_bytes = (size_t)M * ksub * dsub * 4;
   if ((rc = cb.in(nullptr, cb_bytes, mem_kind == DHR_MEM_HOST ? DHR_MEM_HOST : DHR_MEM_DEVICE, s)) != DHR_OK) return rc;
   if (mem_kind == DHR_MEM_DEVICE) cb.dev = codebooks;
   float* d_cb = (float*)cb.dev;
   float* sums = nullptr; uint32_t* counts = nullptr; float* err = nullptr;
   auto done = [&](int code) { hipFree(sums); hipFree(counts); hipFree(err); return code; };
-  if (hipMalloc((void**)&sums, cb_bytes) != hipSuccess || hipMalloc((void**)&counts, (size_t)M * 256 * 4) != hipSuccess ||
+  if (hipMalloc((void**)&sums, cb_bytes) != hipSuccess || hipMalloc((void**)&counts, (size_t)M * ksub * 4) != hipSuccess ||
       hipMalloc((void**)&err, (size_t)M * 4) != hipSuccess)
     return done(set_error(DHR_ERR_HIP, "hipMalloc failed"));
-  if (launch_pq_init((const __half*)v.dev, v_ld, np, v_stride, dsub, M, d_cb, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "pq_init launch failed"));
+  if (launch_pq_init((const __half*)v.dev, v_ld, np, v_stride, dsub, M, d_cb, ksub, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "pq_init launch failed"));
   for (int it = 0; it <= iters; ++it) {
-    if (hipMemsetAsync(sums, 0, cb_bytes, s) != hipSuccess || hipMemsetAsync(counts, 0, (size_t)M * 256 * 4, s) != hipSuccess ||
+    if (hipMemsetAsync(sums, 0, cb_bytes, s) != hipSuccess || hipMemsetAsync(counts, 0, (size_t)M * ksub * 4, s) != hipSuccess ||
         hipMemsetAsync(err, 0, (size_t)M * 4, s) != hipSuccess)
       return done(set_error(DHR_ERR_HIP, "memset failed"));
-    if (launch_pq_assign((const __half*)v.dev, v_ld, np, v_stride, dsub, M, d_cb, nullptr, 0, sums, counts, err, s) != hipSuccess)
+    if (launch_pq_assign((const __half*)v.dev, v_ld, np, v_stride, dsub, M, d_cb, nullptr, 0, sums, counts, err, ksub, s) != hipSuccess)
       return done(set_error(DHR_ERR_HIP, "pq_assign launch failed"));
     if (it == iters) break;                               // the last pass only measures the error
-    if (launch_pq_update(d_cb, sums, counts, dsub, M, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "pq_update launch failed"));
+    if (launch_pq_update(d_cb, sums, counts, dsub, M, ksub, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "pq_update launch failed"));
   }
   if (out_error) {
     std::vector<float> e(M);
@@ -1404,19 +1410,25 @@ extern "C" int dhr_pq_train(int32_t device, int32_t mem_kind, const void* values
 
 extern "C" int dhr_pq_encode(int32_t device, int32_t mem_kind, const void* values, int64_t ld, int64_t n, int32_t d, int32_t M,
                              const float* codebooks, uint8_t* codes, void* stream) {
+  return dhr_pq_encode_nbits(device, mem_kind, values, ld, n, d, M, 8, codebooks, codes, stream);
+}
+extern "C" int dhr_pq_encode_nbits(int32_t device, int32_t mem_kind, const void* values, int64_t ld, int64_t n, int32_t d, int32_t M, int32_t nbits,
+                                   const float* codebooks, uint8_t* codes, void* stream) {
   int rc = pq_check(values, codebooks, n, d, M, ld);
   if (rc) return rc;
+  if (nbits < 1 || nbits > 8) return set_error(DHR_ERR_UNSUPPORTED, "nbits must be in [1, 8]");
+  const int ksub = 1 << nbits;
   if (!codes) return set_error(DHR_ERR_INVALID, "null pointer");
   if (n == 0) return DHR_OK;
   HIP_TRY(hipSetDevice(device));
   hipStream_t s = (hipStream_t)stream;
   const int dsub = d / M;
   Staged cb, cd;
-  if ((rc = cb.in(codebooks, (size_t)M * 256 * dsub * 4, mem_kind, s)) != DHR_OK) return rc;
+  if ((rc = cb.in(codebooks, (size_t)M * ksub * dsub * 4, mem_kind, s)) != DHR_OK) return rc;
   if ((rc = cd.in(nullptr, (size_t)n * M, mem_kind == DHR_MEM_HOST ? DHR_MEM_HOST : DHR_MEM_DEVICE, s)) != DHR_OK) return rc;
   if (mem_kind == DHR_MEM_DEVICE) cd.dev = codes;
   if (mem_kind == DHR_MEM_DEVICE) {
-    HIP_TRY(launch_pq_assign((const __half*)values, ld, n, 1, dsub, M, (const float*)cb.dev, (uint8_t*)cd.dev, M, nullptr, nullptr, nullptr, s));
+    HIP_TRY(launch_pq_assign((const __half*)values, ld, n, 1, dsub, M, (const float*)cb.dev, (uint8_t*)cd.dev, M, nullptr, nullptr, nullptr, ksub, s));
   } else {
     const int64_t block = 1 << 18;                          // rows per staged block
     void* stage = nullptr;
@@ -1424,7 +1436,7 @@ extern "C" int dhr_pq_encode(int32_t device, int32_t mem_kind, const void* value
     for (int64_t lo = 0; lo < n; lo += block) {
       const int64_t rows = std::min(block, n - lo);
       if (hipMemcpy2DAsync(stage, (size_t)d * 2, (const char*)values + lo * ld * 2, (size_t)ld * 2, (size_t)d * 2, (size_t)rows, hipMemcpyHostToDevice, s) != hipSuccess ||
-          launch_pq_assign((const __half*)stage, d, rows, 1, dsub, M, (const float*)cb.dev, (uint8_t*)cd.dev + lo * M, M, nullptr, nullptr, nullptr, s) != hipSuccess ||
+          launch_pq_assign((const __half*)stage, d, rows, 1, dsub, M, (const float*)cb.dev, (uint8_t*)cd.dev + lo * M, M, nullptr, nullptr, nullptr, ksub, s) != hipSuccess ||
           hipStreamSynchronize(s) != hipSuccess) {
         hipFree(stage);
         return set_error(DHR_ERR_HIP, "PQ encoding failed on the device");
@@ -1439,15 +1451,21 @@ extern "C" int dhr_pq_encode(int32_t device, int32_t mem_kind, const void* value
 
 extern "C" int dhr_pq_decode(int32_t device, int32_t mem_kind, const uint8_t* codes, int64_t n, int32_t d, int32_t M, const float* codebooks,
                              void* out_values, int64_t ld_out, void* stream) {
+  return dhr_pq_decode_nbits(device, mem_kind, codes, n, d, M, 8, codebooks, out_values, ld_out, stream);
+}
+extern "C" int dhr_pq_decode_nbits(int32_t device, int32_t mem_kind, const uint8_t* codes, int64_t n, int32_t d, int32_t M, int32_t nbits,
+                                   const float* codebooks, void* out_values, int64_t ld_out, void* stream) {
   int rc = pq_check(codes, codebooks, n, d, M, ld_out);
   if (rc) return rc;
+  if (nbits < 1 || nbits > 8) return set_error(DHR_ERR_UNSUPPORTED, "nbits must be in [1, 8]");
+  const int ksub = 1 << nbits;
   if (!out_values) return set_error(DHR_ERR_INVALID, "null pointer");
   if (n == 0) return DHR_OK;
   HIP_TRY(hipSetDevice(device));
   hipStream_t s = (hipStream_t)stream;
   const int dsub = d / M;
   Staged cb, cd, ov;
-  if ((rc = cb.in(codebooks, (size_t)M * 256 * dsub * 4, mem_kind, s)) != DHR_OK) return rc;
+  if ((rc = cb.in(codebooks, (size_t)M * ksub * dsub * 4, mem_kind, s)) != DHR_OK) return rc;
   if ((rc = cd.in(codes, (size_t)n * M, mem_kind, s)) != DHR_OK) return rc;
   int64_t ld_dev = ld_out;
   if (mem_kind == DHR_MEM_HOST) {
@@ -1456,7 +1474,7 @@ extern "C" int dhr_pq_decode(int32_t device, int32_t mem_kind, const uint8_t* co
   } else {
     ov.dev = out_values;
   }
-  HIP_TRY(launch_pq_decode((const uint8_t*)cd.dev, M, n, M, dsub, (const float*)cb.dev, (__half*)ov.dev, ld_dev, s));
+  HIP_TRY(launch_pq_decode((const uint8_t*)cd.dev, M, n, M, dsub, (const float*)cb.dev, (__half*)ov.dev, ld_dev, ksub, s));
   if (mem_kind == DHR_MEM_HOST)
     HIP_TRY(hipMemcpy2DAsync(out_values, (size_t)ld_out * 2, ov.dev, (size_t)d * 2, (size_t)d * 2, (size_t)n, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));

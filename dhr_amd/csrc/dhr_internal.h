@@ -183,12 +183,12 @@ hipError_t launch_emit(const uint64_t* topk_keys, int kp, int n_queries, int k, 
 hipError_t launch_keys_to_rows(const uint64_t* topk_keys, int kp, int n_queries, int k, uint32_t* rows, hipStream_t s);
 hipError_t launch_densify(const void* lex, int in_is_f32, int64_t ld, int64_t batch, int remove, int dims, int n_groups, void* out_val,
                           int val_is_f32, int64_t ld_val, void* out_idx, int idx_is_i16, int64_t ld_idx, hipStream_t s);
-hipError_t launch_pq_init(const __half* vals, int64_t ld, int64_t n, int64_t stride, int dsub, int M, float* cb, hipStream_t s);
+hipError_t launch_pq_init(const __half* vals, int64_t ld, int64_t n, int64_t stride, int dsub, int M, float* cb, int ksub, hipStream_t s);
 hipError_t launch_pq_assign(const __half* vals, int64_t ld, int64_t n, int64_t stride, int dsub, int M, const float* cb, uint8_t* codes,
-                            int64_t ld_codes, float* sums, uint32_t* counts, float* err, hipStream_t s);
-hipError_t launch_pq_update(float* cb, const float* sums, const uint32_t* counts, int dsub, int M, hipStream_t s);
+                            int64_t ld_codes, float* sums, uint32_t* counts, float* err, int ksub, hipStream_t s);
+hipError_t launch_pq_update(float* cb, const float* sums, const uint32_t* counts, int dsub, int M, int ksub, hipStream_t s);
 hipError_t launch_pq_decode(const uint8_t* codes, int64_t ld_codes, int64_t n, int M, int dsub, const float* cb, __half* out, int64_t ld_out,
-                            hipStream_t s);
+                            int ksub, hipStream_t s);
 // exclusive scan of ceil(min(cnt[q], cap) / per) over the queries -> offs[0 .. n_queries] (one workgroup)
 hipError_t launch_block_offsets(const uint32_t* cnt, uint32_t cap, int n_queries, uint32_t per, uint32_t* offs, hipStream_t s);
 hipError_t launch_max_u32(const uint32_t* v, int n, uint32_t* out_max, unsigned long long* out_sum, hipStream_t s);

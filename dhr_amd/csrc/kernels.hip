@@ -1544,17 +1544,18 @@ constexpr int PQ_MAX_DSUB = 64;
 // grid (point blocks of 256, M).  Centroids of the subspace in LDS; one thread per point.
 template <int DSUB>   // compile-time sub-vector width (registers) or 0 = run-time width up to PQ_MAX_DSUB (scratch)
 __global__ void __launch_bounds__(256) pq_assign_kernel(const __half* __restrict__ vals, int64_t ld, int64_t n, int64_t stride, int dsub_rt,
-                                                        const float* __restrict__ cb /* [M][256][dsub] */, uint8_t* __restrict__ codes,
-                                                        int64_t ld_codes, float* __restrict__ sums /* [M][256][dsub] or null */,
-                                                        uint32_t* __restrict__ counts /* [M][256] or null */, float* __restrict__ err /* [M] or null */) {
+                                                        const float* __restrict__ cb /* [M][ksub][dsub] */, uint8_t* __restrict__ codes,
+                                                        int64_t ld_codes, float* __restrict__ sums /* [M][ksub][dsub] or null */,
+                                                        uint32_t* __restrict__ counts /* [M][ksub] or null */, float* __restrict__ err /* [M] or null */,
+                                                        int ksub /* centroids per subspace = 2^nbits <= 256 */) {
   __shared__ float c[PQ_K * PQ_MAX_DSUB];
   __shared__ float cn[PQ_K];
   const int dsub = DSUB ? DSUB : dsub_rt;
   const int m = blockIdx.y;
-  const float* cbm = cb + (int64_t)m * PQ_K * dsub;
-  for (int i = threadIdx.x; i < PQ_K * dsub; i += 256) c[i] = cbm[i];
+  const float* cbm = cb + (int64_t)m * ksub * dsub;
+  for (int i = threadIdx.x; i < ksub * dsub; i += 256) c[i] = cbm[i];
   __syncthreads();
-  {
+  if ((int)threadIdx.x < ksub) {
     float s = 0.f;
     for (int j = 0; j < dsub; ++j) s += c[threadIdx.x * dsub + j] * c[threadIdx.x * dsub + j];
     cn[threadIdx.x] = s;
@@ -1570,7 +1571,7 @@ __global__ void __launch_bounds__(256) pq_assign_kernel(const __half* __restrict
   // argmin_c |x - c|^2 = argmin_c (|c|^2 - 2 <x, c>); first minimum wins
   float best = INFINITY;
   int arg = 0;
-  for (int k = 0; k < PQ_K; ++k) {
+  for (int k = 0; k < ksub; ++k) {
     float dot = 0.f;
 #pragma unroll
     for (int j = 0; j < (DSUB ? DSUB : 1); ++j)
@@ -1582,8 +1583,8 @@ __global__ void __launch_bounds__(256) pq_assign_kernel(const __half* __restrict
   }
   if (codes) codes[pi * ld_codes + m] = (uint8_t)arg;
   if (sums) {
-    for (int j = 0; j < dsub; ++j) atomicAdd(&sums[((int64_t)m * PQ_K + arg) * dsub + j], xv[j]);
-    atomicAdd(&counts[m * PQ_K + arg], 1u);
+    for (int j = 0; j < dsub; ++j) atomicAdd(&sums[((int64_t)m * ksub + arg) * dsub + j], xv[j]);
+    atomicAdd(&counts[m * ksub + arg], 1u);
     if (err) {
       float xx = 0.f;
       for (int j = 0; j < dsub; ++j) xx += xv[j] * xv[j];
@@ -1594,69 +1595,71 @@ __global__ void __launch_bounds__(256) pq_assign_kernel(const __half* __restrict
 // centroid = mean of its points; an empty cluster takes a copy of the most populated cluster's centroid, nudged
 // (faiss splits a large cluster the same way)
 __global__ void __launch_bounds__(256) pq_update_kernel(float* __restrict__ cb, const float* __restrict__ sums, const uint32_t* __restrict__ counts,
-                                                        int dsub) {
+                                                        int dsub, int ksub) {
   const int m = blockIdx.x, k = threadIdx.x;
   __shared__ uint32_t cnt[PQ_K];
   __shared__ int big;
-  cnt[k] = counts[m * PQ_K + k];
+  cnt[k] = k < ksub ? counts[m * ksub + k] : 0u;
   __syncthreads();
   if (k == 0) {
     int b = 0;
-    for (int i = 1; i < PQ_K; ++i) if (cnt[i] > cnt[b]) b = i;
+    for (int i = 1; i < ksub; ++i) if (cnt[i] > cnt[b]) b = i;
     big = b;
   }
   __syncthreads();
-  float* c = cb + ((int64_t)m * PQ_K + k) * dsub;
+  if (k >= ksub) return;
+  float* c = cb + ((int64_t)m * ksub + k) * dsub;
   if (cnt[k] > 0) {
     const float inv = 1.f / (float)cnt[k];
-    for (int j = 0; j < dsub; ++j) c[j] = sums[((int64_t)m * PQ_K + k) * dsub + j] * inv;
+    for (int j = 0; j < dsub; ++j) c[j] = sums[((int64_t)m * ksub + k) * dsub + j] * inv;
   } else {
     const float inv = 1.f / (float)(cnt[big] ? cnt[big] : 1u);
-    for (int j = 0; j < dsub; ++j) c[j] = sums[((int64_t)m * PQ_K + big) * dsub + j] * inv * (1.f + ((j + k) & 1 ? 1.f : -1.f) / 1024.f);
+    for (int j = 0; j < dsub; ++j) c[j] = sums[((int64_t)m * ksub + big) * dsub + j] * inv * (1.f + ((j + k) & 1 ? 1.f : -1.f) / 1024.f);
   }
 }
-// initial centroids: 256 evenly spaced training points
+// initial centroids: ksub evenly spaced training points
 __global__ void __launch_bounds__(256) pq_init_kernel(const __half* __restrict__ vals, int64_t ld, int64_t n, int64_t stride, int dsub, int M,
-                                                      float* __restrict__ cb) {
+                                                      float* __restrict__ cb, int ksub) {
   const int m = blockIdx.x, k = threadIdx.x;
-  const int64_t pi = (n >= PQ_K) ? (int64_t)k * (n / PQ_K) : (int64_t)(k % (n > 0 ? n : 1));
+  if (k >= ksub) return;
+  const int64_t pi = (n >= ksub) ? (int64_t)k * (n / ksub) : (int64_t)(k % (n > 0 ? n : 1));
   const __half* x = vals + pi * stride * ld + (int64_t)m * dsub;
-  for (int j = 0; j < dsub; ++j) cb[((int64_t)m * PQ_K + k) * dsub + j] = __half2float(x[j]);
+  for (int j = 0; j < dsub; ++j) cb[((int64_t)m * ksub + k) * dsub + j] = __half2float(x[j]);
 }
 // decoded vectors, fp16 [n][ld_out]: column m*dsub + j = centroid(code[m])[j]
 __global__ void __launch_bounds__(256) pq_decode_kernel(const uint8_t* __restrict__ codes, int64_t ld_codes, int64_t n, int M, int dsub,
-                                                        const float* __restrict__ cb, __half* __restrict__ out, int64_t ld_out) {
+                                                        const float* __restrict__ cb, __half* __restrict__ out, int64_t ld_out, int ksub) {
   const int d = M * dsub;
   const int64_t total = n * d;
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
     const int64_t row = g / d;
     const int col = (int)(g - row * d);
     const int m = col / dsub, j = col - m * dsub;
-    out[row * ld_out + col] = __float2half(cb[((int64_t)m * PQ_K + codes[row * ld_codes + m]) * dsub + j]);
+    out[row * ld_out + col] = __float2half(cb[((int64_t)m * ksub + codes[row * ld_codes + m]) * dsub + j]);
   }
 }
-hipError_t launch_pq_init(const __half* vals, int64_t ld, int64_t n, int64_t stride, int dsub, int M, float* cb, hipStream_t s) {
-  hipLaunchKernelGGL(pq_init_kernel, dim3(M), dim3(256), 0, s, vals, ld, n, stride, dsub, M, cb);
+hipError_t launch_pq_init(const __half* vals, int64_t ld, int64_t n, int64_t stride, int dsub, int M, float* cb, int ksub, hipStream_t s) {
+  hipLaunchKernelGGL(pq_init_kernel, dim3(M), dim3(256), 0, s, vals, ld, n, stride, dsub, M, cb, ksub);
   return hipGetLastError();
 }
 hipError_t launch_pq_assign(const __half* vals, int64_t ld, int64_t n, int64_t stride, int dsub, int M, const float* cb, uint8_t* codes,
-                            int64_t ld_codes, float* sums, uint32_t* counts, float* err, hipStream_t s) {
+                            int64_t ld_codes, float* sums, uint32_t* counts, float* err, int ksub, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   const dim3 grid((unsigned)((n + 255) / 256), M);
-#define PQ_GO(D) hipLaunchKernelGGL(pq_assign_kernel<D>, grid, dim3(256), 0, s, vals, ld, n, stride, dsub, cb, codes, ld_codes, sums, counts, err)
+#define PQ_GO(D) hipLaunchKernelGGL(pq_assign_kernel<D>, grid, dim3(256), 0, s, vals, ld, n, stride, dsub, cb, codes, ld_codes, sums, counts, err, ksub)
   if (dsub == 12) PQ_GO(12); else if (dsub == 24) PQ_GO(24); else if (dsub == 14) PQ_GO(14); else if (dsub == 16) PQ_GO(16); else PQ_GO(0);
 #undef PQ_GO
   return hipGetLastError();
 }
-hipError_t launch_pq_update(float* cb, const float* sums, const uint32_t* counts, int dsub, int M, hipStream_t s) {
-  hipLaunchKernelGGL(pq_update_kernel, dim3(M), dim3(256), 0, s, cb, sums, counts, dsub);
+hipError_t launch_pq_update(float* cb, const float* sums, const uint32_t* counts, int dsub, int M, int ksub, hipStream_t s) {
+  hipLaunchKernelGGL(pq_update_kernel, dim3(M), dim3(256), 0, s, cb, sums, counts, dsub, ksub);
   return hipGetLastError();
 }
-hipError_t launch_pq_decode(const uint8_t* codes, int64_t ld_codes, int64_t n, int M, int dsub, const float* cb, __half* out, int64_t ld_out,
+hipError_t launch_pq_decode(const uint8_t* codes, int64_t ld_codes, int64_t n, int M, int dsub, const float* cb, __half* out, int64_t ld_out, int ksub,
                             hipStream_t s) {
   if (n <= 0) return hipSuccess;
   const int64_t blocks = std::min<int64_t>((n * M * dsub + 255) / 256, 65536);
-  hipLaunchKernelGGL(pq_decode_kernel, dim3((unsigned)blocks), dim3(256), 0, s, codes, ld_codes, n, M, dsub, cb, out, ld_out);
+  hipLaunchKernelGGL(pq_decode_kernel, dim3((unsigned)blocks), dim3(256), 0, s, codes, ld_codes, n, M, dsub, cb, out, ld_out, ksub);
   return hipGetLastError();
 }
 

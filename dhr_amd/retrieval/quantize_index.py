@@ -25,42 +25,46 @@ PQ_FORMAT = "dhr-pq"
 
 
 def train_and_encode(values, M: int = 64, n_bits: int = 8, iters: int = 25, max_points: int = 65536, device: int = 0):
-    """values: fp16 [N, d] numpy array (or a torch CUDA tensor).  -> (codebooks float32 [M,256,d/M], codes uint8 [N,M], mse)."""
-    if n_bits != 8:
-        raise NotImplementedError("only --n_bits 8 (256 centroids per sub-quantiser, the reference's default) is built")
+    """values: fp16 [N, d] numpy array (or a torch CUDA tensor).  -> (codebooks float32 [M, 2^n_bits, d/M], codes uint8 [N,M], mse).
+    `--n_bits` as in quantize_index.py:22,29 (faiss.IndexPQ(d, M, nbits)): 1..8; codes are one byte per sub-quantiser here, the
+    bit-packed rows of faiss exist in the index file only (pack_codes / unpack_codes)."""
+    if not 1 <= int(n_bits) <= 8:
+        raise ValueError("--n_bits must be in [1, 8] (faiss' IndexPQ takes up to 24 bits; codes wider than a byte are not built)")
     lib = _lib.load()
     n, d = int(values.shape[0]), int(values.shape[1])
+    ksub = 1 << int(n_bits)
     if d % M:
         raise ValueError(f"the vector width {d} is not a multiple of --qauntized_dim {M}")
     p, ld, kind = _lib._ptr_ld(values)
     err = C.c_double()
     if kind == _lib.MEM_HOST:
-        cb = np.empty((M, 256, d // M), np.float32)
+        cb = np.empty((M, ksub, d // M), np.float32)
         codes = np.empty((n, M), np.uint8)
         pcb, pcodes = cb.ctypes.data, codes.ctypes.data
     else:
         import torch
-        cb = torch.empty((M, 256, d // M), dtype=torch.float32, device=values.device)
+        cb = torch.empty((M, ksub, d // M), dtype=torch.float32, device=values.device)
         codes = torch.empty((n, M), dtype=torch.uint8, device=values.device)
         pcb, pcodes = cb.data_ptr(), codes.data_ptr()
-    _lib.check(lib.dhr_pq_train(device, kind, p, ld, n, d, M, iters, max_points, pcb, C.byref(err), None), "dhr_pq_train")
-    _lib.check(lib.dhr_pq_encode(device, kind, p, ld, n, d, M, pcb, pcodes, None), "dhr_pq_encode")
+    _lib.check(lib.dhr_pq_train_nbits(device, kind, p, ld, n, d, M, int(n_bits), iters, max(max_points, ksub), pcb, C.byref(err), None), "dhr_pq_train")
+    _lib.check(lib.dhr_pq_encode_nbits(device, kind, p, ld, n, d, M, int(n_bits), pcb, pcodes, None), "dhr_pq_encode")
     return cb, codes, float(err.value)
 
 
 def decode(codebooks, codes, device: int = 0):
     """-> fp16 [N, d] reconstruction, same memory kind as the inputs."""
     lib = _lib.load()
-    M, dsub = int(codebooks.shape[0]), int(codebooks.shape[2])
+    M, ksub, dsub = int(codebooks.shape[0]), int(codebooks.shape[1]), int(codebooks.shape[2])
+    nbits = ksub.bit_length() - 1
     n, d = int(codes.shape[0]), M * dsub
     if isinstance(codes, np.ndarray):
         out = np.empty((n, d), np.float16)
-        _lib.check(lib.dhr_pq_decode(device, _lib.MEM_HOST, codes.ctypes.data, n, d, M, np.ascontiguousarray(codebooks, np.float32).ctypes.data,
-                                     out.ctypes.data, d, None), "dhr_pq_decode")
+        _lib.check(lib.dhr_pq_decode_nbits(device, _lib.MEM_HOST, codes.ctypes.data, n, d, M, nbits, np.ascontiguousarray(codebooks, np.float32).ctypes.data,
+                                           out.ctypes.data, d, None), "dhr_pq_decode")
         return out
     import torch
     out = torch.empty((n, d), dtype=torch.float16, device=codes.device)
-    _lib.check(lib.dhr_pq_decode(device, _lib.MEM_DEVICE, codes.data_ptr(), n, d, M, codebooks.data_ptr(), out.data_ptr(), d, None), "dhr_pq_decode")
+    _lib.check(lib.dhr_pq_decode_nbits(device, _lib.MEM_DEVICE, codes.data_ptr(), n, d, M, nbits, codebooks.data_ptr(), out.data_ptr(), d, None), "dhr_pq_decode")
     return out
 
 
@@ -255,7 +259,7 @@ def main(argv=None):
     cb, codes, mse = train_and_encode(corpus_embs, args.qauntized_dim, args.n_bits)
     print('quantisation error (mean squared, per vector): {:.6f}'.format(mse))
     print('write index to {}'.format(args.output_index_path))
-    save_pq(args.output_index_path, cb, codes)
+    save_pq(args.output_index_path, cb, codes, args.n_bits)
     print('finish')
 
 

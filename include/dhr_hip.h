@@ -247,6 +247,15 @@ int dhr_pq_encode(int32_t device, int32_t mem_kind, const void* values_f16, int6
                   const float* codebooks, uint8_t* codes, void* stream);
 int dhr_pq_decode(int32_t device, int32_t mem_kind, const uint8_t* codes, int64_t n, int32_t d, int32_t M, const float* codebooks,
                   void* out_values_f16, int64_t ld_out, void* stream);
+/* The same three with `--n_bits` (quantize_index.py:22,29: faiss.IndexPQ(d, M, nbits)): 2^nbits centroids per sub-quantiser, 1 <= nbits <= 8,
+ * codebooks [M][2^nbits][d / M]; codes stay one byte per sub-quantiser on the device and in these calls (faiss' bit-packed rows are
+ * written / read by the index file code, dhr_amd/retrieval/quantize_index.py).  The functions above are nbits = 8. */
+int dhr_pq_train_nbits(int32_t device, int32_t mem_kind, const void* values_f16, int64_t ld, int64_t n, int32_t d, int32_t M, int32_t nbits,
+                       int32_t iters, int64_t max_points, float* codebooks, double* out_error, void* stream);
+int dhr_pq_encode_nbits(int32_t device, int32_t mem_kind, const void* values_f16, int64_t ld, int64_t n, int32_t d, int32_t M, int32_t nbits,
+                        const float* codebooks, uint8_t* codes, void* stream);
+int dhr_pq_decode_nbits(int32_t device, int32_t mem_kind, const uint8_t* codes, int64_t n, int32_t d, int32_t M, int32_t nbits,
+                        const float* codebooks, void* out_values_f16, int64_t ld_out, void* stream);
 
 int dhr_get_stats(const dhr_index* index, dhr_search_stats* out);
 

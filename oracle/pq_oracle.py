@@ -15,7 +15,7 @@ from __future__ import annotations
 import numpy as np
 
 
-def train(x: np.ndarray, M: int, iters: int = 25, max_points: int = 65536):
+def train(x: np.ndarray, M: int, iters: int = 25, max_points: int = 65536, nbits: int = 8):
     """Lloyd k-means per subspace, the same deterministic schedule as dhr_pq_train (every stride-th row, the first 256
     evenly spaced training rows as initial centroids, empty clusters re-seeded from the largest one)."""
     n, d = x.shape
@@ -23,18 +23,19 @@ def train(x: np.ndarray, M: int, iters: int = 25, max_points: int = 65536):
     stride = max(1, n // max_points)
     t = x[::stride].astype(np.float32)
     npnts = t.shape[0]
-    cb = np.empty((M, 256, dsub), np.float32)
-    pick = (np.arange(256) * (npnts // 256)) if npnts >= 256 else (np.arange(256) % npnts)
+    ksub = 1 << nbits                                  # faiss.IndexPQ(d, M, nbits): 2^nbits centroids per sub-quantiser
+    cb = np.empty((M, ksub, dsub), np.float32)
+    pick = (np.arange(ksub) * (npnts // ksub)) if npnts >= ksub else (np.arange(ksub) % npnts)
     for m in range(M):
         sub = t[:, m * dsub:(m + 1) * dsub]
         c = sub[pick].copy()
         for _ in range(iters):
             a = assign(sub, c)
-            cnt = np.bincount(a, minlength=256)
+            cnt = np.bincount(a, minlength=ksub)
             sums = np.zeros_like(c)
             np.add.at(sums, a, sub)
             big = int(np.argmax(cnt))
-            for k in range(256):
+            for k in range(ksub):
                 if cnt[k] > 0:
                     c[k] = sums[k] / cnt[k]
                 else:

@@ -1210,3 +1210,48 @@ def test_dense_i8_adversarial(G, kind):
         cv[::3, :d] *= np.float16(-1)
         qv[::2, :d] *= -1
     _i8_pair(G, cv, ci, qv, qi, 200)
+
+
+@pytest.mark.parametrize("nbits", [4, 6])
+def test_pq_n_bits_below_8(G, tmp_path, monkeypatch, nbits):
+    """`--n_bits` < 8 (quantize_index.py:22,29): 2^nbits centroids per sub-quantiser -- training, encoding, decoding and the ADC scan
+    against the oracle with the same codebooks; the faiss IndexPQ file carries bit-packed rows; CLI round trip."""
+    import pickle
+    from dhr_amd import synth
+    from dhr_amd.retrieval import quantize_index as QI
+    from oracle import pq_oracle as PO
+    cv, ci, qv, qi = synth.make_pair(43, 12000, 8, 768, 128)
+    q = qv.astype(np.float32)
+    ksub = 1 << nbits
+    cb, codes, err = QI.train_and_encode(cv, 64, nbits, iters=6)
+    assert cb.shape == (64, ksub, 14) and codes.dtype == np.uint8 and int(codes.max()) < ksub
+    ecodes = PO.encode(cv[:3000].astype(np.float32), cb)
+    assert (ecodes != codes[:3000]).mean() < 2e-3
+    ocb = PO.train(cv, 64, iters=6, nbits=nbits)
+    assert PO.mse(cv[:4000], cb) <= 1.03 * PO.mse(cv[:4000], ocb)
+    np.testing.assert_array_equal(QI.decode(cb, codes), PO.decode(codes, cb).astype(np.float16))
+    pix = QI.PqIndex(cb, codes, nbits=nbits)
+    try:
+        adc = PO.adc_scores(q, codes, cb)
+        np.testing.assert_allclose(pix.adc_scores(q).cpu().numpy(), adc, rtol=0, atol=1e-5 * max(1.0, float(np.abs(adc).max())))
+        s1, r1 = pix.search(q, 300)
+        for i in range(8):
+            O.check_topk(r1[i], s1[i], adc[i], 300, atol=1e-4)
+    finally:
+        pix.close()
+    # file: code_size = ceil(64 * nbits / 8) bytes per row, read back identically
+    QI.save_pq(str(tmp_path / "pq.idx"), cb, codes, nbits)
+    back = QI.load_pq(str(tmp_path / "pq.idx"))
+    assert back["nbits"] == nbits and os.path.getsize(tmp_path / "pq.idx") < 12000 * (64 * nbits // 8) + 64 * ksub * 14 * 4 + 256
+    np.testing.assert_array_equal(back["codes"], codes)
+    np.testing.assert_array_equal(back["codebooks"], cb)
+    # CLI with --n_bits
+    monkeypatch.chdir(tmp_path)
+    with open("q.pt", "wb") as f:
+        pickle.dump([qv, qi, ["q%d" % i for i in range(8)]], f, protocol=4)
+    with open("c.pt", "wb") as f:
+        pickle.dump([cv, ci, ["d%d" % i for i in range(12000)]], f, protocol=4)
+    QI.main(["--index_path", "c.pt", "--output_index_path", "pqn_index", "--n_bits", str(nbits)])
+    G.main(["--query_emb_path", "q.pt", "--index_path", "c.pt", "--emb_dim", "768", "--PQIP", "--faiss_pq_index_path", "pqn_index",
+            "--rerank", "--agip_topk", "400", "--topk", "10", "--output", "pqn.trec"])
+    assert len(open("pqn.trec").read().splitlines()) == 80
