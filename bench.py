@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--aux-cus", type=int, default=-1, help="tuning: CUs the refine/rescoring stream is confined to (0 = no mask)")
     ap.add_argument("--gemm-exclusive", type=int, default=-1)
     ap.add_argument("--overlap-aux", type=int, default=-1)
+    ap.add_argument("--progressive-thr", type=int, default=-1, help="tuning: 1 = running exact thresholds only, 2 (library default) = + extrapolated from the scattered fraction seen")
     ap.add_argument("--dense-i8", type=int, default=-1, help="int8 image of the ungated columns in the bound GEMM (dhr_set_option DHR_OPT_DENSE_I8): -1 library default (gated indexes), 0 off, 1 on for dense-only indexes too")
     ap.add_argument("--gemm-variant", type=int, default=-1, help="tuning: bound-GEMM kernel of the 2:4 layout (3 = 12-wave producer / consumer, 4 = 4 waves, 5 = 8 waves)")
     ap.add_argument("--no-progressive-thr", action="store_true", help="A/B: keep the sampled thresholds frozen over the main pass")
@@ -221,6 +222,8 @@ def run_workload(args, spec, ctx):
             index.set_param(prm, flag)
     if args.no_progressive_thr:
         index.set_param(_lib.PARAM_PROGRESSIVE_THR, 0)
+    elif args.progressive_thr >= 0:
+        index.set_param(_lib.PARAM_PROGRESSIVE_THR, args.progressive_thr)
 
     # host samples for the CPU baseline and the in-bench parity check (rank 0, N=1 only; BEFORE the corpus tensors are dropped)
     cpu_sample = par_sample = None

@@ -105,7 +105,7 @@ struct dhr_index {
   int profile = 0, max_growth16 = 32;
   int sample_period = 32;
   int main_chunks = 2;
-  int progressive_thr = 1;
+  int progressive_thr = 2;
   int n_cu = 256;
   int gemm_variant = 0;                    // 2:4 layout kernel of THIS handle (0 = library default)
   int overlap_aux = -1;                    // 0: refine / rescoring / select run on the GEMM's stream (every kernel gets the whole chip); 1: beside the next chunk's GEMM on a CU-masked stream; -1 (default) = 1 for dense-only indexes (110.4 -> 101.7 ms per step at config 2), 0 for gated ones (the same step time, 192.7 vs 193.0 ms, but the overlapped GEMM launches run 7 % longer)
@@ -185,7 +185,7 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
     case DHR_PARAM_MAIN_CHUNKS:
       if (value < 1 || value > 64) return set_error(DHR_ERR_INVALID, "main_chunks must be in [1,64]");
       ix->main_chunks = (int)value; return DHR_OK;
-    case DHR_PARAM_PROGRESSIVE_THR: ix->progressive_thr = value != 0; return DHR_OK;
+    case DHR_PARAM_PROGRESSIVE_THR: ix->progressive_thr = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return DHR_OK;
     case DHR_PARAM_AUX_CUS:
       if (value < 0 || value > 192 || value % 8) return set_error(DHR_ERR_INVALID, "aux_cus must be a multiple of 8 in [0,192]");
       ix->aux_cus = (int)value; return DHR_OK;
@@ -886,6 +886,16 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   // bound GEMM of chunk i+1 (stream s) overlaps the exact rescoring + top-k merge of chunk i (aux stream)
   sel.k = k; sel.kps = w.kp;
   const int64_t n_main = rest - n_sample;
+  // progressive_thr 2 (default, first attempt of an unsharded search only): the main pass visits the non-sample tiles in a scattered
+  // order (i -> i * perm_mul mod n_main, perm_mul ~ 0.618 n_main and coprime), so that what has been seen after any chunk is a
+  // scattered fraction of the corpus whatever the order of the rows, and the thresholds are extrapolated from it (raise_thr_rank_kernel)
+  const bool extrapolate = ix->progressive_thr >= 2 && stage == 0 && depth == 0 && n_main >= 64 && k >= 16;
+  int64_t perm_mul = 1;
+  if (extrapolate) {
+    perm_mul = (int64_t)(0.6180339887 * (double)n_main) | 1;
+    auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
+    while (gcd(perm_mul, n_main) != 1) perm_mul += 2;
+  }
   {
     HIP_TRY(hipMemcpyAsync(w.thr_hat, w.thr, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemsetAsync(w.fail_flags, 0, (size_t)w.q_pad * 4, s));
@@ -961,7 +971,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       if (i >= 2) HIP_TRY(hipStreamWaitEvent(sg, ev_done[i - 2], 0));      // list set is free again
       GemmArgs g{};
       g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = ix->dense_i8 ? w.i8_mul : nullptr;
-      g.seq_lo = lo; g.seq_hi = hi; g.map_mode = 2; g.period = S; g.head = head; g.n_tiles = ix->n_tiles;
+      g.seq_lo = lo; g.seq_hi = hi; g.map_mode = extrapolate ? 3 : 2; g.period = S; g.head = head; g.n_tiles = ix->n_tiles; g.perm_mul = perm_mul; g.perm_n = n_main;
       g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr_hat; g.cand = cand; g.cnt = cnt;
       g.cap = (uint32_t)w.cap; g.n_queries = Q;
       HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)w.q_pad * 4, sg));
@@ -991,6 +1001,11 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       HIP_TRY(launch_mark_overflow(cnt, (uint32_t)w.cap, Q, w.fail_flags, sb));
       if ((rc = rescore_select(ix, w, Q, gate, sel, cand, cnt, w.thr_hat, maxc, tm, st, sb, (int64_t)sumc, w.fail_flags)) != DHR_OK) return rc;
       if (ix->progressive_thr) HIP_TRY(launch_raise_thr(w.thr_hat, sel.thr, Q, sb));   // later chunks filter with the running exact thresholds
+      if (extrapolate && i + 1 < M) {
+        const double f = (double)(head + n_sample + bound[i + 1]) / (double)ix->n_tiles;
+        const int r = (int)std::ceil((double)k * f + 5.0 * std::sqrt((double)k * f * (1.0 - f)) + 4.0);
+        if (r < k) HIP_TRY(launch_raise_thr_rank(w.thr_hat, w.tau_hat, w.topk_keys, w.kp, r, w.margin, Q, sb));
+      }
       HIP_TRY(hipEventRecord(ev_done[i], sb));
     }
     HIP_TRY(hipStreamWaitEvent(s, ev_done[M - 1], 0));

@@ -52,9 +52,10 @@ __host__ __device__ inline float ordered_f32(uint32_t o) {
   v.u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
   return v.f;
 }
-__host__ __device__ inline int64_t seq_to_tile(int64_t i, int map_mode, int period, int64_t head) {
+__host__ __device__ inline int64_t seq_to_tile(int64_t i, int map_mode, int period, int64_t head, int64_t perm_mul = 1, int64_t perm_n = 1) {
   if (map_mode == 0) return i;
   if (map_mode == 1) return head + i * period;
+  if (map_mode == 3) i = (i * perm_mul) % perm_n;        // the non-sample tiles in a scattered order (perm_mul coprime to perm_n, both < 2^24)
   return head + (i / (period - 1)) * period + i % (period - 1) + 1;
 }
 __host__ __device__ inline uint64_t make_key(float score, uint32_t row) {
@@ -72,8 +73,10 @@ struct GemmArgs {
   //   map_mode 0: tile = i                 (contiguous)
   //   map_mode 1: tile = head + i*period   (the strided sample)
   //   map_mode 2: tile = head + (i/(period-1))*period + i%(period-1) + 1   (everything but the sample)
+  //   map_mode 3: as 2 with i -> (i * perm_mul) % perm_n: every range of positions is a scattered subset of the non-sample tiles
   int64_t seq_lo, seq_hi;
   int map_mode, period;
+  int64_t perm_mul, perm_n;
   int64_t head, n_tiles;
   int n_qtiles;               // Q_pad / 256
   int64_t n_rows;             // valid corpus rows (rows >= n_rows are zero padding)
@@ -203,6 +206,7 @@ hipError_t launch_scatter_keys(const uint64_t* src, uint64_t* dst, int kp, const
 hipError_t launch_emit_scores(const uint64_t* topk_keys, int kp, int n_queries, int r, float* out, hipStream_t s);
 hipError_t launch_make_thr(const float* tau, const float* margin, int n_queries, int q_pad, float* thr, hipStream_t s);
 hipError_t launch_raise_thr(float* thr_hat, const float* thr_run, int n_queries, hipStream_t s);
+hipError_t launch_raise_thr_rank(float* thr_hat, float* tau_hat, const uint64_t* topk_keys, int kp, int r, const float* margin, int n_queries, hipStream_t s);
 hipError_t launch_count_ge(const uint64_t* topk_keys, int kp, int k, const float* tau, const uint32_t* fail_flags, int n_queries,
                            int32_t* out, hipStream_t s);
 hipError_t launch_merge_topk(int n_queries, int n_in, const float* in_scores, const int64_t* in_rows, int k_out,

@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
   const int dl = r - qt * DOC_GROUP;
   const int64_t seq = p.seq_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
   if (seq >= p.seq_hi) return;
-  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head);
+  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head, p.perm_mul, p.perm_n);
   if (dt >= p.n_tiles) return;
 
   const int lane = threadIdx.x & 63;

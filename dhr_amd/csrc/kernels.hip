@@ -676,7 +676,7 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_v3_kernel(GemmArg
   const int dl = r - qt * DOC_GROUP;
   const int64_t seq = p.seq_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
   if (seq >= p.seq_hi) return;
-  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head);
+  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head, p.perm_mul, p.perm_n);
   if (dt >= p.n_tiles) return;
 
   const int lane = threadIdx.x & 63;
@@ -796,7 +796,7 @@ __global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(
   const int dl = r - qt * DOC_GROUP;
   const int64_t seq = p.seq_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
   if (seq >= p.seq_hi) return;
-  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head);
+  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head, p.perm_mul, p.perm_n);
   if (dt >= p.n_tiles) return;
 
   const int lane = threadIdx.x & 63;
@@ -1874,6 +1874,24 @@ __global__ void raise_thr_kernel(float* __restrict__ thr_hat, const float* __res
 }
 hipError_t launch_raise_thr(float* thr_hat, const float* thr_run, int n_queries, hipStream_t s) {
   hipLaunchKernelGGL(raise_thr_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, thr_hat, thr_run, n_queries);
+  return hipGetLastError();
+}
+// Extrapolated threshold ("thresholds"): the rows seen so far are a scattered fraction f of the corpus, so the
+// r-th best seen, r = k f + 5 sqrt(k f (1 - f)) + 4, lies below the final k-th best score except with negligible probability; a query
+// for which it does not is caught by the verification against tau_hat (raised here too) and redone.
+__global__ void raise_thr_rank_kernel(float* __restrict__ thr_hat, float* __restrict__ tau_hat, const uint64_t* __restrict__ topk_keys, int kp, int r,
+                                      const float* __restrict__ margin, int n_queries) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_queries) return;
+  const uint64_t key = topk_keys[(int64_t)q * kp + (r - 1)];
+  if (key == 0ull) return;
+  const float t = ordered_f32((uint32_t)(key >> 32));
+  if (!(t > tau_hat[q])) return;
+  tau_hat[q] = t;
+  thr_hat[q] = fmaxf(thr_hat[q], t - margin[q]);
+}
+hipError_t launch_raise_thr_rank(float* thr_hat, float* tau_hat, const uint64_t* topk_keys, int kp, int r, const float* margin, int n_queries, hipStream_t s) {
+  hipLaunchKernelGGL(raise_thr_rank_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, thr_hat, tau_hat, topk_keys, kp, r, margin, n_queries);
   return hipGetLastError();
 }
 // Rows of the final list that reach tau (all valid rows when tau is null); -1 when the shard's lists overflowed.

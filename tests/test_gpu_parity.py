@@ -1255,3 +1255,42 @@ def test_pq_n_bits_below_8(G, tmp_path, monkeypatch, nbits):
     G.main(["--query_emb_path", "q.pt", "--index_path", "c.pt", "--emb_dim", "768", "--PQIP", "--faiss_pq_index_path", "pqn_index",
             "--rerank", "--agip_topk", "400", "--topk", "10", "--output", "pqn.trec"])
     assert len(open("pqn.trec").read().splitlines()) == 80
+
+
+def test_extrapolated_threshold_failure_is_redone(G):
+    """DHR_PARAM_PROGRESSIVE_THR = 2: after every main-pass chunk the threshold is raised to the rank extrapolated from the scattered
+    fraction of the corpus seen so far.  Adversarial placement: 56 outstanding rows (fewer than k = 64), ALL inside the tiles the
+    scattered order visits in the first chunk -- the extrapolation (rank 50 of the seen rows) lands on their score, every later row
+    is filtered, fewer than k rows reach the threshold: the verification must fail and the query be redone exactly.  The visiting
+    order is restated from api.hip (search_core): non-sample position i -> (i * perm_mul) % n_main."""
+    import math
+    from dhr_amd import _lib
+    n, S, k, M = 720_000, 4, 64, 8                      # 2 108 non-sample tiles: the planner allows 8 chunks from 2 048 on
+    rng = np.random.default_rng(11)
+    cv = (rng.standard_normal((n, 64)) * 0.02).astype(np.float16)
+    n_tiles = (n + 255) // 256
+    head = 2                                            # 512 exhaustive rows
+    rest = n_tiles - head
+    n_sample = (rest + S - 1) // S
+    n_main = rest - n_sample
+    perm_mul = int(0.6180339887 * n_main) | 1
+    while math.gcd(perm_mul, n_main) != 1:
+        perm_mul += 2
+    bound1 = min(n_main, -(-int(n_main * 3.0 / 16.0) // 4) * 4)     # chunk 0 of 8: weight 3 of 16, whole tile groups
+    first_tiles = []
+    for i in range(bound1):
+        m = (i * perm_mul) % n_main
+        first_tiles.append(head + (m // (S - 1)) * S + m % (S - 1) + 1)
+    rows = np.concatenate([np.arange(t * 256, min(n, t * 256 + 256)) for t in first_tiles[:20]])
+    boosted = rng.choice(rows, 56, replace=False)
+    cv[boosted, 0] = (2.0 + rng.random(56) * 0.1).astype(np.float16)
+    qv = np.zeros((3, 64), np.float32)
+    qv[:, 0] = 1.0
+    qv[:, 1:] = rng.standard_normal((3, 63)).astype(np.float16) * 0.01
+    params = [(_lib.PARAM_SAMPLE_PERIOD, S), (_lib.PARAM_MAIN_CHUNKS, M)]
+    _, rows2, st2 = _search_check(G, cv, None, qv, None, k, params=params + [(_lib.PARAM_PROGRESSIVE_THR, 2)])
+    assert st2["sample_fallback_queries"] >= 3, st2
+    assert set(boosted.tolist()) <= set(rows2[0].tolist())
+    _, rows1, st1 = _search_check(G, cv, None, qv, None, k, params=params + [(_lib.PARAM_PROGRESSIVE_THR, 1)])
+    assert st1["sample_fallback_queries"] == 0
+    np.testing.assert_array_equal(rows1, rows2)
