@@ -99,6 +99,7 @@ struct dhr_index {
   // maxima of ||d - scale*d8|| and ||scale*d8|| over the ungated part of a row (the filter margin pays for them, query_prep_kernel)
   bool dense_i8 = false;
   float i8_scale = 0.f, i8_ec = 0.f, i8_nc = 0.f;
+  float* i8_col_scale = nullptr;           // [d_cls] int8 step of every ungated column (its largest |value| / 127): outlier columns do not cost the others their resolution
   int64_t index_bytes = 0;
   // params
   int64_t cand_cap = 0, first_rows = 0;   // 0 = default (262144 with refine lists, else 65536)
@@ -146,7 +147,7 @@ extern "C" void dhr_index_destroy(dhr_index* ix) {
   free_ws(ix->ws_fb[1]);
   if (ix->s_aux) hipStreamDestroy(ix->s_aux);
   if (ix->s_gemm) hipStreamDestroy(ix->s_gemm);
-  hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map); hipFree(ix->heavy_key); hipFree(ix->heavy_val);
+  hipFree(ix->i8_col_scale); hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map); hipFree(ix->heavy_key); hipFree(ix->heavy_val);
   delete ix;
 }
 
@@ -239,7 +240,7 @@ static int build_tiles(dhr_index* ix, hipStream_t s) {
   const int64_t n = ix->n_rows, fill = ix->n_tiles * TILE_ROWS;
   if (ix->ts + ix->td > 0)       // stage layout (2:4 sparse stages and / or 32-column dense stages)
     HIP_TRY(launch_tile_rows_sparse(ix->vals_rm, ix->k_rm, 0, n, fill, ix->d_dlr, ix->d_cls, ix->ts, ix->td, ix->c_idx, ix->idx_dtype,
-                                    ix->bucket_map, ix->abs_mode, (char*)ix->tiles, ix->dense_i8 ? 1.f / ix->i8_scale : 0.f, s));
+                                    ix->bucket_map, ix->abs_mode, (char*)ix->tiles, ix->dense_i8 ? 1.f / ix->i8_scale : 0.f, ix->i8_col_scale, s));
   else
     HIP_TRY(launch_tile_rows(ix->vals_rm, ix->k_rm, 0, n, fill, ix->d_dlr, ix->d_cls, ix->n_buckets, ix->kt, ix->c_idx, ix->idx_dtype,
                              ix->bucket_map, ix->abs_mode, ix->tiles, s));
@@ -371,8 +372,32 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
     float gmax;
     memcpy(&gmax, &flags[3], 4);
     ix->i8_scale = std::max(amax > 0.f ? amax / 127.f : 1.f, gmax / 60000.f);      // gated values must fit fp16 in units of the scale
+    // per-column steps: column j is quantised in units of (its own largest |value|) / 127, the query side carries the ratio to the
+    // corpus scale as a weight (query_prep_kernel) -- a few large columns (outlier dimensions of encoder outputs) then do not push
+    // every other column into a handful of int8 levels
+    std::vector<uint32_t> cm((size_t)ix->d_cls, 0u);
+    uint32_t* d_cm = nullptr;
+    if (hipMalloc((void**)&d_cm, cm.size() * 4) != hipSuccess || hipMalloc((void**)&ix->i8_col_scale, cm.size() * 4) != hipSuccess) {
+      hipFree(d_cm);
+      return fail(set_error(DHR_ERR_HIP, "hipMalloc failed"));
+    }
+    if (hipMemsetAsync(d_cm, 0, cm.size() * 4, s) != hipSuccess ||
+        launch_col_absmax(ix->vals_rm, ix->k_rm, ix->n_rows, ix->d_dlr, ix->d_cls, d_cm, s) != hipSuccess ||
+        hipMemcpy(cm.data(), d_cm, cm.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      hipFree(d_cm);
+      return fail(set_error(DHR_ERR_HIP, "column scan failed"));
+    }
+    hipFree(d_cm);
+    std::vector<float> cs(cm.size());
+    for (size_t j = 0; j < cm.size(); ++j) {
+      float m;
+      memcpy(&m, &cm[j], 4);
+      cs[j] = m > 0.f ? std::min(std::max(m / 127.f, ix->i8_scale * (1.f / 1024.f)), ix->i8_scale) : ix->i8_scale;
+    }
+    if (hipMemcpy(ix->i8_col_scale, cs.data(), cs.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return fail(set_error(DHR_ERR_HIP, "hipMemcpy failed"));
     if (hipMemsetAsync(d_flags, 0, 16, s) != hipSuccess ||
-        launch_i8_row_err(ix->vals_rm, ix->k_rm, ix->n_rows, ix->d_dlr, ix->d_cls, ix->i8_scale, 1.f / ix->i8_scale, d_flags, s) != hipSuccess ||
+        launch_i8_row_err(ix->vals_rm, ix->k_rm, ix->n_rows, ix->d_dlr, ix->d_cls, ix->i8_scale, ix->i8_col_scale, d_flags, s) != hipSuccess ||
         hipMemcpy(flags, d_flags, 8, hipMemcpyDeviceToHost) != hipSuccess)
       return fail(set_error(DHR_ERR_HIP, "int8 row-error pass failed"));
     float e2, n2;
@@ -660,7 +685,7 @@ static int prep_queries(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, 
                             qb->n_queries, w.q_pad, ix->d_dlr, ix->d_cls, ix->k_rm, ix->n_buckets, ix->kt, ix->bucket_map,
                             ix->abs_mode, ix->dmax, w.q_tiles, w.q32,
                             w.q_idx, w.margin, w.tau, w.thr, ix->ts, ix->td, w.q_pack, w.q16, w.q_idx8, w.q_inexact, ix->idx_dtype,
-                            ix->dense_i8 ? ix->i8_scale : 0.f, ix->i8_ec, ix->i8_nc, w.i8_mul, s));
+                            ix->dense_i8 ? ix->i8_scale : 0.f, ix->i8_ec, ix->i8_nc, w.i8_mul, ix->i8_col_scale, s));
   return DHR_OK;
 }
 

@@ -148,14 +148,15 @@ struct SelectArgs {
 hipError_t launch_scan_rows(const __half* src, int64_t ld, int64_t n_rows, int d_dlr, int k, uint32_t* max_sq_bits,
                             uint32_t* neg_flag, hipStream_t s);       // max_sq_bits[2] receives max |ungated value| (float bits)
 // dense_i8: per-row quantisation error of the ungated columns -> out_bits[0] = max_r ||d - scale*q(d)||^2, [1] = max_r ||scale*q(d)||^2
-hipError_t launch_i8_row_err(const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls, float scale, float inv_scale,
+hipError_t launch_i8_row_err(const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls, float scale, const float* col_scale,
                              uint32_t* out_bits, hipStream_t s);
+hipError_t launch_col_absmax(const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls, uint32_t* colmax_bits, hipStream_t s);
 hipError_t launch_tile_rows(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
                             int d_dlr, int d_cls, int n_buckets, int kt, const void* idx, int idx_dtype,
                             const uint8_t* map, bool abs_dlr, __half* tiles, hipStream_t s);
 hipError_t launch_tile_rows_sparse(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
                                    int d_dlr, int d_cls, int ts, int td, const void* idx, int idx_dtype, const uint8_t* map,
-                                   bool abs_dlr, char* tiles, float i8_inv_scale /* 0: fp16 dense stages */, hipStream_t s);
+                                   bool abs_dlr, char* tiles, float i8_inv_scale /* 0: fp16 dense stages */, const float* col_scale, hipStream_t s);
 hipError_t launch_copy_rows(const __half* src, int64_t ld, int64_t n_rows, int k, int k_rm, __half* dst, hipStream_t s);
 hipError_t launch_idx_hist(const uint8_t* idx, const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, float* hist, hipStream_t s);
 hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const void* idx, int idx_dtype, int64_t ld_idx,
@@ -163,7 +164,7 @@ hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const 
                              const uint8_t* map, bool abs_dlr, float dmax, __half* q_tiles, float* q32, int16_t* q_idx,
                              float* margin, float* tau, float* thr, int ts, int td, uint32_t* q_pack, __half* q16, uint8_t* q_idx8,
                              uint32_t* q_inexact, int c_idx_dtype,
-                             float i8_scale /* 0: fp16 dense stages */, float i8_ec, float i8_nc, float* i8_mul, hipStream_t s);
+                             float i8_scale /* 0: fp16 dense stages */, float i8_ec, float i8_nc, float* i8_mul, const float* col_scale, hipStream_t s);
 inline int sparse_query_stages(int ts, bool gated) { return ts > 0 ? (gated ? ts : 2 * ts) : 0; }
 hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s);
 hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, int idx_dtype, int64_t n_rows, int d_dlr,

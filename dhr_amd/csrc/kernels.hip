@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) scan_rows_kernel(const __half* __restrict
 // images; what it loses per row is  <q, d - scale*q8(d)>  <= ||q|| * ||d - scale*q8(d)||  and  <q - sq*q8(q), scale*q8(d)>
 // <= ||q - sq*q8(q)|| * ||scale*q8(d)||  (query_prep turns the two corpus-wide maxima into the filter margin).
 __global__ void __launch_bounds__(256) i8_row_err_kernel(const __half* __restrict__ vals_rm, int k_rm, int64_t n_rows, int d_dlr,
-                                                         int d_cls, float scale, float inv_scale, uint32_t* out_bits) {
+                                                         int d_cls, float scale, const float* __restrict__ col_scale, uint32_t* out_bits) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -103,9 +103,13 @@ __global__ void __launch_bounds__(256) i8_row_err_kernel(const __half* __restric
     const __half* r = vals_rm + row * k_rm + d_dlr;
     float se = 0.f, sn = 0.f;
     for (int j = lane; j < d_cls; j += 64) {
+      // column j lives in units of col_scale[j]; the query side multiplies by w_j = col_scale[j] / scale, so the row is measured in
+      // the space d'_j = d_j / w_j, where every column has the step `scale`
+      const float cs = col_scale[j];
       const float f = __half2float(r[j]);
-      const float back = scale * (float)quant_i8(f, inv_scale);
-      const float e = f - back;
+      const float q8 = (float)quant_i8(f, 1.f / cs);
+      const float e = (f - cs * q8) * (scale / cs);
+      const float back = scale * q8;
       se += e * e;
       sn += back * back;
     }
@@ -116,15 +120,34 @@ __global__ void __launch_bounds__(256) i8_row_err_kernel(const __half* __restric
   if (lane == 0 && !(bn >= 0.f)) bn = INFINITY;
   if (lane == 0) { atomicMax(out_bits, __float_as_uint(be)); atomicMax(out_bits + 1, __float_as_uint(bn)); }
 }
-hipError_t launch_i8_row_err(const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls, float scale, float inv_scale,
+hipError_t launch_i8_row_err(const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls, float scale, const float* col_scale,
                              uint32_t* out_bits, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
   const int64_t blocks = (n_rows + 3) / 4;
   hipLaunchKernelGGL(i8_row_err_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, vals_rm, k_rm, n_rows,
-                     d_dlr, d_cls, scale, inv_scale, out_bits);
+                     d_dlr, d_cls, scale, col_scale, out_bits);
   return hipGetLastError();
 }
-
+// Largest finite |value| of every ungated column (thread = column, the threads of a wave read 128 contiguous bytes of a row).
+__global__ void __launch_bounds__(256) col_absmax_kernel(const __half* __restrict__ vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls,
+                                                         int64_t rows_per_block, uint32_t* __restrict__ colmax_bits) {
+  const int j = blockIdx.y * 256 + threadIdx.x;
+  if (j >= d_cls) return;
+  const int64_t lo = (int64_t)blockIdx.x * rows_per_block, hi = lo + rows_per_block < n_rows ? lo + rows_per_block : n_rows;
+  float m = 0.f;
+  for (int64_t row = lo; row < hi; ++row) {
+    const float f = fabsf(__half2float(vals_rm[row * k_rm + d_dlr + j]));
+    if (f <= 65504.f) m = fmaxf(m, f);
+  }
+  if (m > 0.f) atomicMax(colmax_bits + j, __float_as_uint(m));
+}
+hipError_t launch_col_absmax(const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls, uint32_t* colmax_bits, hipStream_t s) {
+  if (n_rows <= 0 || d_cls <= 0) return hipSuccess;
+  const int64_t rpb = 2048;
+  hipLaunchKernelGGL(col_absmax_kernel, dim3((unsigned)((n_rows + rpb - 1) / rpb), (unsigned)((d_cls + 255) / 256)), dim3(256), 0, s, vals_rm, k_rm,
+                     n_rows, d_dlr, d_cls, rpb, colmax_bits);
+  return hipGetLastError();
+}
 hipError_t launch_scan_rows(const __half* src, int64_t ld, int64_t n_rows, int d_dlr, int k, uint32_t* max_sq_bits,
                             uint32_t* neg_flag, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
@@ -230,7 +253,7 @@ __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __r
                                                                int64_t n_rows_src, int64_t n_rows_fill, int d_dlr,
                                                                int d_cls, int ts, int td, const void* __restrict__ idx,
                                                                int idx_dtype, const uint8_t* __restrict__ map, int abs_dlr,
-                                                               char* __restrict__ tiles, float i8_inv) {
+                                                               char* __restrict__ tiles, float i8_inv, const float* __restrict__ col_scale) {
   const int k = d_dlr + d_cls;
   const int sp_chunks = ts * 4, dn_chunks = td * 4;
   const int cpr = sp_chunks + dn_chunks;
@@ -271,7 +294,8 @@ __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __r
       const int dc = c - sp_chunks, st = dc >> 2, cc = dc & 3, j0 = d_dlr + dc * 16;
       union { half8 h; int8_t b[16]; } o;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) o.b[e] = (rl < n_rows_src && j0 + e < k) ? (int8_t)quant_i8(__half2float(src[rl * ld + j0 + e]), i8_inv) : (int8_t)0;
+      for (int e = 0; e < 16; ++e)
+        o.b[e] = (rl < n_rows_src && j0 + e < k) ? (int8_t)quant_i8(__half2float(src[rl * ld + j0 + e]), 1.f / col_scale[j0 + e - d_dlr]) : (int8_t)0;
       char* stg = tile + (int64_t)ts * SP_STAGE_A + (int64_t)st * SP_DENSE;
       *(half8*)(stg + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = o.h;
     } else {
@@ -287,12 +311,12 @@ __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __r
 }
 hipError_t launch_tile_rows_sparse(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
                                    int d_dlr, int d_cls, int ts, int td, const void* idx, int idx_dtype, const uint8_t* map,
-                                   bool abs_dlr, char* tiles, float i8_inv_scale, hipStream_t s) {
+                                   bool abs_dlr, char* tiles, float i8_inv_scale, const float* col_scale, hipStream_t s) {
   if (n_rows_fill <= 0) return hipSuccess;
   const int64_t total = n_rows_fill * (ts * 4 + td * 4);
   const int64_t blocks = (total + 255) / 256;
   hipLaunchKernelGGL(tile_rows_sparse_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, src, ld,
-                     row_lo, n_rows_src, n_rows_fill, d_dlr, d_cls, ts, td, idx, idx_dtype, map, abs_dlr ? 1 : 0, tiles, i8_inv_scale);
+                     row_lo, n_rows_src, n_rows_fill, d_dlr, d_cls, ts, td, idx, idx_dtype, map, abs_dlr ? 1 : 0, tiles, i8_inv_scale, col_scale);
   return hipGetLastError();
 }
 
@@ -365,7 +389,7 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
                                                          uint32_t* __restrict__ q_pack, __half* __restrict__ q16,
                                                          uint8_t* __restrict__ q_idx8, uint32_t* __restrict__ q_inexact,
                                                          int c_idx_dtype, float i8_scale, float i8_ec, float i8_nc,
-                                                         float* __restrict__ i8_mul) {
+                                                         float* __restrict__ i8_mul, const float* __restrict__ col_scale) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= q_pad) return;
@@ -416,9 +440,13 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
   float i8_inv_q = 0.f, i8_sq = 0.f, i8_qn = 0.f, i8_qe = 0.f;
   bool i8_zero = false;
   if (i8_scale > 0.f) {
+    // ungated query values enter weighted, q'_j = q_j * col_scale[j] / scale: the corpus side divided column j by the same factor
+    // (its own int8 step), <q, d> = <q', d'>
+    const float inv_sc = 1.f / i8_scale;
+    auto qw = [&](int j) -> float { return qval(j) * (col_scale[j - d_dlr] * inv_sc); };
     float am = 0.f, gm = 0.f;
     for (int j = lane; j < k; j += 64) {
-      const float v = fabsf(qval(j));
+      const float v = fabsf(j >= d_dlr ? qw(j) : qval(j));
       if (v <= 3.0e38f) { if (j >= d_dlr) am = fmaxf(am, v); else gm = fmaxf(gm, v); }
     }
 #pragma unroll
@@ -430,7 +458,7 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
       i8_zero = it == 3;              // last resort (never seen): an all-zero int8 image, the margin pays the whole ungated part
       float sn = 0.f, se = 0.f, s8 = 0.f;
       for (int j = d_dlr + lane; j < k; j += 64) {
-        const float v = qval(j);
+        const float v = qw(j);
         const float q8 = i8_zero ? 0.f : (float)quant_i8(v, i8_inv_q);
         const float e = v - i8_sq * q8;
         sn += v * v;
@@ -477,7 +505,10 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
         const int dc = c - ts_q * 4, st = dc >> 2, cc = dc & 3;
         union { half8 h; int8_t b[16]; } o;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o.b[e] = i8_zero ? (int8_t)0 : (int8_t)quant_i8(qval(d_dlr + dc * 16 + e), i8_inv_q);     // qval: 0 beyond the data
+        for (int e = 0; e < 16; ++e) {
+          const int j = d_dlr + dc * 16 + e;
+          o.b[e] = (i8_zero || j >= k) ? (int8_t)0 : (int8_t)quant_i8(qval(j) * (col_scale[j - d_dlr] * (1.f / i8_scale)), i8_inv_q);
+        }
         *(half8*)(tile + (int64_t)ts_q * SP_STAGE_B + (int64_t)st * SP_DENSE + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = o.h;
       } else {
         const int dc = c - ts_q * 4, st = dc >> 2, cc = dc & 3;
@@ -534,10 +565,10 @@ hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const 
                              const uint8_t* map, bool abs_dlr, float dmax, __half* q_tiles, float* q32, int16_t* q_idx,
                              float* margin, float* tau, float* thr, int ts, int td, uint32_t* q_pack, __half* q16, uint8_t* q_idx8,
                              uint32_t* q_inexact, int c_idx_dtype, float i8_scale, float i8_ec, float i8_nc, float* i8_mul,
-                             hipStream_t s) {
+                             const float* col_scale, hipStream_t s) {
   hipLaunchKernelGGL(query_prep_kernel, dim3((q_pad + 3) / 4), dim3(256), 0, s, src, src_is_f32, ld, idx, idx_dtype,
                      ld_idx, n_queries, q_pad, d_dlr, d_cls, k_rm, n_buckets, kt, map, abs_dlr ? 1 : 0, dmax, q_tiles, q32,
-                     q_idx, margin, tau, thr, ts, td, q_pack, q16, q_idx8, q_inexact, c_idx_dtype, i8_scale, i8_ec, i8_nc, i8_mul);
+                     q_idx, margin, tau, thr, ts, td, q_pack, q16, q_idx8, q_inexact, c_idx_dtype, i8_scale, i8_ec, i8_nc, i8_mul, col_scale);
   return hipGetLastError();
 }
 
