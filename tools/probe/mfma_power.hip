@@ -14,13 +14,14 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16v __attribute__((ext_vector_type(16)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef int intx16 __attribute__((ext_vector_type(16)));
 typedef int intx4 __attribute__((ext_vector_type(4)));
 union Frag { uint32_t w[4]; half8 h; bf8 b; intx4 i; };
 
-// KIND 0 f16 32x32x16, 1 bf16 32x32x16, 2 f16 16x16x32, 3 smfmac f16 32x32x32, 4 i8 32x32x32.  ORDER 0: A-major (B alternates),
+// KIND 0 f16 32x32x16, 1 bf16 32x32x16, 2 f16 16x16x32, 3 smfmac f16 32x32x32, 4 i8 32x32x32, 5 smfmac bf16 32x32x32 (A-major only).  ORDER 0: A-major (B alternates),
 // 1: B-major (A alternates every instruction).
 template <int KIND, int ORDER>
 __global__ void __launch_bounds__(256) k(const uint32_t* __restrict__ data, float* out, int iters, long long* cyc) {
@@ -56,7 +57,7 @@ __global__ void __launch_bounds__(256) k(const uint32_t* __restrict__ data, floa
   } else {
     floatx16 c[4][2];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) c[i][j][e] = 0.f;
-    union { half16 h; uint32_t w[8]; } bb[2];
+    union { half16 h; bf16v b; uint32_t w[8]; } bb[2];
     for (int j = 0; j < 2; ++j) for (int e = 0; e < 4; ++e) { bb[j].w[e] = b[j].w[e]; bb[j].w[4 + e] = b2[j].w[e]; }
     for (int it = 0; it < iters; ++it) {
       if constexpr (ORDER == 0) {
@@ -67,6 +68,7 @@ __global__ void __launch_bounds__(256) k(const uint32_t* __restrict__ data, floa
             if constexpr (KIND == 0) c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i].h, b[j].h, c[i][j], 0, 0, 0);
             if constexpr (KIND == 1) c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].b, b[j].b, c[i][j], 0, 0, 0);
             if constexpr (KIND == 3) c[i][j] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(a[i].h, bb[j].h, c[i][j], 0x44444444, 0, 0);
+            if constexpr (KIND == 5) c[i][j] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(a[i].b, bb[j].b, c[i][j], 0x44444444, 0, 0);
           }
       } else {
 #pragma unroll
@@ -111,6 +113,9 @@ static void fill(std::vector<uint16_t>& v, int pattern) {
       case 7: x = (uint16_t)rnd(); break;
       case 8: x = f2h(0.1f); break;
       case 9: x = f2h((float)(0.1 * gauss())); if (e < 32) x &= 0xffe0; break;
+      case 10: x = f2bf((float)(unif() < 0.1 ? 0.1 + 2.9 * unif() : 0.02 * unif()) * 200.f); break;      // DLR-like, scaled, bf16
+      case 11: { int a = (int)lrint(32.0 * gauss()), b = (int)lrint(32.0 * gauss()); a = a < -127 ? -127 : a > 127 ? 127 : a; b = b < -127 ? -127 : b > 127 ? 127 : b; x = (uint16_t)((a & 0xff) | ((b & 0xff) << 8)); } break;   // int8 image of Gaussian columns
+      case 12: x = f2h((float)(unif() < 0.1 ? 0.1 + 2.9 * unif() : 0.02 * unif()) * 200.f); break;      // DLR-like, scaled, fp16
     }
     v[i] = x;
   }
@@ -147,6 +152,18 @@ static void run(const char* name, int pattern, double macs_per_inst, int inst_pe
 int main(int argc, char** argv) {
   const double sec = argc > 1 ? atof(argv[1]) : 1.2;
   const double M32 = 32.0 * 32 * 16;
+  if (argc > 2 && atoi(argv[2]) == 2) {      // second set: the operand images of the int8 / scaled-gated kernel
+    run<0, 0>("f16 32x32x16 A-major", 1, M32, 8, sec);
+    run<3, 0>("smfmac f16 32x32x32 A-major", 12, 32.0 * 32 * 32, 8, sec);
+    run<5, 0>("smfmac bf16 32x32x32 A-major", 10, 32.0 * 32 * 32, 8, sec);
+    run<3, 0>("smfmac f16 32x32x32 A-major", 12, 32.0 * 32 * 32, 8, sec);
+    run<5, 0>("smfmac bf16 32x32x32 A-major", 10, 32.0 * 32 * 32, 8, sec);
+    run<4, 0>("i8 32x32x32", 11, 32.0 * 32 * 32, 8, sec);
+    run<4, 0>("i8 32x32x32", 7, 32.0 * 32 * 32, 8, sec);
+    run<1, 0>("bf16 32x32x16 A-major", 6, M32, 8, sec);
+    run<0, 0>("f16 32x32x16 A-major", 1, M32, 8, sec);
+    return 0;
+  }
   run<0, 0>("f16 32x32x16 A-major", 1, M32, 8, sec);      // warm up the box
   run<0, 0>("f16 32x32x16 A-major", 0, M32, 8, sec);
   run<0, 0>("f16 32x32x16 A-major", 8, M32, 8, sec);
