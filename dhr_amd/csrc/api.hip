@@ -1028,7 +1028,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       if (ix->progressive_thr) HIP_TRY(launch_raise_thr(w.thr_hat, sel.thr, Q, sb));   // later chunks filter with the running exact thresholds
       if (extrapolate && i + 1 < M) {
         const double f = (double)(head + n_sample + bound[i + 1]) / (double)ix->n_tiles;
-        const int r = (int)std::ceil((double)k * f + 5.0 * std::sqrt((double)k * f * (1.0 - f)) + 4.0);
+        const int r = (int)std::ceil((double)k * f + 6.0 * std::sqrt((double)k * f * (1.0 - f)) + 4.0);      // 6 sigma: a failure costs a whole extra pass for its query tile
         if (r < k) HIP_TRY(launch_raise_thr_rank(w.thr_hat, w.tau_hat, w.topk_keys, w.kp, r, w.margin, Q, sb));
       }
       HIP_TRY(hipEventRecord(ev_done[i], sb));

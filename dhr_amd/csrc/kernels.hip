@@ -1908,7 +1908,7 @@ hipError_t launch_raise_thr(float* thr_hat, const float* thr_run, int n_queries,
   return hipGetLastError();
 }
 // Extrapolated threshold ("thresholds"): the rows seen so far are a scattered fraction f of the corpus, so the
-// r-th best seen, r = k f + 5 sqrt(k f (1 - f)) + 4, lies below the final k-th best score except with negligible probability; a query
+// r-th best seen, r = k f + 6 sqrt(k f (1 - f)) + 4, lies below the final k-th best score except with negligible probability; a query
 // for which it does not is caught by the verification against tau_hat (raised here too) and redone.
 __global__ void raise_thr_rank_kernel(float* __restrict__ thr_hat, float* __restrict__ tau_hat, const uint64_t* __restrict__ topk_keys, int kp, int r,
                                       const float* __restrict__ margin, int n_queries) {

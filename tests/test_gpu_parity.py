@@ -1254,7 +1254,7 @@ def test_pq_n_bits_below_8(G, tmp_path, monkeypatch, nbits):
 def test_extrapolated_threshold_failure_is_redone(G):
     """DHR_PARAM_PROGRESSIVE_THR = 2: after every main-pass chunk the threshold is raised to the rank extrapolated from the scattered
     fraction of the corpus seen so far.  Adversarial placement: 56 outstanding rows (fewer than k = 64), ALL inside the tiles the
-    scattered order visits in the first chunk -- the extrapolation (rank 50 of the seen rows) lands on their score, every later row
+    scattered order visits in the first chunk -- the extrapolation (rank 53 of the seen rows) lands on their score, every later row
     is filtered, fewer than k rows reach the threshold: the verification must fail and the query be redone exactly.  The visiting
     order is restated from api.hip (search_core): non-sample position i -> (i * perm_mul) % n_main."""
     import math
