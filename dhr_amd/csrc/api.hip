@@ -372,8 +372,8 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
     float gmax;
     memcpy(&gmax, &flags[3], 4);
     ix->i8_scale = std::max(amax > 0.f ? amax / 127.f : 1.f, gmax / 60000.f);      // gated values must fit fp16 in units of the scale
-    // per-column steps: column j is quantised in units of (its own largest |value|) / 127, the query side carries the ratio to the
-    // corpus scale as a weight (query_prep_kernel) -- a few large columns (outlier dimensions of encoder outputs) then do not push
+    // per-column steps: column j is quantised in its own step cs_j <= scale, the query side carries cs_j / scale as a weight
+    // (query_prep_kernel) -- a few large columns (outlier dimensions of encoder outputs) then do not push
     // every other column into a handful of int8 levels
     std::vector<uint32_t> cm((size_t)ix->d_cls, 0u);
     uint32_t* d_cm = nullptr;
@@ -392,7 +392,12 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
     for (size_t j = 0; j < cm.size(); ++j) {
       float m;
       memcpy(&m, &cm[j], 4);
-      cs[j] = m > 0.f ? std::min(std::max(m / 127.f, ix->i8_scale * (1.f / 1024.f)), ix->i8_scale) : ix->i8_scale;
+      // step of column j = scale * (its largest |value| / the largest of all)^(3/4): the exponent splits a column's dynamic range
+      // between the corpus image (finer steps for small columns) and the query weights (which then stay within ~two orders of
+      // magnitude) -- measured on anisotropic columns the margin is 1.8x smaller than with exponent 1 and 4-6x smaller than with
+      // one step for all columns; on iid columns all exponents are equal (tests/test_i8_bound.py)
+      const float ratio = m > 0.f ? std::min(m / (127.f * ix->i8_scale), 1.f) : 1.f;
+      cs[j] = ix->i8_scale * std::max(std::pow(ratio, 0.75f), 1.f / 1024.f);
     }
     if (hipMemcpy(ix->i8_col_scale, cs.data(), cs.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
       return fail(set_error(DHR_ERR_HIP, "hipMemcpy failed"));
