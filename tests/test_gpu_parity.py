@@ -2,7 +2,6 @@
 golden vectors produced by the reference.  Run on the MI355X box with `pytest -m gpu`."""
 import os
 import tempfile
-
 import zlib
 
 import numpy as np
