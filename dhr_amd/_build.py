@@ -7,7 +7,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdhr_hip.so")
-SOURCES = ["kernels.hip", "gemm_w4.hip", "api.hip", "sharded.hip", "pq_adc.hip", "select_global.hip"]
+SOURCES = ["kernels.hip", "gemm_w4.hip", "api.hip", "sharded.hip", "pq_adc.hip", "select_global.hip", "host_io.hip"]
 HEADERS = ["dhr_internal.h", "gemm_common.h", os.path.join("..", "..", "include", "dhr_hip.h")]
 
 

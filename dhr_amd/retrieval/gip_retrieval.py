@@ -254,7 +254,11 @@ def _np(a):
     return a if isinstance(a, np.ndarray) else a.detach().cpu().numpy()
 
 
-def _to_dicts(qids, rows, scores, offset=0):
+def _to_dicts(qids, rows, scores, offset=0, args=None):
+    keep_arrays = getattr(args, "_result_arrays", None)
+    if keep_arrays is not None:        # main(): the run file is written from the arrays by the library (write_trec_native), no dicts
+        keep_arrays.append((np.ascontiguousarray(rows, np.int64), np.ascontiguousarray(scores, np.float32), int(offset)))
+        return {}, {}
     all_results, all_scores = {}, {}
     for i, qid in enumerate(qids):
         r = rows[i]
@@ -292,7 +296,7 @@ def IP_retrieval(qids, query_embs, corpus_embs, args):
     index, owned = _corpus_index(corpus_embs, None, args)
     start_time = time.time()
     scores, rows = _by_chunks(len(qids), lambda lo, hi: index.search(query_embs[lo:hi], None, args.topk))
-    res = _to_dicts(qids, rows, scores, index.row_offset)
+    res = _to_dicts(qids, rows, scores, index.row_offset, args)
     time_per_query = (time.time() - start_time) / len(qids)
     print('Retrieving {} queries ({:0.3f} s/query), average number of index use {}'.format(len(qids), time_per_query, 0.0))
     if owned:
@@ -331,7 +335,7 @@ def GIP_retrieval(qids, query_embs, query_arg_idxs, corpus_embs, corpus_arg_idxs
                     return index.search_rerank(q1[lo:hi], _sl(qi1, lo, hi), q[lo:hi], qi[lo:hi], k1, min(args.topk, k1))   # both stages on the device
                 return index.search(q1[lo:hi], _sl(qi1, lo, hi), k1)
             scores, rows = _by_chunks(len(qids), two_stage)
-        res = _to_dicts(qids, rows, scores, index.row_offset)
+        res = _to_dicts(qids, rows, scores, index.row_offset, args)
     finally:
         if owned:
             index.close()
@@ -369,7 +373,7 @@ def PQ_IP_retrieval(qids, query_embs, query_arg_idxs, corpus_embs, corpus_arg_id
             order = np.lexsort((r1, -s2.astype(np.float64)), axis=1)[:, : args.topk]
             return np.take_along_axis(s2, order, axis=1), np.take_along_axis(r1, order, axis=1)
         scores, rows = _by_chunks(len(qids), pq_stage)
-        res = _to_dicts(qids, rows, scores, index.row_offset)
+        res = _to_dicts(qids, rows, scores, index.row_offset, args)
     finally:
         pq_index.close()
         if owned:
@@ -456,8 +460,40 @@ def write_trec(fout, results, scores, docids, run_name):
                 fout.write('{} Q0 {} {} {} {}\n'.format(query_id, docid, rank + 1, score[rank], run_name))
 
 
+def _id_blob(ids):
+    """list of str -> (bytes: the ids with one newline after each, int64 offsets [n+1]) for dhr_write_trec, or None when the ids are
+    not plain newline-free strings (the Python writer then reproduces the reference's formatting of whatever they are)."""
+    if not all(type(x) is str for x in ids):
+        return None
+    blob = ("\n".join(ids) + "\n").encode("utf-8") if len(ids) else b""
+    ends = np.flatnonzero(np.frombuffer(blob, np.uint8) == 10)
+    if len(ends) != len(ids):
+        return None                                   # an id contains a newline
+    off = np.zeros(len(ids) + 1, np.int64)
+    off[1:] = ends + 1
+    return blob, off
+
+
+def write_trec_native(path, qids, rows, scores, row_base, docids, run_name, append=False):
+    """The writer loop of gip_retrieval.py:333-342 in the library (dhr_write_trec: formatted on the host's cores, byte-identical to
+    write_trec below).  rows: int64 [Q, k] (negative = padding), scores float32 [Q, k].  Returns the number of lines, or None when
+    the ids cannot be handed over as byte blobs (then nothing was written)."""
+    qb, db = _id_blob(list(qids)), _id_blob(docids)
+    if qb is None or db is None:
+        return None
+    lib = _lib.load()
+    rows = np.ascontiguousarray(rows, np.int64)
+    scores = np.ascontiguousarray(scores, np.float32)
+    lines = C.c_int64()
+    _lib.check(lib.dhr_write_trec(os.fsencode(path), 1 if append else 0, rows.shape[0], rows.shape[1], qb[0], qb[1].ctypes.data, db[0], db[1].ctypes.data,
+                                  len(docids), rows.ctypes.data, int(row_base), scores.ctypes.data, run_name.encode("utf-8"), 1, 0, C.byref(lines)),
+               "dhr_write_trec")
+    return int(lines.value)
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    args._result_arrays = []
     _lib.load()                                      # fail before touching the data if the HIP library is missing
     print('Load query embeddings ...')
     query_embs, query_arg_idxs, qids = load_queries(args.query_emb_path, args.emb_dim, args.lamda)
@@ -498,8 +534,10 @@ def main(argv=None):
         name = 'result.trec'
     else:
         name = 'result{}.trec'.format(args.shrad)
-    with open(name, 'w') as fout:
-        write_trec(fout, results, scores, docids, args.run_name)
+    rows_a, scores_a, base = args._result_arrays[-1]
+    if write_trec_native(name, qids, rows_a, scores_a, base, docids, args.run_name) is None:
+        with open(name, 'w') as fout:                 # ids that are not plain strings: the reference's own loop
+            write_trec(fout, *_to_dicts(qids, rows_a, scores_a, base), docids, args.run_name)
     print('finish')
 
 

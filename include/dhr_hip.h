@@ -257,6 +257,18 @@ int dhr_pq_encode_nbits(int32_t device, int32_t mem_kind, const void* values_f16
 int dhr_pq_decode_nbits(int32_t device, int32_t mem_kind, const uint8_t* codes, int64_t n, int32_t d, int32_t M, int32_t nbits,
                         const float* codebooks, void* out_values_f16, int64_t ld_out, void* stream);
 
+/* The TREC run file (gip_retrieval.py:333-342): for every query, in order, one line "qid Q0 docid rank score run_name" per result row,
+ * rank = 1-based position in the query's list (rows < 0 are padding of a short list and take no rank), lines whose docid equals the
+ * query id skipped (their rank stays unused, as in the reference), score printed as Python prints float(score): the shortest digit
+ * string that round-trips the DOUBLE, fixed notation for 1e-4 <= |x| < 1e16.  Ids are handed over as one byte blob each with
+ * n + 1 offsets (id i = blob[off[i], off[i+1] - id_sep_bytes): id_sep_bytes = 1 for ids joined with one separator byte each); rows are [n_queries][k], row - row_base indexes the docid list; formatted on
+ * n_threads host threads (0 = all, at most 64), written in query order.  dhr_format_float: the score formatting alone (returns the
+ * length).  Host code only -- no device is touched. */
+int dhr_write_trec(const char* path, int32_t append, int64_t n_queries, int64_t k, const char* qid_blob, const int64_t* qid_off,
+                   const char* docid_blob, const int64_t* docid_off, int64_t n_docs, const int64_t* rows, int64_t row_base,
+                   const float* scores, const char* run_name, int32_t id_sep_bytes, int32_t n_threads, int64_t* lines_out);
+int dhr_format_float(double x, char* out, int32_t cap);
+
 int dhr_get_stats(const dhr_index* index, dhr_search_stats* out);
 
 /* Debug/test hook: the bound-GEMM scores U[q][row] for rows [row_lo,row_hi) of the shard, written
