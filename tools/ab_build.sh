@@ -5,5 +5,5 @@ set -e
 cd "$(dirname "$0")/../dhr_amd/csrc"
 mkdir -p _ab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -Wno-unused-result $2 -o _ab/libdhr_hip_$1.so \
-  kernels.hip gemm_w4.hip api.hip sharded.hip pq_adc.hip select_global.hip -L/opt/rocm/lib -lrccl
+  kernels.hip gemm_w4.hip api.hip sharded.hip pq_adc.hip select_global.hip host_io.hip -L/opt/rocm/lib -lrccl
 echo built _ab/libdhr_hip_$1.so
