@@ -1592,8 +1592,12 @@ extern "C" int dhr_merge_topk(int32_t device, int32_t n_queries, int32_t n_in, c
                               const int64_t* in_rows, int32_t k_out, float* out_scores, int64_t* out_rows, void* stream) {
   if (n_queries <= 0 || n_in <= 0 || k_out <= 0 || !in_scores || !in_rows || !out_scores || !out_rows)
     return set_error(DHR_ERR_INVALID, "bad argument");
-  if (n_in > 16384) return set_error(DHR_ERR_UNSUPPORTED, "more than 16384 entries per query in the device reduce");
   HIP_TRY(hipSetDevice(device));
+  if (n_in > 16384) {       // beyond one workgroup's LDS: two stable segmented sorts through global memory (select_global.hip)
+    if ((int64_t)n_queries * n_in > (int64_t)0x7fffffff) return set_error(DHR_ERR_UNSUPPORTED, "more than 2^31 entries in one device reduce");
+    HIP_TRY(launch_merge_topk_global(n_queries, n_in, in_scores, in_rows, k_out, out_scores, out_rows, (hipStream_t)stream));
+    return DHR_OK;
+  }
   HIP_TRY(launch_merge_topk(n_queries, n_in, in_scores, in_rows, k_out, out_scores, out_rows, (hipStream_t)stream));
   return DHR_OK;
 }

@@ -182,6 +182,8 @@ hipError_t launch_refine(const RefineArgs& a, hipStream_t s);
 hipError_t launch_rescore(const RescoreArgs& a, hipStream_t s);
 hipError_t launch_select(const SelectArgs& a, hipStream_t s);
 hipError_t launch_select_global(const SelectArgs& a, hipStream_t s);    // k > 16384 (select_global.hip)
+hipError_t launch_merge_topk_global(int n_queries, int n_in, const float* in_scores, const int64_t* in_rows, int k_out, float* out_scores,
+                                    int64_t* out_rows, hipStream_t s);      // dhr_merge_topk with n_in > 16384
 hipError_t launch_emit(const uint64_t* topk_keys, int kp, int n_queries, int k, int64_t row_offset, float* out_scores,
                        int64_t* out_rows, hipStream_t s);
 hipError_t launch_keys_to_rows(const uint64_t* topk_keys, int kp, int n_queries, int k, uint32_t* rows, hipStream_t s);

@@ -199,7 +199,8 @@ int dhr_score_rows(dhr_index* index, const dhr_query_batch* queries, int32_t m, 
 /* The multi-shard reduce (retrieval/merge.result.py:22-42 without the text round trip): per query,
  * the k_out best of n_lists*k_in (score, row) pairs, best first (score desc, row asc); entries with
  * row < 0 are padding.  in_scores/in_rows are [n_queries, n_lists*k_in] (each query's lists
- * concatenated).  All four pointers are DEVICE pointers on `device`. */
+ * concatenated).  All four pointers are DEVICE pointers on `device`.  Any n_in (up to 16 384 entries per query in one workgroup's LDS,
+ * beyond that two stable segmented sorts through global memory; n_queries * n_in < 2^31). */
 int dhr_merge_topk(int32_t device, int32_t n_queries, int32_t n_in, const float* in_scores,
                    const int64_t* in_rows, int32_t k_out, float* out_scores, int64_t* out_rows, void* stream);
 /* Same reduce on HOST pointers (no GPU needed; used by the CPU/gloo tests of the sharded path). */

@@ -1302,3 +1302,28 @@ def test_dense_i8_outlier_columns(G):
     st0, st1, _, _ = _i8_pair(G, cv, ci, qv.astype(np.float32), qi, 200)
     print("exact rescorings fp16 / int8:", st0["candidates_exact"], st1["candidates_exact"])
     assert st1["candidates_exact"] <= 3 * st0["candidates_exact"]
+
+
+@pytest.mark.parametrize("q,n_in,k", [(5, 16385, 1000), (3, 40000, 5000), (2, 24000, 30000)])
+def test_merge_topk_device_beyond_16384_entries(G, q, n_in, k):
+    """dhr_merge_topk with more entries per query than one workgroup's LDS holds (e.g. full-k lists of more than 16 shards): two stable
+    segmented sorts through global memory; the same (score desc, row asc) order as the host reduce and the oracle, ties, 64-bit rows
+    and padding included; k_out > n_in pads."""
+    import torch
+    from dhr_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(n_in)
+    s = np.round(rng.standard_normal((q, n_in)).astype(np.float32), 1) + np.float32(0)        # many exact ties (and no -0.0: the library orders by bit pattern)
+    r = (rng.permutation(50_000_000)[: q * n_in].reshape(q, n_in).astype(np.int64) + (1 << 33))     # rows beyond 32 bits
+    r[:, -11:] = -1
+    s[0, :3] = np.float32("-inf")
+    es, er = O.merge_topk([s], [r], k)
+    hs, hr = np.empty((q, k), np.float32), np.empty((q, k), np.int64)
+    _lib.check(lib.dhr_merge_topk_host(q, n_in, s.ctypes.data, r.ctypes.data, k, hs.ctypes.data, hr.ctypes.data), "host merge")
+    np.testing.assert_array_equal(hr, er)
+    ds, dr = torch.from_numpy(s).cuda(), torch.from_numpy(r).cuda()
+    os_, or_ = torch.empty((q, k), dtype=torch.float32, device="cuda"), torch.empty((q, k), dtype=torch.int64, device="cuda")
+    _lib.check(lib.dhr_merge_topk(0, q, n_in, ds.data_ptr(), dr.data_ptr(), k, os_.data_ptr(), or_.data_ptr(), 0), "dev merge")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(or_.cpu().numpy(), er)
+    np.testing.assert_array_equal(os_.cpu().numpy(), es)
