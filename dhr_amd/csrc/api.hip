@@ -1224,7 +1224,7 @@ extern "C" int32_t dhr_search_sample_rank(const dhr_index* ix, int32_t k) {
 extern "C" int dhr_search_begin(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_sample_scores_dev, void* stream) {
   int rc = check_queries(ix, qb);
   if (rc) return rc;
-  if (k <= 0 || k > 16384) return set_error(DHR_ERR_INVALID, "k must be in [1, 16384]");
+  if (k <= 0 || k > (1 << 20)) return set_error(DHR_ERR_INVALID, "k must be in [1, 1048576]");
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = (hipStream_t)stream;
   ix->pend.valid = false;

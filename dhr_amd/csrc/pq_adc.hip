@@ -253,7 +253,7 @@ extern "C" int dhr_pq_adc_scores(dhr_pq* pq, const dhr_query_batch* qb, int64_t 
 extern "C" int dhr_pq_search(dhr_pq* pq, const dhr_query_batch* qb, int32_t k, float* out_scores, int64_t* out_rows, int32_t out_mem_kind,
                              void* stream) {
   if (!pq || !qb || !qb->value || !out_scores || !out_rows || qb->n_queries <= 0) return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
-  if (k <= 0 || k > 16384) return dhr_set_error_message(DHR_ERR_INVALID, "k must be in [1, 16384]");
+  if (k <= 0 || k > (1 << 20)) return dhr_set_error_message(DHR_ERR_INVALID, "k must be in [1, 1048576]");      // k > 16384: the global-memory merge (select_global.hip)
   PQ_HIP(hipSetDevice(pq->device));
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t e0, e1;

@@ -171,7 +171,7 @@ int dhr_search(dhr_index* index, const dhr_query_batch* queries, int32_t k, floa
  *             <= theta zeroed (:130-136), or index = NULL for the ungated --IP first stage (:139);
  *   stage 2 = exact gated inner product of the FULL batch on exactly those k1 rows (:144-146), top-k of that
  *             (score desc, row asc; fewer than k valid rows -> (-inf, -1) padding).
- * Same n_queries in both batches; 0 < k <= k1 <= 16384. */
+ * Same n_queries in both batches; 0 < k <= k1 <= 1048576 (above 16384 the global-memory merge, slower). */
 int dhr_search_rerank(dhr_index* index, const dhr_query_batch* stage1, const dhr_query_batch* full, int32_t k1, int32_t k,
                       float* out_scores, int64_t* out_rows, int32_t out_mem_kind, void* stream);
 
@@ -291,7 +291,7 @@ int dhr_debug_gemm_time(dhr_index* index, const dhr_query_batch* queries, int32_
  * running top-k threshold filter.  score(q, x) = sum_m LUT[q][m][code_m(x)] in fp32, m ascending.
  *   codes     [n][M] uint8, one code per byte (unpack files with nbits < 8 first)
  *   queries   values only ([n_queries][d], fp16 or fp32; index arrays are ignored: the first stage is ungated)
- *   dhr_pq_search    -> [n_queries][k] (score desc, row asc on exact ties; global rows; (-inf, -1) beyond the corpus), k <= 16384
+ *   dhr_pq_search    -> [n_queries][k] (score desc, row asc on exact ties; global rows; (-inf, -1) beyond the corpus), k <= 1048576 (above 16384 the global-memory merge)
  *   dhr_pq_adc_scores-> raw scores of rows [row_lo, row_hi), device memory [n_queries][row_hi - row_lo] (tests)
  *   dhr_pq_last_scan -> duration (ms, hipEvents) and code bytes read by the scan kernel launches of the last search */
 typedef struct dhr_pq dhr_pq; /* opaque */

@@ -1327,3 +1327,44 @@ def test_merge_topk_device_beyond_16384_entries(G, q, n_in, k):
     torch.cuda.synchronize()
     np.testing.assert_array_equal(or_.cpu().numpy(), er)
     np.testing.assert_array_equal(os_.cpu().numpy(), es)
+
+
+def test_pq_search_k_beyond_16384(G):
+    """IndexPQ.search with k above the LDS select (faiss has no such limit): the global-memory merge, exact top-k of the ADC scores."""
+    from dhr_amd import synth
+    from dhr_amd.retrieval import quantize_index as QI
+    from oracle import pq_oracle as PO
+    cv, _, qv, _ = synth.make_pair(47, 60_000, 3, 768, 128)
+    q = qv.astype(np.float32)
+    cb, codes, _ = QI.train_and_encode(cv, 64, 8, iters=3)
+    pix = QI.PqIndex(cb, codes)
+    try:
+        adc = PO.adc_scores(q, codes, cb)
+        for k in (20000, 60000):
+            s1, r1 = pix.search(q, k)
+            for i in range(3):
+                O.check_topk(r1[i], s1[i], adc[i], k, atol=1e-4)
+    finally:
+        pix.close()
+
+
+def test_search_sharded_local_k_beyond_16384(G):
+    """The sharded search with k above the LDS select / LDS list merge: the shards' lists are reduced by the general device reduce."""
+    from dhr_amd import synth, _lib, dist as D
+    n, ns, k = 200_000, 4, 20000
+    cv, ci, qv, qi = synth.make_pair(52, n, 3, 768, 64)
+    q32 = qv.astype(np.float32)
+    full = G.GipIndex(cv, ci)
+    fs, fr = full.search(q32, qi, k)
+    full.close()
+    shards = []
+    for sh in range(ns):
+        lo, hi = G.shard_bounds(n, ns, sh)
+        shards.append(G.GipIndex(cv[lo:hi], ci[lo:hi], row_offset=lo))
+    try:
+        ss, sr = D.search_sharded_local(shards, q32, qi, k)
+        np.testing.assert_array_equal(sr.cpu().numpy(), fr)
+        np.testing.assert_array_equal(ss.cpu().numpy(), fs)
+    finally:
+        for s in shards:
+            s.close()
