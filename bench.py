@@ -266,6 +266,26 @@ def run_workload(args, spec, ctx):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # N > 1 over RCCL: one untimed trial of the library's own collective path (dhr_search_sharded).  If it raises on any rank, EVERY
+    # rank switches to the torch.distributed restatement of the same steps (dhr_amd/dist.py: same kernels, same thresholds, the
+    # collectives issued by torch) and the JSON line says so -- the scaling run is the first time this path meets more than one GPU.
+    sharded_impl = None
+    if world > 1 and pq is None:
+        import torch.distributed as dist
+        sharded_impl = "dhr_search_sharded (RCCL inside the library)" if dist.get_backend() == "nccl" and os.environ.get("DHR_SHARDED_IMPL") != "torch" \
+            else "torch.distributed collectives (dhr_amd/dist.py)"
+        if sharded_impl.startswith("dhr_search_sharded"):
+            ok, why = 1, ""
+            try:
+                step()
+            except Exception as e:      # noqa: BLE001
+                ok, why = 0, str(e)[:200]
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                os.environ["DHR_SHARDED_IMPL"] = "torch"
+                sharded_impl = "torch.distributed collectives (dhr_amd/dist.py); the library's RCCL path failed in the trial: %s" % (why or "on another rank")
+                print("[bench] rank %d: %s" % (rank, sharded_impl), file=sys.stderr)
     for _ in range(args.warmup):
         step()
     gemm_ms = gemm_flops_alg = 0.0
@@ -373,7 +393,8 @@ def run_workload(args, spec, ctx):
                                        "uniform slice index (adversarial)" if args.uniform_idx else
                                        "whole-word vocabulary, no background" if spec["kind"] == "bm25" else "densify-rule slice index")),
                        "baseline_config": spec["baseline_config"],
-                       "parallelism": "rowshard%d+allgather" % world if world > 1 else "1gpu"},
+                       "parallelism": "rowshard%d+allgather" % world if world > 1 else "1gpu",
+                       **({"collectives": sharded_impl} if sharded_impl else {})},
             "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": round(ach_tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(ach_tf / peak, 4),
