@@ -124,37 +124,45 @@ __device__ __forceinline__ void gemm_epilogue_w(const GemmArgs& p, floatx16 (&ac
 // __device__ functions: the host pass of the compiler rejects the constraints inside a kernel body.  Hazards the compiler
 // cannot see through the asm: VALU write -> matrix read (the expansion instructions sit BEFORE a matrix instruction that
 // does not read them; expand_bucket_columns ends with s_nop 1), matrix write -> VALU read (s_nop padding before the epilogue).
+// AV: the accumulator lives in the architectural registers ("v") instead of the accumulation registers ("a").  Two waves per SIMD
+// (NI = 2) have 256 registers each and the whole kernel fits the 256 architectural ones: no v_accvgpr_read in front of the
+// filter epilogue and 36 registers fewer (218 instead of 126 + 128); NI = 4 needs more than 256 registers, i.e. the "a" file.
+template <bool AV>
 __device__ __forceinline__ void mfma_f16(floatx16& c, const half8& a, const half8& b) {
-  asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  if constexpr (AV) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  else asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 // int8 stages of a dense_i8 index: the same 16-byte fragments, 32 columns deep; the accumulator registers hold int32 sums until
 // the conversion between the dense and the gated stages
+template <bool AV>
 __device__ __forceinline__ void mfma_i8(floatx16& c, const half8& a, const half8& b) {
-  asm("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  if constexpr (AV) asm("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  else asm("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 // Issue group of a sparse block: the two expansion instructions of one register of the NEXT query block's compressed fragment
 // (value v, bucket in the sign bit -> the two bucket columns (max(v,0), max(-v,0))), then one matrix instruction of the current one.
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
-template <int KB>
+// (the constraint letter of the accumulator is the only difference between the AV and the non-AV form)
+#define DHR_SM_UNIT_ASM(ACC, ABID)                                                                                              \
+  asm("v_pk_max_f16 %1, %6, 0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"                                                    \
+      "v_pk_max_f16 %2, %6, 0 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"                                                    \
+      "v_smfmac_f32_32x32x32_f16 %0, %3, %4, %5" ABID                                                                           \
+      : ACC(c), "=&v"(o_lo), "=&v"(o_hi) : "v"(a), "v"(b), "v"(idx), "v"(raw))
+#define DHR_SM_ONLY_ASM(ACC, ABID) asm("v_smfmac_f32_32x32x32_f16 %0, %1, %2, %3" ABID : ACC(c) : "v"(a), "v"(b), "v"(idx))
+template <int KB, bool AV>
 __device__ __forceinline__ void sm_unit(floatx16& c, uint32_t& o_lo, uint32_t& o_hi, const half8& a, const half16& b, uint32_t idx, uint32_t raw) {
 #if W4_ABL == 7 || W4_ABL == 9      // timing only: no expansion instructions (the expanded blocks keep their prologue contents)
-  if constexpr (KB == 0) asm("v_smfmac_f32_32x32x32_f16 %0, %1, %2, %3" : "+a"(c) : "v"(a), "v"(b), "v"(idx));
-  else asm("v_smfmac_f32_32x32x32_f16 %0, %1, %2, %3 abid:1" : "+a"(c) : "v"(a), "v"(b), "v"(idx));
+  if constexpr (KB == 0) { if constexpr (AV) DHR_SM_ONLY_ASM("+v", ""); else DHR_SM_ONLY_ASM("+a", ""); }
+  else { if constexpr (AV) DHR_SM_ONLY_ASM("+v", " abid:1"); else DHR_SM_ONLY_ASM("+a", " abid:1"); }
   return;
 #endif
-  if constexpr (KB == 0)
-    asm("v_pk_max_f16 %1, %6, 0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
-        "v_pk_max_f16 %2, %6, 0 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
-        "v_smfmac_f32_32x32x32_f16 %0, %3, %4, %5"
-        : "+a"(c), "=&v"(o_lo), "=&v"(o_hi) : "v"(a), "v"(b), "v"(idx), "v"(raw));
-  else
-    asm("v_pk_max_f16 %1, %6, 0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
-        "v_pk_max_f16 %2, %6, 0 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"
-        "v_smfmac_f32_32x32x32_f16 %0, %3, %4, %5 abid:1"
-        : "+a"(c), "=&v"(o_lo), "=&v"(o_hi) : "v"(a), "v"(b), "v"(idx), "v"(raw));
+  if constexpr (KB == 0) { if constexpr (AV) DHR_SM_UNIT_ASM("+v", ""); else DHR_SM_UNIT_ASM("+a", ""); }
+  else { if constexpr (AV) DHR_SM_UNIT_ASM("+v", " abid:1"); else DHR_SM_UNIT_ASM("+a", " abid:1"); }
 }
+#undef DHR_SM_UNIT_ASM
+#undef DHR_SM_ONLY_ASM
 
 // timing ablations (wrong results): W4_ABL 1 = no pair barrier, 2 = no DMA wait before it, 3 = neither, 4 = no DMA pieces in the loop,
 // 7 = 4 + no expansion instructions, 8 = 4 + no fragment reads in the loop, 9 = 4 + 7 + 8
@@ -337,7 +345,7 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
       WExp& cur = (ni & 1) ? bfb : bfa;
       WExp& oth = (ni & 1) ? bfa : bfb;
       const uint32_t rw = ni < NI - 1 ? fc.b[ni < NI - 1 ? ni + 1 : 0].w[mi] : fn.b[0].w[mi];
-      sm_unit<KB>(acc[mi][ni], oth.w[2 * mi], oth.w[2 * mi + 1], fc.a[mi], cur.h, pw[mi], rw);
+      sm_unit<KB, NI == 2>(acc[mi][ni], oth.w[2 * mi], oth.w[2 * mi + 1], fc.a[mi], cur.h, pw[mi], rw);
       if (wx_dma_piece<NI, SH>(PH, g) >= 0) dma_piece(wx_dma_piece<NI, SH>(PH, g));
     }
   };
@@ -349,7 +357,7 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
     for (int g = 0; g < NG; ++g) {
       const int ni = g >> 2, mi = g & 3;
       if (do_load && W4_ABL != 8 && W4_ABL != 9) frag_read(fn, sl, g);
-      if constexpr (I8) mfma_i8(acc[mi][ni], fc.a[mi], fc.b[ni].h); else mfma_f16(acc[mi][ni], fc.a[mi], fc.b[ni].h);
+      if constexpr (I8) mfma_i8<NI == 2>(acc[mi][ni], fc.a[mi], fc.b[ni].h); else mfma_f16<NI == 2>(acc[mi][ni], fc.a[mi], fc.b[ni].h);
       if (wx_dma_piece<NI, SH>(PH, g) >= 0) dma_piece(wx_dma_piece<NI, SH>(PH, g));
     }
   };
