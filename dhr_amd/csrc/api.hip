@@ -833,6 +833,11 @@ static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectAr
 // Leaves the sorted top-k keys of every query in w.topk_keys.  qb must already be validated.
 // stage 0: whole search.  stage 1 (dhr_search_begin): stop after the sampled run.  stage 2 (dhr_search_finish):
 // resume at the main pass with the caller's thresholds tau_ext (device [Q]); no local verification.
+// Conservative rank of the sampled threshold: the k/S top rows a 1/S sample holds on average + 5 sigma + 4 (4 sigma until round 2:
+// one query in ~50 000 then saw its sample hold 58 rows above a score that fewer than k rows of the corpus reach, and a failed
+// query costs extra passes over the corpus for its whole query tile; the extrapolated thresholds make the looser start cheap).
+static int sample_rank_of(double mean) { return (int)std::ceil(mean + 5.0 * std::sqrt(mean) + 4.0); }
+
 static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, int k, int depth, Timer& tm,
                        dhr_search_stats& st, hipStream_t s, int stage = 0, const float* tau_ext = nullptr) {
   int rc;
@@ -849,7 +854,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   int r_eff = k;
   if (S >= 2) {
     const double mean = (double)k / S;
-    r_eff = (int)std::ceil(mean + 4.0 * std::sqrt(mean) + 4.0);
+    r_eff = sample_rank_of(mean);
     const int64_t head_guess = round_up(std::max<int64_t>(512, 2 * (int64_t)r_eff), TILE_ROWS) / TILE_ROWS;
     const int64_t rest_guess = ix->n_tiles - head_guess;
     if (r_eff >= k || rest_guess < 32 * (int64_t)S || (rest_guess / S) * TILE_ROWS < 16 * (int64_t)r_eff) S = 0;
@@ -1045,10 +1050,12 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   if (stage == 2) return DHR_OK;                                // the caller verifies across shards
   // ---- verify; queries whose list overflowed or that found < k rows above tau_hat are redone exactly
   HIP_TRY(hipMemsetAsync(w.d_max, 0, 16, s));
+  HIP_TRY(launch_max_u32(w.fail_flags, Q, w.d_max + 1, (unsigned long long*)(w.d_max + 2), s));      // overflow marks so far (the verification adds its own below)
   HIP_TRY(launch_verify(w.topk_keys, w.kp, k, w.tau_hat, Q, w.fail_flags, w.d_max, s));
   HIP_TRY(hipMemcpyAsync(w.h_pinned, w.d_max, 16, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   const uint32_t n_fail = ((uint32_t*)w.h_pinned)[0];
+  const uint32_t n_overflow = ((uint32_t*)w.h_pinned)[1];
   st.sample_fallback_queries += n_fail;
   if (n_fail == 0) return DHR_OK;
 
@@ -1057,6 +1064,10 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   std::vector<int32_t> ids;
   for (int q = 0; q < Q; ++q)
     if (flags[q]) ids.push_back(q);
+  // depth 1 (the same sampling scheme with 16x deeper lists) only cures overflowed lists; a threshold that came out too high would
+  // come out too high again from the same sample: those queries go straight to the plain streaming pass
+  int next_depth = depth + 1;
+  if (depth == 0 && (int)n_overflow == 0) next_depth = 2;
   const int nf = (int)ids.size();
   void* tmp = nullptr;
   const size_t b32 = (size_t)nf * ix->k_rm * 4, bidx = (size_t)nf * std::max(ix->d_dlr, 8) * 2, bids = (size_t)nf * 4;
@@ -1071,8 +1082,8 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   dhr_query_batch sub{};
   sub.n_queries = nf; sub.mem_kind = DHR_MEM_DEVICE; sub.value = f32; sub.value_dtype = DHR_VAL_F32; sub.ld_value = ix->k_rm;
   sub.index = gate ? fidx : nullptr; sub.index_dtype = gate ? DHR_IDX_I16 : DHR_IDX_NONE; sub.ld_index = ix->d_dlr;
-  Workspace& w2 = ix->ws_fb[depth];
-  if ((rc = search_core(ix, w2, &sub, k, depth + 1, tm, st, s)) != DHR_OK) return done(rc);
+  Workspace& w2 = ix->ws_fb[next_depth - 1];
+  if ((rc = search_core(ix, w2, &sub, k, next_depth, tm, st, s)) != DHR_OK) return done(rc);
   if (w2.kp != w.kp) return done(set_error(DHR_ERR_INTERNAL, "fallback workspace mismatch"));
   if (launch_scatter_keys(w2.topk_keys, w.topk_keys, w.kp, d_ids, nf, s) != hipSuccess)
     return done(set_error(DHR_ERR_HIP, "scatter_keys launch failed"));
@@ -1213,7 +1224,7 @@ extern "C" int32_t dhr_search_sample_rank(const dhr_index* ix, int32_t k) {
   const int S = ix->sample_period;
   if (S < 2) return 0;
   const double mean = (double)k / S;
-  const int r = (int)std::ceil(mean + 4.0 * std::sqrt(mean) + 4.0);
+  const int r = sample_rank_of(mean);
   const int64_t group_rows = (int64_t)DOC_GROUP * TILE_ROWS;
   const int64_t head_guess = round_up(std::max<int64_t>(512, 2 * (int64_t)r), TILE_ROWS) / TILE_ROWS;
   const int64_t rest_guess = ix->n_tiles - head_guess;

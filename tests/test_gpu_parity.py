@@ -443,7 +443,7 @@ def test_sampled_threshold_fallbacks(G, boosted_mod):
                              params=[(_lib.PARAM_CAND_CAP, 4096), (_lib.PARAM_SAMPLE_PERIOD, 16)])   # the corpus is built for period 16
     print(boosted_mod, st)
     if boosted_mod == 0:
-        assert st["sample_fallback_queries"] == 10      # all 5 fail at depth 0 and again at depth 1 (16x capacity), then stream
+        assert st["sample_fallback_queries"] == 5       # all 5 fail at depth 0 (no list overflowed) and go straight to the plain streaming pass
     _, _, st2 = _search_check(G, cv, None, qv.astype(np.float32), None, 1000,
                               params=[(_lib.PARAM_SAMPLE_PERIOD, 0)])
     assert st2["sample_fallback_queries"] == 0
