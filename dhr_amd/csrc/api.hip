@@ -42,6 +42,7 @@ static inline int idx_esize(int dt) { return dt == DHR_IDX_I16 ? 2 : 1; }
 struct Workspace {
   int q_pad = 0, kp = 0;
   int64_t cap = 0;       // capacity of the bound-candidate lists (cand, cand2)
+  uint32_t last_maxr = 0;   // fullest survivor list of the latest refine step (before clamping to cap_r): the chunk planner sizes the main pass by it too
   int64_t cap_r = 0;     // capacity of the lists that reach the exact rescoring (refine survivors; == cap without refine)
   int64_t keys_ld = 0, kt = 0, d_dlr = 0;
   int ts_q = 0;          // sparse stages of the current query operand (2:4 layout)
@@ -115,7 +116,7 @@ struct dhr_index {
   hipStream_t s_gemm = nullptr;         // main-pass GEMM stream when CU masks are in use
   hipStream_t s_aux = nullptr;          // non-blocking stream for rescoring/select overlapped with the main-pass GEMM
   // staged search (dhr_search_begin / dhr_search_finish): state carried between the two calls
-  struct { bool valid = false, done = false, gate = false; int Q = 0, k = 0; double rate = 0.0; } pend;
+  struct { bool valid = false, done = false, gate = false; int Q = 0, k = 0; double rate = 0.0, rate_r = 0.0; } pend;
   Workspace ws, ws_fb[2];              // ws_fb[d]: workspace of fallback depth d+1 (16x candidate capacity)
   dhr_search_stats stats{};
 };
@@ -767,6 +768,7 @@ static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectA
     HIP_TRY(launch_max_u32(w.cnt_r, Q, w.d_ref, (unsigned long long*)(w.d_ref + 2), s));
     HIP_TRY(hipMemcpyAsync(w.h_ref, w.d_ref, 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    w.last_maxr = ((uint32_t*)w.h_ref)[0];
     maxr = std::min<uint32_t>(((uint32_t*)w.h_ref)[0], (uint32_t)w.cap_r);
     if (((uint32_t*)w.h_ref)[0] > (uint32_t)w.cap_r) {          // survivors list overflowed: those queries are redone
       if (fail_flags) HIP_TRY(launch_mark_overflow(w.cnt_r, (uint32_t)w.cap_r, Q, fail_flags, s));
@@ -795,7 +797,7 @@ static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectA
 // comes from exact scores already seen, overflowing chunks are re-run in halves).
 static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, int64_t n_seq, int map_mode,
                          int period, int64_t head, int64_t first_chunk, int64_t seen_rows, Timer& tm, dhr_search_stats& st,
-                         hipStream_t s, double* last_rate = nullptr) {
+                         hipStream_t s, double* last_rate = nullptr, double* last_rate_r = nullptr) {
   int64_t pos = 0;
   int64_t chunk = std::max<int64_t>(DOC_GROUP, first_chunk);
   while (pos < n_seq) {
@@ -819,6 +821,7 @@ static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectAr
       continue;
     }
     if (rc != DHR_OK) return rc < 0 ? rc : set_error(DHR_ERR_INTERNAL, "survivor list overflow at the minimum chunk size");
+    if (last_rate_r) *last_rate_r = (gate && ix->heavy_key && maxc > 0) ? (double)w.last_maxr / (double)chunk_rows : 0.0;   // fullest SURVIVOR list per corpus row
     pos = hi;
     seen_rows += chunk_rows;
     // next chunk: aim at cap/4 candidates for the fullest query, never more than growth * rows seen
@@ -902,16 +905,16 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
 
   // ---- sampled run: top-r_eff of {head rows} + {every S-th tile}  ->  tau_hat
   const int64_t n_sample = (rest + S - 1) / S;
-  double rate = 0.0;
+  double rate = 0.0, rate_r = 0.0;
   if (stage != 2) {
-    if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, std::max<int64_t>(head, DOC_GROUP), first_valid, tm, st, s, &rate)) != DHR_OK) return rc;
+    if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, std::max<int64_t>(head, DOC_GROUP), first_valid, tm, st, s, &rate, &rate_r)) != DHR_OK) return rc;
     HIP_TRY(hipMemcpyAsync(w.tau_hat, w.tau, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
     if (stage == 1) {
-      ix->pend.valid = true; ix->pend.done = false; ix->pend.gate = gate; ix->pend.Q = Q; ix->pend.k = k; ix->pend.rate = rate;
+      ix->pend.valid = true; ix->pend.done = false; ix->pend.gate = gate; ix->pend.Q = Q; ix->pend.k = k; ix->pend.rate = rate; ix->pend.rate_r = rate_r;
       return DHR_OK;
     }
   } else {
-    rate = ix->pend.rate;
+    rate = ix->pend.rate; rate_r = ix->pend.rate_r;
     // thresholds agreed between the shards: tau_ext >= this shard's own tau_hat in general
     HIP_TRY(hipMemcpyAsync(w.tau_hat, tau_ext, (size_t)Q * 4, hipMemcpyDeviceToDevice, s));
     HIP_TRY(launch_make_thr(w.tau_hat, w.margin, Q, w.q_pad, w.thr, s));
@@ -978,7 +981,10 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     }
     // chunk count: at least main_chunks, more when the sampled run predicts that the fullest list would not fit
     // (rate = bound candidates per corpus row of the fullest query at the final sample thresholds, 1.5x headroom)
-    const int64_t need = (int64_t)std::ceil(1.5 * rate * (double)n_main * TILE_ROWS / (double)w.cap);
+    // ... and the same for the survivor lists of the refine step, which are shallower (cap_r): a query whose bound the heavy lists
+    // do not tighten fills them first
+    const int64_t need = std::max((int64_t)std::ceil(1.5 * rate * (double)n_main * TILE_ROWS / (double)w.cap),
+                                  (int64_t)std::ceil(1.5 * rate_r * (double)n_main * TILE_ROWS / (double)w.cap_r));
     const int M = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(ix->main_chunks, need), 64),
                                                               n_main / (64 * DOC_GROUP)));
     // chunk i covers [bound[i], bound[i+1]): sizes fall off linearly (weights M, M-1, ..., 1 on top of an equal
