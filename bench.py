@@ -21,6 +21,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -112,6 +113,7 @@ def main():
     ap.add_argument("--n-docs", type=int, default=0, help="override the workload's corpus size")
     ap.add_argument("--n-queries", type=int, default=0, help="override the workload's query count")
     ap.add_argument("--topk", type=int, default=1000)
+    ap.add_argument("--beir-only", default="", help="beir: run this corpus only")
     ap.add_argument("--pq", action="store_true", help="beir: product-quantised first stage (--PQIP: ADC scan to agip_topk candidates, exact GIP rerank) instead of the exact search")
     ap.add_argument("--agip-topk", type=int, default=10000)
     ap.add_argument("--uniform-idx", action="store_true", help="adversarial variant: uniform slice indices")
@@ -160,8 +162,10 @@ def main():
     ctx = dict(torch=torch, _lib=_lib, D=D, synth=synth, world=world, rank=rank, local_rank=local_rank, device=device)
     if args.workload == "beir":
         for name, n_docs, n_q in BEIR:
+            if args.beir_only and name != args.beir_only:
+                continue
             spec = dict(name="beir/" + name, n=args.n_docs or n_docs, nq=args.n_queries or n_q, d_dlr=768, d_cls=128, kind="encoder",
-                        baseline_config="config 5: DeLADE-CLS-P on BEIR-13 (%s)" % name, seed=args.seed + 5 + (hash(name) % 997))
+                        baseline_config="config 5: DeLADE-CLS-P on BEIR-13 (%s)" % name, seed=args.seed + 5 + (zlib.crc32(name.encode()) % 997))
             out = run_workload(args, spec, ctx)
             if rank == 0:
                 print(json.dumps(out), flush=True)

@@ -986,7 +986,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     const int64_t need = std::max((int64_t)std::ceil(1.5 * rate * (double)n_main * TILE_ROWS / (double)w.cap),
                                   (int64_t)std::ceil(1.5 * rate_r * (double)n_main * TILE_ROWS / (double)w.cap_r));
     const int M = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(ix->main_chunks, need), 64),
-                                                              n_main / (64 * DOC_GROUP)));
+                                                              n_main / (16 * DOC_GROUP)));
     // chunk i covers [bound[i], bound[i+1]): sizes fall off linearly (weights M, M-1, ..., 1 on top of an equal
     // share) so that the refine/rescoring tail that cannot overlap a GEMM (the last chunk's) is short
     std::vector<int64_t> bound(M + 1, 0);
@@ -1055,6 +1055,18 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   }
   if (stage == 2) return DHR_OK;                                // the caller verifies across shards
   // ---- verify; queries whose list overflowed or that found < k rows above tau_hat are redone exactly
+  if (getenv("DHR_DEBUG_FAIL")) {        // diagnostics: which queries are about to be redone, and why
+    std::vector<uint32_t> ff(Q); std::vector<float> th(Q);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(ff.data(), w.fail_flags, (size_t)Q * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(th.data(), w.tau_hat, (size_t)Q * 4, hipMemcpyDeviceToHost);
+    for (int q = 0; q < Q; ++q) {
+      uint64_t key = 0;
+      (void)hipMemcpy(&key, w.topk_keys + (size_t)q * w.kp + (k - 1), 8, hipMemcpyDeviceToHost);
+      const float kth = key ? ordered_f32((uint32_t)(key >> 32)) : -INFINITY;
+      if (ff[q] || !(kth >= th[q])) fprintf(stderr, "[dhr] depth %d query %d will be redone: list overflow %u, k-th best %.6f, threshold %.6f\n", depth, q, ff[q], kth, th[q]);
+    }
+  }
   HIP_TRY(hipMemsetAsync(w.d_max, 0, 16, s));
   HIP_TRY(launch_max_u32(w.fail_flags, Q, w.d_max + 1, (unsigned long long*)(w.d_max + 2), s));      // overflow marks so far (the verification adds its own below)
   HIP_TRY(launch_verify(w.topk_keys, w.kp, k, w.tau_hat, Q, w.fail_flags, w.d_max, s));
