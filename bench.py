@@ -418,6 +418,7 @@ def run_workload(args, spec, ctx):
             "candidates_per_query": {"bound": round(stats_acc["candidates_bound"] / args.steps / nq, 1),
                                      "exact": round(stats_acc["candidates_exact"] / args.steps / nq, 1)},
             "sample_fallback_queries_per_step": stats_acc["sample_fallback_queries"] / args.steps,
+            "overflow_retries_per_step": stats_acc["overflow_retries"] / args.steps,
             "setup_s": {"generate": round(t_gen, 2), "index_build": round(t_build, 2)},
             "index_device_gb": round(index.device_bytes() / 1e9, 2),
         }
