@@ -841,6 +841,20 @@ static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectAr
 // query costs extra passes over the corpus for its whole query tile; the extrapolated thresholds make the looser start cheap).
 static int sample_rank_of(double mean) { return (int)std::ceil(mean + 5.0 * std::sqrt(mean) + 4.0); }
 
+// Sample period and rank for this index and k: the configured period, halved (32 -> 16 -> 8 -> 4) while the corpus is too small for it
+// -- the sample must span >= 32 tiles and hold >= 16 r rows, and r must stay below k; S = 0 (r = k): no sampling, plain streaming.
+// (Until round 2 a corpus below ~270 k rows was never sampled: the 100 k-row config 1 rescored 8.7 k rows per query, most of them while
+// the streaming thresholds were still warming up.)
+static void plan_sampling(const dhr_index* ix, int k, int& S, int& r) {
+  for (S = ix->sample_period; S >= 2; S = S >= 8 ? S / 2 : 0) {
+    const int rr = sample_rank_of((double)k / S);
+    const int64_t head_guess = round_up(std::max<int64_t>(512, 2 * (int64_t)rr), TILE_ROWS) / TILE_ROWS;
+    const int64_t rest_guess = ix->n_tiles - head_guess;
+    if (!(rr >= k || rest_guess < 32 * (int64_t)S || (rest_guess / S) * TILE_ROWS < 16 * (int64_t)rr)) { r = rr; return; }
+  }
+  S = 0; r = k;
+}
+
 static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, int k, int depth, Timer& tm,
                        dhr_search_stats& st, hipStream_t s, int stage = 0, const float* tau_ext = nullptr) {
   int rc;
@@ -853,16 +867,8 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   // depth 2: plain streaming, exact for any input
   const bool allow_sampling = depth < 2;
   // sampled threshold: period S, conservative rank r (DESIGN.md "controller")
-  int S = allow_sampling ? ix->sample_period : 0;
-  int r_eff = k;
-  if (S >= 2) {
-    const double mean = (double)k / S;
-    r_eff = sample_rank_of(mean);
-    const int64_t head_guess = round_up(std::max<int64_t>(512, 2 * (int64_t)r_eff), TILE_ROWS) / TILE_ROWS;
-    const int64_t rest_guess = ix->n_tiles - head_guess;
-    if (r_eff >= k || rest_guess < 32 * (int64_t)S || (rest_guess / S) * TILE_ROWS < 16 * (int64_t)r_eff) S = 0;
-  }
-  if (S < 2) r_eff = k;
+  int S = 0, r_eff = k;
+  if (allow_sampling) plan_sampling(ix, k, S, r_eff);
   // rows scored exhaustively in phase 0 (>= the rank that defines tau, so that tau exists afterwards), whole tile groups
   int64_t first = ix->first_rows > 0 ? std::max<int64_t>(ix->first_rows, 2 * (int64_t)r_eff) : std::max<int64_t>(512, 2 * (int64_t)r_eff);
   first = std::min(round_up(first, TILE_ROWS), round_up(n, TILE_ROWS));
@@ -882,7 +888,8 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   SelectArgs sel{};
   sel.topk_keys = w.topk_keys; sel.in_keys = w.rs_keys; sel.ld_keys = w.keys_ld; sel.cap = (uint32_t)w.cap;
   sel.k = r_eff; sel.kp = w.kp; sel.sort_n = 4 * w.kp;
-  sel.kps = 64; while (sel.kps < r_eff) sel.kps <<= 1; sel.margin = w.margin; sel.tau = w.tau; sel.thr = w.thr;
+  sel.k_keep = k;                          // the threshold is the r-th best seen, the list keeps the k best (ties with the final k-th score survive the sampled run)
+  sel.kps = 64; while (sel.kps < k) sel.kps <<= 1; sel.margin = w.margin; sel.tau = w.tau; sel.thr = w.thr;
   sel.n_queries = Q;
 
   // ---- phase 0: exhaustive exact scoring of rows [0, first_valid)
@@ -1239,15 +1246,9 @@ extern "C" int dhr_search_rerank(dhr_index* ix, const dhr_query_batch* qb1, cons
 // query after their sampled runs, so each shard collects only its share of the global top-k.
 extern "C" int32_t dhr_search_sample_rank(const dhr_index* ix, int32_t k) {
   if (!ix || k <= 0) return 0;
-  const int S = ix->sample_period;
-  if (S < 2) return 0;
-  const double mean = (double)k / S;
-  const int r = sample_rank_of(mean);
-  const int64_t group_rows = (int64_t)DOC_GROUP * TILE_ROWS;
-  const int64_t head_guess = round_up(std::max<int64_t>(512, 2 * (int64_t)r), TILE_ROWS) / TILE_ROWS;
-  const int64_t rest_guess = ix->n_tiles - head_guess;
-  if (r >= k || rest_guess < 32 * (int64_t)S || (rest_guess / S) * TILE_ROWS < 16 * (int64_t)r) return 0;
-  return r;
+  int S = 0, r = k;
+  plan_sampling(ix, k, S, r);
+  return S >= 2 ? r : 0;
 }
 
 extern "C" int dhr_search_begin(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_sample_scores_dev, void* stream) {

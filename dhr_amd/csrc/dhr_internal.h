@@ -137,6 +137,8 @@ struct SelectArgs {
   const uint32_t* cnt;        // per query count (null -> count_all)
   uint32_t count_all, cap;
   int k, kp, sort_n;
+  int k_keep;                 // entries the running list keeps (0 = k).  The sampled run publishes the r-th best (k = r) but keeps the k best seen:
+                              // rows of the sample that tie with the final k-th score must not be lost to the rank that only defines the threshold
   int kps;                    // slots of the running list actually in use (power of two >= k, <= kp): sizes the LDS sort
   const float* margin;        // [Q_pad]
   float* tau;                 // [Q_pad] exact k-th best so far (-inf until k results exist)

@@ -1425,8 +1425,9 @@ __global__ void __launch_bounds__(SELECT_SM_THREADS) select_kernel(SelectArgs p)
   __syncthreads();
   uint32_t room = 64;                         // input keys per round: a power of two that fits behind A, at most 2048
   while (room * 2 <= (uint32_t)(p.sort_n - kps) && room < 2048) room <<= 1;
+  const int k_keep = p.k_keep ? p.k_keep : p.k;
   for (uint32_t base = 0; base < count; base += room) {
-    const uint64_t kth = A[p.k - 1];
+    const uint64_t kth = A[k_keep - 1];
     __syncthreads();
     const uint32_t end = (base + room < count) ? base + room : count;
     for (uint32_t j = base + tid; j < end; j += SELECT_SM_THREADS) {
@@ -1471,7 +1472,7 @@ __global__ void __launch_bounds__(SELECT_SM_THREADS) select_kernel(SelectArgs p)
     if (tid == 0) fill = 0;
     __syncthreads();
   }
-  for (int j = tid; j < kps; j += SELECT_SM_THREADS) topk[j] = (j < p.k) ? A[j] : 0ull;
+  for (int j = tid; j < kps; j += SELECT_SM_THREADS) topk[j] = (j < k_keep) ? A[j] : 0ull;
   if (tid == 0) {
     const uint64_t kth = A[p.k - 1];
     const float t = kth ? ordered_f32((uint32_t)(kth >> 32)) : -INFINITY;
@@ -1499,8 +1500,9 @@ __global__ void __launch_bounds__(SELECT_THREADS) select_big_kernel(SelectArgs p
   if (tid == 0) fill = 0;
   __syncthreads();
   const int per_thread = p.kp / SELECT_THREADS;                     // 8 or 16
+  const int k_keep = p.k_keep ? p.k_keep : p.k;
   for (uint32_t base = 0; base < count; base += SELECT_BIG_BATCH) {
-    const uint64_t kth = A[p.k - 1];
+    const uint64_t kth = A[k_keep - 1];
     __syncthreads();
     const uint32_t end = (base + SELECT_BIG_BATCH < count) ? base + SELECT_BIG_BATCH : count;
     for (uint32_t j = base + tid; j < end; j += SELECT_THREADS) {
@@ -1537,7 +1539,7 @@ __global__ void __launch_bounds__(SELECT_THREADS) select_big_kernel(SelectArgs p
     if (tid == 0) fill = 0;
     __syncthreads();
   }
-  for (int j = tid; j < p.kp; j += SELECT_THREADS) topk[j] = (j < p.k) ? A[j] : 0ull;
+  for (int j = tid; j < p.kp; j += SELECT_THREADS) topk[j] = (j < k_keep) ? A[j] : 0ull;
   if (tid == 0) {
     const uint64_t kth = A[p.k - 1];
     const float t = kth ? ordered_f32((uint32_t)(kth >> 32)) : -INFINITY;

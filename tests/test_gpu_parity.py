@@ -1368,3 +1368,37 @@ def test_search_sharded_local_k_beyond_16384(G):
     finally:
         for s in shards:
             s.close()
+
+
+def test_zero_score_ties_under_sampling(G):
+    """Queries with fewer than k matching rows: the tail of the list is rows of score 0.0, and the rule (score desc, row asc) puts the
+    LOWEST rows there.  The sampled run publishes the r-th best as threshold but must keep the k best rows it saw -- the rows of the
+    head and of the sample tiles tie with the final k-th score (a 100 k-row corpus is sampled since the period adapts to the size)."""
+    from dhr_amd import synth, _lib
+    n, k = 100_000, 1000
+    cv, ci, qv, qi = synth.make_pair(77, n, 8, 768, 0, kind="bm25")
+    nz = cv > 0
+    sl = np.broadcast_to(np.arange(768, dtype=np.int64)[None, :], cv.shape)[nz]
+    key = sl * 65536 + (ci.astype(np.int64)[nz] & 0xFFFF)
+    uk, cnt = np.unique(key, return_counts=True)
+    rare = uk[(cnt >= 3) & (cnt <= 400)]
+    rng = np.random.default_rng(5)
+    q32 = np.zeros((12, 768), np.float32)
+    qidx = np.zeros((12, 768), ci.dtype)
+    for i in range(12):
+        for kk_ in rng.choice(rare, 2, replace=False):         # two rare words per query: a few hundred matching rows at most
+            q32[i, kk_ // 65536] = 1.0 + i
+            qidx[i, kk_ // 65536] = kk_ % 65536
+    c32 = cv.astype(np.float32)
+    ix = G.GipIndex(cv, ci)
+    assert ix.sample_rank(k) > 0                                # the search takes the sampled path
+    s, r = ix.search(q32, qidx, k)
+    st = ix.stats()
+    ix.close()
+    assert st["sample_fallback_queries"] == 0
+    for i in range(12):
+        ex = O.gip_scores_f64(q32[i], qidx[i], c32, ci)
+        assert (ex > 0).sum() < k
+        order = np.lexsort((np.arange(n), -ex))[:k]
+        np.testing.assert_array_equal(r[i], order)
+        np.testing.assert_array_equal(s[i], ex[order].astype(np.float32))
