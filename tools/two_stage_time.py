@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Times the two-stage modes of the reference's docs (--theta 0.3 --rerank, --IP --rerank; gip_retrieval.py:128-156) on the config-3
+corpus: dhr_search_rerank with agip_topk = 10 000 candidates, top-1000 after the exact rerank, against the brute-force search."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+
+
+def main():
+    import torch
+    import bench
+    from dhr_amd import synth
+    from dhr_amd.retrieval.gip_retrieval import GipIndex
+    dev = torch.device("cuda", 0)
+    n, nq, k, k1 = 8841823, 6980, 1000, 10000
+    cv, ci = bench.gen_rows(torch, synth, dev, 1237, 0, n, 768, 768, 30, 90, False)
+    qv, qi = bench.gen_rows(torch, synth, dev, 1237 + 999_983, 0, nq, 768, 768, 4, 12, False)
+    ix = GipIndex(cv, ci, device=0)
+    del cv, ci
+    torch.cuda.empty_cache()
+    q = qv.float()
+
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, out
+    ms_b, (sb, rb) = timed(lambda: ix.search(q, qi, k, out_device=True))
+    print("brute force (theta 0)          : %.1f ms per 6 980 queries" % ms_b)
+    for theta in (0.3, 0.1):
+        q1 = torch.where(q > theta, q, torch.zeros_like(q))
+        ms, (s2, r2) = timed(lambda: ix.search_rerank(q1.cpu().numpy(), qi.cpu().numpy(), q.cpu().numpy(), qi.cpu().numpy(), k1, k))
+        rec = np.mean([len(set(r2[i].tolist()) & set(rb[i].cpu().tolist())) / k for i in range(0, nq, 349)])
+        print("theta %.1f --rerank (agip 10000)  : %.1f ms incl. host copies of the batch, overlap with brute force top-1000: %.3f" % (theta, ms, rec))
+    ms, (s2, r2) = timed(lambda: ix.search_rerank(q.cpu().numpy(), None, q.cpu().numpy(), qi.cpu().numpy(), k1, k))
+    rec = np.mean([len(set(r2[i].tolist()) & set(rb[i].cpu().tolist())) / k for i in range(0, nq, 349)])
+    print("--IP --rerank (agip 10000)      : %.1f ms, overlap %.3f" % (ms, rec))
+    ix.close()
+
+
+if __name__ == "__main__":
+    main()
