@@ -54,6 +54,9 @@ struct Workspace {
   uint32_t* q_inexact = nullptr;
   float *margin = nullptr, *tau = nullptr, *thr = nullptr;
   float* i8_mul = nullptr;               // dense_i8 indexes: per-query factor (corpus scale x query scale) of the int8 stages
+  uint8_t* g8_q8 = nullptr;              // gated_i8 indexes: [q_pad][d_dlr] gated int8 operand values, [q_pad] shift, [q_pad] unit of a gated product
+  int32_t* g8_shift = nullptr;
+  float* g8_unit = nullptr;
   uint32_t* cnt = nullptr;
   uint2* cand = nullptr;
   uint64_t *rs_keys = nullptr, *topk_keys = nullptr;
@@ -101,6 +104,13 @@ struct dhr_index {
   bool dense_i8 = false;
   float i8_scale = 0.f, i8_ec = 0.f, i8_nc = 0.f;
   float* i8_col_scale = nullptr;           // [d_cls] int8 step of every ungated column (its largest |value| / 127): outlier columns do not cost the others their resolution
+  // gated_i8: the gated stages are int8 2:4 images too (gemm_g8.hip): column j in units of its own step, rounded up; the query
+  // side carries w_j = step_j / g8_sref as a weight (query_prep_kernel)
+  bool gated_i8 = false;
+  float g8_sref = 0.f;
+  int g8_max_shift = 0;
+  float* g8_inv_cs = nullptr;              // [d_dlr] 1 / step_j (with 1e-6 of head room)
+  float* g8_w = nullptr;                   // [d_dlr] step_j / g8_sref (rounded up)
   int64_t index_bytes = 0;
   // params
   int64_t cand_cap = 0, first_rows = 0;   // 0 = default (262144 with refine lists, else 65536)
@@ -122,7 +132,7 @@ struct dhr_index {
 };
 
 static void free_ws(Workspace& w) {
-  hipFree(w.q_tiles); hipFree(w.q32); hipFree(w.q_idx); hipFree(w.q16); hipFree(w.q_idx8); hipFree(w.q_inexact); hipFree(w.margin); hipFree(w.i8_mul); hipFree(w.tau); hipFree(w.thr);
+  hipFree(w.q_tiles); hipFree(w.q32); hipFree(w.q_idx); hipFree(w.q16); hipFree(w.q_idx8); hipFree(w.q_inexact); hipFree(w.margin); hipFree(w.i8_mul); hipFree(w.g8_q8); hipFree(w.g8_shift); hipFree(w.g8_unit); hipFree(w.tau); hipFree(w.thr);
   hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2); hipFree(w.q_pack); hipFree(w.cand_r); hipFree(w.cnt_r); hipFree(w.blk_off);
   if (w.h_pinned) hipHostFree(w.h_pinned);
   if (w.h_pinned2) hipHostFree(w.h_pinned2);
@@ -148,13 +158,15 @@ extern "C" void dhr_index_destroy(dhr_index* ix) {
   free_ws(ix->ws_fb[1]);
   if (ix->s_aux) hipStreamDestroy(ix->s_aux);
   if (ix->s_gemm) hipStreamDestroy(ix->s_gemm);
-  hipFree(ix->i8_col_scale); hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map); hipFree(ix->heavy_key); hipFree(ix->heavy_val);
+  hipFree(ix->i8_col_scale); hipFree(ix->g8_inv_cs); hipFree(ix->g8_w); hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map); hipFree(ix->heavy_key); hipFree(ix->heavy_val);
   delete ix;
 }
 
 static int g_opt_dense_i8 = -1;      // -1: gated indexes with ungated columns only; 0: never; 1: dense-only indexes too
+static int g_opt_gated_i8 = 1;       // int8 image of the gated half wherever the layout allows it
 extern "C" int dhr_set_option(int32_t option, int64_t value) {
   if (option == DHR_OPT_DENSE_I8) { g_opt_dense_i8 = value < 0 ? -1 : (value != 0); return DHR_OK; }
+  if (option == DHR_OPT_GATED_I8) { g_opt_gated_i8 = value != 0; return DHR_OK; }
   return set_error(DHR_ERR_INVALID, "unknown option");
 }
 extern "C" int dhr_index_get_info(const dhr_index* ix, int32_t what, double* out) {
@@ -165,7 +177,8 @@ extern "C" int dhr_index_get_info(const dhr_index* ix, int32_t what, double* out
     case DHR_INFO_I8_ROW_ERR: *out = ix->i8_ec; return DHR_OK;
     case DHR_INFO_I8_ROW_NORM: *out = ix->i8_nc; return DHR_OK;
     case DHR_INFO_ROW_NORM_MAX: *out = ix->dmax; return DHR_OK;
-    case DHR_INFO_TILE_BYTES: *out = (double)(ix->ts + ix->td > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * SP_STAGE_A + (size_t)ix->td * SP_DENSE)
+    case DHR_INFO_GATED_I8: *out = ix->gated_i8 ? 1.0 : 0.0; return DHR_OK;
+    case DHR_INFO_TILE_BYTES: *out = (double)(ix->ts + ix->td > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * (ix->gated_i8 ? S8_STAGE_A : SP_STAGE_A) + (size_t)ix->td * SP_DENSE)
                                                                       : (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2); return DHR_OK;
   }
   return set_error(DHR_ERR_INVALID, "unknown info id");
@@ -241,7 +254,8 @@ static int build_tiles(dhr_index* ix, hipStream_t s) {
   const int64_t n = ix->n_rows, fill = ix->n_tiles * TILE_ROWS;
   if (ix->ts + ix->td > 0)       // stage layout (2:4 sparse stages and / or 32-column dense stages)
     HIP_TRY(launch_tile_rows_sparse(ix->vals_rm, ix->k_rm, 0, n, fill, ix->d_dlr, ix->d_cls, ix->ts, ix->td, ix->c_idx, ix->idx_dtype,
-                                    ix->bucket_map, ix->abs_mode, (char*)ix->tiles, ix->dense_i8 ? 1.f / ix->i8_scale : 0.f, ix->i8_col_scale, s));
+                                    ix->bucket_map, ix->abs_mode, (char*)ix->tiles, ix->dense_i8 ? 1.f / ix->i8_scale : 0.f, ix->i8_col_scale,
+                                    ix->gated_i8 ? ix->g8_inv_cs : nullptr, s));
   else
     HIP_TRY(launch_tile_rows(ix->vals_rm, ix->k_rm, 0, n, fill, ix->d_dlr, ix->d_cls, ix->n_buckets, ix->kt, ix->c_idx, ix->idx_dtype,
                              ix->bucket_map, ix->abs_mode, ix->tiles, s));
@@ -312,6 +326,11 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
     ix->dense_i8 = d->d_cls > 0 && !(ix->ts & 1) && (want_i8 < 0 || want_i8 > 0);   // stage pairs: the int8 stages run on the 8 / 4-wave kernels only
     ix->td = ix->dense_i8 ? 2 * ((d->d_cls + 127) / 128) : (d->d_cls + 31) / 32;     // ungated columns in 32-column fp16 stages or PAIRS of 64-column int8 stages
     ix->kt = ix->ts * TILE_K + ix->td * 32;            // operand bytes / 2 per row (fp16: logical columns, two bucket columns per gated slice)
+    // gated half as int8 on the 2:4 int8 instruction (gemm_g8.hip): default wherever the stages pair up and the
+    // ungated half (if any) is the int8 image too; DHR_GATED_I8=0 / dhr_set_option(DHR_OPT_GATED_I8, 0) keeps the fp16 image
+    int want_g8 = g_opt_gated_i8;
+    if (const char* e = getenv("DHR_GATED_I8")) want_g8 = atoi(e);
+    ix->gated_i8 = want_g8 != 0 && !(ix->ts & 1) && (d->d_cls == 0 || ix->dense_i8) && d->d_dlr <= 4096;
   } else if (!has_idx && d->idx_buckets == 0) {
     // dense-only index: the same 32-column stage images (ts = 0), so that it runs on the 8-wave kernel of the 2:4 layout
     // (idx_buckets = 1 keeps the K-step tile layout and gemm_filter_v3_kernel)
@@ -334,7 +353,7 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
   int rc = DHR_OK;
   auto fail = [&](int code) { hipFree(stage); hipFree(d_flags); hipFree(d_hist); dhr_index_destroy(ix); return code; };
 
-  const size_t tile_bytes = ix->ts + ix->td > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * SP_STAGE_A + (size_t)ix->td * SP_DENSE)
+  const size_t tile_bytes = ix->ts + ix->td > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * (ix->gated_i8 ? S8_STAGE_A : SP_STAGE_A) + (size_t)ix->td * SP_DENSE)
                                        : (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2;
   if (hipMalloc((void**)&ix->tiles, tile_bytes) != hipSuccess)
     return fail(set_error(DHR_ERR_HIP, "hipMalloc of " + std::to_string(tile_bytes) + " bytes for the corpus tiles failed"));
@@ -410,6 +429,41 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
     memcpy(&e2, &flags[0], 4); memcpy(&n2, &flags[1], 4);
     ix->i8_ec = std::sqrt(e2) * 1.001f;
     ix->i8_nc = std::sqrt(n2) * 1.001f;
+  }
+  if (ix->gated_i8) {
+    // steps of the gated columns: s_ref = (largest gated |value|) / 127, column j in s_ref * (its own largest / the largest)^(3/4)
+    // (the exponent splits a small column's range between a finer corpus step and a smaller query weight, as for the ungated columns)
+    float gmax;
+    memcpy(&gmax, &flags[3], 4);
+    std::vector<uint32_t> cm((size_t)ix->d_dlr, 0u);
+    uint32_t* d_cm = nullptr;
+    if (hipMalloc((void**)&d_cm, cm.size() * 4) != hipSuccess || hipMalloc((void**)&ix->g8_inv_cs, cm.size() * 4) != hipSuccess ||
+        hipMalloc((void**)&ix->g8_w, cm.size() * 4) != hipSuccess) {
+      hipFree(d_cm);
+      return fail(set_error(DHR_ERR_HIP, "hipMalloc failed"));
+    }
+    if (hipMemsetAsync(d_cm, 0, cm.size() * 4, s) != hipSuccess ||
+        launch_col_absmax(ix->vals_rm, ix->k_rm, ix->n_rows, 0, ix->d_dlr, d_cm, s) != hipSuccess ||
+        hipMemcpy(cm.data(), d_cm, cm.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      hipFree(d_cm);
+      return fail(set_error(DHR_ERR_HIP, "column scan failed"));
+    }
+    hipFree(d_cm);
+    ix->g8_sref = (gmax > 0.f ? gmax : 1.f) * (1.00001f / 127.f);
+    std::vector<float> inv(cm.size()), wj(cm.size());
+    for (size_t j = 0; j < cm.size(); ++j) {
+      float m;
+      memcpy(&m, &cm[j], 4);
+      const float ratio = m > 0.f ? std::min(m / gmax, 1.f) : 1.f;
+      const float f = std::max(std::pow(ratio, 0.75f), 1.f / 1024.f);      // m / (s_ref f) = 127 ratio^(1/4) / 1.00001 <= 127
+      inv[j] = 1.000001f / (ix->g8_sref * f);
+      wj[j] = f * 1.000001f;
+    }
+    if (hipMemcpy(ix->g8_inv_cs, inv.data(), inv.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ix->g8_w, wj.data(), wj.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return fail(set_error(DHR_ERR_HIP, "hipMemcpy failed"));
+    ix->g8_max_shift = 0;
+    while (ix->g8_max_shift < 7 && 16129.0 * (double)(ix->ts * 32) * (double)(2 << ix->g8_max_shift) <= 1073741824.0) ++ix->g8_max_shift;
   }
   // bucket maps from the value mass per (slice, index value)
   if (has_idx && ix->n_buckets > 1 && idx_esize(d->index_dtype) == 1) {
@@ -614,6 +668,11 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.q_inexact, 16, tot));
   HIP_TRY(re_malloc(w.margin, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.i8_mul, (size_t)q_pad * 4, tot));
+  if (ix->gated_i8) {
+    HIP_TRY(re_malloc(w.g8_q8, (size_t)q_pad * ix->d_dlr, tot));
+    HIP_TRY(re_malloc(w.g8_shift, (size_t)q_pad * 4, tot));
+    HIP_TRY(re_malloc(w.g8_unit, (size_t)q_pad * 4, tot));
+  }
   HIP_TRY(re_malloc(w.tau, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.thr, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.cnt, (size_t)q_pad * 4, tot));
@@ -685,13 +744,15 @@ static int prep_queries(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, 
       qi = w.qi_stage; ldi = ix->d_dlr;
     }
   }
-  w.ts_q = sparse_query_stages(ix->ts, ix->d_dlr > 0 && qb->index);
+  w.ts_q = sparse_query_stages(ix->ts, ix->d_dlr > 0 && qb->index, ix->gated_i8);
+  G8Prep g8{};
+  if (ix->gated_i8) { g8.inv_cs = ix->g8_inv_cs; g8.w = ix->g8_w; g8.s_ref = ix->g8_sref; g8.max_shift = ix->g8_max_shift; g8.q8 = w.g8_q8; g8.shift = w.g8_shift; g8.unit = w.g8_unit; }
   HIP_TRY(hipMemsetAsync(w.q_inexact, 0, 4, s));
   HIP_TRY(launch_query_prep(v, qb->value_dtype == DHR_VAL_F32, ldv, (ix->d_dlr > 0 && qb->index) ? qi : nullptr, qb->index_dtype, ldi,
                             qb->n_queries, w.q_pad, ix->d_dlr, ix->d_cls, ix->k_rm, ix->n_buckets, ix->kt, ix->bucket_map,
                             ix->abs_mode, ix->dmax, w.q_tiles, w.q32,
                             w.q_idx, w.margin, w.tau, w.thr, ix->ts, ix->td, w.q_pack, w.q16, w.q_idx8, w.q_inexact, ix->idx_dtype,
-                            ix->dense_i8 ? ix->i8_scale : 0.f, ix->i8_ec, ix->i8_nc, w.i8_mul, ix->i8_col_scale, s));
+                            ix->dense_i8 ? ix->i8_scale : 0.f, ix->i8_ec, ix->i8_nc, w.i8_mul, ix->i8_col_scale, g8, s));
   return DHR_OK;
 }
 
@@ -725,7 +786,7 @@ static RescoreArgs base_rescore_args(const dhr_index* ix, const Workspace& w, in
 static int gemm_phase(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi, int map_mode, int period, int64_t head,
                       Timer& tm, dhr_search_stats& st, hipStream_t s, uint32_t* maxc, unsigned long long* sumc) {
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = ix->dense_i8 ? w.i8_mul : nullptr;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr;
   g.seq_lo = lo; g.seq_hi = hi; g.map_mode = map_mode; g.period = period; g.head = head; g.n_tiles = ix->n_tiles;
   g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt;
   g.cap = (uint32_t)w.cap; g.n_queries = Q;
@@ -759,6 +820,7 @@ static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectA
     f.cand = cand; f.cnt = cnt; f.cap = (uint32_t)w.cap; f.heavy_key = ix->heavy_key; f.heavy_val = ix->heavy_val;
     f.q_pack = w.q_pack; f.d_dlr = ix->d_dlr; f.thr = thr; f.out = w.cand_r; f.out_cnt = w.cnt_r; f.out_cap = (uint32_t)w.cap_r;
     f.n_queries = Q; f.max_count = maxr;
+    if (ix->gated_i8) { f.g8_q8 = w.g8_q8; f.g8_inv_cs = ix->g8_inv_cs; f.g8_unit = w.g8_unit; f.abs_mode = ix->abs_mode ? 1 : 0; }
     // flat launch: one workgroup per REAL block of 256 candidates (bound_sum / 256 + Q is an upper bound of their number)
     HIP_TRY(launch_block_offsets(cnt, (uint32_t)w.cap, Q, 256, w.blk_off, s));
     f.blk_off = w.blk_off; f.flat_blocks = (uint32_t)std::min<int64_t>(bound_sum / 256 + Q, (int64_t)0x7fffffff);
@@ -1018,7 +1080,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       const int64_t lo = bound[i], hi = bound[i + 1];
       if (i >= 2) HIP_TRY(hipStreamWaitEvent(sg, ev_done[i - 2], 0));      // list set is free again
       GemmArgs g{};
-      g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = ix->dense_i8 ? w.i8_mul : nullptr;
+      g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr;
       g.seq_lo = lo; g.seq_hi = hi; g.map_mode = extrapolate ? 3 : 2; g.period = S; g.head = head; g.n_tiles = ix->n_tiles; g.perm_mul = perm_mul; g.perm_n = n_main;
       g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr_hat; g.cand = cand; g.cnt = cnt;
       g.cap = (uint32_t)w.cap; g.n_queries = Q;
@@ -1567,7 +1629,7 @@ extern "C" int dhr_debug_bound_scores(dhr_index* ix, const dhr_query_batch* qb, 
   if ((rc = ensure_ws(ix, w, qb->n_queries, 1, 0)) != DHR_OK) return rc;
   if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = ix->dense_i8 ? w.i8_mul : nullptr; g.seq_lo = row_lo / TILE_ROWS;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr; g.seq_lo = row_lo / TILE_ROWS;
   g.seq_hi = (row_hi + TILE_ROWS - 1) / TILE_ROWS; g.map_mode = 0; g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
   g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
   g.dump = out_dev; g.dump_ld = row_hi - row_lo; g.dump_row0 = row_lo;
@@ -1599,7 +1661,7 @@ extern "C" int dhr_debug_gemm_time(dhr_index* ix, const dhr_query_batch* qb, int
   }
   HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = ix->dense_i8 ? w.i8_mul : nullptr; g.seq_lo = 0; g.seq_hi = ix->n_tiles; g.map_mode = 0;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr; g.seq_lo = 0; g.seq_hi = ix->n_tiles; g.map_mode = 0;
   g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
   g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
   HIP_TRY(launch_gemm_filter(g, s));                      // warm-up

@@ -30,6 +30,12 @@ constexpr int SP_STAGE_A = SP_A_BYTES + SP_IDX_BYTES;   // corpus bytes per spar
 constexpr int SP_STAGE_B = 16384;      // query bytes per sparse stage: 256 rows x 32 slice values, bucket in the sign bit (expanded to the two bucket columns in registers)
 constexpr int SP_DENSE = 16384;        // 2:4 layout, ungated columns: 32-column stages, 256 rows x 64 bytes, for corpus and queries
 constexpr int SP_SLOT = SP_STAGE_A + SP_STAGE_B;   // LDS ring slot (34 KiB): corpus part at +0, query part at +SP_STAGE_A
+// gated_i8 indexes (gemm_g8.hip): the gated half as int8 on v_smfmac_i32_32x32x64_i8.  A stage is still 32 slices:
+//   corpus: [8 blocks of 32 rows][lane half h][32 rows][16 stored bytes = slices 16h .. 16h+15] + [8 blocks][h][32 rows] u32 position
+//           words (2 bits per stored value: 2 * (slice & 1) + bucket) = 8 + 2 KiB;
+//   query : [256 queries][64 bytes = 32 slices x (bucket-0 column, bucket-1 column)], 16-byte chunks swizzled like every other image.
+constexpr int S8_A_BYTES = 8192;
+constexpr int S8_STAGE_A = S8_A_BYTES + 2048;
 constexpr int HEAVY = 64;               // per-row list of the largest gated values used by the refine step
 constexpr int DOC_GROUP = 4;                               // doc tiles that share one XCD sweep
 
@@ -89,11 +95,21 @@ struct GemmArgs {
   int64_t dump_row0;
   int n_queries;
   int variant;                // 2:4 layout kernel (3 / 4 / 5), 0 = the library default (g_gemm_variant)
+  const int32_t* g8_shift;    // [Q_pad] or null.  Non-null: gated_i8 index (gemm_g8.hip) -- the ts gated stages are int8 2:4 images and run FIRST into int32
+                              // accumulators, which are then shifted left by this per-query amount (gated unit = 2^shift x ungated unit) before the td
+                              // int8 stages of the ungated columns accumulate on top; i8_mul is the final unit (score = sum * i8_mul)
   const float* i8_mul;        // [Q_pad] or null.  Non-null: the td dense stages hold int8 columns (64 per stage); the kernel runs them
                               // FIRST on v_mfma_i32_32x32x32_i8 and turns the integer sums into fp32 with this per-query factor
                               // (corpus scale x query scale) before the gated stages accumulate on top
 };
 
+// gated_i8: x >= 0 in units of a step, rounded UP to [0, 127].  inv_step carries a relative 1e-6 of head room, so that the fp32
+// rounding of the product can never make  step * q(x) < x ; the SAME expression in the tile builder, query_prep and the refine step
+__host__ __device__ inline int quant_up_i8(float x, float inv_step) {
+  float r = ceilf(x * inv_step);
+  r = r < 0.f ? 0.f : (r > 127.f ? 127.f : r);
+  return (int)r;
+}
 // int8 image of the ungated columns (dense_i8 indexes): q(v) = clamp(rint(v * inv_scale), -127, 127), the SAME expression in the
 // corpus tile kernel, the row-error kernel and query_prep
 __host__ __device__ inline int quant_i8(float v, float inv_scale) {
@@ -152,22 +168,34 @@ hipError_t launch_scan_rows(const __half* src, int64_t ld, int64_t n_rows, int d
 // dense_i8: per-row quantisation error of the ungated columns -> out_bits[0] = max_r ||d - scale*q(d)||^2, [1] = max_r ||scale*q(d)||^2
 hipError_t launch_i8_row_err(const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls, float scale, const float* col_scale,
                              uint32_t* out_bits, hipStream_t s);
-hipError_t launch_col_absmax(const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls, uint32_t* colmax_bits, hipStream_t s);
+hipError_t launch_col_absmax(const __half* vals_rm, int k_rm, int64_t n_rows, int col0, int n_cols, uint32_t* colmax_bits, hipStream_t s);   // columns [col0, col0 + n_cols)
 hipError_t launch_tile_rows(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
                             int d_dlr, int d_cls, int n_buckets, int kt, const void* idx, int idx_dtype,
                             const uint8_t* map, bool abs_dlr, __half* tiles, hipStream_t s);
 hipError_t launch_tile_rows_sparse(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
                                    int d_dlr, int d_cls, int ts, int td, const void* idx, int idx_dtype, const uint8_t* map,
-                                   bool abs_dlr, char* tiles, float i8_inv_scale /* 0: fp16 dense stages */, const float* col_scale, hipStream_t s);
+                                   bool abs_dlr, char* tiles, float i8_inv_scale /* 0: fp16 dense stages */, const float* col_scale,
+                                   const float* g8_inv_cs /* non-null: gated_i8 stages */, hipStream_t s);
 hipError_t launch_copy_rows(const __half* src, int64_t ld, int64_t n_rows, int k, int k_rm, __half* dst, hipStream_t s);
 hipError_t launch_idx_hist(const uint8_t* idx, const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, float* hist, hipStream_t s);
+// gated_i8 indexes: what query_prep needs to build the int8 image of the gated half (all null / 0 otherwise)
+struct G8Prep {
+  const float* inv_cs;   // [d_dlr] 1 / step of gated corpus column j (with 1e-6 of head room); non-null selects the gated_i8 path
+  const float* w;        // [d_dlr] query weight of column j: step_j / s_ref (rounded up)
+  float s_ref;           // reference step: one gated operand product counts step_query * s_ref score units
+  int max_shift;         // largest left shift of the gated sums that cannot overflow int32
+  uint8_t* q8;           // [Q_pad][d_dlr] out: the query's gated int8 operand values (refine step)
+  int32_t* shift;        // [Q_pad] out
+  float* unit;           // [Q_pad] out: score units of one gated product (= i8_mul * 2^shift)
+};
 hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const void* idx, int idx_dtype, int64_t ld_idx,
                              int n_queries, int q_pad, int d_dlr, int d_cls, int k_rm, int n_buckets, int kt,
                              const uint8_t* map, bool abs_dlr, float dmax, __half* q_tiles, float* q32, int16_t* q_idx,
                              float* margin, float* tau, float* thr, int ts, int td, uint32_t* q_pack, __half* q16, uint8_t* q_idx8,
                              uint32_t* q_inexact, int c_idx_dtype,
-                             float i8_scale /* 0: fp16 dense stages */, float i8_ec, float i8_nc, float* i8_mul, const float* col_scale, hipStream_t s);
-inline int sparse_query_stages(int ts, bool gated) { return ts > 0 ? (gated ? ts : 2 * ts) : 0; }
+                             float i8_scale /* 0: fp16 dense stages */, float i8_ec, float i8_nc, float* i8_mul, const float* col_scale,
+                             const G8Prep& g8, hipStream_t s);
+inline int sparse_query_stages(int ts, bool gated, bool g8 = false) { return ts > 0 ? ((gated || g8) ? ts : 2 * ts) : 0; }
 hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s);
 hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, int idx_dtype, int64_t n_rows, int d_dlr,
                               const uint8_t* map, int n_buckets, uint32_t* heavy_key, __half* heavy_val, hipStream_t s);
@@ -179,6 +207,12 @@ struct RefineArgs {
   uint2* out; uint32_t* out_cnt; uint32_t out_cap;           // survivors (row, refined bound), per-query count, list capacity
   int n_queries; uint32_t max_count;
   const uint32_t* blk_off; uint32_t flat_blocks;             // flat launch, as in RescoreArgs
+  // gated_i8 indexes: the bound counted listed entry (slice j, value d) as q8[j] * d8(d, j) * unit[q]; the refine step takes ALL of
+  // a row's listed same-bucket entries off the bound and puts the real-valued product back where the index values agree
+  const uint8_t* g8_q8;                                      // [Q_pad][d_dlr] or null
+  const float* g8_inv_cs;                                    // [d_dlr] 1 / step of gated column j (the tile builder's factor)
+  const float* g8_unit;                                      // [Q_pad] score units of one gated operand product
+  int abs_mode;
 };
 hipError_t launch_refine(const RefineArgs& a, hipStream_t s);
 hipError_t launch_rescore(const RescoreArgs& a, hipStream_t s);

@@ -1,0 +1,368 @@
+// Bound GEMM + filter of a gated_i8 index: BOTH halves of the bound are integer sums.
+//   gated half  : v_smfmac_i32_32x32x64_i8 -- the 2:4 instruction on int8 operands, 64 logical columns (= 32 slices x 2 buckets) per
+//                 issue; measured under the package power cap on DLR-shaped operands (tools/probe/smfmac8_probe.hip,
+//                 profiles/r03_smfmac8_probe.txt): 21.8 ns per instruction and SIMD against 27.9 ns for the fp16 form, which covers
+//                 only 16 slices -- the gated half of a tile costs 24 x 21.8 instead of 48 x 27.9 ns of matrix time per 32 x 32 block;
+//   ungated half: v_mfma_i32_32x32x32_i8 on the int8 image of the ungated columns, as in gemm_w4.hip.
+// One accumulator set of int32: the gated stages run first, the sums are shifted left by the query's `shift` (its gated unit is
+// 2^shift ungated units, query_prep_kernel), the ungated stages accumulate on top, and the filter compares integers.
+// Register layouts of the 2:4 int8 instruction (measured, the probe validates them on random operands):
+//   A: lane l = (row l & 31, half hA = l >> 5) holds 16 stored bytes E = 0..15; bytes 2g, 2g+1 are the two non-zeros of group g,
+//      position of byte E in its group of four logical columns at idx[2E+1 : 2E];
+//   B: group g of half hA multiplies bytes 16 hA + 4 (g & 3) .. + 3 of lane (column, half g >> 2).
+// With slices 16 hA + E in A's bytes and position = 2 (slice & 1) + bucket, lane (n, hB) of B holds the EXPANDED slices
+// (bucket-0 column, bucket-1 column) 8 hB .. 8 hB + 7 in its first 16 bytes and 16 + 8 hB .. in its second: chunks hB and 2 + hB of
+// the query's 64-byte stage row in natural order -- no register expansion at all.
+// Structure: the 8-wave form of gemm_w4.hip (every wave computes and issues its share of the LDS-DMA, stages handed over in
+// pairs, one workgroup barrier per pair); a gated stage is ONE block of 8 matrix instructions per wave (K = 64 logical columns).
+#include "gemm_common.h"
+#include <mutex>
+#include <type_traits>
+#include <climits>
+
+namespace dhr {
+
+typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef int intx8 __attribute__((ext_vector_type(8)));
+
+constexpr int G8_QOFF = 16384;                 // query part of a ring slot (the corpus part is 10 KiB gated / 16 KiB ungated)
+constexpr int G8_SLOT = 32768;
+constexpr int G8_RING_LDS = 4 * G8_SLOT + 64;
+constexpr int G8_NT = 512;
+
+__device__ __forceinline__ void g8_smfmac(floatx16& c, const intx4& a, const intx8& b, uint32_t idx) {
+  asm("v_smfmac_i32_32x32x64_i8 %0, %1, %2, %3" : "+v"(c) : "v"(a), "v"(b), "v"(idx));
+}
+__device__ __forceinline__ void g8_mfma(floatx16& c, const intx4& a, const intx4& b) {
+  asm("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+struct G8Frag {
+  intx4 a[4];                       // corpus fragments of the block's four 32-row blocks
+  uint32_t pw[4];                   // gated blocks: their position words
+  union { intx8 v; intx4 h[2]; } b[2];   // query fragments (ungated blocks use h[0])
+};
+
+// filter threshold of a query in accumulator units, rounded DOWN (a row is kept when sum >= thr)
+__device__ __forceinline__ int g8_thr_units(float thr, float mul) {
+  const float x = thr / mul;
+  if (!(x < 2.1e9f)) return INT_MAX;          // +inf (padded query), NaN, mul == 0
+  if (x < -2.1e9f) return INT_MIN;
+  return (int)floorf(x - fabsf(x) * 1e-6f) - 1;
+}
+__device__ __forceinline__ float g8_score(int sum, float mul) {      // accumulator units -> score units, rounded up
+  const float x = (float)sum * mul;
+  return x + fabsf(x) * 2.4e-7f;
+}
+
+__device__ __forceinline__ void g8_dump_tile(const GemmArgs& p, floatx16 (&acc)[4][2], int64_t dt, int qt, int wm, int wn, int lane,
+                                             const float (&mul_r)[2]) {
+  const int fhalf = lane >> 5;
+  const int64_t row_base = dt * TILE_ROWS + wm * 128;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
+    if (q < p.n_queries) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t row = row_base + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+          if (row < p.n_rows && row >= p.dump_row0 && row - p.dump_row0 < p.dump_ld)
+            p.dump[(int64_t)q * p.dump_ld + (row - p.dump_row0)] = g8_score(__float_as_int(acc[mi][ni][e]), mul_r[ni]);
+        }
+    }
+  }
+}
+
+// Filter epilogue: the scheme of gemm_epilogue_w (private hit stacks in the idle ring, one global atomic per thread and query) on integers.
+__device__ __forceinline__ void g8_epilogue(const GemmArgs& p, floatx16 (&acc)[4][2], int64_t dt, int qt, int wm, int wn, int tid, int lane,
+                                            char* smem, const int (&thr_r)[2], const float (&mul_r)[2]) {
+  __syncthreads();                       // every wave is done with the staging ring
+  const int fhalf = lane >> 5;
+  const int64_t row0 = dt * TILE_ROWS;
+  const int rows_valid = (int)(p.n_rows - row0 < TILE_ROWS ? p.n_rows - row0 : TILE_ROWS);
+  uint2* stack = (uint2*)smem + tid;                       // slot j at stack[j * G8_NT]
+  uint32_t j = 0, jn[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
+    const int t = thr_r[ni];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const floatx16& a = acc[mi][ni];
+      int gm[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        gm[g] = max(max(__float_as_int(a[4 * g]), __float_as_int(a[4 * g + 1])), max(__float_as_int(a[4 * g + 2]), __float_as_int(a[4 * g + 3])));
+      const int mx = max(max(gm[0], gm[1]), max(gm[2], gm[3]));
+      if (mx >= t) {
+        asm volatile("");
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (gm[g] >= t) {
+            asm volatile("");
+#pragma unroll
+            for (int e = 4 * g; e < 4 * g + 4; ++e) {
+              const int v = __float_as_int(a[e]);
+              if (v >= t) {
+                asm volatile("");
+                const int rl = wm * 128 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
+                if (rl < rows_valid) {
+                  const float vs = g8_score(v, mul_r[ni]);
+                  if (j < EPI_STACK) stack[j * G8_NT] = make_uint2((uint32_t)rl, __float_as_uint(vs));
+                  else {
+                    const uint32_t slot = atomicAdd(p.cnt + q, 1u);
+                    if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(row0 + rl), __float_as_uint(vs));
+                  }
+                  ++j;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    jn[ni] = j < EPI_STACK ? j : EPI_STACK;
+  }
+  if (j == 0) return;
+  uint32_t base[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const uint32_t lo = ni ? jn[ni - 1] : 0u, hi = jn[ni];
+    base[ni] = 0u;
+    if (hi > lo) base[ni] = atomicAdd(p.cnt + (qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31)), hi - lo);
+  }
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const uint32_t lo = ni ? jn[ni - 1] : 0u, hi = jn[ni];
+    const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
+    for (uint32_t i = lo; i < hi; ++i) {
+      const uint2 en = stack[i * G8_NT];
+      const uint32_t slot = base[ni] + (i - lo);
+      if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)row0 + en.x, en.y);
+    }
+  }
+}
+
+#ifndef G8_ABL
+#define G8_ABL 0      // timing ablations (wrong results): 4 = no DMA pieces in the loop, 8 = 4 + no fragment reads in the loop
+#endif
+#define G8_PAIR_SYNC() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+
+// DMA piece (of this wave's <= 8 per stage pair) issued behind matrix instruction g of the block in phase ph: 0 = the block behind
+// the pair barrier, 1 = the next pair's first block
+__host__ __device__ constexpr int g8_dma_piece(int ph, int g) { return (ph <= 1 && (g & 1)) ? ph * 4 + (g >> 1) : -1; }
+
+template <bool DUMP>
+__global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_filter_g8_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int64_t b = blockIdx.x;
+  const int xcd = (int)(b & 7);
+  const int64_t i = b >> 3;
+  const int per_group = DOC_GROUP * p.n_qtiles;
+  const int64_t g_local = i / per_group;
+  const int r = (int)(i - g_local * per_group);
+  const int qt = r / DOC_GROUP;
+  const int dl = r - qt * DOC_GROUP;
+  const int64_t seq = p.seq_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
+  if (seq >= p.seq_hi) return;
+  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head, p.perm_mul, p.perm_n);
+  if (dt >= p.n_tiles) return;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ts = p.ts, td = p.td;
+  const int nsp = ts >> 1, npairs = (ts + td) >> 1;      // the launcher selects this kernel only when ts and td are even
+  const char* a_src = (const char*)p.a_tiles + dt * ((int64_t)ts * S8_STAGE_A + (int64_t)td * SP_DENSE);
+  const char* b_src = (const char*)p.b_tiles + (int64_t)qt * ((int64_t)ts * SP_STAGE_B + (int64_t)td * SP_DENSE);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- LDS-DMA, fixed roles: wave w streams half (w & 1) of image ((w >> 1) & 1 ? query : corpus) of stage 2g + (w >> 2)
+  const bool dma_b = ((wave >> 1) & 1) != 0;
+  const int dma_s = wave >> 2;
+  const int dma_h = wave & 1;
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  const uint32_t smem_u = (uint32_t)(uintptr_t)LDS_PTR(smem);
+  const __amdgpu_buffer_rsrc_t role_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(dma_b ? b_src : a_src), (short)0, 0x7fffffff, 0x00020000);
+  int dma_soff = 0, dma_n = 0, nx_soff = 0, nx_n = 0;
+  uint32_t dma_lds = 0, nx_lds = 0;
+  auto dma_prepare = [&](int g) __attribute__((always_inline)) {
+    const int u = 2 * g + dma_s;
+    const bool sp = u < ts;
+    const int half_bytes = dma_h * ((!dma_b && sp) ? S8_STAGE_A / 2 : 8192);
+    if (dma_b) nx_soff = (sp ? u * SP_STAGE_B : ts * SP_STAGE_B + (u - ts) * SP_DENSE) + half_bytes;
+    else nx_soff = (sp ? u * S8_STAGE_A : ts * S8_STAGE_A + (u - ts) * SP_DENSE) + half_bytes;
+    nx_lds = smem_u + (uint32_t)((u & 3) * G8_SLOT + (dma_b ? G8_QOFF : 0) + half_bytes);
+    nx_n = g < npairs ? ((!dma_b && sp) ? 5 : 8) : 0;
+    if (G8_ABL >= 4 && g >= 2) nx_n = 0;
+  };
+  auto dma_commit = [&]() __attribute__((always_inline)) { dma_soff = nx_soff; dma_lds = nx_lds; dma_n = nx_n; };
+  auto dma_piece = [&](int j) __attribute__((always_inline)) {
+    if (j < dma_n) {
+      __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(uintptr_t)(dma_lds + (uint32_t)(j >> 2) * 4096u);
+      const int so = dma_soff + (j >> 2) * 4096;
+      switch (j & 3) {      // the immediate must be a literal
+        case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(role_rsrc, l, 16, (int)lane_off, so, 0, 0); break;
+        case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(role_rsrc, l, 16, (int)lane_off, so, 1024, 0); break;
+        case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(role_rsrc, l, 16, (int)lane_off, so, 2048, 0); break;
+        default: __builtin_amdgcn_raw_ptr_buffer_load_lds(role_rsrc, l, 16, (int)lane_off, so, 3072, 0); break;
+      }
+    }
+  };
+  auto issue_pair = [&](int g) {
+    dma_prepare(g);
+    dma_commit();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma_piece(j);
+  };
+
+  floatx16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;      // bit pattern 0 = int32 0
+  int thr_r[2], sh_r[2];
+  float mul_r[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
+    mul_r[ni] = p.i8_mul[q];
+    thr_r[ni] = g8_thr_units(p.thr[q], mul_r[ni]);
+    sh_r[ni] = p.g8_shift[q];
+    asm volatile("" : "+v"(mul_r[ni]), "+v"(thr_r[ni]), "+v"(sh_r[ni]));
+  }
+
+  // per-lane LDS offsets inside a ring slot
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+  const int swz4 = (frow >> 2) & 3;
+  const int c0 = (fhalf ^ swz4) << 4, c1 = ((2 + fhalf) ^ swz4) << 4;
+  const int a8_off = ((wm * 8 + fhalf) * 32 + frow) * 16;                     // gated corpus values, + mi * 1024
+  const int p8_off = S8_A_BYTES + ((wm * 8 + fhalf) * 32 + frow) * 4;         // position words, + mi * 256
+  const int ad_row = (wm * 128 + frow) * 64;                                  // ungated corpus rows, + mi * 2048
+  const int q_row = G8_QOFF + (wn * 64 + frow) * 64;                          // query rows (both kinds), + ni * 2048
+
+  // fragment read number g (0..11) of the gated stage in ring slot sl: 4 corpus value reads, 4 position words, 2 x 2 query chunks
+  auto read_s8 = [&](G8Frag& f, const char* sl, int g) __attribute__((always_inline)) {
+    if (g < 4) f.b[g >> 1].h[g & 1] = *(const intx4*)(sl + q_row + (g >> 1) * 2048 + ((g & 1) ? c1 : c0));
+    else if (g < 8) f.a[g - 4] = *(const intx4*)(sl + a8_off + (g - 4) * 1024);
+    else if (g < 12) f.pw[g - 8] = *(const uint32_t*)(sl + p8_off + (g - 8) * 256);
+  };
+  // fragment read number g (0..5) of ungated block t (stage t >> 1 of the ungated part, 32-column half t & 1)
+  auto read_dn = [&](G8Frag& f, const char* sl, int cc, int g) __attribute__((always_inline)) {
+    if (g < 2) f.b[g].h[0] = *(const intx4*)(sl + q_row + g * 2048 + cc);
+    else if (g < 6) f.a[g - 2] = *(const intx4*)(sl + ad_row + (g - 2) * 2048 + cc);
+  };
+  // gated block: computes stage `fc` came from; reads the fragments of gated stage un into fn (12 reads spread over the 8 issue groups)
+  auto blk_s8 = [&](const G8Frag& fc, G8Frag& fn, int un, bool do_load, auto ph_c) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph_c)::value;
+    const char* sl = smem + (un & 3) * G8_SLOT;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int ni = g >> 2, mi = g & 3;
+      if (do_load && G8_ABL != 8) {
+        read_s8(fn, sl, g);
+        if (g < 4) read_s8(fn, sl, 8 + g);
+      }
+      g8_smfmac(acc[mi][ni], fc.a[mi], fc.b[ni].v, fc.pw[mi]);
+      if (g8_dma_piece(PH, g) >= 0) dma_piece(g8_dma_piece(PH, g));
+    }
+  };
+  auto blk_dn = [&](const G8Frag& fc, G8Frag& fn, int tn, bool do_load, auto ph_c) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph_c)::value;
+    const char* sl = smem + ((ts + (tn >> 1)) & 3) * G8_SLOT;
+    const int cc = (tn & 1) ? c1 : c0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int ni = g >> 2, mi = g & 3;
+      if (do_load && G8_ABL != 8) read_dn(fn, sl, cc, g);
+      g8_mfma(acc[mi][ni], fc.a[mi], fc.b[ni].h[0]);
+      if (g8_dma_piece(PH, g) >= 0) dma_piece(g8_dma_piece(PH, g));
+    }
+  };
+
+  issue_pair(0);
+  if (npairs > 1) {            // pair 0 landed; pair 1 (<= 8 pieces per wave) may stay in flight
+    issue_pair(1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  G8Frag f0, f1;
+#pragma unroll
+  for (int g = 0; g < 12; ++g) read_s8(f0, smem, g);
+  if (G8_ABL == 8) f1 = f0;
+  constexpr std::integral_constant<int, 0> PH0{};
+  constexpr std::integral_constant<int, 1> PH1{};
+  constexpr std::integral_constant<int, 2> PH2{};
+  dma_n = 0;             // nothing pending during pair 0's first block (pairs 0 and 1 went out above)
+#pragma unroll 1
+  for (int g = 0; g < nsp; ++g) {
+    blk_s8(f0, f1, 2 * g + 1, true, PH1);
+    dma_prepare(g + 2);
+    __builtin_amdgcn_sched_barrier(0);                    // the matrix asm is not volatile: without this the compiler sinks the block above below the wait
+    G8_PAIR_SYNC();
+    dma_commit();                                         // pair g+2 goes into the ring half this pair just left
+    blk_s8(f1, f0, 2 * g + 2, g + 1 < nsp, PH0);
+  }
+  if (td > 0) {
+    // gated sums -> ungated units: every accumulator shifted left by its query's shift, then the first ungated fragments
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");     // the last matrix results are in the accumulators
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = __uint_as_float(__float_as_uint(acc[mi][ni][e]) << sh_r[ni]);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const char* sl = smem + (ts & 3) * G8_SLOT;
+#pragma unroll
+      for (int g = 0; g < 6; ++g) read_dn(f0, sl, c0, g);
+    }
+    asm volatile("s_nop 4" ::: "memory");      // VALU write -> matrix read of the accumulators
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int g = nsp; g < npairs; ++g) {
+      const int t0 = 4 * (g - nsp);
+      blk_dn(f0, f1, t0 + 1, true, PH1);
+      blk_dn(f1, f0, t0 + 2, true, PH2);
+      blk_dn(f0, f1, t0 + 3, true, PH2);
+      dma_prepare(g + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      G8_PAIR_SYNC();
+      dma_commit();
+      blk_dn(f1, f0, t0 + 4, g + 1 < npairs, PH0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // the last matrix results are in the accumulators
+  if (DUMP) { g8_dump_tile(p, acc, dt, qt, wm, wn, lane, mul_r); return; }
+  g8_epilogue(p, acc, dt, qt, wm, wn, (int)threadIdx.x, lane, smem, thr_r, mul_r);
+}
+
+hipError_t launch_gemm_g8(const GemmArgs& a, dim3 grid, hipStream_t s) {
+  static std::mutex attr_mu;                       // per-device, under a lock (handles on different devices / host threads)
+  static bool attr_set_dev[64] = {};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  {
+    std::lock_guard<std::mutex> attr_lock(attr_mu);
+    bool& attr_set = attr_set_dev[dev_ & 63];
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_filter_g8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_RING_LDS);
+      if (e != hipSuccess) return e;
+      e = hipFuncSetAttribute((const void*)gemm_filter_g8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_RING_LDS);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+  }
+  if (a.dump) hipLaunchKernelGGL(gemm_filter_g8_kernel<true>, grid, dim3(G8_NT), G8_RING_LDS, s, a);
+  else hipLaunchKernelGGL(gemm_filter_g8_kernel<false>, grid, dim3(G8_NT), G8_RING_LDS, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace dhr

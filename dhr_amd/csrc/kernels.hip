@@ -128,7 +128,8 @@ hipError_t launch_i8_row_err(const __half* vals_rm, int k_rm, int64_t n_rows, in
                      d_dlr, d_cls, scale, col_scale, out_bits);
   return hipGetLastError();
 }
-// Largest finite |value| of every ungated column (thread = column, the threads of a wave read 128 contiguous bytes of a row).
+// Largest finite |value| of every column of a range (the ungated columns: steps of their int8 image; the gated columns of a gated_i8
+// index likewise) (thread = column, the threads of a wave read 128 contiguous bytes of a row).
 __global__ void __launch_bounds__(256) col_absmax_kernel(const __half* __restrict__ vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls,
                                                          int64_t rows_per_block, uint32_t* __restrict__ colmax_bits) {
   const int j = blockIdx.y * 256 + threadIdx.x;
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(256) col_absmax_kernel(const __half* __restric
   }
   if (m > 0.f) atomicMax(colmax_bits + j, __float_as_uint(m));
 }
-hipError_t launch_col_absmax(const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls, uint32_t* colmax_bits, hipStream_t s) {
+hipError_t launch_col_absmax(const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr /* first column */, int d_cls /* columns */, uint32_t* colmax_bits, hipStream_t s) {
   if (n_rows <= 0 || d_cls <= 0) return hipSuccess;
   const int64_t rpb = 2048;
   hipLaunchKernelGGL(col_absmax_kernel, dim3((unsigned)((n_rows + rpb - 1) / rpb), (unsigned)((d_cls + 255) / 256)), dim3(256), 0, s, vals_rm, k_rm,
@@ -253,11 +254,14 @@ __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __r
                                                                int64_t n_rows_src, int64_t n_rows_fill, int d_dlr,
                                                                int d_cls, int ts, int td, const void* __restrict__ idx,
                                                                int idx_dtype, const uint8_t* __restrict__ map, int abs_dlr,
-                                                               char* __restrict__ tiles, float i8_inv, const float* __restrict__ col_scale) {
+                                                               char* __restrict__ tiles, float i8_inv, const float* __restrict__ col_scale,
+                                                               const float* __restrict__ g8_inv_cs) {
   const int k = d_dlr + d_cls;
-  const int sp_chunks = ts * 4, dn_chunks = td * 4;
+  const bool g8 = g8_inv_cs != nullptr;
+  const int sp_chunks = g8 ? ts * 2 : ts * 4, dn_chunks = td * 4;
   const int cpr = sp_chunks + dn_chunks;
-  const int64_t tile_bytes = (int64_t)ts * SP_STAGE_A + (int64_t)td * SP_DENSE;
+  const int sp_stage = g8 ? S8_STAGE_A : SP_STAGE_A;
+  const int64_t tile_bytes = (int64_t)ts * sp_stage + (int64_t)td * SP_DENSE;
   const int64_t total = n_rows_fill * cpr;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
     const int64_t rl = g / cpr;
@@ -268,7 +272,29 @@ __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __r
     half8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
-    if (c < sp_chunks) {
+    if (c < sp_chunks && g8) {
+      // gated_i8: chunk = the 16 stored bytes of lane half h of stage st (slices 16h .. 16h+15 of the stage's 32), each value in units
+      // of its column's step and rounded UP, + the lane's position word (element E at bits [2E+1:2E]: 2 * (slice & 1) + bucket)
+      const int st = c >> 1, h = c & 1, j0 = st * 32 + h * 16;
+      union { half8 h8; int8_t b[16]; } o;
+      uint32_t bits = 0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int bucket = 0, q8 = 0;
+        if (rl < n_rows_src && j0 + e < d_dlr) {
+          float x = __half2float(src[rl * ld + j0 + e]);
+          if (abs_dlr) x = fabsf(x);
+          q8 = x > 0.f ? quant_up_i8(x, g8_inv_cs[j0 + e]) : 0;          // NaN / inf -> the row's bound is wrong, exactly as with the fp16 image
+          bucket = bucket_of(load_idx(idx, idx_dtype, row * d_dlr + j0 + e), j0 + e, map, 2);
+        }
+        o.b[e] = (int8_t)q8;
+        bits |= (uint32_t)(((e & 1) << 1) | bucket) << (2 * e);
+      }
+      char* stg = tile + (int64_t)st * S8_STAGE_A;
+      const int slot = ((r >> 5) * 2 + h) * 32 + (r & 31);
+      *(half8*)(stg + slot * 16) = o.h8;
+      *(uint32_t*)(stg + S8_A_BYTES + slot * 4) = bits;
+    } else if (c < sp_chunks) {
       const int st = c >> 2, cc = c & 3, j0 = c * 8;
       uint32_t bits = 0;
 #pragma unroll
@@ -296,7 +322,7 @@ __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __r
 #pragma unroll
       for (int e = 0; e < 16; ++e)
         o.b[e] = (rl < n_rows_src && j0 + e < k) ? (int8_t)quant_i8(__half2float(src[rl * ld + j0 + e]), 1.f / col_scale[j0 + e - d_dlr]) : (int8_t)0;
-      char* stg = tile + (int64_t)ts * SP_STAGE_A + (int64_t)st * SP_DENSE;
+      char* stg = tile + (int64_t)ts * sp_stage + (int64_t)st * SP_DENSE;
       *(half8*)(stg + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = o.h;
     } else {
       const int dc = c - sp_chunks, st = dc >> 2, cc = dc & 3, j0 = d_dlr + dc * 8;
@@ -304,19 +330,19 @@ __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __r
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (j0 + e < k) v[e] = (_Float16)__half2float(src[rl * ld + j0 + e]);
-      char* stg = tile + (int64_t)ts * SP_STAGE_A + (int64_t)st * SP_DENSE;
+      char* stg = tile + (int64_t)ts * sp_stage + (int64_t)st * SP_DENSE;
       *(half8*)(stg + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = v;
     }
   }
 }
 hipError_t launch_tile_rows_sparse(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
                                    int d_dlr, int d_cls, int ts, int td, const void* idx, int idx_dtype, const uint8_t* map,
-                                   bool abs_dlr, char* tiles, float i8_inv_scale, const float* col_scale, hipStream_t s) {
+                                   bool abs_dlr, char* tiles, float i8_inv_scale, const float* col_scale, const float* g8_inv_cs, hipStream_t s) {
   if (n_rows_fill <= 0) return hipSuccess;
-  const int64_t total = n_rows_fill * (ts * 4 + td * 4);
+  const int64_t total = n_rows_fill * ((g8_inv_cs ? ts * 2 : ts * 4) + td * 4);
   const int64_t blocks = (total + 255) / 256;
   hipLaunchKernelGGL(tile_rows_sparse_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, src, ld,
-                     row_lo, n_rows_src, n_rows_fill, d_dlr, d_cls, ts, td, idx, idx_dtype, map, abs_dlr ? 1 : 0, tiles, i8_inv_scale, col_scale);
+                     row_lo, n_rows_src, n_rows_fill, d_dlr, d_cls, ts, td, idx, idx_dtype, map, abs_dlr ? 1 : 0, tiles, i8_inv_scale, col_scale, g8_inv_cs);
   return hipGetLastError();
 }
 
@@ -389,7 +415,7 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
                                                          uint32_t* __restrict__ q_pack, __half* __restrict__ q16,
                                                          uint8_t* __restrict__ q_idx8, uint32_t* __restrict__ q_inexact,
                                                          int c_idx_dtype, float i8_scale, float i8_ec, float i8_nc,
-                                                         float* __restrict__ i8_mul, const float* __restrict__ col_scale) {
+                                                         float* __restrict__ i8_mul, const float* __restrict__ col_scale, G8Prep g8) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= q_pad) return;
@@ -430,6 +456,7 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
     q_idx[(int64_t)q * d_dlr + j] = (int16_t)iv;
     if (q_pack) {      // refine step: fp16 bound-operand value << 16 | bucket << 12 | idx low 12 bits
       union { _Float16 h; uint16_t u; } cv; cv.h = (_Float16)(abs_dlr ? fabsf(qval(j)) : fmaxf(qval(j), 0.f));   // the bound operand
+      if (g8.inv_cs && (float)cv.h > 0.f) cv.h = half_up(abs_dlr ? fabsf(qval(j)) : fmaxf(qval(j), 0.f));        // gated_i8: the refine step puts this value's product back, it must not fall below the real one
       const uint32_t bk = (n_buckets > 1 && idx) ? (uint32_t)bucket_of(iv, j, map, n_buckets) : 0u;
       q_pack[(int64_t)q * d_dlr + j] = ((uint32_t)cv.u << 16) | (bk << 12) | ((uint32_t)iv & 0xFFFu);
     }
@@ -439,6 +466,54 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
   // accumulators' 2^23 + 2^22 offset (gemm_w4.hip).  Then the norm of the ungated part and of what the int8 image loses: the margin.
   float i8_inv_q = 0.f, i8_sq = 0.f, i8_qn = 0.f, i8_qe = 0.f;
   bool i8_zero = false;
+  // gated_i8 index: both halves of the bound are integer sums.  Gated operand of the query: qop_j = max(q_j, 0) (|q_j| in abs mode),
+  // weighted by w_j = (step of corpus column j) / s_ref and rounded UP to [0, 127] in the query's own step; one gated product then
+  // counts  q8_j * d8_j  units of  u = step * s_ref >= qop_j * d_j.  The ungated int8 sums are in units of sc * sq, and the kernel
+  // shifts the gated sums left by `shift` bits before it adds them: u = 2^shift * u_f with u_f = sc * sq.  The coarser side gives:
+  // the gated unit is usually ~50x the ungated one, so shift = floor(log2(ratio)) and sq grows by less than 2x (or, the other way
+  // round, the gated step grows to sc * sq / s_ref).
+  float g8_inv_sqg = 0.f, g8_uf = 0.f;
+  int g8_sh = 0;
+  if (g8.inv_cs) {
+    const float inv_sc = i8_scale > 0.f ? 1.f / i8_scale : 0.f;
+    float am = 0.f, gm = 0.f;
+    for (int j = lane; j < k; j += 64) {
+      float v = qval(j);
+      if (j < d_dlr) v = (abs_dlr ? fabsf(v) : fmaxf(v, 0.f)) * g8.w[j]; else v = fabsf(v * (col_scale[j - d_dlr] * inv_sc));
+      if (v <= 3.0e38f) { if (j >= d_dlr) am = fmaxf(am, v); else gm = fmaxf(gm, v); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { am = fmaxf(am, __shfl_xor(am, o, 64)); gm = fmaxf(gm, __shfl_xor(gm, o, 64)); }
+    const float u_nat = fmaxf(gm * (1.00001f / 127.f) * g8.s_ref * 1.000001f, 1e-30f);
+    if (d_cls > 0 && am > 0.f && i8_scale > 0.f) {
+      const float v_nat = i8_scale * (am / 127.f);
+      if (u_nat >= v_nat) {
+        g8_sh = min(g8.max_shift, max(0, ilogbf(u_nat / v_nat)));
+        g8_uf = ldexpf(u_nat, -g8_sh);
+      } else g8_uf = v_nat * 1.000001f;
+      i8_sq = g8_uf * inv_sc;
+    } else {
+      g8_uf = u_nat;
+      i8_sq = i8_scale > 0.f ? g8_uf * inv_sc : 1.f;
+    }
+    g8_inv_sqg = g8.s_ref / ldexpf(g8_uf, g8_sh) * 1.000003f;
+    for (int j = lane; j < d_dlr; j += 64) {
+      const float v = (abs_dlr ? fabsf(qval(j)) : fmaxf(qval(j), 0.f)) * g8.w[j];
+      g8.q8[(int64_t)q * d_dlr + j] = (uint8_t)(v > 0.f ? quant_up_i8(v, g8_inv_sqg) : 0);
+    }
+    if (i8_scale > 0.f) {        // norm of the ungated part and of what its int8 image loses, at the scale chosen above
+      i8_inv_q = 1.f / i8_sq;
+      float sn = 0.f, se = 0.f;
+      for (int j = d_dlr + lane; j < k; j += 64) {
+        const float v = qval(j) * (col_scale[j - d_dlr] * inv_sc);
+        const float e = v - i8_sq * (float)quant_i8(v, i8_inv_q);
+        sn += v * v;
+        se += e * e;
+      }
+      i8_qn = sqrtf(wave_sum(sn));
+      i8_qe = sqrtf(wave_sum(se));
+    }
+  } else
   if (i8_scale > 0.f) {
     // ungated query values enter weighted, q'_j = q_j * col_scale[j] / scale: the corpus side divided column j by the same factor
     // (its own int8 step), <q, d> = <q', d'>
@@ -478,12 +553,30 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
     // registers.  Order inside a 16-slice block: [0-3, 8-11 | 4-7, 12-15], the two 16-byte chunks the two
     // lane halves of the smfmac B operand read.  An ungated batch (plain inner product over a gated index)
     // carries the sparse stages twice, all values in bucket 0, then all in bucket 1.  Then 32-column dense stages.
-    const int ts_q = idx ? ts : 2 * ts;
+    const int ts_q = (idx || g8.inv_cs) ? ts : 2 * ts;
     char* tile = (char*)q_tiles + (int64_t)(q >> 8) * ((int64_t)ts_q * SP_STAGE_B + (int64_t)td * SP_DENSE);
     const int r = q & 255;
     for (int c = lane; c < ts_q * 4 + td * 4; c += 64) {
       half8 h8;
-      if (c < ts_q * 4) {
+      if (c < ts_q * 4 && g8.inv_cs) {
+        // gated_i8: 64-byte row = the stage's 32 slices x (bucket-0 column, bucket-1 column), natural order; an ungated batch
+        // (plain inner product over a gated index) carries the value in both columns
+        const int st = c >> 2, cc = c & 3;
+        union { half8 h; uint8_t b[16]; } o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int j = st * 32 + cc * 8 + e;
+          int v8 = 0, bk = 0;
+          if (j < d_dlr) {
+            const float v = (abs_dlr ? fabsf(qval(j)) : fmaxf(qval(j), 0.f)) * g8.w[j];
+            v8 = v > 0.f ? quant_up_i8(v, g8_inv_sqg) : 0;
+            bk = idx ? bucket_of(qidx(j), j, map, 2) : 2;
+          }
+          o.b[2 * e] = (uint8_t)(bk != 1 ? v8 : 0);
+          o.b[2 * e + 1] = (uint8_t)(bk != 0 ? v8 : 0);
+        }
+        *(half8*)(tile + (int64_t)st * SP_STAGE_B + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = o.h;
+      } else if (c < ts_q * 4) {
         const int st = c >> 2, cc = c & 3;
         const int kb = cc >> 1, hh = cc & 1;
         const int cst = st < ts ? st : st - ts;
@@ -542,6 +635,16 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
   sr = wave_sum(sr);
   if (lane == 0) {
     float m = 1.05f * (float)(kt + 256) * 5.9604645e-8f * sqrtf(s16) * dmax + 1.0001f * sqrtf(sr) * dmax;
+    if (g8.inv_cs) {
+      // integer sums: nothing is rounded in the accumulation, the gated operands are rounded UP from the fp32 query, and what the
+      // int8 image of the ungated columns loses is measured against the fp32 query: the margin is the ungated Cauchy-Schwarz term
+      // (below) + the fp32 conversion of the unit
+      m = 1.001f * (i8_qn * i8_ec + i8_qe * i8_nc) + 1.2e-6f * (i8_qn + i8_qe) * i8_nc + 2.f * g8_uf;
+      if (!(m >= 0.f)) m = INFINITY;
+      i8_mul[q] = real ? g8_uf : 0.f;
+      g8.shift[q] = g8_sh;
+      g8.unit[q] = ldexpf(g8_uf, g8_sh);
+    } else
     if (i8_scale > 0.f) {
       // int8 image of the ungated columns: <q,d> - mul * <q8,d8>  =  <q, d - sc*d8>  +  <q - sq*q8, sc*d8>  +  (sc*sq - mul) <q8,d8>
       // with the corpus-wide maxima ec >= ||d - sc*d8||, nc >= ||sc*d8|| (Cauchy-Schwarz on the first two, fp32 rounding of the
@@ -565,10 +668,10 @@ hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const 
                              const uint8_t* map, bool abs_dlr, float dmax, __half* q_tiles, float* q32, int16_t* q_idx,
                              float* margin, float* tau, float* thr, int ts, int td, uint32_t* q_pack, __half* q16, uint8_t* q_idx8,
                              uint32_t* q_inexact, int c_idx_dtype, float i8_scale, float i8_ec, float i8_nc, float* i8_mul,
-                             const float* col_scale, hipStream_t s) {
+                             const float* col_scale, const G8Prep& g8, hipStream_t s) {
   hipLaunchKernelGGL(query_prep_kernel, dim3((q_pad + 3) / 4), dim3(256), 0, s, src, src_is_f32, ld, idx, idx_dtype,
                      ld_idx, n_queries, q_pad, d_dlr, d_cls, k_rm, n_buckets, kt, map, abs_dlr ? 1 : 0, dmax, q_tiles, q32,
-                     q_idx, margin, tau, thr, ts, td, q_pack, q16, q_idx8, q_inexact, c_idx_dtype, i8_scale, i8_ec, i8_nc, i8_mul, col_scale);
+                     q_idx, margin, tau, thr, ts, td, q_pack, q16, q_idx8, q_inexact, c_idx_dtype, i8_scale, i8_ec, i8_nc, i8_mul, col_scale, g8);
   return hipGetLastError();
 }
 
@@ -1070,6 +1173,7 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
   }
   const dim3 grid((unsigned)blocks);
   const int variant = a.variant ? a.variant : g_gemm_variant;        // per handle (dhr_index_set_param), else the library default
+  if (a.g8_shift) return (a.ts > 0 && !(a.ts & 1) && !(a.td & 1) && a.ts_q == a.ts) ? launch_gemm_g8(a, grid, s) : hipErrorInvalidValue;
   if (a.i8_mul)      // int8 dense stages exist in the every-wave-computes kernels only (dhr_index_create enables them only where those run)
     return (a.ts + a.td > 0 && !(a.ts_q & 1) && !(a.td & 1)) ? launch_gemm_wx(a, grid, variant == 4 ? 4 : 5, s) : hipErrorInvalidValue;
   if (a.ts + a.td > 0 && (variant == 4 || variant == 5) && g_gemm_ablate == 0 && !(a.ts_q & 1) && !(a.td & 1)) return launch_gemm_wx(a, grid, variant, s);   // pairs of stages
@@ -1198,8 +1302,11 @@ hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, 
 // upper bound of the exact score (only certain mismatches are removed; the query side keeps 12 index
 // bits, an alias there only makes the bound looser).  8 lanes per candidate, 8 heavy entries per lane.
 constexpr int REFINE_PER_WG = 256;       // candidates of ONE query per workgroup (its operand words are staged in LDS once)
+template <bool G8>
 __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
   extern __shared__ uint32_t qw[];             // [d_dlr] query words (up to 4096 slices: the slice id has 12 bits in a heavy-list key)
+  float* ics = (float*)(qw + p.d_dlr);         // G8: [d_dlr] 1 / step of the gated corpus columns, then [d_dlr] the query's int8 operand bytes
+  uint8_t* q8 = (uint8_t*)(ics + p.d_dlr);
   int q = blockIdx.y;
   uint32_t blk = blockIdx.x;
   if (p.blk_off && !flat_block(p.blk_off, p.n_queries, blockIdx.x, q, blk)) return;
@@ -1207,14 +1314,20 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
   if (count > p.cap) count = p.cap;
   const uint32_t base = blk * REFINE_PER_WG;
   if (base >= count) return;
-  for (int j = threadIdx.x; j < p.d_dlr; j += 256) qw[j] = p.q_pack[(int64_t)q * p.d_dlr + j];
+  for (int j = threadIdx.x; j < p.d_dlr; j += 256) {
+    qw[j] = p.q_pack[(int64_t)q * p.d_dlr + j];
+    if constexpr (G8) { ics[j] = p.g8_inv_cs[j]; q8[j] = p.g8_q8[(int64_t)q * p.d_dlr + j]; }
+  }
   __syncthreads();
   const int sub = threadIdx.x & 7;
   const float t = p.thr[q];
+  const double unit = G8 ? (double)p.g8_unit[q] : 0.0;
   // (A variant that issued the loads of all 8 candidates of a lane group up front ran 30 % SLOWER: 4x the gathers
   // in flight per CU only thrash the memory system; the dependent chain below at 8 waves per SIMD is the sweet spot.)
   for (uint32_t i = base + (threadIdx.x >> 3); i < base + REFINE_PER_WG; i += 32) {
     float corr = 0.f;
+    int taken = 0;              // G8: operand products (integer units) of the listed same-bucket entries
+    double back = 0.0;          // G8: real-valued products of those whose index values agree
     uint2 c = make_uint2(0u, 0u);
     if (i < count) {
       c = p.cand[(int64_t)q * p.cap + i];
@@ -1226,21 +1339,40 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
       for (int e = 0; e < 8; ++e) {
         const uint32_t key = keys[e];
         if (key != 0xFFFFFFFFu) {
-          const uint32_t w = qw[key >> 20];
+          const uint32_t j = key >> 20;
+          const uint32_t w = qw[j];
           const bool same_bucket = ((w >> 12) & 0xFu) == ((key >> 16) & 0xFu);
           const bool mismatch = (w & 0xFFFu) != (key & 0xFFFu);
-          if (same_bucket && mismatch) {
-            union { uint16_t u; _Float16 h; } qv; qv.u = (uint16_t)(w >> 16);
-            corr += fabsf((float)qv.h * (float)hv[e]);
-          }
+          union { uint16_t u; _Float16 h; } qv; qv.u = (uint16_t)(w >> 16);
+          if constexpr (G8) {
+            if (same_bucket) {
+              const float d = p.abs_mode ? fabsf((float)hv[e]) : (float)hv[e];
+              if (d > 0.f) {
+                taken += (int)q8[j] * quant_up_i8(d, ics[j]);
+                if (!mismatch) back += (double)(float)qv.h * (double)d;
+              }
+            }
+          } else if (same_bucket && mismatch) corr += fabsf((float)qv.h * (float)hv[e]);
         }
       }
     }
-    corr += __shfl_xor(corr, 1, 64);
-    corr += __shfl_xor(corr, 2, 64);
-    corr += __shfl_xor(corr, 4, 64);
+    if constexpr (G8) {
+      taken += __shfl_xor(taken, 1, 64); taken += __shfl_xor(taken, 2, 64); taken += __shfl_xor(taken, 4, 64);
+      back += __shfl_xor(back, 1, 64); back += __shfl_xor(back, 2, 64); back += __shfl_xor(back, 4, 64);
+    } else {
+      corr += __shfl_xor(corr, 1, 64);
+      corr += __shfl_xor(corr, 2, 64);
+      corr += __shfl_xor(corr, 4, 64);
+    }
     if (sub == 0 && i < count) {
-      const float u2 = __uint_as_float(c.y) - corr;
+      float u2;
+      if constexpr (G8) {
+        // U counted `taken` units for the listed same-bucket entries; the entries whose index values agree contribute their real
+        // product, the others nothing.  fp64: exact up to 2^-53 relative; the result is rounded UP to fp32.
+        const double v = (double)__uint_as_float(c.y) - (double)taken * unit + back;
+        u2 = (float)v;
+        if ((double)u2 < v) u2 = nextafterf(u2, INFINITY);
+      } else u2 = __uint_as_float(c.y) - corr;
       if (u2 >= t) {
         const uint32_t slot = atomicAdd(p.out_cnt + q, 1u);
         if (slot < p.out_cap) p.out[(int64_t)q * p.out_cap + slot] = make_uint2(c.x, __float_as_uint(u2));
@@ -1250,10 +1382,12 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
 }
 hipError_t launch_refine(const RefineArgs& a, hipStream_t s) {
   if (a.max_count == 0 || a.n_queries <= 0) return hipSuccess;
-  if (a.blk_off) {
-    if (a.flat_blocks) hipLaunchKernelGGL(refine_kernel, dim3(a.flat_blocks), dim3(256), (size_t)a.d_dlr * 4, s, a);
-  } else
-    hipLaunchKernelGGL(refine_kernel, dim3((a.max_count + REFINE_PER_WG - 1) / REFINE_PER_WG, (unsigned)a.n_queries), dim3(256), (size_t)a.d_dlr * 4, s, a);
+  const bool g8 = a.g8_q8 != nullptr;
+  const size_t lds = (size_t)a.d_dlr * (g8 ? 9 : 4);
+  const dim3 grid = a.blk_off ? dim3(a.flat_blocks) : dim3((a.max_count + REFINE_PER_WG - 1) / REFINE_PER_WG, (unsigned)a.n_queries);
+  if (a.blk_off && !a.flat_blocks) return hipSuccess;
+  if (g8) hipLaunchKernelGGL(refine_kernel<true>, grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(refine_kernel<false>, grid, dim3(256), lds, s, a);
   return hipGetLastError();
 }
 

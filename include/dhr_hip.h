@@ -104,10 +104,14 @@ typedef enum dhr_param {
 
 /* Process-wide options read by dhr_index_create (dhr_set_option). */
 typedef enum dhr_option {
-  DHR_OPT_DENSE_I8 = 1  /* int8 image of the UNGATED columns in the bound GEMM (v_mfma_i32_32x32x32_i8, twice the fp16 instruction's
+  DHR_OPT_DENSE_I8 = 1, /* int8 image of the UNGATED columns in the bound GEMM (v_mfma_i32_32x32x32_i8, twice the fp16 instruction's
                            columns per issue; the quantisation error is paid by the filter margin, results stay exact):
                            -1 (default) = gated indexes that also carry ungated columns, 0 = never, 1 = dense-only indexes too.
                            The environment variable DHR_DENSE_I8 overrides it. */
+  DHR_OPT_GATED_I8 = 2  /* int8 image of the GATED columns too (v_smfmac_i32_32x32x64_i8: the 2:4 instruction on int8 operands, 32 slices
+                           per issue; values rounded UP per column step, so the bound stays a bound and results stay exact):
+                           1 (default) = wherever the layout allows it (two buckets, d_dlr a multiple of 64, the ungated half an int8
+                           image or absent), 0 = keep the fp16 image.  The environment variable DHR_GATED_I8 overrides it. */
 } dhr_option;
 int dhr_set_option(int32_t option, int64_t value);
 /* Read-only facts about a built index (dhr_index_get_info). */
@@ -117,7 +121,8 @@ typedef enum dhr_info {
   DHR_INFO_I8_ROW_ERR = 3,    /* max over rows of || d - scale * q8(d) ||   (ungated part) */
   DHR_INFO_I8_ROW_NORM = 4,   /* max over rows of || scale * q8(d) || */
   DHR_INFO_ROW_NORM_MAX = 5,  /* max over rows of || row || */
-  DHR_INFO_TILE_BYTES = 6     /* bytes of the bound-GEMM operand images */
+  DHR_INFO_TILE_BYTES = 6,    /* bytes of the bound-GEMM operand images */
+  DHR_INFO_GATED_I8 = 7       /* 1 if the gated stages are int8 2:4 images */
 } dhr_info;
 int dhr_index_get_info(const dhr_index* index, int32_t what, double* out);
 
