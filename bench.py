@@ -33,6 +33,7 @@ N_MSMARCO = 8_841_823
 Q_DEV = 6_980
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md chip table
 MFMA_PEAK_I8_TOPS = 5000.0     # dense int8 MFMA peak (same table): the ungated columns of a dense_i8 index run on it
+SMFMAC_I8_PEAK_TOPS = 6650.0   # v_smfmac_i32_32x32x64_i8, logical (2 bucket columns per slice): 48 cycles per issue measured with zero operands (profiles/r03_smfmac8_probe.txt)
 GEN_CHUNK = 1 << 18            # the synthetic corpus is seeded per GLOBAL chunk of this many rows: a shard of any world size is a slice of the same corpus
 
 # BASELINE.json config 5: the 13 public BEIR corpora (documents, test queries), sizes from the public BEIR table
@@ -87,9 +88,14 @@ def cpu_baseline_legs(sample, k, n_full, q_one, q_all):
     from oracle import gip_oracle_torch as OT
     scv, sci, sqv, sqi = sample
     c32, q32 = scv.astype(np.float32), sqv.astype(np.float32)          # the reference's astype(float32) copies (:268-313), outside its timer too
-    cores = os.cpu_count() or 1
+    import torch
+    # threads the process may actually run on: a container can show 256 CPUs and be pinned to a few of them
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable
     s1, _ = OT.gip_loop(q32[:q_one], None if sqi is None else sqi[:q_one], c32, sci, k, 1)
     sa, _ = OT.gip_loop(q32[:q_all], None if sqi is None else sqi[:q_all], c32, sci, k, cores)
+    threads_seen = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(cores, 64)))
     scale = n_full / c32.shape[0]
     what = "torch-CPU restatement of gip_retrieval.py:115-126 (mask * corpus -> einsum -> topk, one query at a time, fp32)"
     return {"value": round(1.0 / (s1 * scale), 5), "unit": "queries/s", "cores": 1, "kind": "port",
@@ -98,7 +104,11 @@ def cpu_baseline_legs(sample, k, n_full, q_one, q_all):
             "all_cores": {"value": round(1.0 / (sa * scale), 5), "unit": "queries/s", "cores": cores,
                           "sample": "%d queries x %d rows, same loop with torch.set_num_threads(%d); %.3f s/query measured, x%.2f"
                                     % (q_all, c32.shape[0], cores, sa, scale)},
-            "host_cpus": cores}
+            "host_cpus": os.cpu_count() or 1, "affinity_cpus": usable, "torch_num_threads_in_all_cores_leg": threads_seen,
+            "time_budget": "the default run spends ~15 s (1 thread) + ~25 s (all cores) here; SURVEY.md section 8(d)'s 32 queries: --cpu-queries 32 --cpu-queries-1t 32 (~3.5 min)",
+            "note": "the reference's op sequence is three elementwise passes over the fp32 corpus per query (mask, product, einsum): one query moves ~15 GB through "
+                    "one socket's memory system, and torch parallelises each pass over the rows but the passes stay bandwidth-bound and serial -- the all-cores leg is "
+                    "barely faster than one thread, as measured"}
 
 
 def main():
@@ -213,6 +223,7 @@ def run_workload(args, spec, ctx):
     _lib.check(_lib.load().dhr_set_option(_lib.OPT_DENSE_I8, args.dense_i8), "dhr_set_option")
     index = GipIndex(cv, ci, device=local_rank, row_offset=lo, idx_buckets=args.idx_buckets)
     dense_i8 = bool(index.info(_lib.INFO_DENSE_I8))
+    gated_i8 = bool(index.info(_lib.INFO_GATED_I8))
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
     index.set_param(_lib.PARAM_PROFILE, 1)
@@ -290,15 +301,28 @@ def run_workload(args, spec, ctx):
                 os.environ["DHR_SHARDED_IMPL"] = "torch"
                 sharded_impl = "torch.distributed collectives (dhr_amd/dist.py); the library's RCCL path failed in the trial: %s" % (why or "on another rank")
                 print("[bench] rank %d: %s" % (rank, sharded_impl), file=sys.stderr)
+    kk = min(k, n)
+    host_s = torch.empty((nq, kk), dtype=torch.float32).pin_memory()
+    host_r = torch.empty((nq, kk), dtype=torch.int64).pin_memory()
+
+    def step_d2h():
+        """One step as the reference's timer sees it (gip_retrieval.py:107,161-163): the query loop incl. top-k AND the copy of the
+        result lists to the host (rank 0 holds the merged lists)."""
+        gs, gr = step()
+        if rank == 0:
+            host_s.copy_(gs[:, :kk], non_blocking=True)
+            host_r.copy_(gr[:, :kk], non_blocking=True)
+        return gs, gr
+
     for _ in range(args.warmup):
-        step()
+        step_d2h()
     gemm_ms = gemm_flops_alg = 0.0
     launches = 0
     stats_acc = {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        gs, gr = step_d2h()
         st = index.stats() if pq is None else dict.fromkeys(("gemm_ms", "phases", "gemm_flops_alg", "refine_ms", "rescore_ms", "select_ms", "prep_ms", "total_ms",
                                                               "candidates_bound", "candidates_exact", "overflow_retries", "gemm_rows", "sample_fallback_queries"), 0)
         if pq is not None:
@@ -321,21 +345,14 @@ def run_workload(args, spec, ctx):
     ms_per_step = elapsed * 1e3 / args.steps
     qps = nq * args.steps / elapsed
 
-    # the same K steps with the result copied to (pinned) host memory inside the timed region: what the reference's timer
-    # (gip_retrieval.py:107,161-163: query loop incl. top-k and the D2H of the lists) covers; `value` stays the device-resident rate
-    kk = min(k, n)
-    host_s = torch.empty((nq, kk), dtype=torch.float32).pin_memory()
-    host_r = torch.empty((nq, kk), dtype=torch.int64).pin_memory()
+    checksum = result_checksum(torch, gs[:, :kk], gr[:, :kk])
+    # side figure: the same K steps with the lists left in device memory (what a caller that consumes them on the GPU sees)
     barrier()
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        gs, gr = step()
-        if rank == 0:
-            host_s.copy_(gs[:, :kk], non_blocking=True)
-            host_r.copy_(gr[:, :kk], non_blocking=True)
+        step()
     barrier()
-    ms_incl_d2h = (time.perf_counter() - t1) * 1e3 / args.steps
-    checksum = result_checksum(torch, gs[:, :kk], gr[:, :kk])
+    ms_device_resident = (time.perf_counter() - t1) * 1e3 / args.steps
 
     # ---- N > 1: size-independent checks of the sharded result, outside the timed region (the oracle cannot hold the
     # corpus): sorted lists of distinct rows; every returned score is the exact score of its row on the rank that holds
@@ -370,25 +387,37 @@ def run_workload(args, spec, ctx):
     if rank == 0:
         ach_tf = gemm_flops_alg / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         sparse_layout = d_dlr > 0 and args.idx_buckets in (0, 2)
+        stage_layout = sparse_layout or (d_dlr == 0 and args.idx_buckets == 0)      # dense-only indexes run on the stage images too (ts = 0)
         variant = args.gemm_variant if args.gemm_variant >= 0 else 5
-        kernel = ("gemm_filter_wx_kernel<NI=%d> (bound GEMM on the 2:4 sparse matrix cores + fused threshold filter, %d waves)" % ((4, 4) if variant == 4 else (2, 8))
-                  if sparse_layout and variant in (4, 5) else
+        kernel = ("gemm_filter_g8_kernel (integer bound GEMM: gated half on v_smfmac_i32_32x32x64_i8, ungated half on v_mfma_i32_32x32x32_i8, fused threshold filter, 8 waves)"
+                  if gated_i8 else
+                  "gemm_filter_wx_kernel<NI=%d> (bound GEMM on the %s + fused threshold filter, %d waves)"
+                  % ((4 if variant == 4 else 2), "2:4 sparse matrix cores" if sparse_layout else "matrix cores, 32-column stage images", (4 if variant == 4 else 8))
+                  if stage_layout and variant in (4, 5) else
                   "gemm_filter_sparse_kernel (bound GEMM on the 2:4 sparse matrix cores + fused threshold filter)" if sparse_layout else
                   "gemm_filter_v3_kernel (bound GEMM + fused threshold filter)")
         # fabric-side (Infinity Cache + HBM) read bytes: PMC passes cannot run inside this process (a torch process hangs under
         # --pmc), so `traffic` is the per-corpus-row figure of the committed rocprofv3 FETCH_SIZE pass over the SAME kernel
         # (tools/prof.sh -> profiles/r02_gemm_pmc.txt; torch-free driver, 6 980 queries) x the average rows per launch
-        traffic_per_row = TRAFFIC_BYTES_PER_ROW.get((d_dlr, d_cls, nq, variant, int(dense_i8))) if sparse_layout and world == 1 else None
-        # peak of the instruction mix: gated columns on the fp16 (2:4 sparse: two bucket columns per slice at twice the rate) matrix
-        # instructions, ungated columns on fp16 or, dense_i8, on the int8 instruction (twice the columns per issue)
-        peak = (d_dlr + d_cls) / (d_dlr / MFMA_PEAK_TFLOPS + d_cls / (MFMA_PEAK_I8_TOPS if dense_i8 else MFMA_PEAK_TFLOPS))
+        traffic_per_row = TRAFFIC_BYTES_PER_ROW.get((d_dlr, d_cls, nq, variant, int(dense_i8), int(gated_i8))) if stage_layout and world == 1 else None
+        # `peak`: the contract's figure for this metric -- the dense fp16 / bf16 matrix peak the north-star prices the Q x D^T against
+        # (BASELINE.json).  Beside it the peak of the instruction mix the kernel really issues: gated columns on the fp16 2:4
+        # instruction (two bucket columns per slice at twice the rate = the fp16 peak per algorithmic column) or, gated_i8, on the
+        # int8 2:4 instruction (6 650 logical TOP/s measured with zero operands, profiles/r03_smfmac8_probe.txt = 3 325 per
+        # algorithmic column); ungated columns on fp16 or, dense_i8, on the dense int8 instruction
+        peak = MFMA_PEAK_TFLOPS
+        peak_mix = (d_dlr + d_cls) / (d_dlr / (SMFMAC_I8_PEAK_TOPS / 2 if gated_i8 else MFMA_PEAK_TFLOPS) + d_cls / (MFMA_PEAK_I8_TOPS if dense_i8 else MFMA_PEAK_TFLOPS))
         rows_per_launch = stats_acc.get("gemm_rows", 0) / max(launches, 1)
         alg_bytes_per_row = 2 * K + d_dlr * (2 if spec["kind"] == "bm25" else 1)
         out = {
             "metric": "queries/sec (exact top-%d, brute-force dense-hybrid GIP retrieval)" % k,
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": ("f16 + i8 (bound: gated columns fp16 x fp16 -> fp32, ungated columns int8 x int8 -> int32 on the matrix cores, the quantisation error paid by the filter margin; "
+            "timed_region": "K steps, each: all queries against the whole corpus, exact top-k, result lists copied to pinned host memory (the reference's timer, "
+                            "gip_retrieval.py:107,161-163); corpus index and queries resident in HBM",
+            "dtype": ("i8 (bound GEMM: gated AND ungated columns int8 x int8 -> int32 on the matrix cores, every gated rounding upward, the ungated quantisation error paid by the "
+                      "filter margin) + f64-accumulated f16 x f32 exact rescoring of the survivors -- the returned scores are the exact scores rounded once, identical to the fp16 bound's" if gated_i8 else
+                      "f16 + i8 (bound: gated columns fp16 x fp16 -> fp32, ungated columns int8 x int8 -> int32 on the matrix cores, the quantisation error paid by the filter margin; "
                       "fp64-accumulated exact rescoring of the survivors in fp16 x fp32 -- results identical to the fp16 bound)" if dense_i8 else
                       "f16 (fp16 x fp16 -> fp32 on the matrix cores for the bound; fp64-accumulated exact rescoring)"), "data": "synthetic",
             "config": {"workload": ("%s: %d rows x (%d DLR + %d dense) fp16%s, %d queries, top-%d, %s"
@@ -402,16 +431,16 @@ def run_workload(args, spec, ctx):
             "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": round(ach_tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(ach_tf / peak, 4),
-                         "peak_note": ("instruction mix: %d gated columns at the 2 500 TFLOP/s fp16 peak, %d ungated columns at the 5 000 TOP/s int8 peak" % (d_dlr, d_cls)
-                                       if dense_i8 else "dense fp16 matrix peak"),
-                         "frac_of_fp16_peak": round(ach_tf / MFMA_PEAK_TFLOPS, 4),
+                         "peak_note": "dense fp16 / bf16 matrix peak (MI355X_MICROARCH.md): the roofline BASELINE.json prices this metric against; algorithmic flops 2 x Q x rows x (d_dlr + d_cls)",
+                         "peak_instruction_mix": round(peak_mix, 1), "frac_of_instruction_mix_peak": round(ach_tf / peak_mix, 4),
                          "traffic": None if traffic_per_row is None else round(traffic_per_row * rows_per_launch, 0),
-                         "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE, gfx950-corrected; profiles/r02_gemm_pmc.txt)",
+                         "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE, gfx950-corrected; profiles/r03_gemm_pmc.txt, dense-only: r02_gemm_pmc.txt)",
                          "algorithmic_bytes_per_launch": round(alg_bytes_per_row * rows_per_launch, 0),
                          "launches": launches, "avg_launch_ms": round(gemm_ms / max(launches, 1), 3),
                          "alg_flops_per_step": gemm_flops_alg / args.steps},
             "whole_job_frac_of_gemm_roofline": round(qps * 2.0 * n * K / (peak * 1e12 * world), 4),
-            "ms_per_step_incl_d2h": round(ms_incl_d2h, 3),
+            "device_resident": {"ms_per_step": round(ms_device_resident, 3), "queries_per_s": round(nq / (ms_device_resident * 1e-3), 1),
+                                "note": "the same steps with the result lists left in device memory"},
             "result_checksum": checksum,
             "phase_ms_per_step": {key: round(v / args.steps, 3) for key, v in stats_acc.items() if key.endswith("_ms")}
                                  | {"gemm_ms": round(gemm_ms / args.steps, 3)},
@@ -462,8 +491,10 @@ def run_workload(args, spec, ctx):
 
 # fabric-side read bytes per corpus row of the bound GEMM, from the committed PMC pass (d_dlr, d_cls, queries, kernel variant)
 # (d_dlr, d_cls, queries, kernel variant, dense_i8) -> fabric-side read bytes per corpus row, profiles/r02_gemm_pmc.txt
-TRAFFIC_BYTES_PER_ROW = {(768, 768, 6980, 5, 0): 34.6e3,     # fp16 image of the ungated columns: 17.31 GB per 500 000-row launch
-                         (768, 768, 6980, 5, 1): 26.2e3}     # int8 image (default): 13.10 GB
+TRAFFIC_BYTES_PER_ROW = {(768, 768, 6980, 5, 0, 0): 34.6e3,     # fp16 image of the ungated columns: 17.31 GB per 500 000-row launch (r02)
+                         (768, 768, 6980, 5, 1, 0): 26.2e3,     # int8 image of the ungated columns, fp16 gated: 13.10 GB (r02)
+                         (768, 768, 6980, 5, 1, 1): 22.5e3,     # gated_i8 (default since round 3): 11.27 GB (profiles/r03_gemm_pmc.txt)
+                         (0, 768, 6980, 5, 0, 0): 15.6e3}       # dense-only index, fp16 stage images (r02)
 
 
 if __name__ == "__main__":

@@ -111,6 +111,7 @@ struct dhr_index {
   int g8_max_shift = 0;
   float* g8_inv_cs = nullptr;              // [d_dlr] 1 / step_j (with 1e-6 of head room)
   float* g8_w = nullptr;                   // [d_dlr] step_j / g8_sref (rounded up)
+  int32_t* g8_rsum = nullptr;              // [n_tiles * 256] 128 x sum of the row's gated int8 values (accumulator start of gemm_g8.hip)
   int64_t index_bytes = 0;
   // params
   int64_t cand_cap = 0, first_rows = 0;   // 0 = default (262144 with refine lists, else 65536)
@@ -158,7 +159,7 @@ extern "C" void dhr_index_destroy(dhr_index* ix) {
   free_ws(ix->ws_fb[1]);
   if (ix->s_aux) hipStreamDestroy(ix->s_aux);
   if (ix->s_gemm) hipStreamDestroy(ix->s_gemm);
-  hipFree(ix->i8_col_scale); hipFree(ix->g8_inv_cs); hipFree(ix->g8_w); hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map); hipFree(ix->heavy_key); hipFree(ix->heavy_val);
+  hipFree(ix->i8_col_scale); hipFree(ix->g8_inv_cs); hipFree(ix->g8_w); hipFree(ix->g8_rsum); hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map); hipFree(ix->heavy_key); hipFree(ix->heavy_val);
   delete ix;
 }
 
@@ -463,7 +464,12 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
         hipMemcpy(ix->g8_w, wj.data(), wj.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
       return fail(set_error(DHR_ERR_HIP, "hipMemcpy failed"));
     ix->g8_max_shift = 0;
-    while (ix->g8_max_shift < 7 && 16129.0 * (double)(ix->ts * 32) * (double)(2 << ix->g8_max_shift) <= 1073741824.0) ++ix->g8_max_shift;
+    while (ix->g8_max_shift < 7 && 255.0 * 127.0 * (double)(ix->ts * 32) * (double)(2 << ix->g8_max_shift) <= 1073741824.0) ++ix->g8_max_shift;
+    const size_t rb = (size_t)ix->n_tiles * TILE_ROWS * 4;
+    if (hipMalloc((void**)&ix->g8_rsum, rb) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMalloc failed"));
+    ix->index_bytes += (int64_t)rb;
+    if (launch_g8_row_sum(ix->vals_rm, ix->k_rm, ix->n_rows, ix->n_tiles * TILE_ROWS, ix->d_dlr, ix->abs_mode, ix->g8_inv_cs, ix->g8_rsum, s) != hipSuccess)
+      return fail(set_error(DHR_ERR_HIP, "g8_row_sum launch failed"));
   }
   // bucket maps from the value mass per (slice, index value)
   if (has_idx && ix->n_buckets > 1 && idx_esize(d->index_dtype) == 1) {
@@ -649,7 +655,9 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   // ... sized by the SHARD: a list cannot hold more rows than the shard has, and the chunk planner of the main pass cuts the pass
   // so that the fullest list fits, so a 1/8 shard gets 1/8 of the depth (floor: 32768 / 16384) instead of the full-corpus workspace
   // (measured at config 3: depth 262 144 / 131 072 / 65 536 = 195.2 / 196.5 / 196.2 ms per step, 100.2 / 85.2 / 77.7 GB)
-  const int64_t by_rows = std::max<int64_t>(ix->n_rows / 128, refine ? 32768 : 16384);
+  // (gated_i8 indexes: the int8 bound passes ~1.5x the rows of the fp16 one, and far more for the few queries with two or three
+  // dominant terms -- the fullest list decides the chunk count of the main pass, so these get 4x the depth: 32 -> 8 chunks at config 3)
+  const int64_t by_rows = std::max<int64_t>(ix->n_rows / (ix->gated_i8 ? 32 : 128), refine ? 32768 : 16384);
   while (base_cap > by_rows && base_cap > 4096) base_cap >>= 1;          // power-of-two floor of n_rows / 128 (65 536 at 8.84 M rows)
   while (base_cap > 4096 && (int64_t)q_pad * base_cap * 16 > ((int64_t)32 << 30)) base_cap >>= 1;
   if (ix->cand_cap > 0) base_cap = ix->cand_cap;
@@ -786,7 +794,7 @@ static RescoreArgs base_rescore_args(const dhr_index* ix, const Workspace& w, in
 static int gemm_phase(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi, int map_mode, int period, int64_t head,
                       Timer& tm, dhr_search_stats& st, hipStream_t s, uint32_t* maxc, unsigned long long* sumc) {
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr; g.g8_rsum = ix->g8_rsum;
   g.seq_lo = lo; g.seq_hi = hi; g.map_mode = map_mode; g.period = period; g.head = head; g.n_tiles = ix->n_tiles;
   g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt;
   g.cap = (uint32_t)w.cap; g.n_queries = Q;
@@ -843,6 +851,8 @@ static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectA
     cand = w.cand_r; cnt = w.cnt_r;
   }
   st.candidates_exact += exact;
+  if (getenv("DHR_DEBUG_PLAN"))
+    fprintf(stderr, "[dhr]   lists: bound %.0f per query (fullest %u) -> exact %.0f per query (fullest %u)\n", (double)bound_sum / Q, maxc, (double)exact / Q, maxr);
   if (maxr == 0) return DHR_OK;
   RescoreArgs r = base_rescore_args(ix, w, Q, gate);
   r.cand = cand; r.cnt = cnt; r.cap = list_cap; r.max_count = maxr;
@@ -868,6 +878,7 @@ static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectAr
     uint32_t maxc; unsigned long long sumc;
     int rc = gemm_phase(ix, w, Q, pos, hi, map_mode, period, head, tm, st, s, &maxc, &sumc);
     if (rc) return rc;
+    if (getenv("DHR_DEBUG_PLAN")) fprintf(stderr, "[dhr] stream phase: tiles [%lld, %lld) of %lld (period %d)\n", (long long)pos, (long long)hi, (long long)n_seq, period);
     const int64_t chunk_rows = (hi - pos) * TILE_ROWS;
     if (maxc > w.cap && chunk > DOC_GROUP) {               // overflow: redo this chunk in halves
       st.overflow_retries++;
@@ -1056,6 +1067,9 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
                                   (int64_t)std::ceil(1.5 * rate_r * (double)n_main * TILE_ROWS / (double)w.cap_r));
     const int M = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(ix->main_chunks, need), 64),
                                                               n_main / (16 * DOC_GROUP)));
+    if (getenv("DHR_DEBUG_PLAN"))
+      fprintf(stderr, "[dhr] main pass: rate %.3e (x n_main rows = %.0f of cap %lld), rate_r %.3e (%.0f of cap_r %lld), need %lld, chunks %d, n_main %lld tiles\n", rate,
+              rate * (double)n_main * TILE_ROWS, (long long)w.cap, rate_r, rate_r * (double)n_main * TILE_ROWS, (long long)w.cap_r, (long long)need, M, (long long)n_main);
     // chunk i covers [bound[i], bound[i+1]): sizes fall off linearly (weights M, M-1, ..., 1 on top of an equal
     // share) so that the refine/rescoring tail that cannot overlap a GEMM (the last chunk's) is short
     std::vector<int64_t> bound(M + 1, 0);
@@ -1080,7 +1094,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       const int64_t lo = bound[i], hi = bound[i + 1];
       if (i >= 2) HIP_TRY(hipStreamWaitEvent(sg, ev_done[i - 2], 0));      // list set is free again
       GemmArgs g{};
-      g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr;
+      g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr; g.g8_rsum = ix->g8_rsum;
       g.seq_lo = lo; g.seq_hi = hi; g.map_mode = extrapolate ? 3 : 2; g.period = S; g.head = head; g.n_tiles = ix->n_tiles; g.perm_mul = perm_mul; g.perm_n = n_main;
       g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr_hat; g.cand = cand; g.cnt = cnt;
       g.cap = (uint32_t)w.cap; g.n_queries = Q;
@@ -1108,6 +1122,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       st.candidates_bound += (int64_t)sumc;
       uint2* cand = (i & 1) ? w.cand2 : w.cand;
       uint32_t* cnt = (i & 1) ? w.cnt2 : w.cnt;
+      if (getenv("DHR_DEBUG_PLAN")) fprintf(stderr, "[dhr] main chunk %d: tiles [%lld, %lld)\n", i, (long long)bound[i], (long long)bound[i + 1]);
       HIP_TRY(launch_mark_overflow(cnt, (uint32_t)w.cap, Q, w.fail_flags, sb));
       if ((rc = rescore_select(ix, w, Q, gate, sel, cand, cnt, w.thr_hat, maxc, tm, st, sb, (int64_t)sumc, w.fail_flags)) != DHR_OK) return rc;
       if (ix->progressive_thr) HIP_TRY(launch_raise_thr(w.thr_hat, sel.thr, Q, sb));   // later chunks filter with the running exact thresholds
@@ -1629,11 +1644,25 @@ extern "C" int dhr_debug_bound_scores(dhr_index* ix, const dhr_query_batch* qb, 
   if ((rc = ensure_ws(ix, w, qb->n_queries, 1, 0)) != DHR_OK) return rc;
   if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr; g.seq_lo = row_lo / TILE_ROWS;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr; g.g8_rsum = ix->g8_rsum; g.seq_lo = row_lo / TILE_ROWS;
   g.seq_hi = (row_hi + TILE_ROWS - 1) / TILE_ROWS; g.map_mode = 0; g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
   g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
   g.dump = out_dev; g.dump_ld = row_hi - row_lo; g.dump_row0 = row_lo;
   HIP_TRY(launch_gemm_filter(g, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return DHR_OK;
+}
+
+extern "C" int dhr_debug_query_margins(dhr_index* ix, const dhr_query_batch* qb, float* out_host, void* stream) {
+  int rc = check_queries(ix, qb);
+  if (rc) return rc;
+  if (!out_host) return set_error(DHR_ERR_INVALID, "null output pointer");
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = (hipStream_t)stream;
+  Workspace& w = ix->ws;
+  if ((rc = ensure_ws(ix, w, qb->n_queries, 1, 0)) != DHR_OK) return rc;
+  if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(out_host, w.margin, (size_t)qb->n_queries * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return DHR_OK;
 }
@@ -1661,7 +1690,7 @@ extern "C" int dhr_debug_gemm_time(dhr_index* ix, const dhr_query_batch* qb, int
   }
   HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));
   GemmArgs g{};
-  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr; g.seq_lo = 0; g.seq_hi = ix->n_tiles; g.map_mode = 0;
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr; g.g8_rsum = ix->g8_rsum; g.seq_lo = 0; g.seq_hi = ix->n_tiles; g.map_mode = 0;
   g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
   g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
   HIP_TRY(launch_gemm_filter(g, s));                      // warm-up

@@ -98,6 +98,8 @@ struct GemmArgs {
   const int32_t* g8_shift;    // [Q_pad] or null.  Non-null: gated_i8 index (gemm_g8.hip) -- the ts gated stages are int8 2:4 images and run FIRST into int32
                               // accumulators, which are then shifted left by this per-query amount (gated unit = 2^shift x ungated unit) before the td
                               // int8 stages of the ungated columns accumulate on top; i8_mul is the final unit (score = sum * i8_mul)
+  const int32_t* g8_rsum;     // gated_i8: [n_tiles * 256] 128 x (sum of the row's gated int8 values): the accumulators START there, which pays for the
+                              // query operand being stored as level - 128 (8 bits of query resolution instead of 7)
   const float* i8_mul;        // [Q_pad] or null.  Non-null: the td dense stages hold int8 columns (64 per stage); the kernel runs them
                               // FIRST on v_mfma_i32_32x32x32_i8 and turns the integer sums into fp32 with this per-query factor
                               // (corpus scale x query scale) before the gated stages accumulate on top
@@ -108,6 +110,12 @@ struct GemmArgs {
 __host__ __device__ inline int quant_up_i8(float x, float inv_step) {
   float r = ceilf(x * inv_step);
   r = r < 0.f ? 0.f : (r > 127.f ? 127.f : r);
+  return (int)r;
+}
+// the query side of a gated_i8 index has 8 bits: levels 0 .. 255, stored as level - 128 (see gemm_g8.hip)
+__host__ __device__ inline int quant_up_u8(float x, float inv_step) {
+  float r = ceilf(x * inv_step);
+  r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
   return (int)r;
 }
 // int8 image of the ungated columns (dense_i8 indexes): q(v) = clamp(rint(v * inv_scale), -127, 127), the SAME expression in the
@@ -176,6 +184,8 @@ hipError_t launch_tile_rows_sparse(const __half* src, int64_t ld, int64_t row_lo
                                    int d_dlr, int d_cls, int ts, int td, const void* idx, int idx_dtype, const uint8_t* map,
                                    bool abs_dlr, char* tiles, float i8_inv_scale /* 0: fp16 dense stages */, const float* col_scale,
                                    const float* g8_inv_cs /* non-null: gated_i8 stages */, hipStream_t s);
+hipError_t launch_g8_row_sum(const __half* vals_rm, int k_rm, int64_t n_rows, int64_t n_rows_fill, int d_dlr, bool abs_dlr, const float* g8_inv_cs,
+                             int32_t* rsum128, hipStream_t s);
 hipError_t launch_copy_rows(const __half* src, int64_t ld, int64_t n_rows, int k, int k_rm, __half* dst, hipStream_t s);
 hipError_t launch_idx_hist(const uint8_t* idx, const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, float* hist, hipStream_t s);
 // gated_i8 indexes: what query_prep needs to build the int8 image of the gated half (all null / 0 otherwise)

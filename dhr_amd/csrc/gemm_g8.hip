@@ -4,7 +4,8 @@
 //                 profiles/r03_smfmac8_probe.txt): 21.8 ns per instruction and SIMD against 27.9 ns for the fp16 form, which covers
 //                 only 16 slices -- the gated half of a tile costs 24 x 21.8 instead of 48 x 27.9 ns of matrix time per 32 x 32 block;
 //   ungated half: v_mfma_i32_32x32x32_i8 on the int8 image of the ungated columns, as in gemm_w4.hip.
-// One accumulator set of int32: the gated stages run first, the sums are shifted left by the query's `shift` (its gated unit is
+// One accumulator set of int32 (started at 128 x the row's sum of gated values: the query's gated operand is stored as level - 128,
+// which gives it 8 bits): the gated stages run first, the sums are shifted left by the query's `shift` (its gated unit is
 // 2^shift ungated units, query_prep_kernel), the ungated stages accumulate on top, and the filter compares integers.
 // Register layouts of the 2:4 int8 instruction (measured, the probe validates them on random operands):
 //   A: lane l = (row l & 31, half hA = l >> 5) holds 16 stored bytes E = 0..15; bytes 2g, 2g+1 are the two non-zeros of group g,
@@ -75,19 +76,22 @@ __device__ __forceinline__ void g8_dump_tile(const GemmArgs& p, floatx16 (&acc)[
   }
 }
 
-// Filter epilogue: the scheme of gemm_epilogue_w (private hit stacks in the idle ring, one global atomic per thread and query) on integers.
-__device__ __forceinline__ void g8_epilogue(const GemmArgs& p, floatx16 (&acc)[4][2], int64_t dt, int qt, int wm, int wn, int tid, int lane,
-                                            char* smem, const int (&thr_r)[2], const float (&mul_r)[2]) {
-  __syncthreads();                       // every wave is done with the staging ring
+// Filter epilogue.  Scheme of gemm_epilogue_w (private hit stacks in the idle ring, one global atomic per thread and query), on
+// integers, with a SMALL hot path: the 128 accumulators of a lane can only be addressed by unrolled code, and in the first cut every
+// one of the 128 copies carried the score conversion and the stack-overflow path (a global atomic + store) -- ~40 KB of code that
+// every tile walked through.  Now a hit pushes (row, raw integer sum) and nothing else; conversion happens in the flush loop, and
+// a lane whose stack is full (EPI_STACK hits in one tile: the hottest queries only) just counts on -- its surplus is appended by a
+// second, cold scan (g8_epilogue_surplus) that only waves with such a lane run.
+template <bool SURPLUS>
+__device__ __forceinline__ uint32_t g8_scan(const GemmArgs& p, floatx16 (&acc)[4][2], int qt, int wm, int wn, int lane, int rows_valid, int64_t row0,
+                                            uint2* stack, const int (&thr_r)[2], const float (&mul_r)[2], uint32_t (&jn)[2]) {
   const int fhalf = lane >> 5;
-  const int64_t row0 = dt * TILE_ROWS;
-  const int rows_valid = (int)(p.n_rows - row0 < TILE_ROWS ? p.n_rows - row0 : TILE_ROWS);
-  uint2* stack = (uint2*)smem + tid;                       // slot j at stack[j * G8_NT]
-  uint32_t j = 0, jn[2];
+  const int rbase = wm * 128 + 4 * fhalf;
+  uint32_t j = 0;
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
-    const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
     const int t = thr_r[ni];
+    const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       const floatx16& a = acc[mi][ni];
@@ -105,50 +109,66 @@ __device__ __forceinline__ void g8_epilogue(const GemmArgs& p, floatx16 (&acc)[4
 #pragma unroll
             for (int e = 4 * g; e < 4 * g + 4; ++e) {
               const int v = __float_as_int(a[e]);
-              if (v >= t) {
+              const int rl = rbase + mi * 32 + (e & 3) + 8 * (e >> 2);
+              if (v >= t && rl < rows_valid) {
                 asm volatile("");
-                const int rl = wm * 128 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
-                if (rl < rows_valid) {
-                  const float vs = g8_score(v, mul_r[ni]);
-                  if (j < EPI_STACK) stack[j * G8_NT] = make_uint2((uint32_t)rl, __float_as_uint(vs));
-                  else {
+                if constexpr (SURPLUS) {
+                  if (j >= EPI_STACK) {
                     const uint32_t slot = atomicAdd(p.cnt + q, 1u);
-                    if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(row0 + rl), __float_as_uint(vs));
+                    if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(row0 + rl), __float_as_uint(g8_score(v, mul_r[ni])));
                   }
-                  ++j;
-                }
+                } else if (j < EPI_STACK) stack[j * G8_NT] = make_uint2((uint32_t)rl, (uint32_t)v);
+                ++j;
               }
             }
           }
         }
       }
     }
-    jn[ni] = j < EPI_STACK ? j : EPI_STACK;
+    jn[ni] = j;
   }
+  return j;
+}
+__device__ __forceinline__ void g8_epilogue_surplus(const GemmArgs& p, floatx16 (&acc)[4][2], int qt, int wm, int wn, int lane, int rows_valid, int64_t row0,
+                                                 const int (&thr_r)[2], const float (&mul_r)[2]) {
+  uint32_t jn[2];
+  (void)g8_scan<true>(p, acc, qt, wm, wn, lane, rows_valid, row0, nullptr, thr_r, mul_r, jn);
+}
+__device__ __forceinline__ void g8_epilogue(const GemmArgs& p, floatx16 (&acc)[4][2], int64_t dt, int qt, int wm, int wn, int tid, int lane,
+                                            char* smem, const int (&thr_r)[2], const float (&mul_r)[2]) {
+  __syncthreads();                       // every wave is done with the staging ring
+  const int64_t row0 = dt * TILE_ROWS;
+  const int rows_valid = (int)(p.n_rows - row0 < TILE_ROWS ? p.n_rows - row0 : TILE_ROWS);
+  uint2* stack = (uint2*)smem + tid;                       // slot j at stack[j * G8_NT]
+  uint32_t jn[2];
+  const uint32_t j = g8_scan<false>(p, acc, qt, wm, wn, lane, rows_valid, row0, stack, thr_r, mul_r, jn);
+  if (__builtin_amdgcn_ballot_w64(j > (uint32_t)EPI_STACK) != 0) g8_epilogue_surplus(p, acc, qt, wm, wn, lane, rows_valid, row0, thr_r, mul_r);
   if (j == 0) return;
-  uint32_t base[2];
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const uint32_t lo = ni ? jn[ni - 1] : 0u, hi = jn[ni];
-    base[ni] = 0u;
-    if (hi > lo) base[ni] = atomicAdd(p.cnt + (qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31)), hi - lo);
-  }
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const uint32_t lo = ni ? jn[ni - 1] : 0u, hi = jn[ni];
-    const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
-    for (uint32_t i = lo; i < hi; ++i) {
-      const uint2 en = stack[i * G8_NT];
-      const uint32_t slot = base[ni] + (i - lo);
-      if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)row0 + en.x, en.y);
-    }
+  // all of a lane's list reservations go out before the first one is waited for: one L2 round trip per tile
+  const uint32_t s0 = jn[0] < (uint32_t)EPI_STACK ? jn[0] : (uint32_t)EPI_STACK, s1 = jn[1] < (uint32_t)EPI_STACK ? jn[1] : (uint32_t)EPI_STACK;
+  const int q0 = qt * TILE_ROWS + wn * 64 + (lane & 31);
+  uint32_t base0 = 0u, base1 = 0u;
+  if (s0 > 0) base0 = atomicAdd(p.cnt + q0, s0);
+  if (s1 > s0) base1 = atomicAdd(p.cnt + q0 + 32, s1 - s0);
+  for (uint32_t i = 0; i < s1; ++i) {
+    const uint2 en = stack[i * G8_NT];
+    const bool second = i >= s0;
+    const int q = q0 + (second ? 32 : 0);
+    const uint32_t slot = second ? base1 + (i - s0) : base0 + i;
+    if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)row0 + en.x, __float_as_uint(g8_score((int)en.y, second ? mul_r[1] : mul_r[0])));
   }
 }
 
 #ifndef G8_ABL
-#define G8_ABL 0      // timing ablations (wrong results): 4 = no DMA pieces in the loop, 8 = 4 + no fragment reads in the loop
+#define G8_ABL 0      // timing ablations (wrong results): 4 = no DMA pieces in the loop, 8 = 4 + no fragment reads in the loop, 16 = no list flush, 32 = no epilogue
 #endif
+#if G8_ABL == 2       // timing only: the pair barrier does not wait for this wave's DMA
+#define G8_PAIR_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#elif G8_ABL == 3     // timing only: neither the DMA wait nor the barrier
+#define G8_PAIR_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#else
 #define G8_PAIR_SYNC() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#endif
 
 // DMA piece (of this wave's <= 8 per stage pair) issued behind matrix instruction g of the block in phase ph: 0 = the block behind
 // the pair barrier, 1 = the next pair's first block
@@ -195,7 +215,7 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
     else nx_soff = (sp ? u * S8_STAGE_A : ts * S8_STAGE_A + (u - ts) * SP_DENSE) + half_bytes;
     nx_lds = smem_u + (uint32_t)((u & 3) * G8_SLOT + (dma_b ? G8_QOFF : 0) + half_bytes);
     nx_n = g < npairs ? ((!dma_b && sp) ? 5 : 8) : 0;
-    if (G8_ABL >= 4 && g >= 2) nx_n = 0;
+    if ((G8_ABL == 4 || G8_ABL == 8) && g >= 2) nx_n = 0;
   };
   auto dma_commit = [&]() __attribute__((always_inline)) { dma_soff = nx_soff; dma_lds = nx_lds; dma_n = nx_n; };
   auto dma_piece = [&](int j) __attribute__((always_inline)) {
@@ -217,13 +237,21 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int j = 0; j < 8; ++j) dma_piece(j);
   };
 
+  // The query's gated operand has 8 bits: level L in [0, 255] is stored as L - 128 (a column that carries nothing as -128), so
+  //   sum_cols (stored + 128) * d8 = sum_cols stored * d8 + 128 * (sum of the row's gated int8 values),
+  // and the second term is a constant of the ROW: the accumulators start there (g8_rsum, built with the index).
   floatx16 acc[4][2];
+  {
+    const int32_t* rs = p.g8_rsum + dt * TILE_ROWS + wm * 128 + 4 * (lane >> 5);
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const intx4 v = *(const intx4*)(rs + mi * 32 + 8 * g4);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;      // bit pattern 0 = int32 0
+        for (int i4 = 0; i4 < 4; ++i4) acc[mi][0][4 * g4 + i4] = acc[mi][1][4 * g4 + i4] = __int_as_float(v[i4]);
+      }
+  }
   int thr_r[2], sh_r[2];
   float mul_r[2];
 #pragma unroll
@@ -285,9 +313,9 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
   };
 
   issue_pair(0);
-  if (npairs > 1) {            // pair 0 landed; pair 1 (<= 8 pieces per wave) may stay in flight
+  if (npairs > 1) {            // pair 0 must have landed; pair 1 (this wave's 5 or 8 pieces, loads return in order) may stay in flight
     issue_pair(1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (dma_n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   G8Frag f0, f1;
@@ -341,6 +369,9 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // the last matrix results are in the accumulators
   if (DUMP) { g8_dump_tile(p, acc, dt, qt, wm, wn, lane, mul_r); return; }
+#if G8_ABL == 32      // timing only: no filter epilogue at all
+  if (p.n_queries >= 0) { if (__float_as_int(acc[0][0][0]) == 0x7fffffff) p.cnt[0] = 1; return; }
+#endif
   g8_epilogue(p, acc, dt, qt, wm, wn, (int)threadIdx.x, lane, smem, thr_r, mul_r);
 }
 

@@ -346,6 +346,34 @@ hipError_t launch_tile_rows_sparse(const __half* src, int64_t ld, int64_t row_lo
   return hipGetLastError();
 }
 
+// gated_i8: 128 x (sum of the row's gated int8 values), one wave per row -- the bound GEMM's accumulators start there (gemm_g8.hip)
+__global__ void __launch_bounds__(256) g8_row_sum_kernel(const __half* __restrict__ vals_rm, int k_rm, int64_t n_rows, int64_t n_rows_fill,
+                                                         int d_dlr, int abs_dlr, const float* __restrict__ inv_cs, int32_t* __restrict__ rsum128) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t row = wave0; row < n_rows_fill; row += nwaves) {
+    int sum = 0;
+    if (row < n_rows)
+      for (int j = lane; j < d_dlr; j += 64) {
+        float x = __half2float(vals_rm[row * k_rm + j]);
+        if (abs_dlr) x = fabsf(x);
+        if (x > 0.f) sum += quant_up_i8(x, inv_cs[j]);
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) rsum128[row] = 128 * sum;
+  }
+}
+hipError_t launch_g8_row_sum(const __half* vals_rm, int k_rm, int64_t n_rows, int64_t n_rows_fill, int d_dlr, bool abs_dlr, const float* g8_inv_cs,
+                             int32_t* rsum128, hipStream_t s) {
+  if (n_rows_fill <= 0) return hipSuccess;
+  const int64_t blocks = (n_rows_fill + 3) / 4;
+  hipLaunchKernelGGL(g8_row_sum_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, vals_rm, k_rm, n_rows, n_rows_fill, d_dlr,
+                     abs_dlr ? 1 : 0, g8_inv_cs, rsum128);
+  return hipGetLastError();
+}
+
 // Row-major fp16 copy [n][k_rm] (zero padded) that the exact rescoring reads: one contiguous row per pair.
 __global__ void __launch_bounds__(256) copy_rows_kernel(const __half* __restrict__ src, int64_t ld, int64_t n_rows, int k,
                                                         int k_rm, __half* __restrict__ dst) {
@@ -467,7 +495,8 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
   float i8_inv_q = 0.f, i8_sq = 0.f, i8_qn = 0.f, i8_qe = 0.f;
   bool i8_zero = false;
   // gated_i8 index: both halves of the bound are integer sums.  Gated operand of the query: qop_j = max(q_j, 0) (|q_j| in abs mode),
-  // weighted by w_j = (step of corpus column j) / s_ref and rounded UP to [0, 127] in the query's own step; one gated product then
+  // weighted by w_j = (step of corpus column j) / s_ref and rounded UP to [0, 255] in the query's own step (8 bits: the operand is
+  // stored as level - 128 and the kernel's accumulators start at 128 x the row's sum of gated values); one gated product then
   // counts  q8_j * d8_j  units of  u = step * s_ref >= qop_j * d_j.  The ungated int8 sums are in units of sc * sq, and the kernel
   // shifts the gated sums left by `shift` bits before it adds them: u = 2^shift * u_f with u_f = sc * sq.  The coarser side gives:
   // the gated unit is usually ~50x the ungated one, so shift = floor(log2(ratio)) and sq grows by less than 2x (or, the other way
@@ -484,7 +513,7 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { am = fmaxf(am, __shfl_xor(am, o, 64)); gm = fmaxf(gm, __shfl_xor(gm, o, 64)); }
-    const float u_nat = fmaxf(gm * (1.00001f / 127.f) * g8.s_ref * 1.000001f, 1e-30f);
+    const float u_nat = fmaxf(gm * (1.00001f / 255.f) * g8.s_ref * 1.000001f, 1e-30f);
     if (d_cls > 0 && am > 0.f && i8_scale > 0.f) {
       const float v_nat = i8_scale * (am / 127.f);
       if (u_nat >= v_nat) {
@@ -499,7 +528,7 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
     g8_inv_sqg = g8.s_ref / ldexpf(g8_uf, g8_sh) * 1.000003f;
     for (int j = lane; j < d_dlr; j += 64) {
       const float v = (abs_dlr ? fabsf(qval(j)) : fmaxf(qval(j), 0.f)) * g8.w[j];
-      g8.q8[(int64_t)q * d_dlr + j] = (uint8_t)(v > 0.f ? quant_up_i8(v, g8_inv_sqg) : 0);
+      g8.q8[(int64_t)q * d_dlr + j] = (uint8_t)(v > 0.f ? quant_up_u8(v, g8_inv_sqg) : 0);
     }
     if (i8_scale > 0.f) {        // norm of the ungated part and of what its int8 image loses, at the scale chosen above
       i8_inv_q = 1.f / i8_sq;
@@ -569,11 +598,11 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
           int v8 = 0, bk = 0;
           if (j < d_dlr) {
             const float v = (abs_dlr ? fabsf(qval(j)) : fmaxf(qval(j), 0.f)) * g8.w[j];
-            v8 = v > 0.f ? quant_up_i8(v, g8_inv_sqg) : 0;
+            v8 = v > 0.f ? quant_up_u8(v, g8_inv_sqg) : 0;
             bk = idx ? bucket_of(qidx(j), j, map, 2) : 2;
           }
-          o.b[2 * e] = (uint8_t)(bk != 1 ? v8 : 0);
-          o.b[2 * e + 1] = (uint8_t)(bk != 0 ? v8 : 0);
+          o.b[2 * e] = (uint8_t)((bk != 1 ? v8 : 0) - 128);        // level - 128 as int8; a column that carries nothing holds -128
+          o.b[2 * e + 1] = (uint8_t)((bk != 0 ? v8 : 0) - 128);
         }
         *(half8*)(tile + (int64_t)st * SP_STAGE_B + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = o.h;
       } else if (c < ts_q * 4) {

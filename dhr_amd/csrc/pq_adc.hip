@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "dhr_internal.h"
+#include <mutex>
 
 using namespace dhr;
 
@@ -95,9 +96,10 @@ __global__ void __launch_bounds__(256) adc_scan_kernel(const uint8_t* __restrict
   const int64_t b_hi = b_lo + ADC_ROWS_PER_WG < row_hi ? b_lo + ADC_ROWS_PER_WG : row_hi;
   for (int64_t row = b_lo + threadIdx.x; row < b_hi; row += 256) {
     const uint8_t* c = codes + row * M;
+    const bool vec16 = (M & 15) == 0;
     float a0 = 0.f, a1 = 0.f;
     int m = 0;
-    for (; m + 16 <= M; m += 16) {                             // 16 codes per 16-byte load
+    for (; vec16 && m + 16 <= M; m += 16) {                    // 16 codes per 16-byte load (rows are 16-byte aligned only when M % 16 == 0)
       const uint4 w = *(const uint4*)(c + m);
       const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
@@ -186,8 +188,14 @@ int build_lut(dhr_pq* pq, const dhr_query_batch* qb, int q_lo, int nq, hipStream
 
 int scan(dhr_pq* pq, int nq, int64_t lo, int64_t hi, bool filter, float* dump, int64_t dump_ld, hipStream_t s) {
   const int lds = pq->M * pq->ksub * 8;
-  static int attr = 0;
-  if (lds > attr) { PQ_HIP(hipFuncSetAttribute((const void*)adc_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = lds; }
+  {      // per device and under a lock: handles on different devices may be used from different host threads (dhr_hip.h)
+    static std::mutex attr_mu;
+    static int attr_dev[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(attr_mu);
+    if (lds > attr_dev[dev & 63]) { PQ_HIP(hipFuncSetAttribute((const void*)adc_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_dev[dev & 63] = lds; }
+  }
   const unsigned blocks = (unsigned)((hi - lo + ADC_ROWS_PER_WG - 1) / ADC_ROWS_PER_WG);
   hipLaunchKernelGGL(adc_scan_kernel, dim3((unsigned)((nq + 1) / 2), blocks), dim3(256), lds, s, pq->codes, pq->M, pq->ksub, lo, hi, pq->lut, nq,
                      filter ? pq->thr : nullptr, pq->cand, pq->cnt, (uint32_t)ADC_CAP, dump, dump_ld);

@@ -35,8 +35,6 @@ struct dhr_comm {
   int world = 1, rank = 0, device = 0;
   void* arena = nullptr;          // grow-only device scratch
   size_t arena_bytes = 0;
-  int agreed_k = -1, agreed_r = -1;   // sample rank all ranks agreed on for agreed_k (one host read, cached)
-  const void* agreed_ix = nullptr;
 };
 
 
@@ -190,8 +188,9 @@ int agree_rank(const std::vector<ShardCtx>& sh, const Gather& g, int k, int* r_o
   for (int i = 1; i < g.n_local; ++i) if (dhr_search_sample_rank(sh[i].ix, k) != r) r = 0;
   if (g.comm && g.world > 1) {
     dhr_comm* c = g.comm;
-    // cached per (k, shard handle): the answer is a function of k, the sample period and the shard sizes
-    if (c->agreed_k == k && c->agreed_ix == (const void*)sh[0].ix) { *r_out = c->agreed_r; return DHR_OK; }
+    // Not cached: the answer depends on every rank's shard size and sample period, a communicator outlives the index handles
+    // (a new index can reuse a freed handle's address), and a rank that hit a cache the others missed would skip a collective they
+    // issue.  The agreement costs one 8-byte all-reduce and one host read per search.
     int32_t* d = (int32_t*)sh[0].arena->get(16);
     if (!d) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory");
     const int32_t h[2] = {r, -r};
@@ -201,7 +200,6 @@ int agree_rank(const std::vector<ShardCtx>& sh, const Gather& g, int k, int* r_o
     SH_HIP(hipMemcpyAsync(o, d + 2, 8, hipMemcpyDeviceToHost, sh[0].stream));
     SH_HIP(hipStreamSynchronize(sh[0].stream));
     r = (o[0] == r && -o[1] == r) ? r : 0;
-    c->agreed_k = k; c->agreed_r = r; c->agreed_ix = (const void*)sh[0].ix;
   }
   *r_out = r;
   return DHR_OK;

@@ -75,6 +75,10 @@ class GipIndex:
     def save(self, path: str, docids=None):
         """Write the built device images to `path`; `docids` (the third element of the reference's index record)
         travels as the file's blob so that one file replaces the pickle."""
+        if getattr(self, "_dlr_pad", 0):
+            # the file would record the zero-padded width; load() could not tell it from a real --emb_dim (ADVICE r02)
+            raise _lib.DhrError("an index whose --emb_dim was padded to a multiple of 8 cannot be saved as a device index file; "
+                                "keep the pickle for such widths")
         blob = pickle.dumps(list(docids), protocol=4) if docids is not None else b""
         _lib.check(self._lib.dhr_index_save(self._h, os.fsencode(path), blob if blob else None, len(blob)), "dhr_index_save")
 

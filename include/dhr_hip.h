@@ -282,6 +282,10 @@ int dhr_get_stats(const dhr_index* index, dhr_search_stats* out);
 int dhr_debug_bound_scores(dhr_index* index, const dhr_query_batch* queries, int64_t row_lo, int64_t row_hi,
                            float* out_dev, void* stream);
 
+/* Debug/test hook: the filter margins of a query batch (HOST buffer [n_queries] fp32): the bound GEMM guarantees
+ * U[q][row] >= exact score - margin[q] for every row, which is what lets the filter drop rows without losing a top-k row. */
+int dhr_debug_query_margins(dhr_index* index, const dhr_query_batch* queries, float* out_host, void* stream);
+
 /* Kernel-tuning hook: the bound GEMM alone over the whole shard with the filter closed; average
  * milliseconds per launch over `iters` launches and the flops one launch issues (padded sizes). */
 int dhr_debug_gemm_time(dhr_index* index, const dhr_query_batch* queries, int32_t iters, double* ms_out,

@@ -8,7 +8,8 @@ number of rows that reach the exact rescoring does.  What the tests pin:
            >= GIP(q, d) - margin_q                                           for every query and every corpus row,
 
 with  s_ref = max |gated value| / 127,  step_j = s_ref * max((colmax_j / max)^(3/4), 1/1024),  d8 = ceil(|d| / step_j) <= 127,
-w_j = step_j / s_ref,  q8_j = ceil(max(q_j, 0) w_j / sqg) <= 127,  u_q = sqg * s_ref  (every rounding goes UP, so the gated
+w_j = step_j / s_ref,  q8_j = ceil(max(q_j, 0) w_j / sqg) <= 255 (8 bits: stored as level - 128, the accumulators start at
+128 x the row's sum of d8),  u_q = sqg * s_ref  (every rounding goes UP, so the gated
 half needs no margin of its own), and the two halves meet in one integer sum: u_q = 2^shift * (sc * sq).
 
 The device computes these in fp32 with ~1e-6 of deliberate head room; this restatement is the nominal arithmetic in float64, so
@@ -37,7 +38,7 @@ def corpus_image(cg: np.ndarray, step: np.ndarray):
 def max_shift(d_dlr: int) -> int:
     s = 0
     ts32 = ((d_dlr + 31) // 32) * 32
-    while s < 7 and 16129.0 * ts32 * (2 << s) <= 2.0 ** 30:
+    while s < 7 and 255.0 * 127.0 * ts32 * (2 << s) <= 2.0 ** 30:
         s += 1
     return s
 
@@ -47,7 +48,7 @@ def query_units(qg: np.ndarray, qd, w: np.ndarray, s_ref: float, cs=None, sc: fl
     qop = np.abs(qg.astype(np.float64)) if abs_mode else np.maximum(qg.astype(np.float64), 0.0)
     qw = qop * w
     gm = float(qw.max()) if qw.size else 0.0
-    u_nat = max(gm * (1.00001 / 127.0) * s_ref, 1e-30)
+    u_nat = max(gm * (1.00001 / 255.0) * s_ref, 1e-30)
     shift = 0
     q8u = None
     sq = 1.0
@@ -67,7 +68,7 @@ def query_units(qg: np.ndarray, qd, w: np.ndarray, s_ref: float, cs=None, sc: fl
             q8u = np.zeros(qd.shape[0])
             sq = u_f / sc
     u = u_f * 2.0 ** shift
-    q8 = np.minimum(np.ceil(qw / (u / s_ref) * (1.0 + 1e-6)), 127.0)
+    q8 = np.minimum(np.ceil(qw / (u / s_ref) * (1.0 + 1e-6)), 255.0)
     return dict(q8=q8, u=u, shift=shift, u_f=u_f, q8u=q8u, sq=sq)
 
 

@@ -145,6 +145,78 @@ def test_g8_bound_layout(G, kind):
     assert np.quantile(diff, 0.99) <= 1e-4 * scale and diff.max() <= 0.02 * scale, (float(np.quantile(diff, 0.99)), float(diff.max()), float(scale))
 
 
+@pytest.mark.parametrize("mode", ["gated_i8", "gated_fp16"])
+@pytest.mark.parametrize("kind", ["bench", "adversarial"])
+def test_bound_never_below_exact_minus_margin(G, monkeypatch, mode, kind):
+    """The inequality the filter rests on, measured at the benchmark's width (768 gated + 768 ungated columns) over ALL pairs of
+    64 queries x 1 M rows of the bench corpus, and over adversarial inputs: U[q][row] >= exact_f64[q][row] - margin[q].  A bound
+    that fell short would silently drop a true top-k row; the minimum head room is printed.  Both images of the gated half: the
+    int8 one (integer sums, every rounding up, margin = the ungated Cauchy-Schwarz term) and the fp16 one (fp32 accumulation on
+    top of the 2^23 offset of the int8 stages)."""
+    import ctypes as C
+    import torch
+    import bench
+    from dhr_amd import _lib, synth
+    if mode == "gated_fp16":
+        monkeypatch.setenv("DHR_GATED_I8", "0")
+    dev = torch.device("cuda", 0)
+    nq, d = 64, 768
+    if kind == "bench":
+        n = 1_000_000
+        cv, ci = bench.gen_shard(torch, synth, dev, 1237, n, d, d, 30, 90, False)
+        qv, qi = bench.gen_shard(torch, synth, dev, 1237 + 999_983, nq, d, d, 4, 12, False)
+        qv = qv.float()
+    else:
+        n = 200_000
+        cv, ci = bench.gen_shard(torch, synth, dev, 99, n, d, d, 30, 90, True)
+        qv, qi = bench.gen_shard(torch, synth, dev, 98, nq, d, d, 4, 12, True)
+        g = torch.Generator(device=dev).manual_seed(5)
+        cv = cv.float(); qv = qv.float()
+        cv[:4000, :d] = 3.0                                       # max-norm rows
+        cv[:, d + 5] *= 50; cv[:, d + 70] *= 30; cv[:, 11] *= 20   # outlier columns, ungated and gated
+        cv[4000:4400, :d] = torch.where(torch.rand((400, d), generator=g, device=dev) < 0.02, torch.full((400, d), 900.0, device=dev), cv[4000:4400, :d])   # huge gated entries
+        qv[0] = 0; qv[0, 17] = 2.5                                # one-hot queries, gated and ungated
+        qv[1] = 0; qv[1, d + 9] = 1.5
+        qv[2] = 0                                                 # a zero query
+        qv[3, :d] *= 300                                          # huge gated query values
+        qv[4, d:] *= 300                                          # huge ungated query values
+        qv[5:20] *= 0.3                                           # fp32 values that are not fp16-representable
+        qv[20, :d] = qv[20, :d].abs() * -1                        # negative gated query values on a non-negative corpus
+        cv = cv.half()
+    ix = G.GipIndex(cv, ci)
+    assert ix.info(_lib.INFO_GATED_I8) == (1 if mode == "gated_i8" else 0)
+    qi16 = qi.to(torch.int16)
+    qb, keep = _lib.make_query_batch(qv, qi16)
+    margin = np.zeros(nq, np.float32)
+    _lib.check(ix._lib.dhr_debug_query_margins(ix._h, C.byref(qb), margin.ctypes.data, None), "margins")
+    mg = torch.from_numpy(margin).to(dev).double()
+    cg, cd = cv[:, :d], cv[:, d:].double()
+    worst = torch.full((nq,), float("inf"), dtype=torch.float64, device=dev)
+    slab = min(250_000, n)                   # n is a multiple of it: the dump's leading dimension is the slab width
+    out = torch.empty((nq, slab), dtype=torch.float32, device=dev)
+    ex_keep = None
+    for lo in range(0, n, slab):
+        hi = min(n, lo + slab)
+        _lib.check(ix._lib.dhr_debug_bound_scores(ix._h, C.byref(qb), lo, hi, out.data_ptr(), None), "debug_bound")
+        ex = torch.empty((nq, hi - lo), dtype=torch.float64, device=dev)
+        cgs, cis = cg[lo:hi].double(), ci[lo:hi].to(torch.int16)
+        dense = qv[:, d:].double() @ cd[lo:hi].T
+        for q in range(nq):
+            ex[q] = (cgs * (cis == qi16[q][None, :])) @ qv[q, :d].double() + dense[q]
+        worst = torch.minimum(worst, (out[:, :hi - lo].double() - ex + mg[:, None]).min(dim=1).values)
+        if lo == 0:
+            ex_keep = ex[:3, :5000].cpu().numpy()
+    ix.close()
+    # the torch float64 scores above are the oracle's (checked on a corner)
+    c32 = cv[:5000].float().cpu().numpy(); cin = ci[:5000].cpu().numpy()
+    for q in range(3):
+        np.testing.assert_allclose(ex_keep[q], O.gip_scores_f64(qv[q].cpu().numpy(), qi16[q].cpu().numpy(), c32, cin), rtol=1e-9, atol=1e-9)
+    w = worst.cpu().numpy()
+    print("\n[%s / %s] minimum head room  U - (exact - margin)  over %d x %d pairs: %.3e (margins %.3e .. %.3e)" %
+          (mode, kind, nq, n, w.min(), margin.min(), margin.max()))
+    assert np.all(w >= 0.0), (w.min(), int(w.argmin()))
+
+
 def _check_theta_mode(info, q, qi, c32, ci, rows, scores, ref_rows=None):
     """theta>0 modes against float64: one-stage = top-k of the stage-1 score; --rerank = the two-stage tie-band rule
     (stage-1 boundary at agip_topk, stage-2 boundary at topk).  Rows that differ from the reference's must lie in a band."""
@@ -948,6 +1020,77 @@ def test_full_size_properties(G, kind):
     del cv, ci
     torch.cuda.empty_cache()
     _search_check(G, cvs, cis, qs[:6], None if qis is None else qis[:6], 100)                     # (5)
+
+
+def test_config4_full_size_8_shards(G):
+    """BASELINE config 4 at FULL size on one GPU: the bench corpus (seed 1237, bench.gen_rows) as the reference's 8 row shards
+    (gip_retrieval.py:292-306: per = N // S, the last shard takes the remainder) through dhr_search_sharded_local -- the same
+    sharded_core the RCCL entry point runs, gathers as device copies -- must reproduce the unsharded search bit for bit (the
+    checksum bench.py prints for N = 1; merge semantics of merge.result.py:22-42 without the text round trip).  Also prints the
+    per-stage times of the slowest shard (the single-GPU emulation of the 8-GPU step that DESIGN.md section 5 quotes)."""
+    import sys, os, time
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    from dhr_amd import synth, _lib, dist as D
+    dev = torch.device("cuda", 0)
+    n, nq, k, ns = 8_841_823, 6980, 1000, 8
+    qv, qi = bench.gen_rows(torch, synth, dev, 1237 + 999_983, 0, nq, 768, 768, 4, 12, False)
+    # the unsharded search first (its index is dropped before the shards are built)
+    cv, ci = bench.gen_rows(torch, synth, dev, 1237, 0, n, 768, 768, 30, 90, False)
+    full = G.GipIndex(cv, ci)
+    del cv, ci
+    torch.cuda.empty_cache()
+    for _ in range(2):
+        fs, fr = full.search(qv, qi, k, out_device=True)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(3):
+        fs, fr = full.search(qv, qi, k, out_device=True)
+    torch.cuda.synchronize(); t_full = (time.perf_counter() - t) / 3
+    want = bench.result_checksum(torch, fs, fr)
+    full.close()
+    del full
+    torch.cuda.empty_cache()
+    shards = []
+    try:
+        for r in range(ns):
+            lo, hi = D.shard_bounds(n, ns, r)
+            scv, sci = bench.gen_rows(torch, synth, dev, 1237, lo, hi, 768, 768, 30, 90, False)
+            shards.append(G.GipIndex(scv, sci, row_offset=lo))
+            del scv, sci
+            torch.cuda.empty_cache()
+        assert [s.n_rows for s in shards] == [n // ns] * (ns - 1) + [n - (ns - 1) * (n // ns)]
+        ss, sr = D.search_sharded_local(shards, qv, qi, k)
+        got = bench.result_checksum(torch, ss, sr)
+        assert got == want, (got, want)
+        assert torch.equal(sr, fr) and torch.equal(ss, fs)
+        # stage times, slowest shard per stage: begin (phase 0 + sampled run) | common threshold | finish (main pass) | merge
+        rnk = shards[0].sample_rank(k)
+        best = None
+        for it in range(3):
+            tb, tf, samples, outs = [], [], [], []
+            for ix in shards:
+                torch.cuda.synchronize(); t = time.perf_counter()
+                samples.append(ix.search_begin(qv, qi, k)); torch.cuda.synchronize(); tb.append(time.perf_counter() - t)
+            torch.cuda.synchronize(); t = time.perf_counter()
+            tau = D.common_threshold(torch.stack(samples), rnk); torch.cuda.synchronize(); tt = time.perf_counter() - t
+            for ix in shards:
+                torch.cuda.synchronize(); t = time.perf_counter()
+                outs.append(ix.search_finish(tau)); torch.cuda.synchronize(); tf.append(time.perf_counter() - t)
+            cnts = torch.stack([o[2] for o in outs]); kk = min(k, (int(cnts.max()) + 63) // 64 * 64)
+            gs = torch.stack([o[0][:, :kk] for o in outs]); gr = torch.stack([o[1][:, :kk] for o in outs])
+            torch.cuda.synchronize(); t = time.perf_counter()
+            ms, mr = D.merge_sorted_lists(gs, gr, k); torch.cuda.synchronize(); tm = time.perf_counter() - t
+            tot = max(tb) + tt + max(tf) + tm
+            if best is None or tot < best[0]:
+                best = (tot, max(tb), tt, max(tf), tm, kk)
+        assert torch.equal(mr, fr) and torch.equal(ms, fs)
+        print("\n[config 4, emulated on one GPU] unsharded step %.1f ms; slowest shard per stage: begin %.2f + threshold %.2f + finish %.2f + merge %.2f "
+              "= %.2f ms (+ the all-gathers of [Q, %d] lists over xGMI, not emulated) -> %.2fx"
+              % (t_full * 1e3, best[1] * 1e3, best[2] * 1e3, best[3] * 1e3, best[4] * 1e3, best[0] * 1e3, best[5], t_full / best[0]))
+    finally:
+        for s in shards:
+            s.close()
 
 
 def test_random_configurations(G, monkeypatch):

@@ -35,6 +35,15 @@ def main():
     hot = np.argsort(-c)[:70]
     print("  hot queries: gated L1 mass %.2f (all %.2f), heavy slices %.1f (all %.1f), k-th score %.3f (all %.3f)" %
           (l1[hot].mean(), l1.mean(), heavy[hot].mean(), heavy.mean(), kth.cpu().numpy()[hot].mean(), float(kth.mean())))
+    mg = np.zeros(nq, np.float32)
+    _lib.check(ix._lib.dhr_debug_query_margins(ix._h, C.byref(qb), mg.ctypes.data, None), "margins")
+    cnt_m = ((U >= (kth - torch.from_numpy(mg).to(dev))[:, None]).sum(1).float() * (n / m)).cpu().numpy()
+    print("  with the filter margin: mean %.0f  p99 %.0f  max %.0f;  margins: mean %.3f  max %.3f" % (cnt_m.mean(), np.percentile(cnt_m, 99), cnt_m.max(), mg.mean(), mg.max()))
+    qg = qv[:, :768].float().cpu().numpy(); qd = qv[:, 768:].float().cpu().numpy()
+    kk = kth.cpu().numpy()
+    for q in np.argsort(-cnt_m)[:8]:
+        print("    query %4d: %8.0f cand. (%.0f without margin)  margin %.3f  k-th %.3f  gated max %.3f  terms>0.05 %d  gated L1 %.2f  ungated norm %.3f max %.3f" %
+              (q, cnt_m[q], c[q], mg[q], kk[q], qg[q].max(), int((qg[q] > 0.05).sum()), qg[q].sum(), np.linalg.norm(qd[q]), np.abs(qd[q]).max()))
     ix.close()
 
 
