@@ -117,6 +117,8 @@ struct dhr_index {
   int64_t cand_cap = 0, first_rows = 0;   // 0 = default (262144 with refine lists, else 65536)
   int profile = 0, max_growth16 = 32;
   int sample_period = 32;
+  int sample_share = 1;                    // shards the sampled threshold is agreed between (dhr_search_sharded sets it): a shard then keeps only the part of
+                                           // the union's r best sample scores it can plausibly hold (local_sample_rank)
   int main_chunks = 2;
   int progressive_thr = 2;
   int n_cu = 256;
@@ -198,6 +200,9 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
     case DHR_PARAM_SAMPLE_PERIOD:
       if (value < 0 || value > 256) return set_error(DHR_ERR_INVALID, "sample_period must be in [0,256] (0/1 = off)");
       ix->sample_period = (int)value; return DHR_OK;
+    case DHR_PARAM_SAMPLE_SHARE:
+      if (value < 1 || value > 4096) return set_error(DHR_ERR_INVALID, "sample_share must be in [1,4096]");
+      ix->sample_share = (int)value; return DHR_OK;
     case DHR_PARAM_MAIN_CHUNKS:
       if (value < 1 || value > 64) return set_error(DHR_ERR_INVALID, "main_chunks must be in [1,64]");
       ix->main_chunks = (int)value; return DHR_OK;
@@ -657,7 +662,10 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   // (measured at config 3: depth 262 144 / 131 072 / 65 536 = 195.2 / 196.5 / 196.2 ms per step, 100.2 / 85.2 / 77.7 GB)
   // (gated_i8 indexes: the int8 bound passes ~1.5x the rows of the fp16 one, and far more for the few queries with two or three
   // dominant terms -- the fullest list decides the chunk count of the main pass, so these get 4x the depth: 32 -> 8 chunks at config 3)
-  const int64_t by_rows = std::max<int64_t>(ix->n_rows / (ix->gated_i8 ? 32 : 128), refine ? 32768 : 16384);
+  // Round 3: n_rows / 8, capped at 262 144 -- a 1/8 shard of config 4 planned 22 chunks at n_rows / 32 (its fullest list is as long as
+  // the whole corpus's in proportion, but the floor of the depth is not), each with its own host round trips.
+  const int64_t by_rows = ix->gated_i8 ? std::min<int64_t>(std::max<int64_t>(ix->n_rows / 8, 32768), 262144)
+                                       : std::max<int64_t>(ix->n_rows / 128, refine ? 32768 : 16384);
   while (base_cap > by_rows && base_cap > 4096) base_cap >>= 1;          // power-of-two floor of n_rows / 128 (65 536 at 8.84 M rows)
   while (base_cap > 4096 && (int64_t)q_pad * base_cap * 16 > ((int64_t)32 << 30)) base_cap >>= 1;
   if (ix->cand_cap > 0) base_cap = ix->cand_cap;
@@ -921,11 +929,21 @@ static int sample_rank_of(double mean) { return (int)std::ceil(mean + 5.0 * std:
 static void plan_sampling(const dhr_index* ix, int k, int& S, int& r) {
   for (S = ix->sample_period; S >= 2; S = S >= 8 ? S / 2 : 0) {
     const int rr = sample_rank_of((double)k / S);
-    const int64_t head_guess = round_up(std::max<int64_t>(512, 2 * (int64_t)rr), TILE_ROWS) / TILE_ROWS;
+    const int64_t head_guess = round_up(std::max<int64_t>(256, 2 * (int64_t)rr), TILE_ROWS) / TILE_ROWS;
     const int64_t rest_guess = ix->n_tiles - head_guess;
     if (!(rr >= k || rest_guess < 32 * (int64_t)S || (rest_guess / S) * TILE_ROWS < 16 * (int64_t)rr)) { r = rr; return; }
   }
   S = 0; r = k;
+}
+
+// Sharded search: the common threshold is the r-th best sample score of the UNION of the shards' samples.  A shard's share of those r
+// scores is ~Binomial(r, 1 / shards), so it only has to report (and, during its sampled run, to chase) its
+// r / shards + 5 sqrt(r / shards) + 4 best: 26 instead of 64 at 8 shards.  A longer share than that only makes the union's r-th best
+// come out LOWER (still a valid threshold, the verification of the counts catches what it costs).
+static int local_sample_rank(const dhr_index* ix, int r) {
+  if (ix->sample_share <= 1 || r <= 0) return r;
+  const double m = (double)r / ix->sample_share;
+  return std::min(r, (int)std::ceil(m + 5.0 * std::sqrt(m) + 4.0));
 }
 
 static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, int k, int depth, Timer& tm,
@@ -942,8 +960,11 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   // sampled threshold: period S, conservative rank r (DESIGN.md "controller")
   int S = 0, r_eff = k;
   if (allow_sampling) plan_sampling(ix, k, S, r_eff);
+  if (S >= 2 && stage != 0) r_eff = local_sample_rank(ix, r_eff);          // staged (sharded) search: this shard's share of the union's rank
   // rows scored exhaustively in phase 0 (>= the rank that defines tau, so that tau exists afterwards), whole tile groups
-  int64_t first = ix->first_rows > 0 ? std::max<int64_t>(ix->first_rows, 2 * (int64_t)r_eff) : std::max<int64_t>(512, 2 * (int64_t)r_eff);
+  // (512 rows until round 3; with sampled thresholds the head only has to hold 2 r rows, and it is a fixed cost of every rank of the
+  // sharded search: 256 rows x 6 980 queries are 1.1 ms of exhaustive rescoring)
+  int64_t first = ix->first_rows > 0 ? std::max<int64_t>(ix->first_rows, 2 * (int64_t)r_eff) : std::max<int64_t>(S >= 2 ? 256 : 512, 2 * (int64_t)r_eff);
   first = std::min(round_up(first, TILE_ROWS), round_up(n, TILE_ROWS));
   const int64_t first_valid = std::min(first, n);
   if ((rc = ensure_ws(ix, w, Q, k, first_valid, depth == 0 ? 1 : 16)) != DHR_OK) return rc;
@@ -1322,6 +1343,12 @@ extern "C" int dhr_search_rerank(dhr_index* ix, const dhr_query_batch* qb1, cons
 // ---- staged search for the row-sharded path (dhr_amd/dist.py): the shards agree on ONE threshold per
 // query after their sampled runs, so each shard collects only its share of the global top-k.
 extern "C" int32_t dhr_search_sample_rank(const dhr_index* ix, int32_t k) {
+  if (!ix || k <= 0) return 0;
+  int S = 0, r = k;
+  plan_sampling(ix, k, S, r);
+  return S >= 2 ? local_sample_rank(ix, r) : 0;
+}
+extern "C" int32_t dhr_search_union_rank(const dhr_index* ix, int32_t k) {
   if (!ix || k <= 0) return 0;
   int S = 0, r = k;
   plan_sampling(ix, k, S, r);

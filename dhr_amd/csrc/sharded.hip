@@ -209,9 +209,11 @@ int sharded_core(std::vector<ShardCtx>& sh, const Gather& g, const dhr_query_bat
                  const std::vector<int64_t*>& out_r) {
   const int nl = g.n_local, world = g.world, Q = qb_in->n_queries;
   std::vector<dhr_query_batch> qb(nl, *qb_in);
+  for (int i = 0; i < nl; ++i) SH_TRY(dhr_index_set_param(sh[i].ix, DHR_PARAM_SAMPLE_SHARE, world));      // a shard chases only its share of the union's rank
   int r = 0;
   SH_TRY(agree_rank(sh, g, k, &r));
   if (r <= 0) return local_path(sh, g, qb, k, out_s, out_r);
+  const int ru = std::min<int>(dhr_search_union_rank(sh[0].ix, k), world * r);      // rank of the union that defines the threshold; the lists are r long
 
   // 1-2: sampled passes, common thresholds
   std::vector<const void*> send(nl);
@@ -229,10 +231,10 @@ int sharded_core(std::vector<ShardCtx>& sh, const Gather& g, const dhr_query_bat
   SH_TRY(g.run(sh, send, recv, (size_t)Q * r * 4));
   for (int i = 0; i < nl; ++i) {
     SH_HIP(hipSetDevice(sh[i].device));
-    float* merged = (float*)sh[i].arena->get((size_t)Q * r * 4);
+    float* merged = (float*)sh[i].arena->get((size_t)Q * ru * 4);
     if (!merged) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the sharded search");
-    SH_TRY(dhr_merge_topk_lists(sh[i].device, Q, world, r, (const float*)recv[i], nullptr, r, merged, nullptr, sh[i].stream));
-    hipLaunchKernelGGL(column_kernel, dim3((Q + 255) / 256), dim3(256), 0, sh[i].stream, merged, r, r - 1, Q, tau[i]);
+    SH_TRY(dhr_merge_topk_lists(sh[i].device, Q, world, r, (const float*)recv[i], nullptr, ru, merged, nullptr, sh[i].stream));
+    hipLaunchKernelGGL(column_kernel, dim3((Q + 255) / 256), dim3(256), 0, sh[i].stream, merged, ru, ru - 1, Q, tau[i]);
   }
   // 3-4: main passes, counts, failure flags
   const int kk = prefix_len(k, world);

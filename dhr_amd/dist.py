@@ -93,8 +93,10 @@ def allgather_merge(local_scores, local_rows, k: int, group=None):
 
 
 def common_threshold(sample_scores_all, r: int):
-    """[world, Q, r] best sample scores of every shard (each list sorted, best first) -> [Q] the r-th best
-    of the union per query."""
+    """[world, Q, r_local] best sample scores of every shard (each list sorted, best first) -> [Q] the r-th best of the union per
+    query (r = GipIndex.union_rank; the lists may be shorter than r when DHR_PARAM_SAMPLE_SHARE is set: then the
+    min(r, world * r_local)-th best, which can only be lower)."""
+    r = min(int(r), sample_scores_all.shape[0] * sample_scores_all.shape[2])
     merged, _ = merge_sorted_lists(sample_scores_all, None, r)
     return merged[:, r - 1].contiguous()
 
@@ -198,6 +200,7 @@ def sharded_search_torch(index, q_value, q_index, k: int, group=None):
     if world == 1:
         scores, rows = index.search(q_value, q_index, k, out_device=True)
         return merge_topk(scores, rows, k)
+    index.set_param(_lib.PARAM_SAMPLE_SHARE, world)                   # a shard reports only its plausible share of the union's r best
     r = index.sample_rank(k)
     dev = getattr(index, "torch_device", None) or torch.device("cuda", index.device)
     rr = torch.tensor([r, -r], dtype=torch.int32, device=dev)
@@ -210,7 +213,7 @@ def sharded_search_torch(index, q_value, q_index, k: int, group=None):
     nq = sample.shape[0]
     gathered = torch.empty((world * nq, r), dtype=torch.float32, device=sample.device)
     dist.all_gather_into_tensor(gathered, sample, group=group)
-    tau = common_threshold(gathered.view(world, nq, r), r)
+    tau = common_threshold(gathered.view(world, nq, r), index.union_rank(k))
     scores, rows, count = index.search_finish(tau)
     # one small all-gather of the per-query counts serves the completeness check AND the useful list length
     counts = torch.empty((world * nq,), dtype=torch.int32, device=count.device)

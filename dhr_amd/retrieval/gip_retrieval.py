@@ -169,6 +169,10 @@ class GipIndex:
     def sample_rank(self, k: int) -> int:
         return int(self._lib.dhr_search_sample_rank(self._h, int(k)))
 
+    def union_rank(self, k: int) -> int:
+        """Rank of the union of the shards' samples that defines the common threshold (dhr_search_union_rank)."""
+        return int(self._lib.dhr_search_union_rank(self._h, int(k)))
+
     def search_begin(self, q_value, q_index, k: int, stream: int = 0):
         """Runs the sampled part; -> torch cuda tensor [Q, r] with this shard's r best sample scores
         (None when the shard is too small to sample: then the whole search already ran)."""

@@ -99,6 +99,9 @@ typedef enum dhr_param {
   DHR_PARAM_OVERLAP_AUX = 11,  /* 0: refine / rescoring / select of a chunk run after its GEMM on the same stream; 1: beside the GEMM of the next chunk on a CU-masked stream; -1 (default): 1 for dense-only indexes, 0 for gated ones */
   DHR_PARAM_PROGRESSIVE_THR = 8, /* later main-pass chunks filter with 1: the running exact k-th best; 2 (default): additionally the rank extrapolated from the scattered fraction of the corpus seen so far (main pass in a scattered tile order; a query whose extrapolation was too high fails the final verification and is redone); 0: the sampled threshold only */
   DHR_PARAM_GEMM_VARIANT = 6, /* bound-GEMM kernel of the 2:4 layout: 3 = 12 waves (producer / consumer), 4 = 4 waves with 128 x 128 wave tiles, 5 = 8 waves with 128 x 64 wave tiles (default) */
+  DHR_PARAM_SAMPLE_SHARE = 12, /* staged search only (dhr_search_begin / finish): the number of shards the sampled threshold is agreed between; a shard then
+                                 reports its r / shards + 5 sqrt(r / shards) + 4 best sample scores (dhr_search_sample_rank) instead of all r
+                                 (dhr_search_union_rank).  dhr_search_sharded[_local] set it themselves.  Default 1. */
   DHR_PARAM_SAMPLE_PERIOD = 5 /* every S-th corpus tile seeds the thresholds (default 32; 0 = plain streaming) */
 } dhr_param;
 
@@ -191,6 +194,10 @@ int dhr_search_rerank(dhr_index* index, const dhr_query_batch* stage1, const dhr
  * those queries are redone with dhr_search.  Replaces one process per shard + merge.result.py.
  * out_sample_scores_dev / tau_hat_dev / out_count_dev are DEVICE pointers. */
 int32_t dhr_search_sample_rank(const dhr_index* index, int32_t k);
+/* The rank of the union of the shards' samples that defines the common threshold (== dhr_search_sample_rank unless
+ * DHR_PARAM_SAMPLE_SHARE > 1): the caller merges the gathered [shards, Q, sample_rank] lists and takes the
+ * min(union_rank, shards * sample_rank)-th best per query. */
+int32_t dhr_search_union_rank(const dhr_index* index, int32_t k);
 int dhr_search_begin(dhr_index* index, const dhr_query_batch* queries, int32_t k, float* out_sample_scores_dev, void* stream);
 int dhr_search_finish(dhr_index* index, const float* tau_hat_dev, float* out_scores, int64_t* out_rows,
                       int32_t* out_count_dev, int32_t out_mem_kind, void* stream);

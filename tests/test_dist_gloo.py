@@ -74,8 +74,18 @@ class _FakeShard:
         self.cv, self.lo, self.period, self.r = cv.astype(np.float64), lo, period, r
         self.calls = []
 
-    def sample_rank(self, k):
+    def set_param(self, param, value):
+        from dhr_amd import _lib
+        if param == _lib.PARAM_SAMPLE_SHARE:
+            self.share = int(value)
+
+    def union_rank(self, k):
         return self.r
+
+    def sample_rank(self, k):                      # this shard's share of the union's rank (api.hip local_sample_rank)
+        share = getattr(self, "share", 1)
+        m = self.r / share
+        return self.r if share <= 1 else min(self.r, int(np.ceil(m + 5.0 * np.sqrt(m) + 4.0)))
 
     def _scores(self, q):
         return np.asarray(q, np.float64) @ self.cv.T
@@ -84,7 +94,7 @@ class _FakeShard:
         import torch
         self.q, self.k = np.asarray(q), k
         s = self._scores(q)[:, ::self.period]
-        top = -np.sort(-s, axis=1)[:, : self.r]
+        top = -np.sort(-s, axis=1)[:, : self.sample_rank(k)]
         self.calls.append("begin")
         return torch.from_numpy(top.astype(np.float32))
 

@@ -541,7 +541,7 @@ def test_larger_random_hybrid(G):
     print(st)
 
 
-def _structured_corpus(n, boosted_mod, period=16, head_tiles=2):   # head = 512 exhaustive rows for k=1000
+def _structured_corpus(n, boosted_mod, period=16, head_tiles=1):   # head = 256 exhaustive rows for k=1000 (max(256, 2 r) with sampled thresholds, api.hip search_core)
     """Dense-only corpus whose best rows all sit in tiles with (tile - head) % period == boosted_mod."""
     rng = np.random.default_rng(5)
     cv = (rng.standard_normal((n, 64)) * 0.05).astype(np.float16)
@@ -666,10 +666,13 @@ def _fake_world_search(G, shards, q32, qi, k):
     """dist.sharded_search with the collectives replaced by in-process tensor ops (one GPU, S shards)."""
     import torch
     from dhr_amd import dist as D
+    from dhr_amd import _lib
+    for s in shards:
+        s.set_param(_lib.PARAM_SAMPLE_SHARE, len(shards))
     r = shards[0].sample_rank(k)
     assert r > 0 and all(s.sample_rank(k) == r for s in shards)
     samples = [s.search_begin(q32, qi, k) for s in shards]
-    tau = D.common_threshold(torch.stack(samples), r)
+    tau = D.common_threshold(torch.stack(samples), shards[0].union_rank(k))
     outs = [s.search_finish(tau) for s in shards]
     count = torch.stack([o[2] for o in outs])
     tot = count.clamp(min=0).sum(0)
@@ -718,7 +721,7 @@ def test_staged_sharded_search_failure_path(G):
     """All high-scoring rows sit in sample tiles of shard 0: the common threshold is too high for the
     union to reach k rows, the count check must catch it and the local fallback must repair it."""
     from dhr_amd import _lib
-    n, k, ns = 400_000, 1000, 2
+    n, k, ns = 401_408, 1000, 2          # shard 1 starts on a multiple of 16 tiles: the boosted tiles are sample tiles of BOTH shards
     cv, qv = _structured_corpus(n, 0)
     q32 = qv.astype(np.float32)
     full = G.GipIndex(cv, None)
@@ -1065,7 +1068,9 @@ def test_config4_full_size_8_shards(G):
         assert got == want, (got, want)
         assert torch.equal(sr, fr) and torch.equal(ss, fs)
         # stage times, slowest shard per stage: begin (phase 0 + sampled run) | common threshold | finish (main pass) | merge
-        rnk = shards[0].sample_rank(k)
+        for ix in shards:
+            ix.set_param(_lib.PARAM_SAMPLE_SHARE, ns)
+        rnk = shards[0].union_rank(k)
         best = None
         for it in range(3):
             tb, tf, samples, outs = [], [], [], []
@@ -1248,7 +1253,7 @@ def test_search_sharded_local_c_abi(G, kind):
         n, ns = 400_000, 4
         cv, ci, qv, qi = synth.make_pair(23, n, 12, 0, 256, kind="dense")
     elif kind == "structured":
-        n, ns, period = 400_000, 2, 16
+        n, ns, period = 401_408, 2, 16          # both shards start on a multiple of 16 tiles (see test_staged_sharded_search_failure_path)
         cv, qv = _structured_corpus(n, 0)
         ci = qi = None
     else:
@@ -1459,7 +1464,7 @@ def test_extrapolated_threshold_failure_is_redone(G):
     rng = np.random.default_rng(11)
     cv = (rng.standard_normal((n, 64)) * 0.02).astype(np.float16)
     n_tiles = (n + 255) // 256
-    head = 2                                            # 512 exhaustive rows
+    head = 1                                            # 256 exhaustive rows (max(256, 2 r), r = 40)
     rest = n_tiles - head
     n_sample = (rest + S - 1) // S
     n_main = rest - n_sample

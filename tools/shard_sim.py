@@ -47,7 +47,9 @@ def main():
         shards.append(ix)
         del cv, ci
         torch.cuda.empty_cache()
-    rnk = shards[0].sample_rank(k)
+    for ix in shards:
+        ix.set_param(_lib.PARAM_SAMPLE_SHARE, a.shards)
+    rnk = shards[0].union_rank(k)
     for it in range(2):
         tb, tf, samples, outs = [], [], [], []
         for ix in shards:
