@@ -73,6 +73,8 @@ struct Workspace {
   void* h_pinned = nullptr;              // 16 bytes pinned mirror
   char* h_pinned2 = nullptr;             // 2 x 16 bytes pinned (main-pass chunk statistics)
   uint32_t* d_max2 = nullptr;            // 2 x 16 bytes device
+  unsigned long long* d_stats = nullptr; // 4 x u64 device: {bound candidates, exact rescorings, -, -} of a search whose controller runs without host read-backs
+  void* h_stats = nullptr;               // pinned mirror
   uint32_t* d_ref = nullptr;             // 16 bytes device: refine survivors {max, pad, sum64}
   void* h_ref = nullptr;                 // pinned mirror
   void* q_stage = nullptr;  size_t q_stage_bytes = 0;
@@ -117,6 +119,8 @@ struct dhr_index {
   int64_t cand_cap = 0, first_rows = 0;   // 0 = default (262144 with refine lists, else 65536)
   int profile = 0, max_growth16 = 32;
   int sample_period = 32;
+  int async_ctl = 1;                       // first attempt of a sampled search: the controller only ENQUEUES (no host read-backs between the phases; list
+                                           // overflows are flagged on the device and cured by the fallback); 0 = the host-driven controller of rounds 1-2
   int sample_share = 1;                    // shards the sampled threshold is agreed between (dhr_search_sharded sets it): a shard then keeps only the part of
                                            // the union's r best sample scores it can plausibly hold (local_sample_rank)
   int main_chunks = 2;
@@ -139,8 +143,9 @@ static void free_ws(Workspace& w) {
   hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2); hipFree(w.q_pack); hipFree(w.cand_r); hipFree(w.cnt_r); hipFree(w.blk_off);
   if (w.h_pinned) hipHostFree(w.h_pinned);
   if (w.h_pinned2) hipHostFree(w.h_pinned2);
-  hipFree(w.d_max2); hipFree(w.d_ref);
+  hipFree(w.d_max2); hipFree(w.d_ref); hipFree(w.d_stats);
   if (w.h_ref) hipHostFree(w.h_ref);
+  if (w.h_stats) hipHostFree(w.h_stats);
   hipFree(w.q_stage); hipFree(w.qi_stage); hipFree(w.out_stage);
   w = Workspace();
 }
@@ -200,6 +205,7 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
     case DHR_PARAM_SAMPLE_PERIOD:
       if (value < 0 || value > 256) return set_error(DHR_ERR_INVALID, "sample_period must be in [0,256] (0/1 = off)");
       ix->sample_period = (int)value; return DHR_OK;
+    case DHR_PARAM_ASYNC_CONTROLLER: ix->async_ctl = value != 0; return DHR_OK;
     case DHR_PARAM_SAMPLE_SHARE:
       if (value < 1 || value > 4096) return set_error(DHR_ERR_INVALID, "sample_share must be in [1,4096]");
       ix->sample_share = (int)value; return DHR_OK;
@@ -710,6 +716,8 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.d_max2, 32, tot));
   HIP_TRY(re_malloc(w.d_ref, 16, tot));
   HIP_TRY(hipHostMalloc(&w.h_ref, 16, hipHostMallocDefault));
+  HIP_TRY(re_malloc(w.d_stats, 32, tot));
+  HIP_TRY(hipHostMalloc(&w.h_stats, 32, hipHostMallocDefault));
   w.q_pad = q_pad; w.kp = kp; w.cap = cap; w.cap_r = cap_r; w.keys_ld = keys_ld; w.kt = ix->kt; w.d_dlr = ix->d_dlr;
   w.bytes = tot;
   return DHR_OK;
@@ -822,6 +830,56 @@ static int gemm_phase(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi
   return DHR_OK;
 }
 
+// The same without a host read-back (controller of the first attempt of a sampled search): list lengths stay in device memory -- the
+// statistics are accumulated there (w.d_stats), a list that overflowed flags its query (fail_flags: redone by the fallback), and the
+// per-candidate kernels are launched with a fixed grid that walks the block list by grid stride.
+static int gemm_phase_async(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi, int map_mode, int period, int64_t head,
+                            Timer& tm, dhr_search_stats& st, hipStream_t s) {
+  GemmArgs g{};
+  g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr; g.g8_rsum = ix->g8_rsum;
+  g.seq_lo = lo; g.seq_hi = hi; g.map_mode = map_mode; g.period = period; g.head = head; g.n_tiles = ix->n_tiles;
+  g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt;
+  g.cap = (uint32_t)w.cap; g.n_queries = Q;
+  HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));
+  tm.begin(T_GEMM); HIP_TRY(launch_gemm_filter(g, s)); tm.end();
+  HIP_TRY(launch_max_u32(w.cnt, Q, w.d_max, w.d_stats + 0, s));
+  HIP_TRY(launch_mark_overflow(w.cnt, (uint32_t)w.cap, Q, w.fail_flags, s));
+  const double rows = (double)(hi - lo) * TILE_ROWS;
+  st.phases++;
+  st.gemm_rows += (int64_t)rows;
+  st.gemm_flops += 2.0 * (double)w.q_pad * rows * (double)ix->kt;
+  st.gemm_flops_alg += 2.0 * (double)Q * rows * (double)ix->k;
+  return DHR_OK;
+}
+static int rescore_select_async(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, const uint2* cand, const uint32_t* cnt,
+                                const float* thr, Timer& tm, hipStream_t s) {
+  uint32_t list_cap = (uint32_t)w.cap;
+  if (gate && ix->heavy_key) {
+    RefineArgs f{};
+    f.cand = cand; f.cnt = cnt; f.cap = (uint32_t)w.cap; f.heavy_key = ix->heavy_key; f.heavy_val = ix->heavy_val;
+    f.q_pack = w.q_pack; f.d_dlr = ix->d_dlr; f.thr = thr; f.out = w.cand_r; f.out_cnt = w.cnt_r; f.out_cap = (uint32_t)w.cap_r;
+    f.n_queries = Q; f.max_count = 1;
+    if (ix->gated_i8) { f.g8_q8 = w.g8_q8; f.g8_inv_cs = ix->g8_inv_cs; f.g8_unit = w.g8_unit; f.abs_mode = ix->abs_mode ? 1 : 0; }
+    HIP_TRY(launch_block_offsets(cnt, (uint32_t)w.cap, Q, 256, w.blk_off, s));
+    f.blk_off = w.blk_off; f.flat_blocks = FLAT_GRID_ASYNC;
+    HIP_TRY(hipMemsetAsync(w.cnt_r, 0, (size_t)w.q_pad * 4, s));
+    tm.begin_on(T_REFINE, s); HIP_TRY(launch_refine(f, s)); tm.end_on(s);
+    HIP_TRY(launch_mark_overflow(w.cnt_r, (uint32_t)w.cap_r, Q, w.fail_flags, s));
+    list_cap = (uint32_t)w.cap_r;
+    cand = w.cand_r; cnt = w.cnt_r;
+  }
+  HIP_TRY(launch_max_u32(cnt, Q, w.d_max, w.d_stats + 1, s));
+  RescoreArgs r = base_rescore_args(ix, w, Q, gate);
+  r.cand = cand; r.cnt = cnt; r.cap = list_cap; r.max_count = 1;
+  r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
+  HIP_TRY(launch_block_offsets(cnt, list_cap, Q, RESCORE_CANDS_PER_WG, w.blk_off + w.q_pad + 1, s));
+  r.blk_off = w.blk_off + w.q_pad + 1; r.flat_blocks = FLAT_GRID_ASYNC;
+  tm.begin_on(T_RESCORE, s); HIP_TRY(launch_rescore(r, s)); tm.end_on(s);
+  sel.cnt = cnt; sel.count_all = 0; sel.cap = list_cap;
+  tm.begin_on(T_SELECT, s); HIP_TRY(launch_select(sel, s)); tm.end_on(s);
+  return DHR_OK;
+}
+
 // Candidates of one phase -> [refine on the heavy lists] -> exact rescoring -> top-k merge, all on `s`.
 // The refine step needs one host read-back (size of the surviving lists) to size the rescoring grid.
 static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, const uint2* cand,
@@ -877,12 +935,21 @@ static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectA
 // comes from exact scores already seen, overflowing chunks are re-run in halves).
 static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, int64_t n_seq, int map_mode,
                          int period, int64_t head, int64_t first_chunk, int64_t seen_rows, Timer& tm, dhr_search_stats& st,
-                         hipStream_t s, double* last_rate = nullptr, double* last_rate_r = nullptr) {
+                         hipStream_t s, double* last_rate = nullptr, double* last_rate_r = nullptr, bool async_ctl = false) {
   int64_t pos = 0;
   int64_t chunk = std::max<int64_t>(DOC_GROUP, first_chunk);
   while (pos < n_seq) {
     chunk = std::min(chunk, round_up(n_seq - pos, DOC_GROUP));
     const int64_t hi = std::min(pos + chunk, n_seq);
+    if (async_ctl) {          // enqueue only: an overflowing list flags its query instead of halving the chunk
+      int rc = gemm_phase_async(ix, w, Q, pos, hi, map_mode, period, head, tm, st, s);
+      if (rc) return rc;
+      if ((rc = rescore_select_async(ix, w, Q, gate, sel, w.cand, w.cnt, w.thr, tm, s)) != DHR_OK) return rc;
+      seen_rows += (hi - pos) * TILE_ROWS;
+      pos = hi;
+      chunk = std::max<int64_t>(DOC_GROUP, round_up(seen_rows * ix->max_growth16 / 16 / TILE_ROWS, DOC_GROUP));
+      continue;
+    }
     uint32_t maxc; unsigned long long sumc;
     int rc = gemm_phase(ix, w, Q, pos, hi, map_mode, period, head, tm, st, s, &maxc, &sumc);
     if (rc) return rc;

@@ -265,6 +265,8 @@ hipError_t launch_merge_lists(int n_queries, int n_lists, int list_len, const fl
 
 extern int g_gemm_variant;
 constexpr int RESCORE_CANDS_PER_WG = 32;
+constexpr uint32_t FLAT_GRID_MAX = 1u << 20;      // flat launches: at most this many workgroups, the rest of the block list by grid stride
+constexpr uint32_t FLAT_GRID_ASYNC = 16384;       // ... and this many when the host does not know the block count (controller without read-backs)
 constexpr int SELECT_THREADS = 1024;
 
 }  // namespace dhr

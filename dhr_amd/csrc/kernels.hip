@@ -1338,11 +1338,13 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
   uint8_t* q8 = (uint8_t*)(ics + p.d_dlr);
   int q = blockIdx.y;
   uint32_t blk = blockIdx.x;
-  if (p.blk_off && !flat_block(p.blk_off, p.n_queries, blockIdx.x, q, blk)) return;
+  for (uint32_t fb = blockIdx.x;; fb += gridDim.x) {       // flat launches: grid stride over the block list (see rescore_kernel); else one pass
+  if (p.blk_off && !flat_block(p.blk_off, p.n_queries, fb, q, blk)) return;
   uint32_t count = p.cnt[q];
   if (count > p.cap) count = p.cap;
   const uint32_t base = blk * REFINE_PER_WG;
-  if (base >= count) return;
+  if (base >= count) { if (p.blk_off) continue; return; }
+  __syncthreads();                                           // the previous block's readers are done with the staged query words
   for (int j = threadIdx.x; j < p.d_dlr; j += 256) {
     qw[j] = p.q_pack[(int64_t)q * p.d_dlr + j];
     if constexpr (G8) { ics[j] = p.g8_inv_cs[j]; q8[j] = p.g8_q8[(int64_t)q * p.d_dlr + j]; }
@@ -1408,12 +1410,14 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
       }
     }
   }
+  if (!p.blk_off) return;
+  }
 }
 hipError_t launch_refine(const RefineArgs& a, hipStream_t s) {
   if (a.max_count == 0 || a.n_queries <= 0) return hipSuccess;
   const bool g8 = a.g8_q8 != nullptr;
   const size_t lds = (size_t)a.d_dlr * (g8 ? 9 : 4);
-  const dim3 grid = a.blk_off ? dim3(a.flat_blocks) : dim3((a.max_count + REFINE_PER_WG - 1) / REFINE_PER_WG, (unsigned)a.n_queries);
+  const dim3 grid = a.blk_off ? dim3(std::min<uint32_t>(a.flat_blocks, FLAT_GRID_MAX)) : dim3((a.max_count + REFINE_PER_WG - 1) / REFINE_PER_WG, (unsigned)a.n_queries);
   if (a.blk_off && !a.flat_blocks) return hipSuccess;
   if (g8) hipLaunchKernelGGL(refine_kernel<true>, grid, dim3(256), lds, s, a);
   else hipLaunchKernelGGL(refine_kernel<false>, grid, dim3(256), lds, s, a);
@@ -1438,12 +1442,9 @@ __device__ __forceinline__ uint32_t pair_mask(uint32_t x, uint32_t sel) {
   t.v = t.v - one.v;
   return t.u;
 }
-__global__ void __launch_bounds__(256) rescore_kernel(RescoreArgs p) {
+__device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q, const uint32_t blk) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  int q = blockIdx.y;
-  uint32_t blk = blockIdx.x;
-  if (p.blk_off && !flat_block(p.blk_off, p.n_queries, blockIdx.x, q, blk)) return;
   uint32_t count;
   if (p.cand) { count = p.cnt[q]; if (count > p.cap) count = p.cap; }
   else if (p.rows32) count = p.count_all;
@@ -1526,11 +1527,21 @@ __global__ void __launch_bounds__(256) rescore_kernel(RescoreArgs p) {
     }
   }
 }
+// Flat launches walk the block list with a grid stride: the grid is the exact block count when the host knows it, and a fixed one when the
+// controller runs without host read-backs (the list lengths then exist in device memory only).
+__global__ void __launch_bounds__(256) rescore_kernel(RescoreArgs p) {
+  if (!p.blk_off) { rescore_block(p, (int)blockIdx.y, blockIdx.x); return; }
+  for (uint32_t b = blockIdx.x;; b += gridDim.x) {
+    int q; uint32_t blk;
+    if (!flat_block(p.blk_off, p.n_queries, b, q, blk)) return;
+    rescore_block(p, q, blk);
+  }
+}
 
 hipError_t launch_rescore(const RescoreArgs& a, hipStream_t s) {
   if (a.max_count == 0 || a.n_queries <= 0) return hipSuccess;
   if (a.blk_off) {
-    if (a.flat_blocks) hipLaunchKernelGGL(rescore_kernel, dim3(a.flat_blocks), dim3(256), 0, s, a);
+    if (a.flat_blocks) hipLaunchKernelGGL(rescore_kernel, dim3(std::min<uint32_t>(a.flat_blocks, FLAT_GRID_MAX)), dim3(256), 0, s, a);
     return hipGetLastError();
   }
   const unsigned gx = (a.max_count + RESCORE_CANDS_PER_WG - 1) / RESCORE_CANDS_PER_WG;
