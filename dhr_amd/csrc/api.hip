@@ -133,7 +133,7 @@ struct dhr_index {
   hipStream_t s_gemm = nullptr;         // main-pass GEMM stream when CU masks are in use
   hipStream_t s_aux = nullptr;          // non-blocking stream for rescoring/select overlapped with the main-pass GEMM
   // staged search (dhr_search_begin / dhr_search_finish): state carried between the two calls
-  struct { bool valid = false, done = false, gate = false; int Q = 0, k = 0; double rate = 0.0, rate_r = 0.0; } pend;
+  struct { bool valid = false, done = false, gate = false; int Q = 0, k = 0; double rate = 0.0, rate_r = 0.0; int64_t dev_bound = 0, dev_exact = 0; } pend;
   Workspace ws, ws_fb[2];              // ws_fb[d]: workspace of fallback depth d+1 (16x candidate capacity)
   dhr_search_stats stats{};
 };
@@ -833,6 +833,10 @@ static int gemm_phase(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi
 // The same without a host read-back (controller of the first attempt of a sampled search): list lengths stay in device memory -- the
 // statistics are accumulated there (w.d_stats), a list that overflowed flags its query (fail_flags: redone by the fallback), and the
 // per-candidate kernels are launched with a fixed grid that walks the block list by grid stride.
+static uint32_t async_grid() {
+  static const uint32_t g = getenv("DHR_FLAT_GRID") ? (uint32_t)atoi(getenv("DHR_FLAT_GRID")) : FLAT_GRID_ASYNC;
+  return g ? g : FLAT_GRID_ASYNC;
+}
 static int gemm_phase_async(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi, int map_mode, int period, int64_t head,
                             Timer& tm, dhr_search_stats& st, hipStream_t s) {
   GemmArgs g{};
@@ -861,7 +865,7 @@ static int rescore_select_async(dhr_index* ix, Workspace& w, int Q, bool gate, S
     f.n_queries = Q; f.max_count = 1;
     if (ix->gated_i8) { f.g8_q8 = w.g8_q8; f.g8_inv_cs = ix->g8_inv_cs; f.g8_unit = w.g8_unit; f.abs_mode = ix->abs_mode ? 1 : 0; }
     HIP_TRY(launch_block_offsets(cnt, (uint32_t)w.cap, Q, 256, w.blk_off, s));
-    f.blk_off = w.blk_off; f.flat_blocks = FLAT_GRID_ASYNC;
+    f.blk_off = w.blk_off; f.flat_blocks = async_grid();
     HIP_TRY(hipMemsetAsync(w.cnt_r, 0, (size_t)w.q_pad * 4, s));
     tm.begin_on(T_REFINE, s); HIP_TRY(launch_refine(f, s)); tm.end_on(s);
     HIP_TRY(launch_mark_overflow(w.cnt_r, (uint32_t)w.cap_r, Q, w.fail_flags, s));
@@ -873,7 +877,7 @@ static int rescore_select_async(dhr_index* ix, Workspace& w, int Q, bool gate, S
   r.cand = cand; r.cnt = cnt; r.cap = list_cap; r.max_count = 1;
   r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
   HIP_TRY(launch_block_offsets(cnt, list_cap, Q, RESCORE_CANDS_PER_WG, w.blk_off + w.q_pad + 1, s));
-  r.blk_off = w.blk_off + w.q_pad + 1; r.flat_blocks = FLAT_GRID_ASYNC;
+  r.blk_off = w.blk_off + w.q_pad + 1; r.flat_blocks = async_grid();
   tm.begin_on(T_RESCORE, s); HIP_TRY(launch_rescore(r, s)); tm.end_on(s);
   sel.cnt = cnt; sel.count_all = 0; sel.cap = list_cap;
   tm.begin_on(T_SELECT, s); HIP_TRY(launch_select(sel, s)); tm.end_on(s);
@@ -1036,10 +1040,16 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   const int64_t first_valid = std::min(first, n);
   if ((rc = ensure_ws(ix, w, Q, k, first_valid, depth == 0 ? 1 : 16)) != DHR_OK) return rc;
 
+  // first attempt of a sampled search: the controller only enqueues (no host read-backs); DHR_ASYNC=0 / DHR_PARAM_ASYNC_CONTROLLER 0 keep the
+  // host-driven controller (and the fallback depths always use it: it is the one that is exact for any input)
+  static const int env_async = getenv("DHR_ASYNC") ? atoi(getenv("DHR_ASYNC")) : -1;
+  const bool async_ctl = depth == 0 && S >= 2 && (env_async < 0 ? ix->async_ctl != 0 : env_async != 0) && !getenv("DHR_DEBUG_PLAN");
   if (stage != 2) {
     tm.begin(T_PREP);
     if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
     HIP_TRY(hipMemsetAsync(w.topk_keys, 0, (size_t)w.q_pad * w.kp * 8, s));
+    HIP_TRY(hipMemsetAsync(w.fail_flags, 0, (size_t)w.q_pad * 4, s));
+    HIP_TRY(hipMemsetAsync(w.d_stats, 0, 32, s));
     tm.end();
   }
 
@@ -1075,7 +1085,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   const int64_t n_sample = (rest + S - 1) / S;
   double rate = 0.0, rate_r = 0.0;
   if (stage != 2) {
-    if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, std::max<int64_t>(head, DOC_GROUP), first_valid, tm, st, s, &rate, &rate_r)) != DHR_OK) return rc;
+    if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, std::max<int64_t>(head, DOC_GROUP), first_valid, tm, st, s, &rate, &rate_r, async_ctl)) != DHR_OK) return rc;
     HIP_TRY(hipMemcpyAsync(w.tau_hat, w.tau, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
     if (stage == 1) {
       ix->pend.valid = true; ix->pend.done = false; ix->pend.gate = gate; ix->pend.Q = Q; ix->pend.k = k; ix->pend.rate = rate; ix->pend.rate_r = rate_r;
@@ -1104,7 +1114,6 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   }
   {
     HIP_TRY(hipMemcpyAsync(w.thr_hat, w.thr, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemsetAsync(w.fail_flags, 0, (size_t)w.q_pad * 4, s));
     if (!w.cand2) {
       int64_t tot = 0;
       HIP_TRY(re_malloc(w.cand2, (size_t)w.q_pad * w.cap * 8, tot));
@@ -1153,8 +1162,16 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     // do not tighten fills them first
     const int64_t need = std::max((int64_t)std::ceil(1.5 * rate * (double)n_main * TILE_ROWS / (double)w.cap),
                                   (int64_t)std::ceil(1.5 * rate_r * (double)n_main * TILE_ROWS / (double)w.cap_r));
-    const int M = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(ix->main_chunks, need), 64),
-                                                              n_main / (16 * DOC_GROUP)));
+    // (without read-backs the sampled run's rates are not known here: a fixed 8 chunks, which the deep lists of round 3 cover at config 3 --
+    // 203 k entries in the fullest list of the first chunk against 262 144 slots; a list that overflows anyway flags its query)
+    // ... scaled with the shard: one chunk per ~4 200 tiles, 2 to 8 (a 1/8 shard of config 4: 2 chunks; 8 cost it 7 ms of launches)
+    // ... and, where that takes at most 12 chunks, so many that the FIRST (largest: 3 / (2 M) of the pass) chunk has no more rows than a list has
+    // slots: a small corpus then cannot overflow a list whatever its scores are (queries with fewer than k matching rows filter at 0)
+    int64_t by_size = std::min<int64_t>(8, std::max<int64_t>(2, (n_main + 4199) / 4200));
+    const int64_t no_overflow = (3 * n_main * TILE_ROWS + 2 * std::min(w.cap, w.cap_r) - 1) / (2 * std::min(w.cap, w.cap_r));
+    if (no_overflow <= 12) by_size = std::max(by_size, no_overflow);
+    const int64_t want = async_ctl ? std::max<int64_t>(ix->main_chunks, by_size) : std::max<int64_t>(ix->main_chunks, need);
+    const int M = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, 64), n_main / (16 * DOC_GROUP)));
     if (getenv("DHR_DEBUG_PLAN"))
       fprintf(stderr, "[dhr] main pass: rate %.3e (x n_main rows = %.0f of cap %lld), rate_r %.3e (%.0f of cap_r %lld), need %lld, chunks %d, n_main %lld tiles\n", rate,
               rate * (double)n_main * TILE_ROWS, (long long)w.cap, rate_r, rate_r * (double)n_main * TILE_ROWS, (long long)w.cap_r, (long long)need, M, (long long)n_main);
@@ -1203,6 +1220,22 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     if ((rc = enqueue_gemm(0)) != DHR_OK) return rc;
     for (int i = 0; i < M; ++i) {
       if (i + 1 < M && (rc = enqueue_gemm(i + 1)) != DHR_OK) return rc;
+      if (async_ctl) {
+        uint2* cand_a = (i & 1) ? w.cand2 : w.cand;
+        uint32_t* cnt_a = (i & 1) ? w.cnt2 : w.cnt;
+        if (sb != sg) HIP_TRY(hipStreamWaitEvent(sb, ev_gemm[i], 0));
+        HIP_TRY(launch_max_u32(cnt_a, Q, w.d_max, w.d_stats + 0, sb));
+        HIP_TRY(launch_mark_overflow(cnt_a, (uint32_t)w.cap, Q, w.fail_flags, sb));
+        if ((rc = rescore_select_async(ix, w, Q, gate, sel, cand_a, cnt_a, w.thr_hat, tm, sb)) != DHR_OK) return rc;
+        if (ix->progressive_thr) HIP_TRY(launch_raise_thr(w.thr_hat, sel.thr, Q, sb));
+        if (extrapolate && i + 1 < M) {
+          const double f = (double)(head + n_sample + bound[i + 1]) / (double)ix->n_tiles;
+          const int r = (int)std::ceil((double)k * f + 6.0 * std::sqrt((double)k * f * (1.0 - f)) + 4.0);
+          if (r < k) HIP_TRY(launch_raise_thr_rank(w.thr_hat, w.tau_hat, w.topk_keys, w.kp, r, w.margin, Q, sb));
+        }
+        HIP_TRY(hipEventRecord(ev_done[i], sb));
+        continue;
+      }
       HIP_TRY(hipEventSynchronize(ev_gemm[i]));
       const uint32_t maxc = *(const uint32_t*)(w.h_pinned2 + 16 * (i & 1));
       unsigned long long sumc;
@@ -1243,7 +1276,12 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   HIP_TRY(launch_max_u32(w.fail_flags, Q, w.d_max + 1, (unsigned long long*)(w.d_max + 2), s));      // overflow marks so far (the verification adds its own below)
   HIP_TRY(launch_verify(w.topk_keys, w.kp, k, w.tau_hat, Q, w.fail_flags, w.d_max, s));
   HIP_TRY(hipMemcpyAsync(w.h_pinned, w.d_max, 16, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  if (async_ctl) HIP_TRY(hipMemcpyAsync(w.h_stats, w.d_stats, 32, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));            // the ONE host read of a search whose first attempt succeeds: how many queries must be redone
+  if (async_ctl) {
+    st.candidates_bound += (int64_t)((unsigned long long*)w.h_stats)[0];
+    st.candidates_exact += (int64_t)((unsigned long long*)w.h_stats)[1];
+  }
   const uint32_t n_fail = ((uint32_t*)w.h_pinned)[0];
   const uint32_t n_overflow = ((uint32_t*)w.h_pinned)[1];
   st.sample_fallback_queries += n_fail;
@@ -1422,7 +1460,9 @@ extern "C" int32_t dhr_search_union_rank(const dhr_index* ix, int32_t k) {
   return S >= 2 ? r : 0;
 }
 
-extern "C" int dhr_search_begin(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_sample_scores_dev, void* stream) {
+// sync = false (dhr_search_sharded*): only enqueues when the controller runs without read-backs -- the shards of a one-process search then
+// work concurrently until the collective layer's own synchronisation; statistics and timers are then not collected
+static int search_begin_impl(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_sample_scores_dev, void* stream, bool sync) {
   int rc = check_queries(ix, qb);
   if (rc) return rc;
   if (k <= 0 || k > (1 << 20)) return set_error(DHR_ERR_INVALID, "k must be in [1, 1048576]");
@@ -1438,16 +1478,31 @@ extern "C" int dhr_search_begin(dhr_index* ix, const dhr_query_batch* qb, int32_
     if (!out_sample_scores_dev) return set_error(DHR_ERR_INVALID, "null sample score buffer");
     HIP_TRY(launch_emit_scores(ix->ws.topk_keys, ix->ws.kp, qb->n_queries, r, out_sample_scores_dev, s));
   }
-  HIP_TRY(hipStreamSynchronize(s));
-  double ms[5] = {0, 0, 0, 0, 0};
-  tm.collect(ms);
-  st.gemm_ms = ms[T_GEMM]; st.refine_ms = ms[T_REFINE]; st.rescore_ms = ms[T_RESCORE]; st.select_ms = ms[T_SELECT]; st.prep_ms = ms[T_PREP];
+  ix->pend.dev_bound = ix->pend.dev_exact = 0;
+  if (sync || ix->profile) {
+    HIP_TRY(hipMemcpyAsync(ix->ws.h_stats, ix->ws.d_stats, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // controller without read-backs: the counters live on the device (zero otherwise); remember what has been folded in
+    ix->pend.dev_bound = (int64_t)((unsigned long long*)ix->ws.h_stats)[0];
+    ix->pend.dev_exact = (int64_t)((unsigned long long*)ix->ws.h_stats)[1];
+    st.candidates_bound += ix->pend.dev_bound;
+    st.candidates_exact += ix->pend.dev_exact;
+    double ms[5] = {0, 0, 0, 0, 0};
+    tm.collect(ms);
+    st.gemm_ms = ms[T_GEMM]; st.refine_ms = ms[T_REFINE]; st.rescore_ms = ms[T_RESCORE]; st.select_ms = ms[T_SELECT]; st.prep_ms = ms[T_PREP];
+  }
   ix->stats = st;
   return DHR_OK;
 }
+extern "C" int dhr_search_begin(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_sample_scores_dev, void* stream) {
+  return search_begin_impl(ix, qb, k, out_sample_scores_dev, stream, true);
+}
+extern "C" int dhr_internal_search_begin_async(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_sample_scores_dev, void* stream) {
+  return search_begin_impl(ix, qb, k, out_sample_scores_dev, stream, false);
+}
 
-extern "C" int dhr_search_finish(dhr_index* ix, const float* tau_hat_dev, float* out_scores, int64_t* out_rows,
-                                 int32_t* out_count_dev, int32_t out_mem_kind, void* stream) {
+static int search_finish_impl(dhr_index* ix, const float* tau_hat_dev, float* out_scores, int64_t* out_rows,
+                              int32_t* out_count_dev, int32_t out_mem_kind, void* stream, bool sync) {
   if (!ix || !ix->pend.valid) return set_error(DHR_ERR_INVALID, "dhr_search_finish without a matching dhr_search_begin");
   if (!out_scores || !out_rows || !out_count_dev) return set_error(DHR_ERR_INVALID, "null output pointer");
   if (!ix->pend.done && !tau_hat_dev) return set_error(DHR_ERR_INVALID, "thresholds are required (the shard ran a sampled pass)");
@@ -1474,13 +1529,27 @@ extern "C" int dhr_search_finish(dhr_index* ix, const float* tau_hat_dev, float*
     HIP_TRY(hipMemcpyAsync(out_rows, d_rows, (size_t)Q * k * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(out_scores, d_scores, (size_t)Q * k * 4, hipMemcpyDeviceToHost, s));
   }
-  HIP_TRY(hipStreamSynchronize(s));
-  double ms[5] = {0, 0, 0, 0, 0};
-  tm.collect(ms);
-  st.gemm_ms += ms[T_GEMM]; st.refine_ms += ms[T_REFINE]; st.rescore_ms += ms[T_RESCORE]; st.select_ms += ms[T_SELECT];
+  if (sync || ix->profile || out_mem_kind == DHR_MEM_HOST) {
+    HIP_TRY(hipMemcpyAsync(w.h_stats, w.d_stats, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // device counters of a controller without read-backs: they run on from the begin call
+    st.candidates_bound += (int64_t)((unsigned long long*)w.h_stats)[0] - ix->pend.dev_bound;
+    st.candidates_exact += (int64_t)((unsigned long long*)w.h_stats)[1] - ix->pend.dev_exact;
+    double ms[5] = {0, 0, 0, 0, 0};
+    tm.collect(ms);
+    st.gemm_ms += ms[T_GEMM]; st.refine_ms += ms[T_REFINE]; st.rescore_ms += ms[T_RESCORE]; st.select_ms += ms[T_SELECT];
+  }
   ix->stats = st;
   ix->pend.valid = false;
   return DHR_OK;
+}
+extern "C" int dhr_search_finish(dhr_index* ix, const float* tau_hat_dev, float* out_scores, int64_t* out_rows,
+                                 int32_t* out_count_dev, int32_t out_mem_kind, void* stream) {
+  return search_finish_impl(ix, tau_hat_dev, out_scores, out_rows, out_count_dev, out_mem_kind, stream, true);
+}
+extern "C" int dhr_internal_search_finish_async(dhr_index* ix, const float* tau_hat_dev, float* out_scores, int64_t* out_rows,
+                                                int32_t* out_count_dev, int32_t out_mem_kind, void* stream) {
+  return search_finish_impl(ix, tau_hat_dev, out_scores, out_rows, out_count_dev, out_mem_kind, stream, false);
 }
 
 extern "C" int dhr_score_rows(dhr_index* ix, const dhr_query_batch* qb, int32_t m, const int64_t* rows, float* out_scores,

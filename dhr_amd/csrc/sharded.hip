@@ -225,7 +225,7 @@ int sharded_core(std::vector<ShardCtx>& sh, const Gather& g, const dhr_query_bat
     recv[i] = sh[i].arena->get((size_t)world * Q * r * 4);
     tau[i] = (float*)sh[i].arena->get((size_t)Q * 4);
     if (!sample || !recv[i] || !tau[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the sharded search");
-    SH_TRY(dhr_search_begin(sh[i].ix, &qb[i], k, sample, sh[i].stream));
+    SH_TRY(dhr_internal_search_begin_async(sh[i].ix, &qb[i], k, sample, sh[i].stream));
     send[i] = sample;
   }
   SH_TRY(g.run(sh, send, recv, (size_t)Q * r * 4));
@@ -252,7 +252,7 @@ int sharded_core(std::vector<ShardCtx>& sh, const Gather& g, const dhr_query_bat
     fail_ids[i] = (int32_t*)sh[i].arena->get((size_t)Q * 4);
     n_failed[i] = (int32_t*)sh[i].arena->get(256);
     if (!ls[i] || !lr[i] || !cnt || !recv_c[i] || !fail_ids[i] || !n_failed[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the sharded search");
-    SH_TRY(dhr_search_finish(sh[i].ix, tau[i], ls[i], lr[i], cnt, DHR_MEM_DEVICE, sh[i].stream));
+    SH_TRY(dhr_internal_search_finish_async(sh[i].ix, tau[i], ls[i], lr[i], cnt, DHR_MEM_DEVICE, sh[i].stream));
     send_c[i] = cnt;
   }
   SH_TRY(g.run(sh, send_c, recv_c, (size_t)Q * 4));

@@ -1098,6 +1098,53 @@ def test_config4_full_size_8_shards(G):
             s.close()
 
 
+def test_search_enqueues_without_host_readbacks(G):
+    """SURVEY.md section 8b ("asynchronous on the given stream"): the first attempt of a sampled search only ENQUEUES.  Two shard
+    handles on two streams: the staged entry points return to the host long before their streams drain, the two streams' work
+    overlaps on the device, and the results equal the synchronous calls'.  (dhr_search itself ends with its one host read -- the
+    count of queries to redo -- so the enqueue-only behaviour is observed through the begin step the sharded search uses.)"""
+    import ctypes as C
+    import time
+    import torch
+    from dhr_amd import _lib, synth
+    lib = _lib.load()
+    lib.dhr_internal_search_begin_async.argtypes = [C.c_void_p, C.POINTER(_lib.QueryBatch), C.c_int32, C.c_void_p, C.c_void_p]
+    n, nq, k = 600_000, 2048, 1000
+    cv, ci, qv, qi = synth.make_pair(31, n, nq, 768, 64)
+    dev = torch.device("cuda", 0)
+    qd, qid = torch.from_numpy(qv).to(dev), torch.from_numpy(qi).to(dev)
+    shards = [G.GipIndex(cv[: n // 2], ci[: n // 2]), G.GipIndex(cv[n // 2:], ci[n // 2:], row_offset=n // 2)]
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    try:
+        r = shards[0].sample_rank(k)
+        assert r > 0
+        ref = [s.search_begin(qd, qid, k).clone() for s in shards]                  # synchronous calls (default stream), also warms the workspaces
+        outs = [torch.empty((nq, r), dtype=torch.float32, device=dev) for _ in shards]
+        qbs = [s._qb(qd, qid) for s in shards]
+
+        def enqueue(i):
+            _lib.check(lib.dhr_internal_search_begin_async(shards[i]._h, C.byref(qbs[i][0]), k, outs[i].data_ptr(), streams[i].cuda_stream), "begin_async")
+
+        for i in range(2):                      # first use of a stream maps a hardware queue (milliseconds): not what is measured
+            enqueue(i)
+        # one handle alone: host return vs completion
+        torch.cuda.synchronize(); t0 = time.perf_counter(); enqueue(0); t_ret = time.perf_counter() - t0
+        streams[0].synchronize(); t_one = time.perf_counter() - t0
+        # both handles back to back on their own streams
+        torch.cuda.synchronize(); t0 = time.perf_counter(); enqueue(0); enqueue(1); t_ret2 = time.perf_counter() - t0
+        streams[0].synchronize(); streams[1].synchronize(); t_two = time.perf_counter() - t0
+        print("\n[enqueue-only begin] one handle: host returns after %.2f ms, stream done after %.2f ms; two handles on two streams: "
+              "host returns after %.2f ms, both done after %.2f ms (%.2fx one)" % (t_ret * 1e3, t_one * 1e3, t_ret2 * 1e3, t_two * 1e3, t_two / t_one))
+        assert t_ret < 0.6 * t_one, (t_ret, t_one)               # the call returned while most of its work was still queued
+        assert t_ret2 < 0.6 * t_two
+        assert t_two < 1.9 * t_one                                # the two streams overlap (2.0 = strictly one after the other)
+        for i in range(2):
+            assert torch.equal(outs[i], ref[i])
+    finally:
+        for s in shards:
+            s.close()
+
+
 def test_random_configurations(G, monkeypatch):
     """A slice of tools/stress.py (randomised shapes / dtypes / signs / fp32-or-fp16 queries / bucket counts / mixed query and
     corpus index dtypes, each checked against the oracle's float64 scores)."""
