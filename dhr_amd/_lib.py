@@ -19,7 +19,7 @@ INFO_DENSE_I8, INFO_I8_SCALE, INFO_I8_ROW_ERR, INFO_I8_ROW_NORM, INFO_ROW_NORM_M
 
 EXPORTS = ["dhr_version", "dhr_abi_sizes", "dhr_set_option", "dhr_index_get_info", "dhr_last_error", "dhr_index_create", "dhr_index_destroy", "dhr_index_set_param",
            "dhr_index_device_bytes", "dhr_search", "dhr_score_rows", "dhr_merge_topk", "dhr_merge_topk_host", "dhr_merge_topk_lists", "dhr_merge_topk_lists_host",
-           "dhr_get_stats", "dhr_debug_bound_scores", "dhr_debug_query_margins", "dhr_debug_gemm_time", "dhr_search_sample_rank", "dhr_search_union_rank", "dhr_search_begin",
+           "dhr_get_stats", "dhr_debug_bound_scores", "dhr_debug_query_margins", "dhr_debug_gemm_time", "dhr_debug_seq_to_tile", "dhr_search_sample_rank", "dhr_search_union_rank", "dhr_search_begin",
            "dhr_search_finish", "dhr_search_rerank", "dhr_comm_unique_id", "dhr_comm_create", "dhr_comm_wrap", "dhr_comm_destroy", "dhr_search_sharded", "dhr_search_sharded_local", "dhr_pq_create", "dhr_pq_destroy", "dhr_pq_device_bytes", "dhr_pq_search", "dhr_pq_adc_scores", "dhr_pq_last_scan", "dhr_index_save", "dhr_index_file_info", "dhr_index_load", "dhr_densify", "dhr_pq_train", "dhr_pq_encode", "dhr_pq_decode", "dhr_pq_train_nbits", "dhr_pq_encode_nbits", "dhr_pq_decode_nbits", "dhr_write_trec", "dhr_format_float"]
 
 
@@ -148,6 +148,9 @@ def load():
     lib.dhr_debug_query_margins.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_void_p, C.c_void_p]
     lib.dhr_debug_gemm_time.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_int32, C.POINTER(C.c_double),
                                         C.POINTER(C.c_double), C.c_void_p]
+    if hasattr(lib, "dhr_debug_seq_to_tile"):      # (A/B libraries built from older sources lack it)
+        lib.dhr_debug_seq_to_tile.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
+        lib.dhr_debug_seq_to_tile.restype = None
     lib.dhr_search_sample_rank.argtypes = [C.c_void_p, C.c_int32]
     lib.dhr_search_sample_rank.restype = C.c_int32
     lib.dhr_search_union_rank.argtypes = [C.c_void_p, C.c_int32]

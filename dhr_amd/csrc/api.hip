@@ -1832,6 +1832,10 @@ extern "C" int dhr_debug_query_margins(dhr_index* ix, const dhr_query_batch* qb,
 
 // Kernel-tuning hook: the bound GEMM alone over the whole shard with the filter closed (thr = +inf),
 // `iters` launches, average milliseconds per launch (hipEvents on the stream).
+extern "C" void dhr_debug_seq_to_tile(int64_t seq, int32_t map_mode, int32_t period, int64_t head, int64_t perm_mul, int64_t perm_n, int64_t out[2]) {
+  out[0] = seq_to_tile_fast(seq, map_mode, period, head, perm_mul, perm_n, 1.0 / (double)(perm_n > 0 ? perm_n : 1), 1.0 / (double)(period > 1 ? period - 1 : 1));
+  out[1] = seq_to_tile(seq, map_mode, period, head, perm_mul, perm_n);
+}
 extern "C" int dhr_debug_gemm_time(dhr_index* ix, const dhr_query_batch* qb, int32_t iters, double* ms_out, double* flops_out,
                                    void* stream) {
   int rc = check_queries(ix, qb);

@@ -69,6 +69,28 @@ __host__ __device__ inline int64_t seq_to_tile(int64_t i, int map_mode, int peri
   if (map_mode == 3) i = (i * perm_mul) % perm_n;        // the non-sample tiles in a scattered order (perm_mul coprime to perm_n, both < 2^24)
   return head + (i / (period - 1)) * period + i % (period - 1) + 1;
 }
+// The same map without integer division (the bound-GEMM kernels call it once per workgroup, before anything else can start: the
+// 64-bit  %  and  /  above expand to ~400 dependent scalar instructions, ~1 us of every 26 us tile).  All operands are below 2^24
+// (tile counts of a shard), so the product i * perm_mul < 2^48 is exact in a double and a quotient estimated with the
+// precomputed reciprocal is off by at most one: one correction step makes it exact (checked against the integer form on the host:
+// dhr_debug_seq_to_tile, tests/test_host_logic.py).
+__host__ __device__ inline int64_t divmod24(int64_t x, int64_t n, double inv_n, int64_t& rem) {      // 0 <= x < 2^48, x / n < 2^24
+  const double xd = (double)(int32_t)(x >> 24) * 16777216.0 + (double)(int32_t)(x & 0xFFFFFF);
+  int64_t q = (int64_t)(int32_t)(xd * inv_n);
+  int64_t r = x - q * n;
+  if (r < 0) { r += n; --q; } else if (r >= n) { r -= n; ++q; }
+  rem = r;
+  return q;
+}
+__host__ __device__ inline int64_t seq_to_tile_fast(int64_t i, int map_mode, int period, int64_t head, int64_t perm_mul, int64_t perm_n,
+                                                    double inv_perm_n, double inv_pm1) {
+  if (map_mode == 0) return i;
+  if (map_mode == 1) return head + i * period;
+  if (map_mode == 3) (void)divmod24(i * perm_mul, perm_n, inv_perm_n, i);
+  int64_t rem;
+  const int64_t q = divmod24(i, period - 1, inv_pm1, rem);
+  return head + q * period + rem + 1;
+}
 __host__ __device__ inline uint64_t make_key(float score, uint32_t row) {
   return ((uint64_t)f32_ordered(score) << 32) | (uint64_t)(0xFFFFFFFFu - row);
 }
@@ -88,6 +110,7 @@ struct GemmArgs {
   int64_t seq_lo, seq_hi;
   int map_mode, period;
   int64_t perm_mul, perm_n;
+  double inv_perm_n, inv_pm1; // 1 / perm_n and 1 / (period - 1): filled in by launch_gemm_filter (seq_to_tile_fast)
   int64_t head, n_tiles;
   int n_qtiles;               // Q_pad / 256
   int64_t n_rows;             // valid corpus rows (rows >= n_rows are zero padding)
@@ -210,6 +233,21 @@ hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const 
                              uint32_t* q_inexact, int c_idx_dtype,
                              float i8_scale /* 0: fp16 dense stages */, float i8_ec, float i8_nc, float* i8_mul, const float* col_scale,
                              const G8Prep& g8, hipStream_t s);
+#if defined(__HIPCC__)
+// Workgroup -> (corpus tile dt, query tile qt) of a bound-GEMM launch.  Grid = (8, DOC_GROUP * n_qtiles, tile groups per XCD): workgroups
+// are dispatched x-fastest and dealt round-robin to the 8 XCDs, so blockIdx.x is the XCD, and each XCD sweeps DOC_GROUP corpus tiles
+// against all query tiles before it moves on (its L2 holds those corpus tiles; the query tile set streams from the Infinity Cache) --
+// the linear order of the former 1-D grid, without its division by DOC_GROUP * n_qtiles.
+__device__ __forceinline__ bool gemm_wg_tile(const GemmArgs& p, int64_t& dt, int& qt) {
+  const int r = (int)blockIdx.y;
+  qt = r / DOC_GROUP;
+  const int dl = r - qt * DOC_GROUP;
+  const int64_t seq = p.seq_lo + ((int64_t)blockIdx.z * 8 + (int64_t)blockIdx.x) * DOC_GROUP + dl;
+  if (seq >= p.seq_hi) return false;
+  dt = seq_to_tile_fast(seq, p.map_mode, p.period, p.head, p.perm_mul, p.perm_n, p.inv_perm_n, p.inv_pm1);
+  return dt < p.n_tiles;
+}
+#endif
 inline int sparse_query_stages(int ts, bool gated, bool g8 = false) { return ts > 0 ? ((gated || g8) ? ts : 2 * ts) : 0; }
 hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s);
 hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, int idx_dtype, int64_t n_rows, int d_dlr,

@@ -11,7 +11,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 constexpr int EPI_STACK = 32;          // private hit-stack slots per thread in the filter epilogue
-constexpr int GEMM_RING_LDS = 4 * SP_SLOT + 64;   // 4-slot stage ring of the 2:4 kernels (136 KiB)
+constexpr int WX_META = 4 * SP_SLOT;              // behind the ring: 2 x 1 KiB = thresholds and (int8 image) units of the tile's 256 queries
+constexpr int GEMM_RING_LDS = 4 * SP_SLOT + 2048 + 64;   // 4-slot stage ring of the 2:4 kernels (136 KiB) + the per-query constants
 
 // Compressed query fragment -> smfmac B operand: each fp16 slice value v (bucket in the sign bit) becomes its two
 // bucket columns (max(v,0), max(-v,0)), one v_pk_max_f16 per output register.  One asm block, so that the two

@@ -28,7 +28,8 @@ typedef int intx8 __attribute__((ext_vector_type(8)));
 
 constexpr int G8_QOFF = 16384;                 // query part of a ring slot (the corpus part is 10 KiB gated / 16 KiB ungated)
 constexpr int G8_SLOT = 32768;
-constexpr int G8_RING_LDS = 4 * G8_SLOT + 64;
+constexpr int G8_META = 4 * G8_SLOT;           // behind the ring: 4 x 1 KiB = the tile's 256 row sums, and unit / threshold / shift of its 256 queries
+constexpr int G8_RING_LDS = 4 * G8_SLOT + 4096 + 64;
 constexpr int G8_NT = 512;
 
 __device__ __forceinline__ void g8_smfmac(floatx16& c, const intx4& a, const intx8& b, uint32_t idx) {
@@ -177,18 +178,9 @@ __host__ __device__ constexpr int g8_dma_piece(int ph, int g) { return (ph <= 1 
 template <bool DUMP>
 __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_filter_g8_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int64_t b = blockIdx.x;
-  const int xcd = (int)(b & 7);
-  const int64_t i = b >> 3;
-  const int per_group = DOC_GROUP * p.n_qtiles;
-  const int64_t g_local = i / per_group;
-  const int r = (int)(i - g_local * per_group);
-  const int qt = r / DOC_GROUP;
-  const int dl = r - qt * DOC_GROUP;
-  const int64_t seq = p.seq_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
-  if (seq >= p.seq_hi) return;
-  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head, p.perm_mul, p.perm_n);
-  if (dt >= p.n_tiles) return;
+  int64_t dt;
+  int qt;
+  if (!gemm_wg_tile(p, dt, qt)) return;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -237,32 +229,7 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int j = 0; j < 8; ++j) dma_piece(j);
   };
 
-  // The query's gated operand has 8 bits: level L in [0, 255] is stored as L - 128 (a column that carries nothing as -128), so
-  //   sum_cols (stored + 128) * d8 = sum_cols stored * d8 + 128 * (sum of the row's gated int8 values),
-  // and the second term is a constant of the ROW: the accumulators start there (g8_rsum, built with the index).
-  floatx16 acc[4][2];
-  {
-    const int32_t* rs = p.g8_rsum + dt * TILE_ROWS + wm * 128 + 4 * (lane >> 5);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const intx4 v = *(const intx4*)(rs + mi * 32 + 8 * g4);
-#pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) acc[mi][0][4 * g4 + i4] = acc[mi][1][4 * g4 + i4] = __int_as_float(v[i4]);
-      }
-  }
-  int thr_r[2], sh_r[2];
-  float mul_r[2];
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
-    mul_r[ni] = p.i8_mul[q];
-    thr_r[ni] = g8_thr_units(p.thr[q], mul_r[ni]);
-    sh_r[ni] = p.g8_shift[q];
-    asm volatile("" : "+v"(mul_r[ni]), "+v"(thr_r[ni]), "+v"(sh_r[ni]));
-  }
-
+  floatx16 acc[4][2];          // set in the prologue below (row sums of the gated image)
   // per-lane LDS offsets inside a ring slot
   const int frow = lane & 31;
   const int fhalf = lane >> 5;
@@ -312,12 +279,47 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
     }
   };
 
+  // ---- prologue.  ONE memory round trip before the first matrix instruction, and nothing the compiler's wait-count model has to
+  // guess about: the tile's per-row and per-query constants (accumulator start values; unit, threshold and shift of the queries) travel
+  // as four 1 KiB LDS-DMA pieces ahead of the first stage pair and are read from the LDS behind the first barrier.  (Until round 3
+  // they were per-lane global loads, each pinned by an empty asm -- four serialised L2 round trips before the first DMA piece was
+  // even issued, behind ~400 scalar instructions of 64-bit division: together most of the 2.5 us "per-tile constant" that neither a
+  // persistent workgroup nor a skipped first-pair wait had removed in rounds 1-2.)
+  if (wave < 4) {
+    const char* src = wave == 0 ? (const char*)(p.g8_rsum + dt * TILE_ROWS) : wave == 1 ? (const char*)(p.i8_mul + qt * TILE_ROWS)
+                    : wave == 2 ? (const char*)(p.thr + qt * TILE_ROWS) : (const char*)(p.g8_shift + qt * TILE_ROWS);
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + lane_off), LDS_PTR(smem + G8_META + wave * 1024), 16, 0, 0);
+  }
   issue_pair(0);
-  if (npairs > 1) {            // pair 0 must have landed; pair 1 (this wave's 5 or 8 pieces, loads return in order) may stay in flight
+  if (npairs > 1) {            // the constants and pair 0 must have landed; pair 1 (this wave's 5 or 8 pieces, loads return in order) may stay in flight
     issue_pair(1);
     if (dma_n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  // The query's gated operand has 8 bits: level L in [0, 255] is stored as L - 128 (a column that carries nothing as -128), so
+  //   sum_cols (stored + 128) * d8 = sum_cols stored * d8 + 128 * (sum of the row's gated int8 values),
+  // and the second term is a constant of the ROW: the accumulators start there (g8_rsum, built with the index).
+  {
+    const int32_t* rs = (const int32_t*)(smem + G8_META) + wm * 128 + 4 * (lane >> 5);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const intx4 v = *(const intx4*)(rs + mi * 32 + 8 * g4);
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) acc[mi][0][4 * g4 + i4] = acc[mi][1][4 * g4 + i4] = __int_as_float(v[i4]);
+      }
+  }
+  int sh_r[2];
+  float mul_r[2], thr_f[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int ql = wn * 64 + ni * 32 + (lane & 31);
+    mul_r[ni] = ((const float*)(smem + G8_META + 1024))[ql];
+    thr_f[ni] = ((const float*)(smem + G8_META + 2048))[ql];
+    sh_r[ni] = ((const int*)(smem + G8_META + 3072))[ql];
+    asm volatile("" : "+v"(mul_r[ni]), "+v"(thr_f[ni]), "+v"(sh_r[ni]));      // in registers from here on: the epilogue reuses the LDS
+  }
   G8Frag f0, f1;
 #pragma unroll
   for (int g = 0; g < 12; ++g) read_s8(f0, smem, g);
@@ -369,6 +371,12 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // the last matrix results are in the accumulators
   if (DUMP) { g8_dump_tile(p, acc, dt, qt, wm, wn, lane, mul_r); return; }
+  int thr_r[2];                // thresholds in accumulator units: a division per query, off the start-up path
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    asm volatile("" : "+v"(thr_f[ni]));
+    thr_r[ni] = g8_thr_units(thr_f[ni], mul_r[ni]);
+  }
 #if G8_ABL == 32      // timing only: no filter epilogue at all
   if (p.n_queries >= 0) { if (__float_as_int(acc[0][0][0]) == 0x7fffffff) p.cnt[0] = 1; return; }
 #endif

@@ -212,18 +212,9 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
   constexpr int WN = NWAVES / 2;             // waves along the queries
   constexpr int MAXP = NI == 4 ? 18 : 9;     // DMA pieces per wave and stage pair
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int64_t b = blockIdx.x;
-  const int xcd = (int)(b & 7);
-  const int64_t i = b >> 3;
-  const int per_group = DOC_GROUP * p.n_qtiles;
-  const int64_t g_local = i / per_group;
-  const int r = (int)(i - g_local * per_group);
-  const int qt = r / DOC_GROUP;
-  const int dl = r - qt * DOC_GROUP;
-  const int64_t seq = p.seq_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
-  if (seq >= p.seq_hi) return;
-  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head, p.perm_mul, p.perm_n);
-  if (dt >= p.n_tiles) return;
+  int64_t dt;
+  int qt;
+  if (!gemm_wg_tile(p, dt, qt)) return;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -292,22 +283,8 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = I8 ? I8_MAGIC : 0.f;
-  float thr_r[NI];                                // this lane's query thresholds for the filter epilogue, fetched now
-  float mul_r[NI];                                // I8: accumulator units -> score units of this lane's queries
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int q = qt * TILE_ROWS + wn * (32 * NI) + ni * 32 + (lane & 31);
-    thr_r[ni] = p.thr[q];
-    if constexpr (I8) {
-      // the accumulators run in units of mul (corpus scale x query scale) above I8_MAGIC; the roundings here and in the fp32
-      // accumulation on top of the 2^23-sized offset are paid by the filter margin (query_prep_kernel)
-      mul_r[ni] = p.i8_mul[q];
-      thr_r[ni] = fmaf(thr_r[ni], 1.f / mul_r[ni], I8_MAGIC);
-      asm volatile("" : "+v"(mul_r[ni]));
-    } else mul_r[ni] = 1.f;
-    asm volatile("" : "+v"(thr_r[ni]));
-  }
-
+  float thr_r[NI];                                // this lane's query thresholds for the filter epilogue and (I8) accumulator units ->
+  float mul_r[NI];                                // score units of its queries: read from the LDS behind the first barrier (prologue below)
   // Per-lane LDS offsets inside a ring slot.  All three images (corpus values, query values, dense columns of either side) have
   // 64-byte rows with the 16-byte chunk c stored at c ^ ((row>>2)&3); 16-slice / 16-column block kb is chunk kb*2 + fhalf.
   const int frow = lane & 31;
@@ -362,12 +339,32 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
     }
   };
 
+  // Prologue: ONE memory round trip before the first matrix instruction.  The per-query constants of the tile (thresholds; I8: units)
+  // travel as 1 KiB LDS-DMA pieces ahead of the first stage pair and are read from the LDS behind the first barrier -- until round 3
+  // they were per-lane global loads pinned by an empty asm, i.e. serialised L2 round trips in front of the first DMA piece.
+  if (wave < (I8 ? 2 : 1)) {
+    const char* src = wave == 0 ? (const char*)(p.thr + qt * TILE_ROWS) : (const char*)(p.i8_mul + qt * TILE_ROWS);
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + lane_off), LDS_PTR(smem + WX_META + wave * 1024), 16, 0, 0);
+  }
   issue_pair(0);
-  if (npairs > 1) {            // pair 0 landed; pair 1 (MAXP - MAXP/9 or MAXP pieces per wave) may stay in flight
+  if (npairs > 1) {            // the constants and pair 0 landed; pair 1 (MAXP - MAXP/9 or MAXP pieces per wave) may stay in flight
     issue_pair(1);
     if constexpr (NI == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int ql = wn * (32 * NI) + ni * 32 + (lane & 31);
+    thr_r[ni] = ((const float*)(smem + WX_META))[ql];
+    if constexpr (I8) {
+      // the accumulators run in units of mul (corpus scale x query scale) above I8_MAGIC; the roundings here and in the fp32
+      // accumulation on top of the 2^23-sized offset are paid by the filter margin (query_prep_kernel)
+      mul_r[ni] = ((const float*)(smem + WX_META + 1024))[ql];
+      thr_r[ni] = fmaf(thr_r[ni], 1.f / mul_r[ni], I8_MAGIC);
+      asm volatile("" : "+v"(mul_r[ni]));
+    } else mul_r[ni] = 1.f;
+    asm volatile("" : "+v"(thr_r[ni]));          // in registers from here on: the epilogue reuses the LDS
+  }
   WFrag<NI> f0, f1;
   if (nsp > 0 && sp_lo == 0) load_pw(pwx, 0);
   {

@@ -829,18 +829,9 @@ template <bool DUMP>
 __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_v3_kernel(GemmArgs p) {
   constexpr int ABL = 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int64_t b = blockIdx.x;
-  const int xcd = (int)(b & 7);
-  const int64_t i = b >> 3;
-  const int per_group = DOC_GROUP * p.n_qtiles;
-  const int64_t g_local = i / per_group;
-  const int r = (int)(i - g_local * per_group);
-  const int qt = r / DOC_GROUP;
-  const int dl = r - qt * DOC_GROUP;
-  const int64_t seq = p.seq_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
-  if (seq >= p.seq_hi) return;
-  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head, p.perm_mul, p.perm_n);
-  if (dt >= p.n_tiles) return;
+  int64_t dt;
+  int qt;
+  if (!gemm_wg_tile(p, dt, qt)) return;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -949,18 +940,9 @@ constexpr int GEMM_PC_LDS = GEMM_PC_SLOTS * SP_SLOT + 64;      // 136 KiB ring (
 template <bool DUMP, int ABL = 0>
 __global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int64_t b = blockIdx.x;
-  const int xcd = (int)(b & 7);
-  const int64_t i = b >> 3;
-  const int per_group = DOC_GROUP * p.n_qtiles;
-  const int64_t g_local = i / per_group;
-  const int r = (int)(i - g_local * per_group);
-  const int qt = r / DOC_GROUP;
-  const int dl = r - qt * DOC_GROUP;
-  const int64_t seq = p.seq_lo + (g_local * 8 + xcd) * DOC_GROUP + dl;
-  if (seq >= p.seq_hi) return;
-  const int64_t dt = seq_to_tile(seq, p.map_mode, p.period, p.head, p.perm_mul, p.perm_n);
-  if (dt >= p.n_tiles) return;
+  int64_t dt;
+  int qt;
+  if (!gemm_wg_tile(p, dt, qt)) return;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1170,18 +1152,34 @@ int g_gemm_variant = 5;   // DHR_PARAM_GEMM_VARIANT: 2:4 layout kernels 3 (12 wa
 
 // The bound GEMM + filter over the tiles [seq_lo, seq_hi) of the sequence: gemm_filter_sparse_kernel for the 2:4 layout
 // (a.ts > 0), gemm_filter_v3_kernel for the K-step tile layout (dense-only indexes, other bucket counts).
-hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
+static hipError_t launch_gemm_filter_grid(const GemmArgs& a, dim3 grid, hipStream_t s);
+hipError_t launch_gemm_filter(const GemmArgs& a_in, hipStream_t s) {
   static bool env_read = false;
   if (!env_read) {
     if (const char* e = getenv("DHR_GEMM_ABLATE")) g_gemm_ablate = atoi(e);
     if (const char* e = getenv("DHR_GEMM_VARIANT")) g_gemm_variant = atoi(e);     // tuning only (the torch-free PMC driver)
     env_read = true;
   }
-  const int64_t n_tiles = a.seq_hi - a.seq_lo;
+  const int64_t n_tiles = a_in.seq_hi - a_in.seq_lo;
   if (n_tiles <= 0) return hipSuccess;
   const int64_t groups = (n_tiles + DOC_GROUP - 1) / DOC_GROUP;
   const int64_t groups_per_xcd = (groups + 7) / 8;
-  const int64_t blocks = groups_per_xcd * 8 * DOC_GROUP * a.n_qtiles;
+  if ((int64_t)DOC_GROUP * a_in.n_qtiles > 65535 || a_in.perm_n >= (1 << 24) || a_in.period > (1 << 20)) return hipErrorInvalidValue;
+  GemmArgs a = a_in;
+  a.inv_perm_n = 1.0 / (double)(a.perm_n > 0 ? a.perm_n : 1);
+  a.inv_pm1 = 1.0 / (double)(a.period > 1 ? a.period - 1 : 1);
+  // grid = (XCD, corpus tile of the group x query tile, tile group of the XCD): gemm_wg_tile (dhr_internal.h); gridDim.z <= 65535, so a
+  // launch over more than 65535 x 32 corpus tiles (537 M rows) is cut into several
+  for (int64_t z0 = 0; z0 < groups_per_xcd; z0 += 65535) {
+    GemmArgs c = a;
+    c.seq_lo = a.seq_lo + z0 * 8 * DOC_GROUP;
+    const dim3 grid(8u, (unsigned)(DOC_GROUP * a.n_qtiles), (unsigned)std::min<int64_t>(65535, groups_per_xcd - z0));
+    const hipError_t e = launch_gemm_filter_grid(c, grid, s);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+static hipError_t launch_gemm_filter_grid(const GemmArgs& a, dim3 grid, hipStream_t s) {
   // per-device, under a lock: handles on different devices may be used from different host threads (dhr_hip.h)
   static std::mutex attr_mu;
   static bool attr_set_dev[64] = {};
@@ -1200,7 +1198,6 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const dim3 grid((unsigned)blocks);
   const int variant = a.variant ? a.variant : g_gemm_variant;        // per handle (dhr_index_set_param), else the library default
   if (a.g8_shift) return (a.ts > 0 && !(a.ts & 1) && !(a.td & 1) && a.ts_q == a.ts) ? launch_gemm_g8(a, grid, s) : hipErrorInvalidValue;
   if (a.i8_mul)      // int8 dense stages exist in the every-wave-computes kernels only (dhr_index_create enables them only where those run)
@@ -1468,8 +1465,12 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
       // added in fp64 -- bit-identical to the general path below at ~5 instead of ~8 vector instructions per element
       // (the kernel is VALU-bound on conversions and fp64 adds, not on the row gathers).
       for (int c = lane; c < nchunks; c += 64) {
-        const uint4 dv = *(const uint4*)(p.vals_rm + (int64_t)row * p.k_rm + c * 8);
         const uint4 qv = *(const uint4*)(p.q16 + (int64_t)q * p.k_rm + c * 8);
+        // a chunk of eight zero query values adds exactly nothing: its corpus bytes are not fetched.  The restricted batches of the
+        // two-stage modes (gip_retrieval.py:130-136: only the columns with q > theta) keep 4-12 of 1 536 columns -- their stage-1
+        // rescoring then reads ~5 % of a row instead of all of it
+        if (((qv.x | qv.y | qv.z | qv.w) & 0x7fff7fffu) == 0u) continue;
+        const uint4 dv = *(const uint4*)(p.vals_rm + (int64_t)row * p.k_rm + c * 8);
         uint32_t d[4] = {dv.x, dv.y, dv.z, dv.w};
         const uint32_t qq[4] = {qv.x, qv.y, qv.z, qv.w};
         if (c < dlr_chunks && p.gate) {
@@ -1488,10 +1489,11 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
       acc = wave_sum_f64(acc);
     } else if (valid) {
       for (int c = lane; c < nchunks; c += 64) {
-        const half8 dv = *(const half8*)(p.vals_rm + (int64_t)row * p.k_rm + c * 8);
         const float4 qa = *(const float4*)(q32 + c * 8);
         const float4 qb = *(const float4*)(q32 + c * 8 + 4);
         const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        if (qa.x == 0.f && qa.y == 0.f && qa.z == 0.f && qa.w == 0.f && qb.x == 0.f && qb.y == 0.f && qb.z == 0.f && qb.w == 0.f) continue;   // as above
+        const half8 dv = *(const half8*)(p.vals_rm + (int64_t)row * p.k_rm + c * 8);
         if (c < dlr_chunks && p.gate) {
           int ci[8];
           if (p.c_idx_dtype == DHR_IDX_I16) {

@@ -302,6 +302,10 @@ int dhr_debug_bound_scores(dhr_index* index, const dhr_query_batch* queries, int
  * U[q][row] >= exact score - margin[q] for every row, which is what lets the filter drop rows without losing a top-k row. */
 int dhr_debug_query_margins(dhr_index* index, const dhr_query_batch* queries, float* out_host, void* stream);
 
+/* Test hook (host code only, no device needed): the corpus tile that position `seq` of a bound-GEMM launch maps to, computed with
+ * the kernels' division-free arithmetic (out[0]) and with plain integer division (out[1]); the two must agree for every input. */
+void dhr_debug_seq_to_tile(int64_t seq, int32_t map_mode, int32_t period, int64_t head, int64_t perm_mul, int64_t perm_n, int64_t out[2]);
+
 /* Kernel-tuning hook: the bound GEMM alone over the whole shard with the filter closed; average
  * milliseconds per launch over `iters` launches and the flops one launch issues (padded sizes). */
 int dhr_debug_gemm_time(dhr_index* index, const dhr_query_batch* queries, int32_t iters, double* ms_out,

@@ -122,3 +122,33 @@ def test_file_info_struct_and_bad_files(tmp_path):
     assert lib.dhr_index_file_info(str(tmp_path / "missing").encode(), C.byref(info)) < 0
     h = C.c_void_p()
     assert lib.dhr_index_load(str(bad).encode(), 0, -1, C.byref(h)) < 0 and not h.value
+
+
+def test_division_free_tile_map_equals_integer_division():
+    """The bound-GEMM kernels map a launch position to a corpus tile with reciprocal multiplications (dhr_internal.h:
+    seq_to_tile_fast); the library's host build of the same function must agree with plain integer division for every
+    map mode, at the extremes of the operand range (tile counts below 2^24) and on random inputs."""
+    import math
+    import random
+    from dhr_amd import _lib
+    lib = _lib.load()
+    out = (C.c_int64 * 2)()
+    rng = random.Random(7)
+
+    def check(seq, mode, period, head, mul, n):
+        lib.dhr_debug_seq_to_tile(seq, mode, period, head, mul, n, out)
+        assert out[0] == out[1], (seq, mode, period, head, mul, n, out[0], out[1])
+    for n in (1, 2, 31, 64, 1000, 34275, 65521, (1 << 24) - 1, (1 << 24) - 3):
+        mul = int(0.6180339887 * n) | 1
+        while math.gcd(mul, n) != 1:
+            mul += 2
+        for period in (2, 3, 4, 8, 16, 32, 33, 64, 256):
+            seqs = {0, 1, n - 1, n // 2, max(0, n - 2)} | {rng.randrange(n) for _ in range(40)}
+            for seq in seqs:
+                for mode in (0, 1, 2, 3):
+                    check(seq, mode, period, rng.randrange(0, 9), mul, n)
+    # quotients that are exact multiples (the one place where a truncated estimate can come out one short)
+    for n in (31, 4096, 999983, (1 << 24) - 1):
+        for m in (0, 1, 2, 12345, n - 1):
+            check(m, 3, 32, 4, n - 1 if n > 2 else 1, n)      # (m * (n - 1)) % n
+            check(m * 31 % max(n, 1), 2, 32, 0, 1, n)

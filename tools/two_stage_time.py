@@ -27,16 +27,29 @@ def main():
             out = fn()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e3, out
+    from dhr_amd import _lib
+    ix.set_param(_lib.PARAM_PROFILE, 1)
+
+    def brief():
+        st = ix.stats()
+        return ("phases %d  gemm %.1f refine %.1f rescore %.1f select %.1f total %.1f ms  bound %.0f exact %.0f per query  redone %d  overflow retries %d"
+                % (st["phases"], st["gemm_ms"], st["refine_ms"], st["rescore_ms"], st["select_ms"], st["total_ms"], st["candidates_bound"] / nq,
+                   st["candidates_exact"] / nq, st["sample_fallback_queries"], st["overflow_retries"]))
     ms_b, (sb, rb) = timed(lambda: ix.search(q, qi, k, out_device=True))
     print("brute force (theta 0)          : %.1f ms per 6 980 queries" % ms_b)
+    print("   ", brief())
     for theta in (0.3, 0.1):
         q1 = torch.where(q > theta, q, torch.zeros_like(q))
-        ms, (s2, r2) = timed(lambda: ix.search_rerank(q1.cpu().numpy(), qi.cpu().numpy(), q.cpu().numpy(), qi.cpu().numpy(), k1, k))
+        ms, (s2, r2) = timed(lambda: ix.search_rerank(q1, qi, q, qi, k1, k))
         rec = np.mean([len(set(r2[i].tolist()) & set(rb[i].cpu().tolist())) / k for i in range(0, nq, 349)])
-        print("theta %.1f --rerank (agip 10000)  : %.1f ms incl. host copies of the batch, overlap with brute force top-1000: %.3f" % (theta, ms, rec))
-    ms, (s2, r2) = timed(lambda: ix.search_rerank(q.cpu().numpy(), None, q.cpu().numpy(), qi.cpu().numpy(), k1, k))
+        print("theta %.1f --rerank (agip 10000)  : %.1f ms (batches resident on the device, result lists copied to the host), overlap with brute force top-1000: %.3f" % (theta, ms, rec))
+        print("   ", brief())
+        nz = (q1 > 0).sum(1).float()
+        print("    non-zero stage-1 query columns: mean %.1f max %d; gated %.1f dense %.1f" % (nz.mean(), int(nz.max()), (q1[:, :768] > 0).sum(1).float().mean(), (q1[:, 768:] > 0).sum(1).float().mean()))
+    ms, (s2, r2) = timed(lambda: ix.search_rerank(q, None, q, qi, k1, k))
     rec = np.mean([len(set(r2[i].tolist()) & set(rb[i].cpu().tolist())) / k for i in range(0, nq, 349)])
     print("--IP --rerank (agip 10000)      : %.1f ms, overlap %.3f" % (ms, rec))
+    print("   ", brief())
     ix.close()
 
 
