@@ -655,12 +655,17 @@ static hipError_t re_malloc(T*& p, size_t bytes, int64_t& total) {
   return hipMalloc((void**)&p, bytes ? bytes : 16);
 }
 
-static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t keys_ld_min, int64_t cap_mult = 1) {
+// use_refine: the batch goes through the refine step (gated batch on an index with heavy lists).  An UNGATED batch on such an index
+// (plain inner product: --IP stage 1) rescores its bound lists directly, so they must not be deeper than the key buffer: it gets the
+// list depths of an index without heavy lists.  (Until round 3 it kept the 262 144-entry bound lists over a 32 768-entry key buffer:
+// a query with more than 32 768 bound candidates in one chunk wrote its keys over the next queries' -- found by the verification
+// failures of the --IP mode at full size, 62 of 6 980 queries per step.)
+static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t keys_ld_min, int64_t cap_mult = 1, bool use_refine = true) {
   const int q_pad = (int)round_up(n_queries, TILE_ROWS);
   int kp = 1;
   while (kp < k) kp <<= 1;
   if (kp < 64) kp = 64;
-  const bool refine = ix->heavy_key != nullptr;
+  const bool refine = ix->heavy_key != nullptr && use_refine;
   // default list depth: 262144 (refine) / 65536, but never more than ~32 GiB for the two bound-list sets of a big batch
   int64_t base_cap = refine ? 262144 : 65536;
   // ... sized by the SHARD: a list cannot hold more rows than the shard has, and the chunk planner of the main pass cuts the pass
@@ -677,9 +682,11 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   if (ix->cand_cap > 0) base_cap = ix->cand_cap;
   // fallback depths serve a handful of queries: 16x deeper lists there cost little memory
   const int64_t cap = std::min<int64_t>(base_cap * cap_mult, (int64_t)1 << 22);
-  const int64_t cap_r = refine ? std::min<int64_t>(cap, 32768 * cap_mult) : cap;
+  // survivor lists: 32 768 entries, and at least 4 x the padded k (agip_topk 10 000: a chunk of the main pass must be able to bring
+  // a hot query's share of its 10 000 best -- 12 queries per step overflowed 32 768 and were redone)
+  const int64_t cap_r = refine ? std::min<int64_t>(cap, std::max<int64_t>(32768, 4 * (int64_t)kp) * cap_mult) : cap;
   const int64_t keys_ld = std::max<int64_t>(cap_r, keys_ld_min);
-  if (w.q_pad == q_pad && w.kp == kp && w.cap == cap && w.keys_ld >= keys_ld && w.kt == ix->kt) return DHR_OK;
+  if (w.q_pad == q_pad && w.kp == kp && w.cap == cap && w.cap_r == cap_r && w.keys_ld >= keys_ld && w.kt == ix->kt) return DHR_OK;
   free_ws(w);
   int64_t tot = 0;
   HIP_TRY(re_malloc(w.q_tiles, (size_t)q_pad * ix->kt * 2, tot));
@@ -706,7 +713,7 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.fail_flags, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.thr_hat, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.blk_off, (size_t)2 * (q_pad + 1) * 4, tot));
-  if (ix->heavy_key) {
+  if (refine) {
     HIP_TRY(re_malloc(w.q_pack, (size_t)q_pad * ix->d_dlr * 4, tot));
     HIP_TRY(re_malloc(w.cand_r, (size_t)q_pad * cap_r * 8, tot));
     HIP_TRY(re_malloc(w.cnt_r, (size_t)q_pad * 4, tot));
@@ -771,7 +778,7 @@ static int prep_queries(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, 
   w.ts_q = sparse_query_stages(ix->ts, ix->d_dlr > 0 && qb->index, ix->gated_i8);
   G8Prep g8{};
   if (ix->gated_i8) { g8.inv_cs = ix->g8_inv_cs; g8.w = ix->g8_w; g8.s_ref = ix->g8_sref; g8.max_shift = ix->g8_max_shift; g8.q8 = w.g8_q8; g8.shift = w.g8_shift; g8.unit = w.g8_unit; }
-  HIP_TRY(hipMemsetAsync(w.q_inexact, 0, 4, s));
+  HIP_TRY(hipMemsetAsync(w.q_inexact, 0, 8, s));      // [0] some query is not fp16-representable, [1] some query has an all-zero chunk
   HIP_TRY(launch_query_prep(v, qb->value_dtype == DHR_VAL_F32, ldv, (ix->d_dlr > 0 && qb->index) ? qi : nullptr, qb->index_dtype, ldi,
                             qb->n_queries, w.q_pad, ix->d_dlr, ix->d_cls, ix->k_rm, ix->n_buckets, ix->kt, ix->bucket_map,
                             ix->abs_mode, ix->dmax, w.q_tiles, w.q32,
@@ -797,6 +804,9 @@ struct Timer {
 };
 enum { T_GEMM = 0, T_REFINE = 1, T_RESCORE = 2, T_SELECT = 3, T_PREP = 4 };
 
+// The refine step serves gated batches, and -- on gated_i8 indexes -- ungated ones too (--IP stage 1): there it takes the int8
+// products of a row's listed entries off the bound and puts their real products back, whatever the index values (RefineArgs::ungated).
+static inline bool uses_refine(const dhr_index* ix, bool gate) { return ix->heavy_key != nullptr && (gate || ix->gated_i8); }
 static RescoreArgs base_rescore_args(const dhr_index* ix, const Workspace& w, int n_queries, bool gate) {
   RescoreArgs r{};
   r.vals_rm = ix->vals_rm; r.c_idx = ix->c_idx; r.c_idx_dtype = ix->idx_dtype;
@@ -858,12 +868,12 @@ static int gemm_phase_async(dhr_index* ix, Workspace& w, int Q, int64_t lo, int6
 static int rescore_select_async(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, const uint2* cand, const uint32_t* cnt,
                                 const float* thr, Timer& tm, hipStream_t s) {
   uint32_t list_cap = (uint32_t)w.cap;
-  if (gate && ix->heavy_key) {
+  if (uses_refine(ix, gate)) {
     RefineArgs f{};
     f.cand = cand; f.cnt = cnt; f.cap = (uint32_t)w.cap; f.heavy_key = ix->heavy_key; f.heavy_val = ix->heavy_val;
     f.q_pack = w.q_pack; f.d_dlr = ix->d_dlr; f.thr = thr; f.out = w.cand_r; f.out_cnt = w.cnt_r; f.out_cap = (uint32_t)w.cap_r;
     f.n_queries = Q; f.max_count = 1;
-    if (ix->gated_i8) { f.g8_q8 = w.g8_q8; f.g8_inv_cs = ix->g8_inv_cs; f.g8_unit = w.g8_unit; f.abs_mode = ix->abs_mode ? 1 : 0; }
+    if (ix->gated_i8) { f.g8_q8 = w.g8_q8; f.g8_inv_cs = ix->g8_inv_cs; f.g8_unit = w.g8_unit; f.abs_mode = ix->abs_mode ? 1 : 0; f.ungated = gate ? 0 : 1; }
     HIP_TRY(launch_block_offsets(cnt, (uint32_t)w.cap, Q, 256, w.blk_off, s));
     f.blk_off = w.blk_off; f.flat_blocks = async_grid();
     HIP_TRY(hipMemsetAsync(w.cnt_r, 0, (size_t)w.q_pad * 4, s));
@@ -893,12 +903,12 @@ static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectA
   if (maxr == 0) return DHR_OK;
   int64_t exact = bound_sum;
   uint32_t list_cap = (uint32_t)w.cap;
-  if (gate && ix->heavy_key) {
+  if (uses_refine(ix, gate)) {
     RefineArgs f{};
     f.cand = cand; f.cnt = cnt; f.cap = (uint32_t)w.cap; f.heavy_key = ix->heavy_key; f.heavy_val = ix->heavy_val;
     f.q_pack = w.q_pack; f.d_dlr = ix->d_dlr; f.thr = thr; f.out = w.cand_r; f.out_cnt = w.cnt_r; f.out_cap = (uint32_t)w.cap_r;
     f.n_queries = Q; f.max_count = maxr;
-    if (ix->gated_i8) { f.g8_q8 = w.g8_q8; f.g8_inv_cs = ix->g8_inv_cs; f.g8_unit = w.g8_unit; f.abs_mode = ix->abs_mode ? 1 : 0; }
+    if (ix->gated_i8) { f.g8_q8 = w.g8_q8; f.g8_inv_cs = ix->g8_inv_cs; f.g8_unit = w.g8_unit; f.abs_mode = ix->abs_mode ? 1 : 0; f.ungated = gate ? 0 : 1; }
     // flat launch: one workgroup per REAL block of 256 candidates (bound_sum / 256 + Q is an upper bound of their number)
     HIP_TRY(launch_block_offsets(cnt, (uint32_t)w.cap, Q, 256, w.blk_off, s));
     f.blk_off = w.blk_off; f.flat_blocks = (uint32_t)std::min<int64_t>(bound_sum / 256 + Q, (int64_t)0x7fffffff);
@@ -973,7 +983,7 @@ static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectAr
       continue;
     }
     if (rc != DHR_OK) return rc < 0 ? rc : set_error(DHR_ERR_INTERNAL, "survivor list overflow at the minimum chunk size");
-    if (last_rate_r) *last_rate_r = (gate && ix->heavy_key && maxc > 0) ? (double)w.last_maxr / (double)chunk_rows : 0.0;   // fullest SURVIVOR list per corpus row
+    if (last_rate_r) *last_rate_r = (uses_refine(ix, gate) && maxc > 0) ? (double)w.last_maxr / (double)chunk_rows : 0.0;   // fullest SURVIVOR list per corpus row
     pos = hi;
     seen_rows += chunk_rows;
     // next chunk: aim at cap/4 candidates for the fullest query, never more than growth * rows seen
@@ -1038,7 +1048,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   int64_t first = ix->first_rows > 0 ? std::max<int64_t>(ix->first_rows, 2 * (int64_t)r_eff) : std::max<int64_t>(S >= 2 ? 256 : 512, 2 * (int64_t)r_eff);
   first = std::min(round_up(first, TILE_ROWS), round_up(n, TILE_ROWS));
   const int64_t first_valid = std::min(first, n);
-  if ((rc = ensure_ws(ix, w, Q, k, first_valid, depth == 0 ? 1 : 16)) != DHR_OK) return rc;
+  if ((rc = ensure_ws(ix, w, Q, k, first_valid, depth == 0 ? 1 : 16, gate || ix->gated_i8)) != DHR_OK) return rc;
 
   // first attempt of a sampled search: the controller only enqueues (no host read-backs); DHR_ASYNC=0 / DHR_PARAM_ASYNC_CONTROLLER 0 keep the
   // host-driven controller (and the fallback depths always use it: it is the one that is exact for any input)

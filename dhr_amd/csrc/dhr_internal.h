@@ -266,6 +266,7 @@ struct RefineArgs {
   const float* g8_inv_cs;                                    // [d_dlr] 1 / step of gated column j (the tile builder's factor)
   const float* g8_unit;                                      // [Q_pad] score units of one gated operand product
   int abs_mode;
+  int ungated;                                               // gated_i8, plain inner product batch: every listed entry counts in both directions (no bucket / index test)
 };
 hipError_t launch_refine(const RefineArgs& a, hipStream_t s);
 hipError_t launch_rescore(const RescoreArgs& a, hipStream_t s);

@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
   auto qidx = [&](int j) -> int { return (real && idx) ? load_idx(idx, idx_dtype, (int64_t)q * ld_idx + j) : 0; };
   // exact fp32 copy (row-major, what the rescoring multiplies with) + norms of q16 and of the fp16 residual
   float s16 = 0.f, sr = 0.f;
-  bool inexact = false;
+  bool inexact = false, zero_chunk = false;
   for (int j = lane; j < k_rm; j += 64) {
     const float v = qval(j);
     q32[(int64_t)q * k_rm + j] = v;
@@ -466,6 +466,12 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
     s16 += back * back;
     sr += (v - back) * (v - back);
     inexact |= (back != v) && (v == v);
+    {   // a chunk of eight zero columns (8 consecutive lanes): the rescoring kernel then builds per-query chunk masks (q_inexact[1])
+      const uint64_t nzb = __ballot(v != 0.f);
+      const int c0 = (j - lane) >> 3;
+      for (int g = 0; g < 8; ++g)
+        if ((c0 + g) * 8 < k && ((nzb >> (8 * g)) & 0xFFull) == 0ull) zero_chunk = true;
+    }
     if (q16) {
       // fast rescoring path: a gated value whose index no corpus byte can equal contributes nothing -> store 0
       bool dead = false;
@@ -477,6 +483,7 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
     }
   }
   if (inexact && q_inexact) atomicOr(q_inexact, 1u);
+  if (zero_chunk && real && q_inexact && lane == 0) atomicOr(q_inexact + 1, 1u);
   if (q_idx8)
     for (int j = lane; j < d_dlr; j += 64) q_idx8[(int64_t)q * d_dlr + j] = (uint8_t)(qidx(j) & 0xFF);
   for (int j = lane; j < d_dlr; j += 64) {
@@ -1369,8 +1376,8 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
         if (key != 0xFFFFFFFFu) {
           const uint32_t j = key >> 20;
           const uint32_t w = qw[j];
-          const bool same_bucket = ((w >> 12) & 0xFu) == ((key >> 16) & 0xFu);
-          const bool mismatch = (w & 0xFFFu) != (key & 0xFFFu);
+          const bool same_bucket = (G8 && p.ungated) || ((w >> 12) & 0xFu) == ((key >> 16) & 0xFu);
+          const bool mismatch = !(G8 && p.ungated) && (w & 0xFFFu) != (key & 0xFFFu);
           union { uint16_t u; _Float16 h; } qv; qv.u = (uint16_t)(w >> 16);
           if constexpr (G8) {
             if (same_bucket) {
@@ -1453,6 +1460,74 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
   const int nchunks = p.k_rm >> 3;
   const int dlr_chunks = p.d_dlr >> 3;
   const bool fast = p.q16 && *p.q_inexact == 0u && (!p.gate || p.d_dlr == 0 || p.c_idx_dtype == DHR_IDX_U8 || p.c_idx_dtype == DHR_IDX_I8);
+  // Which of this lane's chunks (c = lane + 64 t, bit t) hold a non-zero query value: computed once per block, BEFORE the candidate
+  // loop, so that the skip below does not put a query load in front of every corpus load.  The restricted batches of the two-stage
+  // modes (gip_retrieval.py:130-136: only the columns with q > theta) keep 4-12 of 1 536 columns.
+  // (only for batches in which SOME query has an all-zero chunk -- q_inexact[1], set by query_prep_kernel: an ordinary batch pays nothing)
+  const bool some_zero = p.q_inexact && p.q_inexact[1] != 0u;
+  uint32_t nz_mask = some_zero ? 0u : 0xFFFFFFFFu;
+  for (int c = lane, t = 0; some_zero && c < nchunks; c += 64, ++t) {
+    const float4 qa = *(const float4*)(q32 + c * 8);
+    const float4 qb = *(const float4*)(q32 + c * 8 + 4);
+    if (qa.x != 0.f || qa.y != 0.f || qa.z != 0.f || qa.w != 0.f || qb.x != 0.f || qb.y != 0.f || qb.z != 0.f || qb.w != 0.f) nz_mask |= 1u << t;
+  }
+  // Sparse queries (at most 8 non-zero chunks in the whole query: stage 1 of --theta 0.3 --rerank keeps 4-12 columns): a wave per
+  // pair would run 1-8 of its 64 lanes and still pay a full memory round trip per pair.  Instead 8 lanes per pair, 8 pairs per wave:
+  // lane (pair slot ci, s) owns the s-th non-zero chunk.  Same products, fp64 sums over at most 64 terms (the zero chunks the dense
+  // path adds are exact zeros).
+  if (fast && some_zero) {
+    int nzc[8];
+    int m = 0;
+    for (int c0 = 0, t = 0; c0 < nchunks && m <= 8; c0 += 64, ++t) {
+      uint64_t b = __ballot((nz_mask >> t) & 1u);
+      while (b && m <= 8) { if (m < 8) nzc[m] = c0 + (__ffsll((unsigned long long)b) - 1); ++m; b &= b - 1; }
+    }
+    if (m <= 8) {
+      const int ci = lane >> 3, sl = lane & 7;
+      int myc = -1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (e < m && sl == e) myc = nzc[e];
+      uint4 qv = make_uint4(0u, 0u, 0u, 0u);
+      uint2 qi8 = make_uint2(0u, 0u);
+      const bool gated_chunk = myc >= 0 && myc < dlr_chunks && p.gate;
+      if (myc >= 0) qv = *(const uint4*)(p.q16 + (int64_t)q * p.k_rm + myc * 8);
+      if (gated_chunk) qi8 = *(const uint2*)(p.q_idx8 + (int64_t)q * p.d_dlr + myc * 8);
+      const uint32_t i = base + wave * 8 + ci;
+      static_assert(RESCORE_CANDS_PER_WG == 32, "4 waves x 8 pairs");
+      const bool live = i < count;
+      uint32_t row = 0u;
+      if (live) {
+        if (p.cand) row = p.cand[(int64_t)q * p.cap + i].x;
+        else if (p.rows32) row = p.rows32[(int64_t)q * p.ld_rows + i];
+        else row = (uint32_t)(p.row0 + i);
+      }
+      const bool valid = live && (int64_t)row < p.n_rows;
+      double acc = 0.0;
+      if (valid && myc >= 0) {
+        const uint4 dv = *(const uint4*)(p.vals_rm + (int64_t)row * p.k_rm + myc * 8);
+        uint32_t d[4] = {dv.x, dv.y, dv.z, dv.w};
+        const uint32_t qq[4] = {qv.x, qv.y, qv.z, qv.w};
+        if (gated_chunk) {
+          const uint2 cix = *(const uint2*)((const uint8_t*)p.c_idx + (int64_t)row * p.d_dlr + myc * 8);
+          const uint32_t x0 = cix.x ^ qi8.x, x1 = cix.y ^ qi8.y;
+          d[0] &= pair_mask(x0, 0x0c010c00u); d[1] &= pair_mask(x0, 0x0c030c02u);
+          d[2] &= pair_mask(x1, 0x0c010c00u); d[3] &= pair_mask(x1, 0x0c030c02u);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc += (double)fmix_lo(d[e], qq[e]);
+          acc += (double)fmix_hi(d[e], qq[e]);
+        }
+      }
+      acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+      if (sl == 0 && live) {
+        const float sc = valid ? (float)acc : -INFINITY;
+        if (p.out_keys) p.out_keys[(int64_t)q * p.ld_keys + i] = valid ? make_key(sc, row) : 0ull;
+        if (p.out_scores && q < p.n_queries) p.out_scores[(int64_t)q * p.ld_scores + i] = sc;
+      }
+      return;
+    }
+  }
   for (uint32_t i = base + wave; i < base + RESCORE_CANDS_PER_WG && i < count; i += 4) {
     uint32_t row;
     if (p.cand) row = p.cand[(int64_t)q * p.cap + i].x;
@@ -1465,12 +1540,9 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
       // added in fp64 -- bit-identical to the general path below at ~5 instead of ~8 vector instructions per element
       // (the kernel is VALU-bound on conversions and fp64 adds, not on the row gathers).
       for (int c = lane; c < nchunks; c += 64) {
-        const uint4 qv = *(const uint4*)(p.q16 + (int64_t)q * p.k_rm + c * 8);
-        // a chunk of eight zero query values adds exactly nothing: its corpus bytes are not fetched.  The restricted batches of the
-        // two-stage modes (gip_retrieval.py:130-136: only the columns with q > theta) keep 4-12 of 1 536 columns -- their stage-1
-        // rescoring then reads ~5 % of a row instead of all of it
-        if (((qv.x | qv.y | qv.z | qv.w) & 0x7fff7fffu) == 0u) continue;
+        if (!((nz_mask >> (c >> 6)) & 1u)) continue;      // eight zero query values add exactly nothing: the corpus bytes are not fetched
         const uint4 dv = *(const uint4*)(p.vals_rm + (int64_t)row * p.k_rm + c * 8);
+        const uint4 qv = *(const uint4*)(p.q16 + (int64_t)q * p.k_rm + c * 8);
         uint32_t d[4] = {dv.x, dv.y, dv.z, dv.w};
         const uint32_t qq[4] = {qv.x, qv.y, qv.z, qv.w};
         if (c < dlr_chunks && p.gate) {
@@ -1489,11 +1561,11 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
       acc = wave_sum_f64(acc);
     } else if (valid) {
       for (int c = lane; c < nchunks; c += 64) {
+        if (!((nz_mask >> (c >> 6)) & 1u)) continue;
+        const half8 dv = *(const half8*)(p.vals_rm + (int64_t)row * p.k_rm + c * 8);
         const float4 qa = *(const float4*)(q32 + c * 8);
         const float4 qb = *(const float4*)(q32 + c * 8 + 4);
         const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-        if (qa.x == 0.f && qa.y == 0.f && qa.z == 0.f && qa.w == 0.f && qb.x == 0.f && qb.y == 0.f && qb.z == 0.f && qb.w == 0.f) continue;   // as above
-        const half8 dv = *(const half8*)(p.vals_rm + (int64_t)row * p.k_rm + c * 8);
         if (c < dlr_chunks && p.gate) {
           int ci[8];
           if (p.c_idx_dtype == DHR_IDX_I16) {
@@ -1531,7 +1603,7 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
 }
 // Flat launches walk the block list with a grid stride: the grid is the exact block count when the host knows it, and a fixed one when the
 // controller runs without host read-backs (the list lengths then exist in device memory only).
-__global__ void __launch_bounds__(256) rescore_kernel(RescoreArgs p) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) rescore_kernel(RescoreArgs p) {
   if (!p.blk_off) { rescore_block(p, (int)blockIdx.y, blockIdx.x); return; }
   for (uint32_t b = blockIdx.x;; b += gridDim.x) {
     int q; uint32_t blk;

@@ -50,7 +50,8 @@ namespace {
 
 constexpr int ADC_CAP = 32768;          // candidate list depth per query
 constexpr int ADC_Q_CHUNK = 1024;       // queries per pass over the codes (bounds the workspace: 0.77 GB)
-constexpr int ADC_ROWS_PER_WG = 8192;
+constexpr int ADC_THREADS = 1024;        // 16 waves share one pair's tables: with 256 threads the 128 KiB of LDS left ONE wave per SIMD to hide the gather latency (0.27 of the HBM rate)
+constexpr int ADC_ROWS_PER_WG = 32768;
 
 #define PQ_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return dhr_set_error_message(DHR_ERR_HIP, (std::string(#x) + ": " + hipGetErrorString(e_)).c_str()); } while (0)
 
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(256) adc_lut_kernel(const float* __restrict__ 
 }
 // grid (query pairs, row blocks): consecutive workgroups share the row block (L2), each with another pair's tables.
 // thr == nullptr: dump mode (scores of rows [row_lo, row_hi) to out[q][row - row_lo]).
-__global__ void __launch_bounds__(256) adc_scan_kernel(const uint8_t* __restrict__ codes, int M, int ksub, int64_t row_lo, int64_t row_hi,
+__global__ void __launch_bounds__(ADC_THREADS) adc_scan_kernel(const uint8_t* __restrict__ codes, int M, int ksub, int64_t row_lo, int64_t row_hi,
                                                        const float* __restrict__ lut, int n_queries, const float* __restrict__ thr,
                                                        uint2* __restrict__ cand, uint32_t* __restrict__ cnt, uint32_t cap,
                                                        float* __restrict__ dump, int64_t dump_ld) {
@@ -87,14 +88,14 @@ __global__ void __launch_bounds__(256) adc_scan_kernel(const uint8_t* __restrict
   const int pair = blockIdx.x;
   const int64_t per_q = (int64_t)M * ksub;
   const float4* src = (const float4*)(lut + (int64_t)pair * per_q * 2);
-  for (int i = threadIdx.x; i < per_q / 2; i += 256) ((float4*)t)[i] = src[i];
+  for (int i = threadIdx.x; i < per_q / 2; i += ADC_THREADS) ((float4*)t)[i] = src[i];
   __syncthreads();
   const int q0 = 2 * pair, q1 = q0 + 1;
   const bool has1 = q1 < n_queries;
   const float t0 = thr ? thr[q0] : 0.f, t1 = (thr && has1) ? thr[q1] : 0.f;
   const int64_t b_lo = row_lo + (int64_t)blockIdx.y * ADC_ROWS_PER_WG;
   const int64_t b_hi = b_lo + ADC_ROWS_PER_WG < row_hi ? b_lo + ADC_ROWS_PER_WG : row_hi;
-  for (int64_t row = b_lo + threadIdx.x; row < b_hi; row += 256) {
+  for (int64_t row = b_lo + threadIdx.x; row < b_hi; row += ADC_THREADS) {
     const uint8_t* c = codes + row * M;
     const bool vec16 = (M & 15) == 0;
     float a0 = 0.f, a1 = 0.f;
@@ -197,7 +198,7 @@ int scan(dhr_pq* pq, int nq, int64_t lo, int64_t hi, bool filter, float* dump, i
     if (lds > attr_dev[dev & 63]) { PQ_HIP(hipFuncSetAttribute((const void*)adc_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr_dev[dev & 63] = lds; }
   }
   const unsigned blocks = (unsigned)((hi - lo + ADC_ROWS_PER_WG - 1) / ADC_ROWS_PER_WG);
-  hipLaunchKernelGGL(adc_scan_kernel, dim3((unsigned)((nq + 1) / 2), blocks), dim3(256), lds, s, pq->codes, pq->M, pq->ksub, lo, hi, pq->lut, nq,
+  hipLaunchKernelGGL(adc_scan_kernel, dim3((unsigned)((nq + 1) / 2), blocks), dim3(ADC_THREADS), lds, s, pq->codes, pq->M, pq->ksub, lo, hi, pq->lut, nq,
                      filter ? pq->thr : nullptr, pq->cand, pq->cnt, (uint32_t)ADC_CAP, dump, dump_ld);
   PQ_HIP(hipGetLastError());
   return DHR_OK;

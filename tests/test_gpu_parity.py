@@ -1649,3 +1649,29 @@ def test_zero_score_ties_under_sampling(G):
         order = np.lexsort((np.arange(n), -ex))[:k]
         np.testing.assert_array_equal(r[i], order)
         np.testing.assert_array_equal(s[i], ex[order].astype(np.float32))
+
+
+def test_ungated_batch_deep_candidate_lists(G):
+    """Plain inner product (--IP stage 1: a batch without an index array) on a GATED index whose rows all score nearly alike, so that
+    the filter passes almost every row: one main-pass chunk brings a query far more than 32 768 candidates.  Until round 3 such a
+    batch kept the refine-depth bound lists over the shallower key buffer, and a long list overwrote the neighbouring queries' keys
+    (found at full size: 62 of 6 980 --IP queries failed their verification per step).  Exact inner products from the oracle."""
+    rng = np.random.default_rng(77)
+    n, nq, d_dlr, d_cls, k = 150_000, 6, 64, 64, 500
+    base = np.abs(rng.normal(0, 1, (1, d_dlr + d_cls))).astype(np.float32)
+    cv = (base + rng.normal(0, 2e-3, (n, d_dlr + d_cls)).astype(np.float32))
+    cv[:, :d_dlr] = np.abs(cv[:, :d_dlr])
+    cv = cv.astype(np.float16)
+    ci = rng.integers(0, 39, (n, d_dlr)).astype(np.uint8)
+    q = np.abs(rng.normal(0, 1, (nq, d_dlr + d_cls))).astype(np.float16).astype(np.float32)
+    ix = G.GipIndex(cv, ci)
+    try:
+        sc, rows = ix.search(q, None, k)
+        st = ix.stats()
+        assert st["candidates_bound"] / nq > 40_000, st          # the lists really were deep
+        c64 = cv.astype(np.float64)
+        for i in range(nq):
+            ex = c64 @ q[i].astype(np.float64)
+            O.check_topk(rows[i], sc[i], ex, k)
+    finally:
+        ix.close()
