@@ -128,7 +128,7 @@ struct dhr_index {
   int n_cu = 256;
   int gemm_variant = 0;                    // 2:4 layout kernel of THIS handle (0 = library default)
   int overlap_aux = -1;                    // 0: refine / rescoring / select run on the GEMM's stream (every kernel gets the whole chip); 1: beside the next chunk's GEMM on a CU-masked stream; -1 (default) = 1 for dense-only indexes (110.4 -> 101.7 ms per step at config 2), 0 for gated ones (the same step time, 192.7 vs 193.0 ms, but the overlapped GEMM launches run 7 % longer)
-  int aux_cus = 128, gemm_exclusive = 0;   // CU-masked streams of the main pass (0 = off)
+  int aux_cus = -1, gemm_exclusive = 0;    // CU-masked streams of the main pass (0 = no mask; -1 = default: 128 CUs for dense-only indexes, no mask for gated ones)
   int aux_cus_made = -1, gemm_excl_made = -1;
   hipStream_t s_gemm = nullptr;         // main-pass GEMM stream when CU masks are in use
   hipStream_t s_aux = nullptr;          // non-blocking stream for rescoring/select overlapped with the main-pass GEMM
@@ -166,7 +166,7 @@ extern "C" void dhr_index_destroy(dhr_index* ix) {
   free_ws(ix->ws_fb[1]);
   if (ix->s_aux) hipStreamDestroy(ix->s_aux);
   if (ix->s_gemm) hipStreamDestroy(ix->s_gemm);
-  hipFree(ix->i8_col_scale); hipFree(ix->g8_inv_cs); hipFree(ix->g8_w); hipFree(ix->g8_rsum); hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map); hipFree(ix->heavy_key); hipFree(ix->heavy_val);
+  hipFree(ix->i8_col_scale); hipFree(ix->g8_inv_cs); hipFree(ix->g8_w); hipFree(ix->g8_rsum); hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map); hipFree(ix->heavy_key);      // (heavy_val points into the heavy_key records)
   delete ix;
 }
 
@@ -500,10 +500,11 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
   // pass 2: operand tiles
   if ((rc = build_tiles(ix, s)) != DHR_OK) return fail(rc);
   if (has_idx && d->d_dlr <= 4096) {
-    const size_t hkb = (size_t)d->n_rows * HEAVY * 4, hvb = (size_t)d->n_rows * HEAVY * 2;
-    if (hipMalloc((void**)&ix->heavy_key, hkb) != hipSuccess || hipMalloc((void**)&ix->heavy_val, hvb) != hipSuccess)
+    const size_t hb = (size_t)d->n_rows * HEAVY_KEY_STRIDE * 4;       // one 384-byte record per row: 64 keys, then 64 values
+    if (hipMalloc((void**)&ix->heavy_key, hb) != hipSuccess)
       return fail(set_error(DHR_ERR_HIP, "hipMalloc of the refine lists failed"));
-    ix->index_bytes += (int64_t)(hkb + hvb);
+    ix->heavy_val = (__half*)((char*)ix->heavy_key + HEAVY * 4);
+    ix->index_bytes += (int64_t)hb;
     if (launch_heavy_build(ix->vals_rm, ix->k_rm, ix->c_idx, ix->idx_dtype, d->n_rows, d->d_dlr, ix->bucket_map, ix->n_buckets,
                            ix->heavy_key, ix->heavy_val, s) != hipSuccess)
       return fail(set_error(DHR_ERR_HIP, "heavy_build launch failed"));
@@ -1134,14 +1135,17 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     // non-blocking aux stream.  With aux_cus = N the aux stream is confined to N CUs (the low N bits of the CU
     // mask are spread evenly over the 8 XCDs) so that the memory-bound aux kernels take only the CUs they need
     // from the GEMM; gemm_exclusive additionally keeps the GEMM (on an internal stream) off those CUs.
-    if (ix->aux_cus_made != ix->aux_cus || ix->gemm_excl_made != ix->gemm_exclusive) {
+    // (measured on a 1/8 shard of config 4, round 3: unmasked 17.0 ms per finish, 128 CUs 18.2, no overlap 18.1; dense-only indexes
+    // measured best with 128 CUs in round 1)
+    const int aux_cus = ix->aux_cus >= 0 ? ix->aux_cus : (ix->d_dlr == 0 ? 128 : 0);
+    if (ix->aux_cus_made != aux_cus || ix->gemm_excl_made != ix->gemm_exclusive) {
       if (ix->s_aux) { hipStreamDestroy(ix->s_aux); ix->s_aux = nullptr; }
       if (ix->s_gemm) { hipStreamDestroy(ix->s_gemm); ix->s_gemm = nullptr; }
-      if (ix->aux_cus > 0) {
+      if (aux_cus > 0) {
         uint32_t m_aux[8], m_gemm[8];
         for (int i = 0; i < 8; ++i) {
           const int lo = i * 32;
-          const int n = std::max(0, std::min(32, ix->aux_cus - lo));
+          const int n = std::max(0, std::min(32, aux_cus - lo));
           m_aux[i] = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
           m_gemm[i] = ix->gemm_exclusive ? ~m_aux[i] : 0xffffffffu;
         }
@@ -1154,10 +1158,13 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
         }
       }
       if (!ix->s_aux) HIP_TRY(hipStreamCreateWithFlags(&ix->s_aux, hipStreamNonBlocking));
-      ix->aux_cus_made = ix->aux_cus; ix->gemm_excl_made = ix->gemm_exclusive;
+      ix->aux_cus_made = aux_cus; ix->gemm_excl_made = ix->gemm_exclusive;
     }
     hipStream_t sg = ix->s_gemm ? ix->s_gemm : s;
-    const bool overlap = ix->overlap_aux < 0 ? ix->d_dlr == 0 : ix->overlap_aux != 0;
+    // default: dense-only indexes, and the main pass of a SHARD (staged search: its refine / rescoring / select are a larger share of a
+    // shorter step -- 18.1 -> 17.0 ms per finish on a 1/8 shard of config 4; the unsharded gated search gains 2 % and its GEMM launches
+    // would be timed under contention, so it keeps them serial)
+    const bool overlap = ix->overlap_aux < 0 ? (ix->d_dlr == 0 || stage == 2) : ix->overlap_aux != 0;
     hipStream_t sb = overlap ? ix->s_aux : sg;
     hipEvent_t ev_enter = nullptr;
     if (sg != s) {

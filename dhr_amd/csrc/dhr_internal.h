@@ -42,6 +42,10 @@ constexpr int SP_SLOT = SP_STAGE_A + SP_STAGE_B;   // LDS ring slot (34 KiB): co
 constexpr int S8_A_BYTES = 8192;
 constexpr int S8_STAGE_A = S8_A_BYTES + 2048;
 constexpr int HEAVY = 64;               // per-row list of the largest gated values used by the refine step
+// ... stored as ONE 384-byte record per row: 64 u32 keys, then 64 fp16 values (a candidate's refine read is one contiguous segment
+// instead of a 256-byte and a 128-byte one in two arrays): heavy_key = record base, heavy_val = base + 256 bytes
+constexpr int HEAVY_KEY_STRIDE = 96;    // u32 per record
+constexpr int HEAVY_VAL_STRIDE = 192;   // fp16 per record
 constexpr int DOC_GROUP = 4;                               // doc tiles that share one XCD sweep
 
 __host__ __device__ inline int64_t tiled_chunk_offset(int64_t row, int chunk, int ksteps) {

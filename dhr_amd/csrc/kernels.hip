@@ -1301,15 +1301,15 @@ __global__ void __launch_bounds__(256) heavy_build_kernel(const __half* __restri
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { const uint32_t ob = __shfl_xor(best, o, 64); best = ob > best ? ob : best; }
       if (best == 0u) {                       // fewer than HEAVY non-zero entries: pad
-        if (lane == 0) for (int rr = r; rr < HEAVY; ++rr) { heavy_key[row * HEAVY + rr] = 0xFFFFFFFFu; heavy_val[row * HEAVY + rr] = __float2half(0.f); }
+        if (lane == 0) for (int rr = r; rr < HEAVY; ++rr) { heavy_key[row * HEAVY_KEY_STRIDE + rr] = 0xFFFFFFFFu; heavy_val[row * HEAVY_VAL_STRIDE + rr] = __float2half(0.f); }
         break;
       }
       const int j = MAXJ - (int)(best & 0xFFFFu);
       if ((j & 63) == lane) {                 // owner lane writes the entry and retires it
         const int iv = load_idx(idx, idx_dtype, row * d_dlr + j);
         const uint32_t bk = n_buckets > 1 ? (uint32_t)bucket_of(iv, j, map, n_buckets) : 0u;
-        heavy_key[row * HEAVY + r] = ((uint32_t)j << 20) | (bk << 16) | ((uint32_t)iv & 0xFFFFu);
-        heavy_val[row * HEAVY + r] = vals_rm[row * k_rm + j];
+        heavy_key[row * HEAVY_KEY_STRIDE + r] = ((uint32_t)j << 20) | (bk << 16) | ((uint32_t)iv & 0xFFFFu);
+        heavy_val[row * HEAVY_VAL_STRIDE + r] = vals_rm[row * k_rm + j];
 #pragma unroll
         for (int sl = 0; sl < SL; ++sl) if (sl == (j >> 6)) key[sl] = 0u;
       }
@@ -1366,9 +1366,9 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
     uint2 c = make_uint2(0u, 0u);
     if (i < count) {
       c = p.cand[(int64_t)q * p.cap + i];
-      const uint32_t* hk = p.heavy_key + (int64_t)c.x * HEAVY + sub * 8;
+      const uint32_t* hk = p.heavy_key + (int64_t)c.x * HEAVY_KEY_STRIDE + sub * 8;
       const uint4 k0 = *(const uint4*)hk, k1 = *(const uint4*)(hk + 4);
-      const half8 hv = *(const half8*)(p.heavy_val + (int64_t)c.x * HEAVY + sub * 8);
+      const half8 hv = *(const half8*)(p.heavy_val + (int64_t)c.x * HEAVY_VAL_STRIDE + sub * 8);
       const uint32_t keys[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) {

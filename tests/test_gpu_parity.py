@@ -1675,3 +1675,50 @@ def test_ungated_batch_deep_candidate_lists(G):
             O.check_topk(rows[i], sc[i], ex, k)
     finally:
         ix.close()
+
+
+def test_pq_first_stage_beir_size(G):
+    """Config 5's quantised-index leg at a BEIR corpus size (quora: 522 931 rows, 768 + 128; parity with faiss UNPINNED): the ADC scan
+    over resident codes against the library's own raw ADC scores on the whole corpus (the scan's top-k must be the exact top-k of
+    those table sums), a slice of the raw scores against the oracle's table sums, and recall of the reranked result against the
+    exact search -- properties that do not depend on the corpus size."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    from dhr_amd import synth
+    from dhr_amd.retrieval import quantize_index as QI
+    from oracle import pq_oracle as PO
+    dev = torch.device("cuda", 0)
+    n, nq, k1, k = 522_931, 512, 10_000, 100
+    cv, ci = bench.gen_rows(torch, synth, dev, 4242, 0, n, 768, 128, 30, 90, False)
+    qv, qi = bench.gen_rows(torch, synth, dev, 4242 + 999_983, 0, nq, 768, 128, 4, 12, False)
+    cb, codes, err = QI.train_and_encode(cv, 64, 8, iters=4)
+    pix = QI.PqIndex(cb, codes)
+    ix = G.GipIndex(cv, ci)
+    try:
+        q = qv.float()
+        s1, r1 = pix.search(q, k1, out_device=True)
+        assert pix.device_bytes() < n * 64 + 64 * 256 * 14 * 4 + (2 << 30)            # codes + codebooks + the bounded search workspace
+        raw = pix.adc_scores(q[:32])                                                    # [32, n] table sums of the library
+        top = torch.topk(raw, k1, dim=1)
+        for i in range(32):
+            got = s1[i].double().cpu().numpy()
+            want = top.values[i].double().cpu().numpy()
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * max(1.0, float(np.abs(want).max())))        # same multiset of scores
+            kth = float(want[-1])
+            inside = raw[i][r1[i]]                                                      # every returned row really has its returned score
+            np.testing.assert_allclose(inside.cpu().numpy(), s1[i].cpu().numpy(), rtol=0, atol=1e-4 * max(1.0, abs(kth)))
+        # a slice of the raw scores against the oracle's table sums
+        sl = slice(100_000, 104_000)
+        adc = PO.adc_scores(q[:8].cpu().numpy(), codes[sl].cpu().numpy(), cb.cpu().numpy())
+        np.testing.assert_allclose(raw[:8, sl].cpu().numpy(), adc, rtol=0, atol=1e-5 * max(1.0, float(np.abs(adc).max())))
+        # --PQIP --rerank: exact GIP on the 10 000 ADC candidates vs the exact search
+        se, re_ = ix.search(q, qi, k, out_device=True)
+        s2 = ix.score_rows_device(q, qi, r1)
+        order = torch.argsort(s2, dim=1, descending=True)[:, :10]
+        rr = torch.gather(r1, 1, order)
+        rec = np.mean([len(set(rr[i].tolist()) & set(re_[i, :10].tolist())) / 10.0 for i in range(0, nq, 8)])
+        assert rec >= 0.9, rec
+    finally:
+        pix.close(); ix.close()

@@ -5,7 +5,9 @@
 //   mode 0: ds_add_f32 (LDS atomic, no return) to data-dependent addresses (scores of a 256-row x 64-query block = 64 KiB in LDS)
 //   mode 1: the same addresses, conflict-free by construction (lane l only ever touches bank l: the upper bound of the primitive)
 //   mode 2: non-atomic read-modify-write (ds_read_b32, v_add, ds_write_b32) on lane-private addresses
-// Build: hipcc --offload-arch=gfx950 -O3 -o lds_scatter_probe lds_scatter_probe.hip ; run: ./lds_scatter_probe
+//   mode 3: ds_add_u32 (integer LDS atomic: scores in fixed point), data-dependent addresses
+// Build: hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -o lds_scatter_probe lds_scatter_probe.hip   (without -munsafe-fp-atomics
+// the float atomicAdd on LDS compiles to a compare-and-swap loop, 30x slower than the native ds_add_f32); run: ./lds_scatter_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -22,13 +24,14 @@ __global__ void __launch_bounds__(1024) k(const uint32_t* __restrict__ addr, con
   float v[16];
   for (int j = 0; j < 16; ++j) {
     const uint32_t r = addr[(size_t)(blockIdx.x * blockDim.x + threadIdx.x) * 16 + j] & 16383u;
-    a[j] = MODE == 0 ? r : ((r & ~63u) | (uint32_t)lane);      // modes 1, 2: lane l stays in bank l (and in its own words)
+    a[j] = (MODE == 0 || MODE == 3) ? r : ((r & ~63u) | (uint32_t)lane);      // modes 1, 2: lane l stays in bank l (and in its own words)
     v[j] = val[(threadIdx.x * 16 + j) & 4095];
   }
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       if (MODE == 2) { const float x = acc[a[j]]; acc[a[j]] = x + v[j]; }
+      else if (MODE == 3) atomicAdd((uint32_t*)&acc[a[j]], __float_as_uint(v[j]) & 0xFFFFu);      // ds_add_u32
       else atomicAdd(&acc[a[j]], v[j]);             // ds_add_f32 (result unused)
     }
   }
@@ -76,6 +79,7 @@ int main() {
   run<0>("ds_add_f32, data-dependent addresses (the scatter itself)", d_addr, d_val, d_sink, n_cu);
   run<1>("ds_add_f32, conflict-free (lane l in bank l)", d_addr, d_val, d_sink, n_cu);
   run<2>("ds_read + v_add + ds_write, conflict-free, non-atomic", d_addr, d_val, d_sink, n_cu);
+  run<3>("ds_add_u32, data-dependent addresses (fixed-point scores)", d_addr, d_val, d_sink, n_cu);
   printf("for comparison: the whole search step (bound GEMM + refine + exact rescoring + select) takes ~137 ms\n");
   return 0;
 }

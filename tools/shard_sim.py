@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--only", type=int, default=0, help="build only the first N shards of the partition (lets the default list capacity fit one GPU)")
     ap.add_argument("--cand-cap", type=int, default=65536)
     ap.add_argument("--sample-period", type=int, default=-1)
+    ap.add_argument("--overlap-aux", type=int, default=-1)
+    ap.add_argument("--aux-cus", type=int, default=-1)
     a = ap.parse_args()
     import torch
     import bench
@@ -44,6 +46,10 @@ def main():
             ix.set_param(_lib.PARAM_FIRST_ROWS, a.first_rows)
         if a.sample_period >= 0:
             ix.set_param(_lib.PARAM_SAMPLE_PERIOD, a.sample_period)
+        if a.overlap_aux >= 0:
+            ix.set_param(_lib.PARAM_OVERLAP_AUX, a.overlap_aux)
+        if a.aux_cus >= 0:
+            ix.set_param(_lib.PARAM_AUX_CUS, a.aux_cus)
         shards.append(ix)
         del cv, ci
         torch.cuda.empty_cache()
