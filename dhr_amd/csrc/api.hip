@@ -87,6 +87,9 @@ struct dhr_index {
   int device = 0;
   int64_t n_rows = 0, n_tiles = 0, row_offset = 0;
   int d_dlr = 0, d_cls = 0, k = 0, idx_dtype = DHR_IDX_NONE;
+  int dlr_pad = 0;     // zero slices appended to the caller's gated half so that d_dlr is a multiple of 8 (16-byte operand chunks): the caller's
+                       // records are [d_dlr - dlr_pad gated | d_cls ungated] wide, the library's [d_dlr | d_cls]; a padded slice holds value 0 and index 0
+                       // on both sides and adds 0 * 0 to every score (gip_retrieval.py:238 takes any --emb_dim)
   int k_rm = 0;        // row-major padded width (k rounded up to 64): q32 rows, vals_rm rows
   int n_buckets = 1;   // index buckets per gated slice in the bound operands
   int idx_buckets_req = 0;   // what the caller asked for (dhr_index_desc.idx_buckets), kept for dhr_index_save
@@ -246,7 +249,17 @@ static int ingest(dhr_index* ix, const dhr_index_desc* d, uint32_t* d_flags /* {
     const int64_t rows = std::min(block_rows, n - lo);
     const __half* src;
     int64_t ld;
-    if (d->mem_kind == DHR_MEM_HOST) {
+    if (ix->dlr_pad > 0) {        // [gated | ungated] of the caller -> [gated | zero slices | ungated] (the staging buffer was zeroed once)
+      const hipMemcpyKind kind = d->mem_kind == DHR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+      const int d_in = ix->d_dlr - ix->dlr_pad;
+      const char* base = (const char*)d->value + lo * d->ld_value * 2;
+      HIP_TRY(hipMemcpy2DAsync(stage, (size_t)ix->k * 2, base, (size_t)d->ld_value * 2, (size_t)d_in * 2, (size_t)rows, kind, s));
+      if (ix->d_cls > 0)
+        HIP_TRY(hipMemcpy2DAsync((char*)stage + (size_t)ix->d_dlr * 2, (size_t)ix->k * 2, base + (size_t)d_in * 2, (size_t)d->ld_value * 2,
+                                 (size_t)ix->d_cls * 2, (size_t)rows, kind, s));
+      src = (const __half*)stage;
+      ld = ix->k;
+    } else if (d->mem_kind == DHR_MEM_HOST) {
       HIP_TRY(hipMemcpy2DAsync(stage, (size_t)ix->k * 2, (const char*)d->value + lo * d->ld_value * 2,
                                (size_t)d->ld_value * 2, (size_t)ix->k * 2, (size_t)rows, hipMemcpyHostToDevice, s));
       src = (const __half*)stage;
@@ -257,7 +270,7 @@ static int ingest(dhr_index* ix, const dhr_index_desc* d, uint32_t* d_flags /* {
     }
     HIP_TRY(launch_scan_rows(src, ld, rows, ix->d_dlr, ix->k, d_flags, d_flags + 1, s));
     HIP_TRY(launch_copy_rows(src, ld, rows, ix->k, ix->k_rm, ix->vals_rm + lo * ix->k_rm, s));
-    if (d->mem_kind == DHR_MEM_HOST) HIP_TRY(hipStreamSynchronize(s));   // the staging buffer is reused
+    if (d->mem_kind == DHR_MEM_HOST || ix->dlr_pad > 0) HIP_TRY(hipStreamSynchronize(s));   // the staging buffer is reused
   }
   return DHR_OK;
 }
@@ -298,8 +311,17 @@ static void build_bucket_map(const std::vector<float>& hist, int d_dlr, int nb, 
   }
 }
 
-extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
-  if (!d || !out) return set_error(DHR_ERR_INVALID, "null argument");
+extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
+  if (!d_user || !out) return set_error(DHR_ERR_INVALID, "null argument");
+  // --emb_dim that is not a multiple of 8: the library appends zero slices (dhr_index::dlr_pad); below, `d` is the descriptor with
+  // the padded width -- only the two places that READ the caller's arrays (the index copy, ingest) use the caller's widths
+  dhr_index_desc d_padded = *d_user;
+  const int dlr_pad = (d_user->d_dlr > 0 && d_user->index != nullptr && d_user->d_dlr % 8) ? 8 - d_user->d_dlr % 8 : 0;
+  if (d_user->ld_value < (int64_t)d_user->d_dlr + d_user->d_cls) return set_error(DHR_ERR_INVALID, "bad value pointer / ld_value");
+  if (d_user->index && d_user->index_dtype != DHR_IDX_NONE && d_user->ld_index < d_user->d_dlr) return set_error(DHR_ERR_INVALID, "bad ld_index");
+  d_padded.d_dlr += dlr_pad;
+  if (dlr_pad) { d_padded.ld_value = std::max<int64_t>(d_padded.ld_value, (int64_t)d_padded.d_dlr + d_padded.d_cls); d_padded.ld_index = std::max<int64_t>(d_padded.ld_index, d_padded.d_dlr); }
+  const dhr_index_desc* d = &d_padded;
   *out = nullptr;
   if (d->n_rows <= 0 || d->n_rows >= (int64_t)0xFFFFFF00ll) return set_error(DHR_ERR_INVALID, "n_rows must be in [1, 2^32-256)");
   if (d->d_dlr < 0 || d->d_cls < 0 || d->d_dlr + d->d_cls <= 0) return set_error(DHR_ERR_INVALID, "bad d_dlr/d_cls");
@@ -309,7 +331,6 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
     return set_error(DHR_ERR_INVALID, "an index array is required iff d_dlr > 0 (dense-only: index=NULL, d_dlr=0)");
   if (has_idx && (d->index_dtype < DHR_IDX_U8 || d->index_dtype > DHR_IDX_I16)) return set_error(DHR_ERR_INVALID, "bad index_dtype");
   if (has_idx && d->ld_index < d->d_dlr) return set_error(DHR_ERR_INVALID, "bad ld_index");
-  if (d->d_dlr % 8) return set_error(DHR_ERR_UNSUPPORTED, "d_dlr (--emb_dim) must be a multiple of 8");
   if (d->d_dlr + d->d_cls > 8192) return set_error(DHR_ERR_UNSUPPORTED, "more than 8192 columns");
   if (d->idx_buckets < 0 || d->idx_buckets > 16) return set_error(DHR_ERR_INVALID, "idx_buckets must be in [0,16] (0 = default)");
   if (d->mem_kind != DHR_MEM_HOST && d->mem_kind != DHR_MEM_DEVICE) return set_error(DHR_ERR_INVALID, "bad mem_kind");
@@ -323,6 +344,7 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
   ix->row_offset = d->row_offset;
   ix->d_dlr = d->d_dlr;
   ix->d_cls = d->d_cls;
+  ix->dlr_pad = dlr_pad;
   ix->k = d->d_dlr + d->d_cls;
   ix->k_rm = (int)round_up(ix->k, TILE_K);
   // default for gated indexes: two buckets on the sparse matrix cores (needs 32-slice stages);
@@ -381,17 +403,20 @@ extern "C" int dhr_index_create(const dhr_index_desc* d, dhr_index** out) {
     const size_t ib = (size_t)d->n_rows * d->d_dlr * es;
     if (hipMalloc(&ix->c_idx, ib) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMalloc of the index array failed"));
     ix->index_bytes += (int64_t)ib;
-    if (hipMemcpy2DAsync(ix->c_idx, (size_t)d->d_dlr * es, d->index, (size_t)d->ld_index * es, (size_t)d->d_dlr * es,
+    if (dlr_pad && hipMemsetAsync(ix->c_idx, 0, ib, s) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMemsetAsync failed"));
+    if (hipMemcpy2DAsync(ix->c_idx, (size_t)d->d_dlr * es, d_user->index, (size_t)d_user->ld_index * es, (size_t)d_user->d_dlr * es,
                          (size_t)d->n_rows, d->mem_kind == DHR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
                          s) != hipSuccess)
       return fail(set_error(DHR_ERR_HIP, "copy of the index array failed"));
   }
   // pass 1: row-major device copy of the values (+ norms, sign scan)
   const int64_t block_rows = 65536;
-  if (d->mem_kind == DHR_MEM_HOST &&
+  if ((d->mem_kind == DHR_MEM_HOST || dlr_pad > 0) &&
       hipMalloc(&stage, (size_t)std::min<int64_t>(block_rows, d->n_rows) * ix->k * 2) != hipSuccess)
     return fail(set_error(DHR_ERR_HIP, "hipMalloc of the staging buffer failed"));
-  if ((rc = ingest(ix, d, d_flags, stage, block_rows, s)) != DHR_OK) return fail(rc);
+  if (dlr_pad > 0 && hipMemsetAsync(stage, 0, (size_t)std::min<int64_t>(block_rows, d->n_rows) * ix->k * 2, s) != hipSuccess)
+    return fail(set_error(DHR_ERR_HIP, "hipMemsetAsync failed"));
+  if ((rc = ingest(ix, d_user, d_flags, stage, block_rows, s)) != DHR_OK) return fail(rc);
   uint32_t flags[4] = {0, 0, 0, 0};
   if (hipMemcpy(flags, d_flags, 16, hipMemcpyDeviceToHost) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMemcpy failed"));
   float max_sq;
@@ -572,6 +597,7 @@ extern "C" int dhr_index_save(const dhr_index* ix, const char* path, const void*
   h.version = FILE_VERSION; h.header_bytes = 4096;
   h.n_rows = ix->n_rows; h.row_offset = ix->row_offset;
   h.d_dlr = ix->d_dlr; h.d_cls = ix->d_cls; h.k_rm = ix->k_rm; h.idx_dtype = ix->idx_dtype; h.idx_buckets = ix->idx_buckets_req;
+  h.pad0 = ix->dlr_pad;            // the file holds the padded records; a loaded index takes the caller's unpadded queries again
   h.val_offset = 4096; h.val_bytes = (uint64_t)ix->n_rows * ix->k_rm * 2;
   h.idx_offset = (h.val_offset + h.val_bytes + 4095) / 4096 * 4096;
   h.idx_bytes = ix->c_idx ? (uint64_t)ix->n_rows * ix->d_dlr * idx_esize(ix->idx_dtype) : 0;
@@ -609,7 +635,7 @@ extern "C" int dhr_index_file_info(const char* path, dhr_file_info* out) {
   FileHeader h;
   int rc = read_header(path, h, nullptr);
   if (rc) return rc;
-  out->n_rows = h.n_rows; out->row_offset = h.row_offset; out->d_dlr = h.d_dlr; out->d_cls = h.d_cls;
+  out->n_rows = h.n_rows; out->row_offset = h.row_offset; out->d_dlr = h.d_dlr - ((h.pad0 > 0 && h.pad0 < 8) ? h.pad0 : 0); out->d_cls = h.d_cls;
   out->index_dtype = h.idx_dtype; out->idx_buckets = h.idx_buckets; out->file_version = h.version; out->reserved = 0;
   out->payload_bytes = (int64_t)(h.val_bytes + h.idx_bytes);
   out->blob_offset = (int64_t)h.blob_offset; out->blob_bytes = (int64_t)h.blob_bytes;
@@ -644,6 +670,7 @@ extern "C" int dhr_index_load(const char* path, int32_t device, int64_t row_offs
   d.row_offset = row_offset >= 0 ? row_offset : h.row_offset;
   rc = dhr_index_create(&d, out);
   munmap(map, (size_t)sb.st_size);
+  if (rc == DHR_OK && h.pad0 > 0 && h.pad0 < 8) (*out)->dlr_pad = h.pad0;
   return rc;
 }
 
@@ -734,17 +761,20 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
 static int check_queries(const dhr_index* ix, const dhr_query_batch* qb) {
   if (!ix || !qb) return set_error(DHR_ERR_INVALID, "null argument");
   if (qb->n_queries <= 0) return set_error(DHR_ERR_INVALID, "n_queries must be > 0");
-  if (!qb->value || qb->ld_value < ix->k) return set_error(DHR_ERR_INVALID, "bad query value pointer / ld_value");
+  if (!qb->value || qb->ld_value < ix->k - ix->dlr_pad) return set_error(DHR_ERR_INVALID, "bad query value pointer / ld_value");
   if (qb->value_dtype != DHR_VAL_F16 && qb->value_dtype != DHR_VAL_F32) return set_error(DHR_ERR_INVALID, "bad value_dtype");
   const bool has_idx = qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE;
   if (has_idx && ix->d_dlr == 0)
     return set_error(DHR_ERR_INVALID, "the query batch has an index array but the corpus index was built without one");
   if (has_idx && (qb->index_dtype < DHR_IDX_U8 || qb->index_dtype > DHR_IDX_I16)) return set_error(DHR_ERR_INVALID, "bad index_dtype");
-  if (has_idx && qb->ld_index < ix->d_dlr) return set_error(DHR_ERR_INVALID, "bad query ld_index");
+  if (has_idx && qb->ld_index < ix->d_dlr - ix->dlr_pad) return set_error(DHR_ERR_INVALID, "bad query ld_index");
   if (qb->mem_kind != DHR_MEM_HOST && qb->mem_kind != DHR_MEM_DEVICE) return set_error(DHR_ERR_INVALID, "bad mem_kind");
   return DHR_OK;
 }
 
+// internal sub-batches (the queries a fallback redoes) are gathered from the library's own padded copies: their records already have the
+// padded width, unlike a caller's batch (dhr_index::dlr_pad)
+constexpr int32_t MEM_DEVICE_PADDED = 2;
 static int grow(void*& p, size_t& have, size_t need, int64_t& total) {
   if (have >= need) return DHR_OK;
   if (p) hipFree(p);
@@ -761,7 +791,27 @@ static int prep_queries(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, 
   const void* qi = qb->index;
   int64_t ldv = qb->ld_value, ldi = qb->ld_index;
   const int es = qb->value_dtype == DHR_VAL_F32 ? 4 : 2;
-  if (qb->mem_kind == DHR_MEM_HOST) {
+  if (ix->dlr_pad > 0 && qb->mem_kind != MEM_DEVICE_PADDED) {          // the caller's [gated | ungated] records -> [gated | zero slices | ungated], index -> [index | zeros]
+    const hipMemcpyKind kind = qb->mem_kind == DHR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    const int d_in = ix->d_dlr - ix->dlr_pad;
+    int rc = grow(w.q_stage, w.q_stage_bytes, (size_t)qb->n_queries * ix->k * es, w.bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(w.q_stage, 0, (size_t)qb->n_queries * ix->k * es, s));
+    HIP_TRY(hipMemcpy2DAsync(w.q_stage, (size_t)ix->k * es, qb->value, (size_t)qb->ld_value * es, (size_t)d_in * es, (size_t)qb->n_queries, kind, s));
+    if (ix->d_cls > 0)
+      HIP_TRY(hipMemcpy2DAsync((char*)w.q_stage + (size_t)ix->d_dlr * es, (size_t)ix->k * es, (const char*)qb->value + (size_t)d_in * es,
+                               (size_t)qb->ld_value * es, (size_t)ix->d_cls * es, (size_t)qb->n_queries, kind, s));
+    v = w.q_stage; ldv = ix->k;
+    if (qb->index && qb->index_dtype != DHR_IDX_NONE) {
+      const int ies = idx_esize(qb->index_dtype);
+      rc = grow(w.qi_stage, w.qi_stage_bytes, (size_t)qb->n_queries * ix->d_dlr * ies, w.bytes);
+      if (rc) return rc;
+      HIP_TRY(hipMemsetAsync(w.qi_stage, 0, (size_t)qb->n_queries * ix->d_dlr * ies, s));
+      HIP_TRY(hipMemcpy2DAsync(w.qi_stage, (size_t)ix->d_dlr * ies, qb->index, (size_t)qb->ld_index * ies, (size_t)d_in * ies,
+                               (size_t)qb->n_queries, kind, s));
+      qi = w.qi_stage; ldi = ix->d_dlr;
+    }
+  } else if (qb->mem_kind == DHR_MEM_HOST) {
     int rc = grow(w.q_stage, w.q_stage_bytes, (size_t)qb->n_queries * ix->k * es, w.bytes);
     if (rc) return rc;
     HIP_TRY(hipMemcpy2DAsync(w.q_stage, (size_t)ix->k * es, qb->value, (size_t)qb->ld_value * es, (size_t)ix->k * es,
@@ -1325,7 +1375,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   if (launch_gather_queries(w.q32, w.q_idx, ix->k_rm, ix->d_dlr, d_ids, nf, f32, fidx, s) != hipSuccess)
     return done(set_error(DHR_ERR_HIP, "gather_queries launch failed"));
   dhr_query_batch sub{};
-  sub.n_queries = nf; sub.mem_kind = DHR_MEM_DEVICE; sub.value = f32; sub.value_dtype = DHR_VAL_F32; sub.ld_value = ix->k_rm;
+  sub.n_queries = nf; sub.mem_kind = ix->dlr_pad > 0 ? MEM_DEVICE_PADDED : DHR_MEM_DEVICE; sub.value = f32; sub.value_dtype = DHR_VAL_F32; sub.ld_value = ix->k_rm;
   sub.index = gate ? fidx : nullptr; sub.index_dtype = gate ? DHR_IDX_I16 : DHR_IDX_NONE; sub.ld_index = ix->d_dlr;
   Workspace& w2 = ix->ws_fb[next_depth - 1];
   if ((rc = search_core(ix, w2, &sub, k, next_depth, tm, st, s)) != DHR_OK) return done(rc);
@@ -1861,16 +1911,36 @@ extern "C" int dhr_debug_gemm_time(dhr_index* ix, const dhr_query_batch* qb, int
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = (hipStream_t)stream;
   Workspace& w = ix->ws;
-  if ((rc = ensure_ws(ix, w, qb->n_queries, 1, 0)) != DHR_OK) return rc;
-  if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
   // DHR_GEMM_TIME_OPEN=1 (tuning): filter with the final thresholds of the previous dhr_search on this handle (same queries),
-  // i.e. a realistic hit rate in the epilogue, instead of the closed filter
-  const bool open = getenv("DHR_GEMM_TIME_OPEN") && atoi(getenv("DHR_GEMM_TIME_OPEN")) != 0 && w.thr_hat;
+  // i.e. a realistic hit rate in the epilogue, instead of the closed filter.  (The workspace must be the one that search left:
+  // same k, or ensure_ws would re-allocate it and the thresholds would be uninitialised memory -- as they were for a while.)
+  const bool open = getenv("DHR_GEMM_TIME_OPEN") && atoi(getenv("DHR_GEMM_TIME_OPEN")) != 0 && w.thr_hat && ix->stats.k > 0 && ix->stats.n_queries == qb->n_queries;
+  if ((rc = ensure_ws(ix, w, qb->n_queries, open ? (int)ix->stats.k : 1, 0)) != DHR_OK) return rc;
+  if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
   if (open) {
     HIP_TRY(hipMemcpyAsync(w.thr, w.thr_hat, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
   } else {
     std::vector<float> inf((size_t)w.q_pad, INFINITY);
     HIP_TRY(hipMemcpyAsync(w.thr, inf.data(), (size_t)w.q_pad * 4, hipMemcpyHostToDevice, s));
+  }
+  // DHR_GEMM_THR_SAVE / DHR_GEMM_THR_LOAD (tuning): the thresholds of an open-filter timing written to / read from a file, so that an
+  // ablation build of the library (whose own searches are meaningless) can be timed at the thresholds of a correct one
+  bool opened = open;
+  if (const char* f = getenv("DHR_GEMM_THR_SAVE")) {
+    if (open) {
+      std::vector<float> t((size_t)w.q_pad);
+      HIP_TRY(hipMemcpyAsync(t.data(), w.thr, t.size() * 4, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (FILE* fp = fopen(f, "wb")) { fwrite(t.data(), 4, t.size(), fp); fclose(fp); }
+    }
+  } else if (const char* f = getenv("DHR_GEMM_THR_LOAD")) {
+    std::vector<float> t((size_t)w.q_pad);
+    FILE* fp = fopen(f, "rb");
+    if (!fp || fread(t.data(), 4, t.size(), fp) != t.size()) { if (fp) fclose(fp); return set_error(DHR_ERR_INVALID, "DHR_GEMM_THR_LOAD: cannot read the threshold file"); }
+    fclose(fp);
+    HIP_TRY(hipMemcpyAsync(w.thr, t.data(), t.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    opened = true;
   }
   HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));
   GemmArgs g{};
@@ -1881,7 +1951,10 @@ extern "C" int dhr_debug_gemm_time(dhr_index* ix, const dhr_query_batch* qb, int
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
   HIP_TRY(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i) HIP_TRY(launch_gemm_filter(g, s));
+  for (int i = 0; i < iters; ++i) {
+    if (opened) HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));       // the lists fill as in a search (a full list takes the cold surplus path)
+    HIP_TRY(launch_gemm_filter(g, s));
+  }
   HIP_TRY(hipEventRecord(e1, s));
   HIP_TRY(hipStreamSynchronize(s));
   float ms = 0.f;

@@ -21,6 +21,9 @@
 #include <type_traits>
 #include <climits>
 
+#ifndef G8_ABL
+#define G8_ABL 0      // timing ablations (wrong results): 4 = no DMA pieces in the loop, 8 = 4 + no fragment reads in the loop, 16 = no list flush, 32 = no epilogue
+#endif
 namespace dhr {
 
 typedef int intx4 __attribute__((ext_vector_type(4)));
@@ -145,6 +148,9 @@ __device__ __forceinline__ void g8_epilogue(const GemmArgs& p, floatx16 (&acc)[4
   const uint32_t j = g8_scan<false>(p, acc, qt, wm, wn, lane, rows_valid, row0, stack, thr_r, mul_r, jn);
   if (__builtin_amdgcn_ballot_w64(j > (uint32_t)EPI_STACK) != 0) g8_epilogue_surplus(p, acc, qt, wm, wn, lane, rows_valid, row0, thr_r, mul_r);
   if (j == 0) return;
+#if G8_ABL == 16       // timing only: hits are found and stacked, never flushed to the lists
+  return;
+#endif
   // all of a lane's list reservations go out before the first one is waited for: one L2 round trip per tile
   const uint32_t s0 = jn[0] < (uint32_t)EPI_STACK ? jn[0] : (uint32_t)EPI_STACK, s1 = jn[1] < (uint32_t)EPI_STACK ? jn[1] : (uint32_t)EPI_STACK;
   const int q0 = qt * TILE_ROWS + wn * 64 + (lane & 31);
@@ -160,9 +166,6 @@ __device__ __forceinline__ void g8_epilogue(const GemmArgs& p, floatx16 (&acc)[4
   }
 }
 
-#ifndef G8_ABL
-#define G8_ABL 0      // timing ablations (wrong results): 4 = no DMA pieces in the loop, 8 = 4 + no fragment reads in the loop, 16 = no list flush, 32 = no epilogue
-#endif
 #if G8_ABL == 2       // timing only: the pair barrier does not wait for this wave's DMA
 #define G8_PAIR_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #elif G8_ABL == 3     // timing only: neither the DMA wait nor the barrier

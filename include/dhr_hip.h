@@ -53,7 +53,8 @@ typedef struct dhr_index_desc {
   int32_t device;      /* HIP device ordinal */
   int32_t mem_kind;    /* dhr_mem_kind of value/index */
   int64_t n_rows;      /* rows of THIS shard (gip_retrieval.py:292-306 slice) */
-  int32_t d_dlr;       /* gated columns == --emb_dim when index != NULL, else 0 */
+  int32_t d_dlr;       /* gated columns == --emb_dim when index != NULL, else 0.  Any width: where it is not a multiple of 8 the library
+                          appends zero slices to its own copies (of the corpus and of every query batch) */
   int32_t d_cls;       /* ungated columns */
   const void* value;   /* fp16 */
   int64_t ld_value;    /* elements between consecutive rows (>= d_dlr + d_cls) */

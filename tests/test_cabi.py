@@ -46,7 +46,11 @@ def test_invalid_arguments_return_codes_not_crashes():
     d.n_rows, d.d_dlr, d.d_cls, d.value, d.ld_value = 4, 12, 8, v.ctypes.data, 20
     i = np.zeros((4, 12), np.uint8)
     d.index, d.index_dtype, d.ld_index = i.ctypes.data, _lib.IDX_U8, 12
-    assert lib.dhr_index_create(C.byref(d), C.byref(h)) == -2          # d_dlr % 8
+    d.d_cls = 9000
+    assert lib.dhr_index_create(C.byref(d), C.byref(h)) == -1          # ld_value too small for d_dlr + d_cls
+    d.d_cls, d.ld_value = 8190, 8202
+    assert lib.dhr_index_create(C.byref(d), C.byref(h)) == -2          # more than 8192 columns: legal input the kernels do not cover
+    assert b"8192" in lib.dhr_last_error()
     assert lib.dhr_merge_topk_host(0, 1, None, None, 1, None, None) == -1
 
 

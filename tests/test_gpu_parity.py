@@ -953,19 +953,40 @@ def test_odd_shapes(G, n, q, d_dlr, d_cls, k):
 
 
 def test_emb_dim_not_a_multiple_of_8(G):
-    """--emb_dim that is not a multiple of 8 (the reference takes any width): the C ABI refuses it explicitly (DHR_ERR_UNSUPPORTED,
-    no silent fallback), the host mirror zero-pads the gated half on both sides and the results equal the oracle's."""
+    """--emb_dim that is not a multiple of 8 (the reference takes any width, gip_retrieval.py:238): the C ABI appends zero slices to the
+    gated half itself (corpus and every query batch, host or device arrays; since round 3 -- it used to refuse) and the host mirror
+    does the same before it calls; both equal the oracle."""
     import ctypes as C
     from dhr_amd import _lib, synth
     cv, ci, qv, qi = synth.make_pair(51, 3000, 6, 100, 28)
     lib = _lib.load()
-    desc = _lib.IndexDesc()
-    desc.device, desc.n_rows, desc.d_dlr, desc.d_cls = 0, 3000, 100, 28
-    desc.value, desc.ld_value, desc.mem_kind = _lib._ptr_ld(cv)
-    desc.index, desc.ld_index, _ = _lib._ptr_ld(ci)
-    desc.index_dtype = _lib.IDX_U8
-    h = C.c_void_p()
-    assert lib.dhr_index_create(C.byref(desc), C.byref(h)) == -2 and b"multiple of 8" in lib.dhr_last_error()
+    q32 = qv.astype(np.float32)
+    for dev_arrays in (False, True):
+        if dev_arrays:
+            import torch
+            a_cv, a_ci, a_q, a_qi = (torch.from_numpy(x).cuda() for x in (cv, ci, q32, qi))
+        else:
+            a_cv, a_ci, a_q, a_qi = cv, ci, q32, qi
+        desc = _lib.IndexDesc()
+        desc.device, desc.n_rows, desc.d_dlr, desc.d_cls = 0, 3000, 100, 28
+        desc.value, desc.ld_value, desc.mem_kind = _lib._ptr_ld(a_cv)
+        desc.index, desc.ld_index, _ = _lib._ptr_ld(a_ci)
+        desc.index_dtype = _lib.IDX_U8
+        h = C.c_void_p()
+        _lib.check(lib.dhr_index_create(C.byref(desc), C.byref(h)), "dhr_index_create")
+        try:
+            qb, keep = _lib.make_query_batch(a_q, a_qi)
+            sc = np.empty((6, 50), np.float32); rows = np.empty((6, 50), np.int64)
+            _lib.check(lib.dhr_search(h, C.byref(qb), 50, sc.ctypes.data, rows.ctypes.data, _lib.MEM_HOST, None), "dhr_search")
+            for i in range(6):
+                ex = O.gip_scores_f64(q32[i], qi[i], cv.astype(np.float32), ci)
+                O.check_topk(rows[i], sc[i], ex, 50)
+            qb1, keep1 = _lib.make_query_batch(a_q, None)                    # plain inner product over the same (unpadded) records
+            _lib.check(lib.dhr_search(h, C.byref(qb1), 50, sc.ctypes.data, rows.ctypes.data, _lib.MEM_HOST, None), "dhr_search")
+            for i in range(6):
+                O.check_topk(rows[i], sc[i], cv.astype(np.float64) @ q32[i].astype(np.float64), 50)
+        finally:
+            lib.dhr_index_destroy(h)
     _search_check(G, cv, ci, qv.astype(np.float32), qi, 50)
     ix = G.GipIndex(cv, ci)
     assert (ix.k, ix.d_dlr) == (128, 100)
