@@ -80,90 +80,89 @@ __device__ __forceinline__ void g8_dump_tile(const GemmArgs& p, floatx16 (&acc)[
   }
 }
 
-// Filter epilogue.  Scheme of gemm_epilogue_w (private hit stacks in the idle ring, one global atomic per thread and query), on
-// integers, with a SMALL hot path: the 128 accumulators of a lane can only be addressed by unrolled code, and in the first cut every
-// one of the 128 copies carried the score conversion and the stack-overflow path (a global atomic + store) -- ~40 KB of code that
-// every tile walked through.  Now a hit pushes (row, raw integer sum) and nothing else; conversion happens in the flush loop, and
-// a lane whose stack is full (EPI_STACK hits in one tile: the hottest queries only) just counts on -- its surplus is appended by a
-// second, cold scan (g8_epilogue_surplus) that only waves with such a lane run.
-template <bool SURPLUS>
-__device__ __forceinline__ uint32_t g8_scan(const GemmArgs& p, floatx16 (&acc)[4][2], int qt, int wm, int wn, int lane, int rows_valid, int64_t row0,
-                                            uint2* stack, const int (&thr_r)[2], const float (&mul_r)[2], uint32_t (&jn)[2]) {
+// The 128 accumulators of a lane can only be addressed by unrolled code; in the first cut every one of the 128 copies carried the score
+// conversion and the stack-overflow path (a global atomic + store) -- ~40 KB of code that every tile walked through.
+// One query column (ni) of the lane's accumulators.  Two levels: the maximum of a group of four accumulators against the threshold,
+// then the four elements.  (A third level over the 16 accumulators of a 32 x 32 block was dropped in round 3: at the bench's hit
+// rate of 0.23 % per accumulator, 91 % of the blocks hold a hit in SOME lane of the wave, so the test was nearly always taken and
+// only cost its 15 maxima.)
+template <bool SURPLUS, int NI_>
+__device__ __forceinline__ void g8_scan_half(const GemmArgs& p, floatx16 (&acc)[4][2], int qt, int wm, int wn, int lane, int rows_valid, int64_t row0,
+                                             uint2* stack, const int t, const float mul, uint32_t& j) {
   const int fhalf = lane >> 5;
   const int rbase = wm * 128 + 4 * fhalf;
-  uint32_t j = 0;
+  const int q = qt * TILE_ROWS + wn * 64 + NI_ * 32 + (lane & 31);
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int t = thr_r[ni];
-    const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
+  for (int mi = 0; mi < 4; ++mi) {
+    const floatx16& a = acc[mi][NI_];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const floatx16& a = acc[mi][ni];
-      int gm[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        gm[g] = max(max(__float_as_int(a[4 * g]), __float_as_int(a[4 * g + 1])), max(__float_as_int(a[4 * g + 2]), __float_as_int(a[4 * g + 3])));
-      const int mx = max(max(gm[0], gm[1]), max(gm[2], gm[3]));
-      if (mx >= t) {
+    for (int g = 0; g < 4; ++g) {
+      const int gm = max(max(__float_as_int(a[4 * g]), __float_as_int(a[4 * g + 1])), max(__float_as_int(a[4 * g + 2]), __float_as_int(a[4 * g + 3])));
+      if (gm >= t) {
         asm volatile("");
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if (gm[g] >= t) {
+        for (int e = 4 * g; e < 4 * g + 4; ++e) {
+          const int v = __float_as_int(a[e]);
+          const int rl = rbase + mi * 32 + (e & 3) + 8 * (e >> 2);
+          if (v >= t && rl < rows_valid) {
             asm volatile("");
-#pragma unroll
-            for (int e = 4 * g; e < 4 * g + 4; ++e) {
-              const int v = __float_as_int(a[e]);
-              const int rl = rbase + mi * 32 + (e & 3) + 8 * (e >> 2);
-              if (v >= t && rl < rows_valid) {
-                asm volatile("");
-                if constexpr (SURPLUS) {
-                  if (j >= EPI_STACK) {
-                    const uint32_t slot = atomicAdd(p.cnt + q, 1u);
-                    if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(row0 + rl), __float_as_uint(g8_score(v, mul_r[ni])));
-                  }
-                } else if (j < EPI_STACK) stack[j * G8_NT] = make_uint2((uint32_t)rl, (uint32_t)v);
-                ++j;
+            if constexpr (SURPLUS) {
+              if (j >= EPI_STACK) {
+                const uint32_t slot = atomicAdd(p.cnt + q, 1u);
+                if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(row0 + rl), __float_as_uint(g8_score(v, mul)));
               }
-            }
+            } else if (j < EPI_STACK) stack[j * G8_NT] = make_uint2((uint32_t)rl, (uint32_t)v);
+            ++j;
           }
         }
       }
     }
-    jn[ni] = j;
   }
-  return j;
 }
 __device__ __forceinline__ void g8_epilogue_surplus(const GemmArgs& p, floatx16 (&acc)[4][2], int qt, int wm, int wn, int lane, int rows_valid, int64_t row0,
                                                  const int (&thr_r)[2], const float (&mul_r)[2]) {
-  uint32_t jn[2];
-  (void)g8_scan<true>(p, acc, qt, wm, wn, lane, rows_valid, row0, nullptr, thr_r, mul_r, jn);
+  uint32_t j = 0;
+  g8_scan_half<true, 0>(p, acc, qt, wm, wn, lane, rows_valid, row0, nullptr, thr_r[0], mul_r[0], j);
+  g8_scan_half<true, 1>(p, acc, qt, wm, wn, lane, rows_valid, row0, nullptr, thr_r[1], mul_r[1], j);
 }
+// Filter epilogue.  Scheme of gemm_epilogue_w (private hit stacks in the idle ring, one global atomic per lane and query), on
+// integers, with a SMALL hot path: a hit pushes (row, raw integer sum) and nothing else; conversion happens in the flush loop, and
+// a lane whose stack is full (EPI_STACK hits in one tile: the hottest queries only) just counts on -- its surplus is appended by a
+// second, cold scan (g8_epilogue_surplus) that only waves with such a lane run.  The list reservation of the first query column goes
+// out BEFORE the second column is scanned, so that its L2 round trip (~1.5 us, 5 % of an open-filter tile when both were waited for
+// behind the scan) runs under the second half of the scan; the second one runs under the flush of the first column's hits.
 __device__ __forceinline__ void g8_epilogue(const GemmArgs& p, floatx16 (&acc)[4][2], int64_t dt, int qt, int wm, int wn, int tid, int lane,
                                             char* smem, const int (&thr_r)[2], const float (&mul_r)[2]) {
   __syncthreads();                       // every wave is done with the staging ring
   const int64_t row0 = dt * TILE_ROWS;
   const int rows_valid = (int)(p.n_rows - row0 < TILE_ROWS ? p.n_rows - row0 : TILE_ROWS);
   uint2* stack = (uint2*)smem + tid;                       // slot j at stack[j * G8_NT]
-  uint32_t jn[2];
-  const uint32_t j = g8_scan<false>(p, acc, qt, wm, wn, lane, rows_valid, row0, stack, thr_r, mul_r, jn);
-  if (__builtin_amdgcn_ballot_w64(j > (uint32_t)EPI_STACK) != 0) g8_epilogue_surplus(p, acc, qt, wm, wn, lane, rows_valid, row0, thr_r, mul_r);
-  if (j == 0) return;
-#if G8_ABL == 16       // timing only: hits are found and stacked, never flushed to the lists
-  return;
-#endif
-  // all of a lane's list reservations go out before the first one is waited for: one L2 round trip per tile
-  const uint32_t s0 = jn[0] < (uint32_t)EPI_STACK ? jn[0] : (uint32_t)EPI_STACK, s1 = jn[1] < (uint32_t)EPI_STACK ? jn[1] : (uint32_t)EPI_STACK;
   const int q0 = qt * TILE_ROWS + wn * 64 + (lane & 31);
+  uint32_t j = 0;
+  g8_scan_half<false, 0>(p, acc, qt, wm, wn, lane, rows_valid, row0, stack, thr_r[0], mul_r[0], j);
+  const uint32_t s0 = j < (uint32_t)EPI_STACK ? j : (uint32_t)EPI_STACK;
+#if G8_ABL != 16
   uint32_t base0 = 0u, base1 = 0u;
   if (s0 > 0) base0 = atomicAdd(p.cnt + q0, s0);
+#endif
+  g8_scan_half<false, 1>(p, acc, qt, wm, wn, lane, rows_valid, row0, stack, thr_r[1], mul_r[1], j);
+  const uint32_t s1 = j < (uint32_t)EPI_STACK ? j : (uint32_t)EPI_STACK;
+#if G8_ABL == 16       // timing only: hits are found and stacked, never flushed to the lists
+  return;
+#else
   if (s1 > s0) base1 = atomicAdd(p.cnt + q0 + 32, s1 - s0);
-  for (uint32_t i = 0; i < s1; ++i) {
+  if (__builtin_amdgcn_ballot_w64(j > (uint32_t)EPI_STACK) != 0) g8_epilogue_surplus(p, acc, qt, wm, wn, lane, rows_valid, row0, thr_r, mul_r);
+  for (uint32_t i = 0; i < s0; ++i) {
     const uint2 en = stack[i * G8_NT];
-    const bool second = i >= s0;
-    const int q = q0 + (second ? 32 : 0);
-    const uint32_t slot = second ? base1 + (i - s0) : base0 + i;
-    if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)row0 + en.x, __float_as_uint(g8_score((int)en.y, second ? mul_r[1] : mul_r[0])));
+    const uint32_t slot = base0 + i;
+    if (slot < p.cap) p.cand[(int64_t)q0 * p.cap + slot] = make_uint2((uint32_t)row0 + en.x, __float_as_uint(g8_score((int)en.y, mul_r[0])));
   }
+  for (uint32_t i = s0; i < s1; ++i) {
+    const uint2 en = stack[i * G8_NT];
+    const uint32_t slot = base1 + (i - s0);
+    if (slot < p.cap) p.cand[(int64_t)(q0 + 32) * p.cap + slot] = make_uint2((uint32_t)row0 + en.x, __float_as_uint(g8_score((int)en.y, mul_r[1])));
+  }
+#endif
 }
 
 #if G8_ABL == 2       // timing only: the pair barrier does not wait for this wave's DMA
