@@ -174,10 +174,18 @@ extern "C" void dhr_index_destroy(dhr_index* ix) {
 }
 
 static int g_opt_dense_i8 = -1;      // -1: gated indexes with ungated columns only; 0: never; 1: dense-only indexes too
-static int g_opt_gated_i8 = 1;       // int8 image of the gated half wherever the layout allows it
+static int g_opt_gated_i8 = -1;      // int8 image of the gated half: -1 by corpus size (>= GATED_I8_MIN_ROWS rows; _NARROW where the ungated half is narrower than half the gated one), 0 never, 1 wherever the layout allows it
+// The int8 gated image takes ~30 % off the bound GEMM and lets ~1.5-2x the rows through the filter (its values are rounded UP): the GEMM scales
+// with the rows of the shard, the extra refine / rescoring work with the queries only.  Measured (exact search, ms per step, fp16 / int8 image):
+// 8.84 M x (768+768) 169.7 / 137.1; a 1.1 M-row shard of it 3.5 / 2.9 per eighth of the step; 5.4 M x (768+128) 80.0 / 71.9 and 84.9 / 85.6;
+// 2.7 M 28.5 / 35.7; 0.52 M 27.8 / 44.5; 58 k 2.9 / 3.7.
+// Break-even: ~2 M rows where the ungated half is as wide as the gated one (0.66 ps saved per (query, row) pair against ~1.4 us of extra
+// refine / rescoring per query), ~5 M rows with a narrow ungated half (0.35 ps per pair); a SHARD of a sharded search collects only its share
+// of the candidates, so it breaks even 8x earlier -- hence 1 M / 4 M.
+constexpr int64_t GATED_I8_MIN_ROWS = 1000000, GATED_I8_MIN_ROWS_NARROW = 4000000;
 extern "C" int dhr_set_option(int32_t option, int64_t value) {
   if (option == DHR_OPT_DENSE_I8) { g_opt_dense_i8 = value < 0 ? -1 : (value != 0); return DHR_OK; }
-  if (option == DHR_OPT_GATED_I8) { g_opt_gated_i8 = value != 0; return DHR_OK; }
+  if (option == DHR_OPT_GATED_I8) { g_opt_gated_i8 = value < 0 ? -1 : (value != 0); return DHR_OK; }
   return set_error(DHR_ERR_INVALID, "unknown option");
 }
 extern "C" int dhr_index_get_info(const dhr_index* ix, int32_t what, double* out) {
@@ -364,6 +372,7 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
     // ungated half (if any) is the int8 image too; DHR_GATED_I8=0 / dhr_set_option(DHR_OPT_GATED_I8, 0) keeps the fp16 image
     int want_g8 = g_opt_gated_i8;
     if (const char* e = getenv("DHR_GATED_I8")) want_g8 = atoi(e);
+    if (want_g8 < 0) want_g8 = d->n_rows >= (2 * d->d_cls >= d->d_dlr ? GATED_I8_MIN_ROWS : GATED_I8_MIN_ROWS_NARROW) ? 1 : 0;
     ix->gated_i8 = want_g8 != 0 && !(ix->ts & 1) && (d->d_cls == 0 || ix->dense_i8) && d->d_dlr <= 4096;
   } else if (!has_idx && d->idx_buckets == 0) {
     // dense-only index: the same 32-column stage images (ts = 0), so that it runs on the 8-wave kernel of the 2:4 layout
@@ -1237,6 +1246,16 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     int64_t by_size = std::min<int64_t>(8, std::max<int64_t>(2, (n_main + 4199) / 4200));
     const int64_t no_overflow = (3 * n_main * TILE_ROWS + 2 * std::min(w.cap, w.cap_r) - 1) / (2 * std::min(w.cap, w.cap_r));
     if (no_overflow <= 12) by_size = std::max(by_size, no_overflow);
+    // ... and so many that the HOTTEST queries fit: on the benchmark's data a query passes ~20 k rows per 1 000 results through the bound
+    // filter and ~4 k through the refine step, the hottest ten times that, whatever the corpus size -- on a 0.5 M-row corpus (BEIR quora,
+    // 10 000 queries) that is a fifth of the rows of a chunk, and with 2 chunks 195 queries per step overflowed their 65 536-entry lists and
+    // were redone (60 ms per step instead of 28).  The first chunk is 3 / (2 M) of the pass.  (A shard chases its share of k.)
+    {
+      const double k_eff = (double)k / (double)std::max(1, stage == 2 ? ix->sample_share : 1);
+      const int64_t by_hot = (int64_t)std::ceil(300.0 * k_eff / (double)w.cap);
+      const int64_t by_hot_r = (int64_t)std::ceil(65.0 * k_eff / (double)w.cap_r);
+      by_size = std::max(by_size, std::min<int64_t>(24, std::max(by_hot, by_hot_r)));
+    }
     const int64_t want = async_ctl ? std::max<int64_t>(ix->main_chunks, by_size) : std::max<int64_t>(ix->main_chunks, need);
     const int M = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, 64), n_main / (16 * DOC_GROUP)));
     if (getenv("DHR_DEBUG_PLAN"))

@@ -36,14 +36,8 @@ class GipIndex:
         d_dlr = 0 if index is None else int(index.shape[1])
         if index is not None and emb_dim is not None and emb_dim != d_dlr:
             raise ValueError(f"--emb_dim {emb_dim} does not match the index array width {d_dlr}")
-        # the kernels take gated widths that are a multiple of 8 (16-byte operand chunks); other --emb_dim values (the reference has
-        # no such limit) are zero-padded here: [dlr | 0-pad | dense] with index value 0 on both sides -- a padded slice contributes
-        # 0 * 0 to every score, so results are unchanged
-        self._dlr_pad = 0
-        if index is not None and d_dlr % 8:
-            self._dlr_pad = 8 - d_dlr % 8
-            value, index = _pad_dlr(value, index, d_dlr, self._dlr_pad)
-            k, d_dlr = k + self._dlr_pad, d_dlr + self._dlr_pad
+        # (--emb_dim that is not a multiple of 8: the library appends zero slices to its own copies of the corpus and of every
+        # query batch -- dhr_index_create; until round 3 this mirror padded the arrays on the host)
         desc = _lib.IndexDesc()
         desc.device = device
         desc.n_rows = n
@@ -61,24 +55,16 @@ class GipIndex:
         h = C.c_void_p()
         _lib.check(lib.dhr_index_create(C.byref(desc), C.byref(h)), "dhr_index_create")
         self._h, self._lib = h, lib
-        self.n_rows, self.k, self.d_dlr, self.device, self.row_offset = n, k - self._dlr_pad, d_dlr - self._dlr_pad, device, row_offset
+        self.n_rows, self.k, self.d_dlr, self.device, self.row_offset = n, k, d_dlr, device, row_offset
 
     def _qb(self, q_value, q_index):
-        """Query batch for the library (padded like the corpus when --emb_dim is not a multiple of 8)."""
-        if getattr(self, "_dlr_pad", 0) and q_index is not None:
-            q_value, q_index = _pad_dlr(q_value, q_index, self.d_dlr, self._dlr_pad)
-        elif getattr(self, "_dlr_pad", 0):
-            q_value, _ = _pad_dlr(q_value, None, self.d_dlr, self._dlr_pad)
+        """Query batch for the library (the caller's own record width; the library pads where --emb_dim is not a multiple of 8)."""
         return _lib.make_query_batch(q_value, q_index)
 
     # ---- device-ready index file (dhr_index_save / dhr_index_load; SURVEY section 8f row 2)
     def save(self, path: str, docids=None):
         """Write the built device images to `path`; `docids` (the third element of the reference's index record)
         travels as the file's blob so that one file replaces the pickle."""
-        if getattr(self, "_dlr_pad", 0):
-            # the file would record the zero-padded width; load() could not tell it from a real --emb_dim (ADVICE r02)
-            raise _lib.DhrError("an index whose --emb_dim was padded to a multiple of 8 cannot be saved as a device index file; "
-                                "keep the pickle for such widths")
         blob = pickle.dumps(list(docids), protocol=4) if docids is not None else b""
         _lib.check(self._lib.dhr_index_save(self._h, os.fsencode(path), blob if blob else None, len(blob)), "dhr_index_save")
 
@@ -224,18 +210,6 @@ class GipIndex:
         _lib.check(self._lib.dhr_score_rows(self._h, C.byref(qb), int(rows.shape[1]), rows.data_ptr(), out.data_ptr(), _lib.MEM_DEVICE, 0), "dhr_score_rows")
         del keep
         return out
-
-
-def _pad_dlr(value, index, d_dlr, pad):
-    """[dlr | dense] -> [dlr | pad zeros | dense] (numpy or torch), index -> [index | pad zeros]."""
-    if isinstance(value, np.ndarray):
-        v = np.concatenate([value[:, :d_dlr], np.zeros((value.shape[0], pad), value.dtype), value[:, d_dlr:]], axis=1)
-        i = None if index is None else np.concatenate([index, np.zeros((index.shape[0], pad), index.dtype)], axis=1)
-        return np.ascontiguousarray(v), None if i is None else np.ascontiguousarray(i)
-    import torch
-    v = torch.cat([value[:, :d_dlr], torch.zeros((value.shape[0], pad), dtype=value.dtype, device=value.device), value[:, d_dlr:]], dim=1)
-    i = None if index is None else torch.cat([index, torch.zeros((index.shape[0], pad), dtype=index.dtype, device=index.device)], dim=1)
-    return v.contiguous(), None if i is None else i.contiguous()
 
 
 def _as_f16(a):

@@ -123,8 +123,11 @@ typedef enum dhr_option {
                            The environment variable DHR_DENSE_I8 overrides it. */
   DHR_OPT_GATED_I8 = 2  /* int8 image of the GATED columns too (v_smfmac_i32_32x32x64_i8: the 2:4 instruction on int8 operands, 32 slices
                            per issue; values rounded UP per column step, so the bound stays a bound and results stay exact):
-                           1 (default) = wherever the layout allows it (two buckets, d_dlr a multiple of 64, the ungated half an int8
-                           image or absent), 0 = keep the fp16 image.  The environment variable DHR_GATED_I8 overrides it. */
+                           -1 (default) = shards of at least 1 000 000 rows (4 000 000 where the ungated half is narrower than half the
+                           gated one), where the cheaper GEMM outweighs the extra candidates the looser bound lets through (below
+                           that the refine / rescoring work dominates the step); 1 = wherever the layout
+                           allows it (two buckets, d_dlr a multiple of 64, the ungated half an int8 image or absent); 0 = keep the fp16
+                           image.  The environment variable DHR_GATED_I8 (-1 / 0 / 1) overrides it. */
 } dhr_option;
 int dhr_set_option(int32_t option, int64_t value);
 /* Read-only facts about a built index (dhr_index_get_info). */

@@ -990,6 +990,17 @@ def test_emb_dim_not_a_multiple_of_8(G):
     _search_check(G, cv, ci, qv.astype(np.float32), qi, 50)
     ix = G.GipIndex(cv, ci)
     assert (ix.k, ix.d_dlr) == (128, 100)
+    # index file of such a width: the file holds the padded records and remembers the pad; a loaded index takes the caller's queries
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "odd.dhr")
+        ix.save(path, ["d%d" % i for i in range(3000)])
+        ix2, ids = G.GipIndex.load(path)
+        assert (ix2.k, ix2.d_dlr, len(ids)) == (128, 100, 3000)
+        sa, ra = ix.search(qv.astype(np.float32), qi, 50)
+        sb, rb = ix2.search(qv.astype(np.float32), qi, 50)
+        ix2.close()
+        np.testing.assert_array_equal(ra, rb)
+        np.testing.assert_array_equal(sa, sb)
     s2, r2 = ix.search_rerank(np.where(qv > 0.3, qv, 0).astype(np.float32), qi, qv.astype(np.float32), qi, 300, 20)
     rows = np.arange(3000, dtype=np.int64)[None, :].repeat(6, 0)
     ex = ix.score_rows(qv.astype(np.float32), qi, rows)
@@ -1743,3 +1754,23 @@ def test_pq_first_stage_beir_size(G):
         assert rec >= 0.9, rec
     finally:
         pix.close(); ix.close()
+
+
+def test_gated_image_default_by_size(G, monkeypatch):
+    """DHR_OPT_GATED_I8 = -1 (the library's default): a small shard keeps the fp16 image of the gated columns (below 1 M rows the extra
+    candidates of the looser int8 bound cost more than its cheaper GEMM saves); 0 / 1 force it.  Results are identical either way."""
+    from dhr_amd import _lib, synth
+    cv, ci, qv, qi = synth.make_pair(61, 20_000, 8, 768, 128)
+    q32 = qv.astype(np.float32)
+    out = {}
+    for setting in ("-1", "0", "1"):
+        monkeypatch.setenv("DHR_GATED_I8", setting)
+        ix = G.GipIndex(cv, ci)
+        try:
+            assert ix.info(_lib.INFO_GATED_I8) == (1 if setting == "1" else 0)
+            out[setting] = ix.search(q32, qi, 100)
+        finally:
+            ix.close()
+    for setting in ("0", "1"):
+        np.testing.assert_array_equal(out[setting][1], out["-1"][1])
+        np.testing.assert_array_equal(out[setting][0], out["-1"][0])
