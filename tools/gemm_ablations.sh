@@ -1,4 +1,5 @@
 #!/bin/bash
+# usage: build the ablation libraries first:  for a in 16 32 4; do bash tools/ab_build.sh abl$a "-DG8_ABL=$a"; done; cp dhr_amd/csrc/libdhr_hip.so dhr_amd/csrc/_ab/libdhr_hip_abl0.so
 # where the in-bench time of the int8 bound GEMM goes: closed filter vs the thresholds of a real search, with ablation builds of the epilogue
 O=gpurun_out/r4d; mkdir -p $O
 GB="timeout 300 python tools/gemm_bench.py --synth --dlr 768 --rows 2000000 --iters 8"
