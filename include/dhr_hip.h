@@ -10,12 +10,13 @@
  * Threading: one handle is used by one host thread at a time; distinct handles (e.g. one per
  * device / per rank) may be used concurrently.
  *
- * Streams: every entry point works on the stream it is given.  dhr_search ENQUEUES its whole first attempt (sampled run, main
- * pass, refine / rescoring / select of every chunk: no host read-backs between them since round 3) and then performs exactly ONE host
- * read on that stream: the number of queries whose verification failed (a list overflowed, or the sampled threshold came out too
- * high -- adversarial row orders), because those are redone by a host-driven controller that is exact for any input.  It therefore
+ * Streams: every entry point works on the stream it is given.  dhr_search ENQUEUES its first attempt (sampled run, main pass, refine /
+ * rescoring / select of every chunk: no host read-backs between the phases since round 3) with two small host reads on that stream: 32
+ * bytes after the sampled run (the fullest candidate lists, which size the chunks of the main pass; DHR_PARAM_ASYNC_CONTROLLER = 1 drops
+ * it for a fixed plan) and, at the end, the number of queries whose verification failed (a list overflowed, or the sampled threshold came
+ * out too high -- adversarial row orders), because those are redone by a host-driven controller that is exact for any input.  It
  * returns with the stream idle.  Corpora too small to sample (below ~33 k rows) use the host-driven controller throughout.
- * dhr_search_sharded over RCCL likewise enqueues everything up to its one host read (the count of queries to repair).
+ * dhr_search_begin / dhr_search_finish and dhr_search_sharded over RCCL enqueue everything up to ONE host read (the count of queries to repair).
  */
 #ifndef DHR_HIP_H
 #define DHR_HIP_H
@@ -106,9 +107,11 @@ typedef enum dhr_param {
   DHR_PARAM_OVERLAP_AUX = 11,  /* 0: refine / rescoring / select of a chunk run after its GEMM on the same stream; 1: beside the GEMM of the next chunk on a CU-masked stream; -1 (default): 1 for dense-only indexes and for the main pass of a shard (dhr_search_finish / dhr_search_sharded), 0 for the unsharded search of a gated index */
   DHR_PARAM_PROGRESSIVE_THR = 8, /* later main-pass chunks filter with 1: the running exact k-th best; 2 (default): additionally the rank extrapolated from the scattered fraction of the corpus seen so far (main pass in a scattered tile order; a query whose extrapolation was too high fails the final verification and is redone); 0: the sampled threshold only */
   DHR_PARAM_GEMM_VARIANT = 6, /* bound-GEMM kernel of the 2:4 layout: 3 = 12 waves (producer / consumer), 4 = 4 waves with 128 x 128 wave tiles, 5 = 8 waves with 128 x 64 wave tiles (default) */
-  DHR_PARAM_ASYNC_CONTROLLER = 13, /* 1 (default): the first attempt of a sampled search only ENQUEUES work -- no host read-backs between its phases, ONE
-                                     host read at the end (the number of queries whose verification failed); 0: the host-driven controller (reads the
-                                     list lengths back after every phase, adapts the chunk count to them).  DHR_ASYNC overrides. */
+  DHR_PARAM_ASYNC_CONTROLLER = 13, /* the first attempt of a sampled search ENQUEUES its phases without reading list lengths back between them.
+                                     2 (default): one 32-byte read after the sampled run (the fullest lists: how many chunks the main pass
+                                     needs) + ONE at the end (the number of queries whose verification failed); 1: the final read only (fixed
+                                     chunk plan; what the staged / sharded entry points always do); 0: the host-driven controller (reads the list
+                                     lengths back after every phase).  DHR_ASYNC overrides. */
   DHR_PARAM_SAMPLE_SHARE = 12, /* staged search only (dhr_search_begin / finish): the number of shards the sampled threshold is agreed between; a shard then
                                  reports its r / shards + 5 sqrt(r / shards) + 4 best sample scores (dhr_search_sample_rank) instead of all r
                                  (dhr_search_union_rank).  dhr_search_sharded[_local] set it themselves.  Default 1. */
