@@ -114,8 +114,8 @@ def cpu_baseline_legs(sample, k, n_full, q_one, q_all):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="hybrid", choices=["hybrid", "dense", "bm25", "beir"],
                     help="hybrid = config 3 / 4 (768 DLR + 768 dense, 8.84 M rows); dense = config 2 (768 dense, no index array); "
                          "bm25 = config 1 (100 k rows, DLR only, int16 whole-word slice index); beir = config 5 sweep (13 corpus sizes, "
