@@ -330,14 +330,25 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
   constexpr std::integral_constant<int, 1> PH1{};
   constexpr std::integral_constant<int, 2> PH2{};
   dma_n = 0;             // nothing pending during pair 0's first block (pairs 0 and 1 went out above)
+  // (the last pair is peeled so that "read the next fragments" is a compile-time fact in both bodies: as a run-time flag it put a scalar
+  // branch and an address computation in front of each of the 12 reads of every pair's second block)
 #pragma unroll 1
-  for (int g = 0; g < nsp; ++g) {
+  for (int g = 0; g + 1 < nsp; ++g) {
     blk_s8(f0, f1, 2 * g + 1, true, PH1);
     dma_prepare(g + 2);
     __builtin_amdgcn_sched_barrier(0);                    // the matrix asm is not volatile: without this the compiler sinks the block above below the wait
     G8_PAIR_SYNC();
     dma_commit();                                         // pair g+2 goes into the ring half this pair just left
-    blk_s8(f1, f0, 2 * g + 2, g + 1 < nsp, PH0);
+    blk_s8(f1, f0, 2 * g + 2, true, PH0);
+  }
+  if (nsp > 0) {
+    const int g = nsp - 1;
+    blk_s8(f0, f1, 2 * g + 1, true, PH1);
+    dma_prepare(g + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    G8_PAIR_SYNC();
+    dma_commit();
+    blk_s8(f1, f0, 2 * g + 2, false, PH0);
   }
   if (td > 0) {
     // gated sums -> ungated units: every accumulator shifted left by its query's shift, then the first ungated fragments
@@ -359,7 +370,7 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
     asm volatile("s_nop 4" ::: "memory");      // VALU write -> matrix read of the accumulators
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
-    for (int g = nsp; g < npairs; ++g) {
+    for (int g = nsp; g + 1 < npairs; ++g) {
       const int t0 = 4 * (g - nsp);
       blk_dn(f0, f1, t0 + 1, true, PH1);
       blk_dn(f1, f0, t0 + 2, true, PH2);
@@ -368,7 +379,19 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
       __builtin_amdgcn_sched_barrier(0);
       G8_PAIR_SYNC();
       dma_commit();
-      blk_dn(f1, f0, t0 + 4, g + 1 < npairs, PH0);
+      blk_dn(f1, f0, t0 + 4, true, PH0);
+    }
+    {
+      const int g = npairs - 1;
+      const int t0 = 4 * (g - nsp);
+      blk_dn(f0, f1, t0 + 1, true, PH1);
+      blk_dn(f1, f0, t0 + 2, true, PH2);
+      blk_dn(f0, f1, t0 + 3, true, PH2);
+      dma_prepare(g + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      G8_PAIR_SYNC();
+      dma_commit();
+      blk_dn(f1, f0, t0 + 4, false, PH0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // the last matrix results are in the accumulators

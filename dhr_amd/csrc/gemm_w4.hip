@@ -381,36 +381,49 @@ __global__ void __launch_bounds__(1024 / NI) __attribute__((amdgpu_waves_per_eu(
   constexpr std::integral_constant<int, 2> PH2{};
   constexpr std::integral_constant<int, 3> PH3{};
   dma_n = 0;             // nothing pending during pair 0's first blocks (pairs 0 and 1 went out above)
+  // The tile's LAST pair is peeled out of its loop, so that "read the next block's fragments" is a compile-time fact in both copies of
+  // the body: as a run-time flag it put a scalar branch and an address computation in front of every read of each pair's last block
+  // (gemm_g8.hip, measured there: -4 % per launch).
+  constexpr std::integral_constant<bool, true> MORE{};
+  constexpr std::integral_constant<bool, false> LAST{};
   auto run_sparse = [&](auto sh_c) __attribute__((always_inline)) {
+    auto pair = [&](int g, auto more_c) __attribute__((always_inline)) {
+      constexpr bool more = decltype(more_c)::value;
+      const int t0 = 4 * g;
+      blk_sparse(f0, f1, t0 + 1, true, KB0, PH1, pwx, sh_c);
+      blk_sparse(f1, f0, t0 + 2, true, KB1, PH2, pwx, sh_c);
+      load_pw(pwy, 2 * g + 1);
+      blk_sparse(f0, f1, t0 + 3, true, KB0, PH3, pwy, sh_c);
+      // every read of this pair's ring half has been issued; the next pair must have landed before anybody reads it
+      dma_prepare(g + 2);
+      __builtin_amdgcn_sched_barrier(0);                    // the matrix asm is not volatile: without this the compiler sinks the block above below the wait
+      W4_PAIR_SYNC();
+      dma_commit();                                         // pair g+2 goes into the ring half this pair just left
+      if (g + 1 < sp_hi) load_pw(pwx, 2 * (g + 1));
+      blk_sparse(f1, f0, t0 + 4, more, KB1, PH0, pwy, sh_c);
+    };
+    const bool tail = sp_hi == npairs && sp_hi > sp_lo;
 #pragma unroll 1
-  for (int g = sp_lo; g < sp_hi; ++g) {
-    const int t0 = 4 * g;
-    blk_sparse(f0, f1, t0 + 1, true, KB0, PH1, pwx, sh_c);
-    blk_sparse(f1, f0, t0 + 2, true, KB1, PH2, pwx, sh_c);
-    load_pw(pwy, 2 * g + 1);
-    blk_sparse(f0, f1, t0 + 3, true, KB0, PH3, pwy, sh_c);
-    // every read of this pair's ring half has been issued; the next pair must have landed before anybody reads it
-    dma_prepare(g + 2);
-    __builtin_amdgcn_sched_barrier(0);                    // the matrix asm is not volatile: without this the compiler sinks the block above below the wait
-    W4_PAIR_SYNC();
-    dma_commit();                                         // pair g+2 goes into the ring half this pair just left
-    if (g + 1 < sp_hi) load_pw(pwx, 2 * (g + 1));
-    blk_sparse(f1, f0, t0 + 4, g + 1 < npairs, KB1, PH0, pwy, sh_c);
-  }
+    for (int g = sp_lo; g < sp_hi - (tail ? 1 : 0); ++g) pair(g, MORE);
+    if (tail) pair(sp_hi - 1, LAST);
   };
   auto run_dense = [&](auto sh_c) __attribute__((always_inline)) {
+    auto pair = [&](int g, auto more_c) __attribute__((always_inline)) {
+      constexpr bool more = decltype(more_c)::value;
+      const int t0 = 4 * g;
+      blk_dense(f0, f1, t0 + 1, true, PH1, sh_c);
+      blk_dense(f1, f0, t0 + 2, true, PH2, sh_c);
+      blk_dense(f0, f1, t0 + 3, true, PH3, sh_c);
+      dma_prepare(g + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      W4_PAIR_SYNC();
+      dma_commit();
+      blk_dense(f1, f0, t0 + 4, more, PH0, sh_c);
+    };
+    const bool tail = dn_hi == npairs && dn_hi > dn_lo;
 #pragma unroll 1
-  for (int g = dn_lo; g < dn_hi; ++g) {
-    const int t0 = 4 * g;
-    blk_dense(f0, f1, t0 + 1, true, PH1, sh_c);
-    blk_dense(f1, f0, t0 + 2, true, PH2, sh_c);
-    blk_dense(f0, f1, t0 + 3, true, PH3, sh_c);
-    dma_prepare(g + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    W4_PAIR_SYNC();
-    dma_commit();
-    blk_dense(f1, f0, t0 + 4, g + 1 < npairs, PH0, sh_c);
-  }
+    for (int g = dn_lo; g < dn_hi - (tail ? 1 : 0); ++g) pair(g, MORE);
+    if (tail) pair(dn_hi - 1, LAST);
   };
   auto run_loops = [&](auto sh_c) __attribute__((always_inline)) {
     if constexpr (I8) {
