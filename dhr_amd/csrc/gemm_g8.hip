@@ -86,7 +86,7 @@ __device__ __forceinline__ void g8_dump_tile(const GemmArgs& p, floatx16 (&acc)[
 // then the four elements.  (A third level over the 16 accumulators of a 32 x 32 block was dropped in round 3: at the bench's hit
 // rate of 0.23 % per accumulator, 91 % of the blocks hold a hit in SOME lane of the wave, so the test was nearly always taken and
 // only cost its 15 maxima.)
-template <bool SURPLUS, int NI_>
+template <bool SURPLUS, int NI_, bool CHECK_ROWS = true>
 __device__ __forceinline__ void g8_scan_half(const GemmArgs& p, floatx16 (&acc)[4][2], int qt, int wm, int wn, int lane, int rows_valid, int64_t row0,
                                              uint2* stack, const int t, const float mul, uint32_t& j) {
   const int fhalf = lane >> 5;
@@ -104,7 +104,7 @@ __device__ __forceinline__ void g8_scan_half(const GemmArgs& p, floatx16 (&acc)[
         for (int e = 4 * g; e < 4 * g + 4; ++e) {
           const int v = __float_as_int(a[e]);
           const int rl = rbase + mi * 32 + (e & 3) + 8 * (e >> 2);
-          if (v >= t && rl < rows_valid) {
+          if (v >= t && (!CHECK_ROWS || rl < rows_valid)) {
             asm volatile("");
             if constexpr (SURPLUS) {
               if (j >= EPI_STACK) {
@@ -138,14 +138,19 @@ __device__ __forceinline__ void g8_epilogue(const GemmArgs& p, floatx16 (&acc)[4
   const int rows_valid = (int)(p.n_rows - row0 < TILE_ROWS ? p.n_rows - row0 : TILE_ROWS);
   uint2* stack = (uint2*)smem + tid;                       // slot j at stack[j * G8_NT]
   const int q0 = qt * TILE_ROWS + wn * 64 + (lane & 31);
+  // every tile but a shard's last one is full: its copy of the scan has no per-element row test (one compare and one scalar AND less in
+  // each of the ~90 serial test chains of a tile)
+  const bool full = rows_valid == TILE_ROWS;
   uint32_t j = 0;
-  g8_scan_half<false, 0>(p, acc, qt, wm, wn, lane, rows_valid, row0, stack, thr_r[0], mul_r[0], j);
+  if (full) g8_scan_half<false, 0, false>(p, acc, qt, wm, wn, lane, rows_valid, row0, stack, thr_r[0], mul_r[0], j);
+  else g8_scan_half<false, 0, true>(p, acc, qt, wm, wn, lane, rows_valid, row0, stack, thr_r[0], mul_r[0], j);
   const uint32_t s0 = j < (uint32_t)EPI_STACK ? j : (uint32_t)EPI_STACK;
 #if G8_ABL != 16
   uint32_t base0 = 0u, base1 = 0u;
   if (s0 > 0) base0 = atomicAdd(p.cnt + q0, s0);
 #endif
-  g8_scan_half<false, 1>(p, acc, qt, wm, wn, lane, rows_valid, row0, stack, thr_r[1], mul_r[1], j);
+  if (full) g8_scan_half<false, 1, false>(p, acc, qt, wm, wn, lane, rows_valid, row0, stack, thr_r[1], mul_r[1], j);
+  else g8_scan_half<false, 1, true>(p, acc, qt, wm, wn, lane, rows_valid, row0, stack, thr_r[1], mul_r[1], j);
   const uint32_t s1 = j < (uint32_t)EPI_STACK ? j : (uint32_t)EPI_STACK;
 #if G8_ABL == 16       // timing only: hits are found and stacked, never flushed to the lists
   return;
