@@ -100,6 +100,20 @@ __device__ __forceinline__ void g8_scan_half(const GemmArgs& p, floatx16 (&acc)[
       const int gm = max(max(__float_as_int(a[4 * g]), __float_as_int(a[4 * g + 1])), max(__float_as_int(a[4 * g + 2]), __float_as_int(a[4 * g + 3])));
       if (gm >= t) {
         asm volatile("");
+        if constexpr (!SURPLUS && !CHECK_ROWS) {
+          // full tile, stack pass: BRANCH-FREE pushes.  Every lane of the active group writes all four (row, sum) pairs to its current stack
+          // slot and advances only on a hit -- a miss is overwritten by the lane's next write; slot EPI_STACK (full stack) is this thread's 8
+          // bytes of the constants' area behind the ring, idle by now.  (A push used to be a serial v_cmp -> s_and_saveexec -> s_cbranch
+          // chain of ~35 cycles, ~58 of them per tile with nothing to overlap.)
+#pragma unroll
+          for (int e = 4 * g; e < 4 * g + 4; ++e) {
+            const int v = __float_as_int(a[e]);
+            const int rl = rbase + mi * 32 + (e & 3) + 8 * (e >> 2);
+            const uint32_t slot = j < (uint32_t)EPI_STACK ? j : (uint32_t)EPI_STACK;
+            stack[slot * G8_NT] = make_uint2((uint32_t)rl, (uint32_t)v);
+            j += v >= t ? 1u : 0u;
+          }
+        } else
 #pragma unroll
         for (int e = 4 * g; e < 4 * g + 4; ++e) {
           const int v = __float_as_int(a[e]);
