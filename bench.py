@@ -354,6 +354,25 @@ def run_workload(args, spec, ctx):
     barrier()
     ms_device_resident = (time.perf_counter() - t1) * 1e3 / args.steps
 
+    # side figure 2 (N = 1): the bound GEMM ALONE.  In the timed steps refine / rescoring / select of a chunk run beside the next chunk's GEMM
+    # (library default since round 4), so the GEMM's launch durations there include what it loses to the gathers; two extra steps with
+    # DHR_PARAM_OVERLAP_AUX = 0 time the same launches with the chip to themselves (roofline.achieved; the timed region's own figure beside it)
+    serial = None
+    if world == 1 and pq is None and args.overlap_aux < 0:
+        index.set_param(_lib.PARAM_OVERLAP_AUX, 0)
+        step()
+        s_ms = s_fl = 0.0
+        s_n = 0
+        t2 = time.perf_counter()
+        for _ in range(3):
+            step()
+            st = index.stats()
+            s_ms += st["gemm_ms"]; s_fl += st["gemm_flops_alg"]; s_n += st["phases"]
+        torch.cuda.synchronize()
+        serial = {"gemm_ms_per_step": s_ms / 3, "tf": s_fl / (s_ms * 1e-3) / 1e12 if s_ms > 0 else 0.0, "launches": s_n,
+                  "ms_per_step": (time.perf_counter() - t2) * 1e3 / 3}
+        index.set_param(_lib.PARAM_OVERLAP_AUX, -1)
+
     # ---- N > 1: size-independent checks of the sharded result, outside the timed region (the oracle cannot hold the
     # corpus): sorted lists of distinct rows; every returned score is the exact score of its row on the rank that holds
     # the row (dhr_score_rows, an independent code path); no sampled row of any shard outside a list beats its k-th score
@@ -386,6 +405,7 @@ def run_workload(args, spec, ctx):
     out = None
     if rank == 0:
         ach_tf = gemm_flops_alg / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        ach_k = serial["tf"] if serial else ach_tf
         sparse_layout = d_dlr > 0 and args.idx_buckets in (0, 2)
         stage_layout = sparse_layout or (d_dlr == 0 and args.idx_buckets == 0)      # dense-only indexes run on the stage images too (ts = 0)
         variant = args.gemm_variant if args.gemm_variant >= 0 else 5
@@ -429,14 +449,20 @@ def run_workload(args, spec, ctx):
                        "parallelism": "rowshard%d+allgather" % world if world > 1 else "1gpu",
                        **({"collectives": sharded_impl} if sharded_impl else {})},
             "roofline": {"bound": "mfma", "kernel": kernel,
-                         "achieved": round(ach_tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(ach_tf / peak, 4),
+                         "achieved": round(ach_k, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(ach_k / peak, 4),
+                         "achieved_note": ("kernel alone: hipEvent durations of the same %d launches per step in 3 extra steps with refine / rescoring / select serialised behind each "
+                                           "launch (DHR_PARAM_OVERLAP_AUX = 0, %.1f ms per step); inside the timed region the launches share the chip with the gathers of the previous "
+                                           "chunk: achieved_in_timed_region" % (serial["launches"] // 3, serial["ms_per_step"])) if serial else
+                                          "hipEvent durations of the launches inside the timed region",
+                         "achieved_in_timed_region": round(ach_tf, 1), "frac_in_timed_region": round(ach_tf / peak, 4),
                          "peak_note": "dense fp16 / bf16 matrix peak (MI355X_MICROARCH.md): the roofline BASELINE.json prices this metric against; algorithmic flops 2 x Q x rows x (d_dlr + d_cls)",
-                         "peak_instruction_mix": round(peak_mix, 1), "frac_of_instruction_mix_peak": round(ach_tf / peak_mix, 4),
+                         "peak_instruction_mix": round(peak_mix, 1), "frac_of_instruction_mix_peak": round(ach_k / peak_mix, 4),
                          "traffic": None if traffic_per_row is None else round(traffic_per_row * rows_per_launch, 0),
                          "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE, gfx950-corrected; profiles/r03_gemm_pmc.txt, dense-only: r02_gemm_pmc.txt)",
                          "algorithmic_bytes_per_launch": round(alg_bytes_per_row * rows_per_launch, 0),
                          "launches": launches, "avg_launch_ms": round(gemm_ms / max(launches, 1), 3),
+                         "avg_launch_ms_kernel_alone": round(serial["gemm_ms_per_step"] * 3 / max(serial["launches"], 1), 3) if serial else None,
                          "alg_flops_per_step": gemm_flops_alg / args.steps},
             "whole_job_frac_of_gemm_roofline": round(qps * 2.0 * n * K / (peak * 1e12 * world), 4),
             "device_resident": {"ms_per_step": round(ms_device_resident, 3), "queries_per_s": round(nq / (ms_device_resident * 1e-3), 1),

@@ -130,7 +130,7 @@ struct dhr_index {
   int progressive_thr = 2;
   int n_cu = 256;
   int gemm_variant = 0;                    // 2:4 layout kernel of THIS handle (0 = library default)
-  int overlap_aux = -1;                    // 0: refine / rescoring / select run on the GEMM's stream (every kernel gets the whole chip); 1: beside the next chunk's GEMM on a CU-masked stream; -1 (default) = 1 for dense-only indexes (110.4 -> 101.7 ms per step at config 2), 0 for gated ones (the same step time, 192.7 vs 193.0 ms, but the overlapped GEMM launches run 7 % longer)
+  int overlap_aux = -1;                    // 0: refine / rescoring / select run on the GEMM's stream (every kernel gets the whole chip); 1: beside the next chunk's GEMM on the aux stream; -1 (default) = 1 (round 4; until then gated unsharded searches ran serially)
   int aux_cus = -1, gemm_exclusive = 0;    // CU-masked streams of the main pass (0 = no mask; -1 = default: 128 CUs for dense-only indexes, no mask for gated ones)
   int aux_cus_made = -1, gemm_excl_made = -1;
   hipStream_t s_gemm = nullptr;         // main-pass GEMM stream when CU masks are in use
@@ -1007,15 +1007,34 @@ static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectA
 
 // Streaming phases over a tile sequence with growing chunks (exact for any input: tau only ever
 // comes from exact scores already seen, overflowing chunks are re-run in halves).
+// Rank that defines the threshold of a sampled run after a fraction phi of the sample has been seen.  The run's goal is the r-th best
+// score of the WHOLE sample; of the sample's r best rows a scattered fraction phi holds r phi +- sqrt(r phi (1 - phi)), so the
+// (r phi + 6 sigma + 4)-th best seen lies below the sample's final r-th best except with negligible probability (Poisson tail < 1e-8 per
+// check at every phi; a query for which it does not fails the final verification -- thresholds only ever rise, tau_hat is their maximum --
+// and is redone).  With the fixed rank r of rounds 1-3 every phase of the sampled run let ~r x (rows of the phase / rows seen) x the
+// bound's amplification through: 1 400 of the 4 340 exact rescorings per query of a config-3 step were spent finding the 64 best of
+// the 1/32 sample.
+static int adaptive_rank(int r, double phi) {
+  static const int on = getenv("DHR_ADAPTIVE_RANK") ? atoi(getenv("DHR_ADAPTIVE_RANK")) : 1;
+  if (!on || !(phi < 1.0)) return r;
+  if (phi < 0.0) phi = 0.0;
+  const double m = (double)r * phi;
+  return std::max(1, std::min(r, (int)std::ceil(m + 6.0 * std::sqrt(m * (1.0 - phi)) + 4.0)));
+}
+
 static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, int64_t n_seq, int map_mode,
                          int period, int64_t head, int64_t first_chunk, int64_t seen_rows, Timer& tm, dhr_search_stats& st,
                          hipStream_t s, double* last_rate = nullptr, double* last_rate_r = nullptr, bool async_ctl = false,
-                         int64_t* last_rows = nullptr) {
+                         int64_t* last_rows = nullptr, int rank_target = 0, int64_t rank_rows = 0) {
   int64_t pos = 0;
   int64_t chunk = std::max<int64_t>(DOC_GROUP, first_chunk);
   while (pos < n_seq) {
     chunk = std::min(chunk, round_up(n_seq - pos, DOC_GROUP));
     const int64_t hi = std::min(pos + chunk, n_seq);
+    if (rank_target > 0) {        // sampled run: the rank grows with the fraction of the sample seen once this phase is merged
+      sel.k = adaptive_rank(rank_target, (double)(seen_rows + (hi - pos) * TILE_ROWS) / (double)std::max<int64_t>(rank_rows, 1));
+      sel.monotone = 1;
+    }
     if (async_ctl) {          // enqueue only: an overflowing list flags its query instead of halving the chunk
       // (d_max2: {fullest bound list, -, -, -, fullest survivor list} of the latest phase -- what the chunk plan of the main pass reads)
       HIP_TRY(hipMemsetAsync(w.d_max2, 0, 32, s));
@@ -1145,6 +1164,11 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
     tm.begin(T_RESCORE); HIP_TRY(launch_rescore(r, s)); tm.end();
     sel.cnt = nullptr; sel.count_all = (uint32_t)first_valid;
+    if (S >= 2 && rest > 0) {       // the head is the first part of the sample (adaptive_rank)
+      const int64_t sample_rows = first_valid + ((rest + S - 1) / S) * TILE_ROWS;
+      sel.k = adaptive_rank(r_eff, (double)first_valid / (double)sample_rows);
+      sel.monotone = 1;
+    }
     tm.begin(T_SELECT); HIP_TRY(launch_select(sel, s)); tm.end();
     st.candidates_exact += (int64_t)first_valid * Q;
   }
@@ -1161,7 +1185,8 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   double rate = 0.0, rate_r = 0.0;
   if (stage != 2) {
     int64_t last_rows = 0;
-    if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, std::max<int64_t>(head, DOC_GROUP), first_valid, tm, st, s, &rate, &rate_r, async_ctl, &last_rows)) != DHR_OK) return rc;
+    if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, std::max<int64_t>(head, DOC_GROUP), first_valid, tm, st, s, &rate, &rate_r, async_ctl, &last_rows,
+                            r_eff, first_valid + n_sample * TILE_ROWS)) != DHR_OK) return rc;
     HIP_TRY(hipMemcpyAsync(w.tau_hat, w.tau, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
     if (async_ctl && plan_read && stage == 0 && last_rows > 0) {
       // the ONE read-back besides the final one: 32 bytes, the fullest bound / survivor list of the last sampled phase -> how many chunks
@@ -1181,12 +1206,13 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     rate = ix->pend.rate; rate_r = ix->pend.rate_r;
     // thresholds agreed between the shards: tau_ext >= this shard's own tau_hat in general
     HIP_TRY(hipMemcpyAsync(w.tau_hat, tau_ext, (size_t)Q * 4, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(launch_flag_tau_above(w.tau, w.tau_hat, Q, w.fail_flags, s));      // sample rows this shard dropped below its own (higher) threshold
     HIP_TRY(launch_make_thr(w.tau_hat, w.margin, Q, w.q_pad, w.thr, s));
   }
 
   // ---- main pass: all other tiles with the FROZEN threshold tau_hat - margin, in a few chunks; the
   // bound GEMM of chunk i+1 (stream s) overlaps the exact rescoring + top-k merge of chunk i (aux stream)
-  sel.k = k; sel.kps = w.kp;
+  sel.k = k; sel.kps = w.kp; sel.monotone = 0;
   const int64_t n_main = rest - n_sample;
   // progressive_thr 2 (default, first attempt of an unsharded search only): the main pass visits the non-sample tiles in a scattered
   // order (i -> i * perm_mul mod n_main, perm_mul ~ 0.618 n_main and coprime), so that what has been seen after any chunk is a
@@ -1239,7 +1265,10 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     // default: dense-only indexes, and the main pass of a SHARD (staged search: its refine / rescoring / select are a larger share of a
     // shorter step -- 18.1 -> 17.0 ms per finish on a 1/8 shard of config 4; the unsharded gated search gains 2 % and its GEMM launches
     // would be timed under contention, so it keeps them serial)
-    const bool overlap = ix->overlap_aux < 0 ? (ix->d_dlr == 0 || stage == 2) : ix->overlap_aux != 0;
+    // Round 4: the default everywhere.  The unsharded gated search gains 2 ms per config-3 step (124.5 vs 126.2 ms; 1.5 % in round 3); its GEMM
+    // launches then share CUs and the memory system with the gathers (92 -> 116 ms of launch durations per step), so the kernel's own rate
+    // is profiled with DHR_PARAM_OVERLAP_AUX = 0 (bench.py reports both).
+    const bool overlap = ix->overlap_aux < 0 ? true : ix->overlap_aux != 0;
     hipStream_t sb = overlap ? ix->s_aux : sg;
     hipEvent_t ev_enter = nullptr;
     if (sg != s) {

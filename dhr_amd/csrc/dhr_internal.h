@@ -196,6 +196,7 @@ struct SelectArgs {
   int k_keep;                 // entries the running list keeps (0 = k).  The sampled run publishes the r-th best (k = r) but keeps the k best seen:
                               // rows of the sample that tie with the final k-th score must not be lost to the rank that only defines the threshold
   int kps;                    // slots of the running list actually in use (power of two >= k, <= kp): sizes the LDS sort
+  int monotone;               // 1: the published threshold never falls (tau = max(old tau, k-th best)): sampled runs whose rank grows with the fraction seen
   const float* margin;        // [Q_pad]
   float* tau;                 // [Q_pad] exact k-th best so far (-inf until k results exist)
   float* thr;                 // [Q_pad] tau - margin
@@ -303,6 +304,7 @@ hipError_t launch_scatter_keys(const uint64_t* src, uint64_t* dst, int kp, const
 hipError_t launch_emit_scores(const uint64_t* topk_keys, int kp, int n_queries, int r, float* out, hipStream_t s);
 hipError_t launch_make_thr(const float* tau, const float* margin, int n_queries, int q_pad, float* thr, hipStream_t s);
 hipError_t launch_raise_thr(float* thr_hat, const float* thr_run, int n_queries, hipStream_t s);
+hipError_t launch_flag_tau_above(const float* tau_own, const float* tau_ext, int n_queries, uint32_t* fail_flags, hipStream_t s);
 hipError_t launch_raise_thr_rank(float* thr_hat, float* tau_hat, const uint64_t* topk_keys, int kp, int r, const float* margin, int n_queries, hipStream_t s);
 hipError_t launch_count_ge(const uint64_t* topk_keys, int kp, int k, const float* tau, const uint32_t* fail_flags, int n_queries,
                            int32_t* out, hipStream_t s);

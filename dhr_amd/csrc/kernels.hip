@@ -1334,6 +1334,11 @@ hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, 
 // nothing to the exact score, so |q_j d_j| is taken off the bound.  U2 = U - sum(corr) is still an
 // upper bound of the exact score (only certain mismatches are removed; the query side keeps 12 index
 // bits, an alias there only makes the bound looser).  8 lanes per candidate, 8 heavy entries per lane.
+// (Round 4: marking the row gathers of the refine / rescoring kernels non-temporal -- they are read once, the idea being that they should
+// not evict the bound GEMM's operand tiles from L2 when the two overlap -- made BOTH kernels slower, with and without overlap: refine
+// 12.0 -> 14.1 ms, rescoring 15.8 -> 16.6 ms per config-3 step, step 121.7 -> 124.5 ms.  Plain loads stay.)
+static __device__ __forceinline__ uint4 gather16(const void* p) { return *(const uint4*)p; }
+static __device__ __forceinline__ uint2 gather8(const void* p) { return *(const uint2*)p; }
 constexpr int REFINE_PER_WG = 256;       // candidates of ONE query per workgroup (its operand words are staged in LDS once)
 template <bool G8>
 __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
@@ -1367,8 +1372,10 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
     if (i < count) {
       c = p.cand[(int64_t)q * p.cap + i];
       const uint32_t* hk = p.heavy_key + (int64_t)c.x * HEAVY_KEY_STRIDE + sub * 8;
-      const uint4 k0 = *(const uint4*)hk, k1 = *(const uint4*)(hk + 4);
-      const half8 hv = *(const half8*)(p.heavy_val + (int64_t)c.x * HEAVY_VAL_STRIDE + sub * 8);
+      const uint4 k0 = gather16(hk), k1 = gather16(hk + 4);
+      union { uint4 u; half8 h; } hvu;
+      hvu.u = gather16(p.heavy_val + (int64_t)c.x * HEAVY_VAL_STRIDE + sub * 8);
+      const half8 hv = hvu.h;
       const uint32_t keys[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -1541,12 +1548,12 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
       // (the kernel is VALU-bound on conversions and fp64 adds, not on the row gathers).
       for (int c = lane; c < nchunks; c += 64) {
         if (!((nz_mask >> (c >> 6)) & 1u)) continue;      // eight zero query values add exactly nothing: the corpus bytes are not fetched
-        const uint4 dv = *(const uint4*)(p.vals_rm + (int64_t)row * p.k_rm + c * 8);
+        const uint4 dv = gather16(p.vals_rm + (int64_t)row * p.k_rm + c * 8);
         const uint4 qv = *(const uint4*)(p.q16 + (int64_t)q * p.k_rm + c * 8);
         uint32_t d[4] = {dv.x, dv.y, dv.z, dv.w};
         const uint32_t qq[4] = {qv.x, qv.y, qv.z, qv.w};
         if (c < dlr_chunks && p.gate) {
-          const uint2 ci = *(const uint2*)((const uint8_t*)p.c_idx + (int64_t)row * p.d_dlr + c * 8);
+          const uint2 ci = gather8((const uint8_t*)p.c_idx + (int64_t)row * p.d_dlr + c * 8);
           const uint2 qi8 = *(const uint2*)(p.q_idx8 + (int64_t)q * p.d_dlr + c * 8);
           const uint32_t x0 = ci.x ^ qi8.x, x1 = ci.y ^ qi8.y;
           d[0] &= pair_mask(x0, 0x0c010c00u); d[1] &= pair_mask(x0, 0x0c030c02u);
@@ -1723,7 +1730,8 @@ __global__ void __launch_bounds__(SELECT_SM_THREADS) select_kernel(SelectArgs p)
   for (int j = tid; j < kps; j += SELECT_SM_THREADS) topk[j] = (j < k_keep) ? A[j] : 0ull;
   if (tid == 0) {
     const uint64_t kth = A[p.k - 1];
-    const float t = kth ? ordered_f32((uint32_t)(kth >> 32)) : -INFINITY;
+    float t = kth ? ordered_f32((uint32_t)(kth >> 32)) : -INFINITY;
+    if (p.monotone) t = fmaxf(t, p.tau[q]);      // the rank that defines the threshold changes between the phases of a sampled run
     p.tau[q] = t;
     p.thr[q] = (q < p.n_queries) ? t - p.margin[q] : INFINITY;
   }
@@ -1790,7 +1798,8 @@ __global__ void __launch_bounds__(SELECT_THREADS) select_big_kernel(SelectArgs p
   for (int j = tid; j < p.kp; j += SELECT_THREADS) topk[j] = (j < k_keep) ? A[j] : 0ull;
   if (tid == 0) {
     const uint64_t kth = A[p.k - 1];
-    const float t = kth ? ordered_f32((uint32_t)(kth >> 32)) : -INFINITY;
+    float t = kth ? ordered_f32((uint32_t)(kth >> 32)) : -INFINITY;
+    if (p.monotone) t = fmaxf(t, p.tau[q]);      // the rank that defines the threshold changes between the phases of a sampled run
     p.tau[q] = t;
     p.thr[q] = (q < p.n_queries) ? t - p.margin[q] : INFINITY;
   }
@@ -2155,6 +2164,17 @@ __global__ void raise_thr_kernel(float* __restrict__ thr_hat, const float* __res
 }
 hipError_t launch_raise_thr(float* thr_hat, const float* thr_run, int n_queries, hipStream_t s) {
   hipLaunchKernelGGL(raise_thr_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, thr_hat, thr_run, n_queries);
+  return hipGetLastError();
+}
+// Staged (sharded) search: the sampled run of this shard dropped sample rows below ITS OWN thresholds (maximum: tau_own).  The common
+// threshold tau_ext normally lies far above them (a shard chases only its share of the union's rank); where it does not, rows of the
+// sample tiles in [tau_ext, tau_own) may be missing from the shard's list, so the query is flagged and redone with local thresholds.
+__global__ void flag_tau_above_kernel(const float* __restrict__ tau_own, const float* __restrict__ tau_ext, int n_queries, uint32_t* __restrict__ fail_flags) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n_queries && tau_own[q] > tau_ext[q]) fail_flags[q] = 1u;
+}
+hipError_t launch_flag_tau_above(const float* tau_own, const float* tau_ext, int n_queries, uint32_t* fail_flags, hipStream_t s) {
+  hipLaunchKernelGGL(flag_tau_above_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, tau_own, tau_ext, n_queries, fail_flags);
   return hipGetLastError();
 }
 // Extrapolated threshold ("thresholds"): the rows seen so far are a scattered fraction f of the corpus, so the

@@ -26,7 +26,8 @@ __global__ void sg_take_kernel(SelectArgs p, int64_t L, const uint64_t* __restri
     const uint64_t key = sorted[(int64_t)q * L + j];
     topk[j] = key;
     if (j == p.k - 1 && key != 0ull) {
-      const float t = ordered_f32((uint32_t)(key >> 32));
+      float t = ordered_f32((uint32_t)(key >> 32));
+      if (p.monotone) t = fmaxf(t, p.tau[q]);
       p.tau[q] = t;
       p.thr[q] = t - p.margin[q];
     }

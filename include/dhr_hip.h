@@ -104,7 +104,7 @@ typedef enum dhr_param {
   DHR_PARAM_MAIN_CHUNKS = 7,  /* lower limit of the number of main-pass chunks (the controller adds chunks so that the candidate lists fit) */
   DHR_PARAM_AUX_CUS = 9,      /* main pass: confine refine / rescoring / select to this many CUs (multiple of 8, spread over the XCDs; 0 = no CU mask; default: 128 for dense-only indexes, no mask for gated ones) */
   DHR_PARAM_GEMM_EXCLUSIVE = 10, /* with AUX_CUS: 1 = run the bound GEMM on the other CUs only */
-  DHR_PARAM_OVERLAP_AUX = 11,  /* 0: refine / rescoring / select of a chunk run after its GEMM on the same stream; 1: beside the GEMM of the next chunk on a CU-masked stream; -1 (default): 1 for dense-only indexes and for the main pass of a shard (dhr_search_finish / dhr_search_sharded), 0 for the unsharded search of a gated index */
+  DHR_PARAM_OVERLAP_AUX = 11,  /* 0: refine / rescoring / select of a chunk run after its GEMM on the same stream; 1: beside the GEMM of the next chunk on a CU-masked stream; -1 (default): 1 */
   DHR_PARAM_PROGRESSIVE_THR = 8, /* later main-pass chunks filter with 1: the running exact k-th best; 2 (default): additionally the rank extrapolated from the scattered fraction of the corpus seen so far (main pass in a scattered tile order; a query whose extrapolation was too high fails the final verification and is redone); 0: the sampled threshold only */
   DHR_PARAM_GEMM_VARIANT = 6, /* bound-GEMM kernel of the 2:4 layout: 3 = 12 waves (producer / consumer), 4 = 4 waves with 128 x 128 wave tiles, 5 = 8 waves with 128 x 64 wave tiles (default) */
   DHR_PARAM_ASYNC_CONTROLLER = 13, /* the first attempt of a sampled search ENQUEUES its phases without reading list lengths back between them.

@@ -96,7 +96,7 @@ def test_bound_gemm_layout(G, golden):
 
 
 @pytest.mark.parametrize("kind", ["hybrid", "no_ungated", "ungated_batch", "abs_mode"])
-def test_g8_bound_layout(G, kind):
+def test_g8_bound_layout(G, kind, force_gated_i8):
     """The integer bound GEMM of a gated_i8 index (gemm_g8.hip: 2:4 int8 stage images, position words, fragment mapping, the shift
     between the two halves) == the restated integer bound (oracle/g8_bound_oracle.py), and >= the exact score - margin.  Corpus and
     query index values are drawn from two values per slice with equal mass, which the bucket maps separate: a bucket match is then
@@ -157,8 +157,7 @@ def test_bound_never_below_exact_minus_margin(G, monkeypatch, mode, kind):
     import torch
     import bench
     from dhr_amd import _lib, synth
-    if mode == "gated_fp16":
-        monkeypatch.setenv("DHR_GATED_I8", "0")
+    monkeypatch.setenv("DHR_GATED_I8", "1" if mode == "gated_i8" else "0")
     dev = torch.device("cuda", 0)
     nq, d = 64, 768
     if kind == "bench":
@@ -239,7 +238,7 @@ FN_BRUTE = ["F1_bm25_brute", "F1b_mix8_brute", "F3_hyb_brute_k100", "F3_hyb_brut
 
 
 @pytest.mark.parametrize("case", FN_BRUTE)
-def test_gip_retrieval_golden(G, golden, case):
+def test_gip_retrieval_golden(G, golden, case, gated_image):
     """GIP_retrieval (HIP) vs the reference's recorded rows/scores and vs the exact oracle."""
     info, ref_rows, ref_scores = golden.case(case)
     d = golden.inputs(info["inputs"])
@@ -269,7 +268,7 @@ def test_ip_retrieval_golden(G, golden):
 
 @pytest.mark.parametrize("case", ["F6_hyb_theta03_rerank", "F6_hyb_theta03_norerank", "F6_hyb_ip_rerank",
                                   "F6_hyb_ip_norerank"])
-def test_theta_modes_golden(G, golden, case):
+def test_theta_modes_golden(G, golden, case, gated_image):
     info, ref_rows, ref_scores = golden.case(case)
     d = golden.inputs("hyb")
     q, qi = O.prepare_queries(d["qv"], d["qi"], 768, 1.0)
@@ -302,7 +301,7 @@ def test_k_larger_than_n(G, golden):
 
 
 @pytest.mark.parametrize("cap,first,nb", [(1024, 0, 1), (4096, 2048, 2), (16384, 0, 4), (1024, 0, 3)])
-def test_multi_phase_and_overflow(G, cap, first, nb):
+def test_multi_phase_and_overflow(G, cap, first, nb, gated_image):
     """Small candidate capacity forces many bound-GEMM phases and overflow retries; results must not
     change.  N is ragged, K = 768+128."""
     from dhr_amd import _lib, synth
@@ -435,7 +434,7 @@ def test_merge_sorted_lists_beyond_lds_falls_back_to_general_reduce(G):
     np.testing.assert_array_equal(mr.cpu().numpy(), er)
 
 
-def test_sharded_equals_unsharded(G):
+def test_sharded_equals_unsharded(G, gated_image):
     """Row shards (gip_retrieval.py:292-306 arithmetic) + the shard reduce == one index."""
     from dhr_amd import synth, _lib
     cv, ci, qv, qi = synth.make_pair(14, 10007, 16, 768, 128)
@@ -460,7 +459,7 @@ def test_sharded_equals_unsharded(G):
     ("golden_main_hyb_shard1.trec", ["--brute_force", "--topk", "100", "--total_shrad", "3", "--shrad", "1"]),
     ("golden_main_hyb_shard2.trec", ["--brute_force", "--topk", "100", "--total_shrad", "3", "--shrad", "2"]),
 ])
-def test_cli_main_trec(G, golden, fname, argv):
+def test_cli_main_trec(G, golden, fname, argv, gated_image):
     d = golden.inputs("hyb")
     mq = golden.inputs("main_queries")
     cwd = os.getcwd()
@@ -532,7 +531,7 @@ def test_cli_dense_merged_index(G, golden):
         np.testing.assert_allclose([x[2] for x in ref[qid]], [x[2] for x in out[qid]], rtol=3e-6, atol=3e-6)
 
 
-def test_larger_random_hybrid(G):
+def test_larger_random_hybrid(G, gated_image):
     """N = 200k x 1536, 300 queries (two query tiles), k = 1000; a sample of queries is checked
     against the exact oracle."""
     from dhr_amd import synth
@@ -555,7 +554,7 @@ def _structured_corpus(n, boosted_mod, period=16, head_tiles=1):   # head = 256 
 
 
 @pytest.mark.parametrize("boosted_mod", [0, 3])
-def test_sampled_threshold_fallbacks(G, boosted_mod):
+def test_sampled_threshold_fallbacks(G, boosted_mod, gated_image):
     """Adversarial row order for the sampled threshold: (0) every high-scoring row sits in a SAMPLE tile,
     so tau_hat is far too high and fewer than k rows reach it -> the queries must be redone exactly;
     (3) every high-scoring row sits in one non-sample residue -> tau_hat is low, lists overflow.
@@ -690,7 +689,7 @@ def _fake_world_search(G, shards, q32, qi, k):
 
 
 @pytest.mark.parametrize("kind", ["hybrid", "dense"])
-def test_staged_sharded_search_common_threshold(G, kind):
+def test_staged_sharded_search_common_threshold(G, kind, gated_image):
     """Shards exchange their sample scores, agree on one threshold per query, and the union of their
     (now much shorter) lists still equals the unsharded exact result."""
     from dhr_amd import synth, _lib
@@ -1318,7 +1317,7 @@ def test_query_chunking_same_result(G, golden, monkeypatch):
 
 
 @pytest.mark.parametrize("kind", ["hybrid", "dense", "structured", "tiny"])
-def test_search_sharded_local_c_abi(G, kind):
+def test_search_sharded_local_c_abi(G, kind, gated_image):
     """dhr_search_sharded_local (one process, S shard handles; the same sharded_core as the RCCL entry point, gathers by device
     copies) == the unsharded search, bit for bit: common-threshold path (hybrid, dense), its failure repair (structured: every
     high-scoring row sits in sample tiles of shard 0), and the local-threshold path (tiny shards, k > rows of a shard)."""
@@ -1531,7 +1530,7 @@ def test_pq_n_bits_below_8(G, tmp_path, monkeypatch, nbits):
     assert len(open("pqn.trec").read().splitlines()) == 80
 
 
-def test_extrapolated_threshold_failure_is_redone(G):
+def test_extrapolated_threshold_failure_is_redone(G, gated_image):
     """DHR_PARAM_PROGRESSIVE_THR = 2: after every main-pass chunk the threshold is raised to the rank extrapolated from the scattered
     fraction of the corpus seen so far.  Adversarial placement: 56 outstanding rows (fewer than k = 64), ALL inside the tiles the
     scattered order visits in the first chunk -- the extrapolation (rank 53 of the seen rows) lands on their score, every later row
@@ -1649,7 +1648,7 @@ def test_search_sharded_local_k_beyond_16384(G):
             s.close()
 
 
-def test_zero_score_ties_under_sampling(G):
+def test_zero_score_ties_under_sampling(G, gated_image):
     """Queries with fewer than k matching rows: the tail of the list is rows of score 0.0, and the rule (score desc, row asc) puts the
     LOWEST rows there.  The sampled run publishes the r-th best as threshold but must keep the k best rows it saw -- the rows of the
     head and of the sample tiles tie with the final k-th score (a 100 k-row corpus is sampled since the period adapts to the size)."""
@@ -1683,7 +1682,7 @@ def test_zero_score_ties_under_sampling(G):
         np.testing.assert_array_equal(s[i], ex[order].astype(np.float32))
 
 
-def test_ungated_batch_deep_candidate_lists(G):
+def test_ungated_batch_deep_candidate_lists(G, force_gated_i8):
     """Plain inner product (--IP stage 1: a batch without an index array) on a GATED index whose rows all score nearly alike, so that
     the filter passes almost every row: one main-pass chunk brings a query far more than 32 768 candidates.  Until round 3 such a
     batch kept the refine-depth bound lists over the shallower key buffer, and a long list overwrote the neighbouring queries' keys

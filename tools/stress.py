@@ -30,8 +30,10 @@ def main():
         sparse_vals = bool(rng.random() < 0.5)
         nb = int(rng.choice([0, 0, 0, 1, 2, 3, 4]))
         ungated = bool(d_dlr and rng.random() < 0.15)
+        g8 = int(rng.integers(0, 2))                   # image of the gated half: fp16 2:4 (the library's choice at these sizes) or int8 2:4
+        os.environ["DHR_GATED_I8"] = str(g8)
         cfg = dict(case=case, n=n, q=q, d_dlr=d_dlr, d_cls=d_cls, k=k, idx=np.dtype(idx_dtype).name, n_idx=n_idx, neg=neg, q32=q32,
-                   sparse=sparse_vals, nb=nb, ungated=ungated)
+                   sparse=sparse_vals, nb=nb, ungated=ungated, gated_i8=g8)
         K = d_dlr + d_cls
         def vals(m):
             v = np.abs(rng.standard_normal((m, K))) * 0.5

@@ -32,8 +32,10 @@ def main():
         order = str(rng.choice(["random", "random", "sorted_desc", "sorted_asc", "sample_tiles", "one_residue"]))
         shards = int(rng.choice([1, 1, 2, 3]))
         nb = int(rng.choice([0, 0, 1, 2, 3]))
+        g8 = int(rng.integers(0, 2))                   # image of the gated half: fp16 2:4 (the library's choice at these sizes) or int8 2:4
+        os.environ["DHR_GATED_I8"] = str(g8)
         cfg = dict(case=case, n=n, q=q, d_dlr=d_dlr, d_cls=d_cls, k=k, period=period, cap=cap, chunks=chunks, first=first,
-                   order=order, shards=shards, nb=nb)
+                   order=order, shards=shards, nb=nb, gated_i8=g8)
         K = d_dlr + d_cls
         cv = np.abs(rng.standard_normal((n, K), dtype=np.float32)) * 0.3
         cv[:, d_dlr:] = rng.standard_normal((n, d_cls), dtype=np.float32) * 0.1
