@@ -281,15 +281,17 @@ def run_workload(args, spec, ctx):
             dist.barrier()
         torch.cuda.synchronize()
 
-    # N > 1 over RCCL: one untimed trial of the library's own collective path (dhr_search_sharded).  If it raises on any rank, EVERY
-    # rank switches to the torch.distributed restatement of the same steps (dhr_amd/dist.py: same kernels, same thresholds, the
-    # collectives issued by torch) and the JSON line says so -- the scaling run is the first time this path meets more than one GPU.
+    # N > 1 over RCCL: one untimed trial of dhr_search_sharded on the library's own RCCL communicator.  If it raises on any rank, EVERY rank
+    # switches the communicator's transport to torch.distributed all-gathers on host buffers (dhr_comm_create_callback: the SAME control
+    # flow in the library, only the gathers change) and the JSON line says so -- the scaling run is the first time this path meets more
+    # than one GPU.
     sharded_impl = None
     if world > 1 and pq is None:
         import torch.distributed as dist
-        sharded_impl = "dhr_search_sharded (RCCL inside the library)" if dist.get_backend() == "nccl" and os.environ.get("DHR_SHARDED_IMPL") != "torch" \
-            else "torch.distributed collectives (dhr_amd/dist.py)"
-        if sharded_impl.startswith("dhr_search_sharded"):
+        host_tr = dist.get_backend() != "nccl" or os.environ.get("DHR_SHARDED_TRANSPORT") == "host"
+        sharded_impl = "dhr_search_sharded, all-gathers by torch.distributed on host buffers (callback communicator)" if host_tr \
+            else "dhr_search_sharded (RCCL inside the library)"
+        if not host_tr:
             ok, why = 1, ""
             try:
                 step()
@@ -298,8 +300,8 @@ def run_workload(args, spec, ctx):
             flag = torch.tensor([ok], dtype=torch.int32, device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
-                os.environ["DHR_SHARDED_IMPL"] = "torch"
-                sharded_impl = "torch.distributed collectives (dhr_amd/dist.py); the library's RCCL path failed in the trial: %s" % (why or "on another rank")
+                os.environ["DHR_SHARDED_TRANSPORT"] = "host"
+                sharded_impl = "dhr_search_sharded, all-gathers by torch.distributed on host buffers; the library's RCCL communicator failed in the trial: %s" % (why or "on another rank")
                 print("[bench] rank %d: %s" % (rank, sharded_impl), file=sys.stderr)
     kk = min(k, n)
     host_s = torch.empty((nq, kk), dtype=torch.float32).pin_memory()

@@ -697,7 +697,12 @@ static hipError_t re_malloc(T*& p, size_t bytes, int64_t& total) {
 // list depths of an index without heavy lists.  (Until round 3 it kept the 262 144-entry bound lists over a 32 768-entry key buffer:
 // a query with more than 32 768 bound candidates in one chunk wrote its keys over the next queries' -- found by the verification
 // failures of the --IP mode at full size, 62 of 6 980 queries per step.)
-static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t keys_ld_min, int64_t cap_mult = 1, bool use_refine = true) {
+// queries_only: the caller needs the per-query buffers only (dhr_score_rows: no lists, no running top-k) -- ANY workspace of this index
+// with enough query rows serves, so that stage 2 of a composed --rerank / --PQIP step between two searches does not free and re-allocate
+// the multi-GB lists every time (hipFree synchronises the device).
+static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t keys_ld_min, int64_t cap_mult = 1, bool use_refine = true,
+                     bool queries_only = false) {
+  if (queries_only && w.q_pad >= (int)round_up(n_queries, TILE_ROWS) && w.kt == ix->kt && w.q32 != nullptr) return DHR_OK;
   const int q_pad = (int)round_up(n_queries, TILE_ROWS);
   int kp = 1;
   while (kp < k) kp <<= 1;
@@ -770,6 +775,9 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
 static int check_queries(const dhr_index* ix, const dhr_query_batch* qb) {
   if (!ix || !qb) return set_error(DHR_ERR_INVALID, "null argument");
   if (qb->n_queries <= 0) return set_error(DHR_ERR_INVALID, "n_queries must be > 0");
+  // the bound GEMM's grid carries DOC_GROUP x (padded queries / 256) in one 16-bit dimension (launch_gemm_filter)
+  if ((int64_t)DOC_GROUP * ((qb->n_queries + TILE_ROWS - 1) / TILE_ROWS) > 65535)
+    return set_error(DHR_ERR_UNSUPPORTED, "more than 4 194 048 queries in one call: split the batch (the Python mirror hands over 8 192 at a time)");
   if (!qb->value || qb->ld_value < ix->k - ix->dlr_pad) return set_error(DHR_ERR_INVALID, "bad query value pointer / ld_value");
   if (qb->value_dtype != DHR_VAL_F16 && qb->value_dtype != DHR_VAL_F32) return set_error(DHR_ERR_INVALID, "bad value_dtype");
   const bool has_idx = qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE;
@@ -1688,12 +1696,14 @@ extern "C" int dhr_score_rows(dhr_index* ix, const dhr_query_batch* qb, int32_t 
   int rc = check_queries(ix, qb);
   if (rc) return rc;
   if (m <= 0 || !rows || !out_scores) return set_error(DHR_ERR_INVALID, "bad m / null pointer");
+  if (ix->pend.valid && !ix->pend.done)      // the staged search keeps its query batch in the workspace this call would overwrite
+    return set_error(DHR_ERR_INVALID, "dhr_score_rows between dhr_search_begin and dhr_search_finish on the same handle");
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = (hipStream_t)stream;
   const int Q = qb->n_queries;
   const bool gate = ix->d_dlr > 0 && qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE;
   Workspace& w = ix->ws;
-  if ((rc = ensure_ws(ix, w, Q, 1, 0)) != DHR_OK) return rc;
+  if ((rc = ensure_ws(ix, w, Q, 1, 0, 1, true, true)) != DHR_OK) return rc;
   if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
   const size_t n = (size_t)Q * m;
   void* tmp = nullptr;                     // [rows64 (host input only)] [rows32] [scores]

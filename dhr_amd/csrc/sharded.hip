@@ -7,7 +7,10 @@
 //   dhr_search_sharded_local  one process, several shards (handles on one or more devices): the same control flow with the
 //                             all-gather done by device copies -- also what the single-GPU tests drive
 //
-// Both run ONE implementation (sharded_core) over a "gather" callback.  Sequence (collectives on the caller's stream):
+//   dhr_search_sharded_host   the same control flow over caller-supplied host shards and a caller-supplied all-gather (no device):
+//                             what the CPU test-suite drives with world size 2 / 3 over gloo
+//
+// All run ONE implementation (sharded_core) over a Backend.  Sequence (collectives on the caller's stream):
 //   1. every shard runs its sampled pass (dhr_search_begin) and holds the r best exact sample scores per query;
 //   2. all-gather of [Q, r] fp32; the r-th best of the union is the common threshold tau_q, so a shard collects only ITS SHARE
 //      of the global top-k (rank merge of the sorted lists in place, dhr_merge_topk_lists without rows);
@@ -30,11 +33,15 @@
 #include "dhr_internal.h"
 
 struct dhr_comm {
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr;      // RCCL (dhr_comm_create / dhr_comm_wrap), or
+  dhr_allgather_fn cb = nullptr;  // ... a host transport supplied by the caller (dhr_comm_create_callback): HOST buffers
+  void* cb_user = nullptr;
   bool owned = false;
   int world = 1, rank = 0, device = 0;
   void* arena = nullptr;          // grow-only device scratch
   size_t arena_bytes = 0;
+  void* h_stage = nullptr;        // pinned staging of the callback transport: [send | recv]
+  size_t h_stage_bytes = 0;
 };
 
 
@@ -46,11 +53,221 @@ using namespace dhr;
 #define SH_NCCL(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return dhr_set_error_message(DHR_ERR_HIP, (std::string(#x) + ": " + ncclGetErrorString(r_)).c_str()); } while (0)
 #define SH_TRY(x) do { int rc_ = (x); if (rc_ != DHR_OK) return rc_; } while (0)
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The sharded search is ONE control flow (sharded_core below) over a Backend: where the shards live, how their blocks are
+// gathered, and the handful of per-query reductions between the collectives.  Two backends:
+//   HipBackend   shards = dhr_index handles on GPUs; gathers = RCCL all-gathers (one process per GPU), a caller-supplied host
+//                transport (dhr_comm_create_callback: torch.distributed over gloo, MPI, ...), or device copies (one process,
+//                several shards); reductions = the kernels of this file and kernels.hip.  The product.
+//   HostBackend  shards = caller-supplied callbacks on host memory, gathers = a caller-supplied callback, reductions = plain
+//                loops (dhr_merge_topk_lists_host).  No device is touched: it exists so that the CPU test-suite can drive
+//                THIS control flow with world size 2 / 3 over gloo (tests/test_dist_gloo.py) -- until round 4 those tests ran
+//                a torch restatement of it (dhr_amd/dist.py sharded_search_torch, now deleted).
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct Backend {
+  int world = 1, n_local = 1;
+  virtual ~Backend() {}
+  virtual void* alloc(int i, size_t bytes) = 0;                 // scratch in local shard i's memory, released when the call ends
+  virtual int set_share(int i, int share) = 0;                  // DHR_PARAM_SAMPLE_SHARE
+  virtual int sample_rank(int i, int k) = 0;
+  virtual int union_rank(int i, int k) = 0;
+  virtual int begin(int i, const dhr_query_batch* qb, int k, float* sample) = 0;
+  virtual int finish(int i, const float* tau, float* ls, int64_t* lr, int32_t* cnt) = 0;
+  virtual int search(int i, const dhr_query_batch* qb, int k, float* s, int64_t* r) = 0;
+  // all-gather of `bytes` per shard: send[i] (local shard i's block) -> recv[i] = [world][bytes] in local shard i's memory
+  virtual int gather(const std::vector<const void*>& send, const std::vector<void*>& recv, size_t bytes) = 0;
+  virtual int min_over_ranks(int32_t v[4]) = 0;                 // element-wise minimum over all processes; one host read
+  // [world, Q, r] sorted sample scores -> tau[q] = the ru-th best of the union
+  virtual int union_threshold(int i, const float* gathered, int Q, int r, int ru, float* tau) = 0;
+  // counts [world][Q] -> compact list of failed query ids + their number (a query is complete iff the union holds >= k rows, no
+  // shard overflowed (-1) and no shard's share exceeds the gathered prefix kk)
+  virtual int flag_failures(int i, const int32_t* counts, int Q, int k, int kk, int32_t* fail_ids, int32_t* n_failed) = 0;
+  virtual int prefix(int i, const float* s, const int64_t* r, int k, int kk, int Q, float* os, int64_t* orow) = 0;
+  virtual int merge(int i, int Q, int L, const float* gs, const int64_t* gr, int k, float* os, int64_t* orow) = 0;   // [world, Q, L] sorted lists -> [Q, k]
+  virtual int read_failed(const std::vector<int32_t*>& n_failed, const std::vector<int32_t*>& fail_ids, std::vector<int32_t>& ids) = 0;   // THE host read
+  virtual int sub_batch(int i, const dhr_query_batch* in, const std::vector<int32_t>& ids, dhr_query_batch* out, int32_t** ids_mem) = 0;
+  virtual int scatter(int i, const float* s, const int64_t* r, const int32_t* ids_mem, int F, int k, float* os, int64_t* orow) = 0;
+  virtual int sync(int i) = 0;
+};
+
+int prefix_len(int k, int world) {
+  if (world <= 2) return k;
+  const int kk = ((3 * k + world - 1) / world + 64 + 63) / 64 * 64;
+  return std::min(k, kk);
+}
+
+// host-side pieces shared by both backends ------------------------------------------------------------------------------------------
+void host_flag_failures(const int32_t* counts, int world, int Q, int k, int kk, int32_t* fail_ids, int32_t* n_failed) {
+  int nf = 0;
+  for (int q = 0; q < Q; ++q) {
+    int64_t tot = 0;
+    bool bad = false;
+    for (int w = 0; w < world; ++w) {
+      const int32_t c = counts[(int64_t)w * Q + q];
+      if (c < 0 || c > kk) bad = true;
+      tot += c > 0 ? c : 0;
+    }
+    if (bad || tot < k) fail_ids[nf++] = q;
+  }
+  *n_failed = nf;
+}
+// rows `ids` of a HOST query batch, gathered into `v` / `x`
+void host_sub_batch(const dhr_query_batch* in, const std::vector<int32_t>& ids, std::vector<char>& v, std::vector<char>& x, dhr_query_batch* out) {
+  const int vsz = in->value_dtype == DHR_VAL_F32 ? 4 : 2, isz = in->index_dtype == DHR_IDX_I16 ? 2 : 1;
+  const int64_t vrow = in->ld_value * vsz, irow = in->index ? in->ld_index * isz : 0;
+  const int F = (int)ids.size();
+  v.resize((size_t)F * vrow);
+  for (int f = 0; f < F; ++f) memcpy(v.data() + (size_t)f * vrow, (const char*)in->value + (size_t)ids[f] * vrow, vrow);
+  if (in->index) {
+    x.resize((size_t)F * irow);
+    for (int f = 0; f < F; ++f) memcpy(x.data() + (size_t)f * irow, (const char*)in->index + (size_t)ids[f] * irow, irow);
+  }
+  *out = *in;
+  out->n_queries = F;
+  out->value = v.data();
+  out->index = in->index ? x.data() : nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// local thresholds for a (sub-)batch: every shard searches with k, full lists gathered and merged.  out_* [n_q, k] per local shard.
+int local_path(Backend& B, const std::vector<dhr_query_batch>& qb, int k, const std::vector<float*>& out_s, const std::vector<int64_t*>& out_r) {
+  const int nl = B.n_local, world = B.world, Q = qb[0].n_queries;
+  std::vector<const void*> send_s(nl), send_r(nl);
+  std::vector<void*> recv_s(nl), recv_r(nl);
+  for (int i = 0; i < nl; ++i) {
+    float* ls = (float*)B.alloc(i, (size_t)Q * k * 4);
+    int64_t* lr = (int64_t*)B.alloc(i, (size_t)Q * k * 8);
+    recv_s[i] = B.alloc(i, (size_t)world * Q * k * 4);
+    recv_r[i] = B.alloc(i, (size_t)world * Q * k * 8);
+    if (!ls || !lr || !recv_s[i] || !recv_r[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
+    SH_TRY(B.search(i, &qb[i], k, ls, lr));
+    send_s[i] = ls; send_r[i] = lr;
+  }
+  SH_TRY(B.gather(send_s, recv_s, (size_t)Q * k * 4));
+  SH_TRY(B.gather(send_r, recv_r, (size_t)Q * k * 8));
+  for (int i = 0; i < nl; ++i) SH_TRY(B.merge(i, Q, k, (const float*)recv_s[i], (const int64_t*)recv_r[i], k, out_s[i], out_r[i]));
+  return DHR_OK;
+}
+
+// agree on the sample ranks: all shards must report the same local share r > 0 AND the same union rank ru (local_sample_rank is many-to-one:
+// unequal shard sizes or per-handle sample periods can give equal shares of different union ranks, and the count check of step 4 assumes
+// ONE common threshold column).  Not cached: the answer depends on every rank's shard size and sample period, a communicator outlives the
+// index handles, and a rank that hit a cache the others missed would skip a collective they issue.
+int agree_rank(Backend& B, int k, int* r_out, int* ru_out) {
+  int r = B.sample_rank(0, k);
+  int ru = B.union_rank(0, k);
+  for (int i = 1; i < B.n_local; ++i)
+    if (B.sample_rank(i, k) != r || B.union_rank(i, k) != ru) r = 0;
+  int32_t v[4] = {r, -r, ru, -ru};
+  SH_TRY(B.min_over_ranks(v));
+  *r_out = (v[0] == r && -v[1] == r && v[2] == ru && -v[3] == ru) ? r : 0;
+  *ru_out = ru;
+  return DHR_OK;
+}
+// DHR_PARAM_SAMPLE_SHARE is handle state: the sharded entry points set it for their own staged calls and put 1 back on every way out, so
+// that a later dhr_search_begin / finish on the same handle (another shard count, or none) does not inherit a stale share
+struct ShareGuard {
+  Backend& B;
+  ~ShareGuard() { for (int i = 0; i < B.n_local; ++i) (void)B.set_share(i, 1); }
+};
+
+int sharded_core(Backend& B, const dhr_query_batch* qb_in, int k, const std::vector<float*>& out_s, const std::vector<int64_t*>& out_r) {
+  const int nl = B.n_local, world = B.world, Q = qb_in->n_queries;
+  std::vector<dhr_query_batch> qb(nl, *qb_in);
+  ShareGuard share_guard{B};
+  for (int i = 0; i < nl; ++i) SH_TRY(B.set_share(i, world));      // a shard chases only its share of the union's rank
+  int r = 0, ru_all = 0;
+  SH_TRY(agree_rank(B, k, &r, &ru_all));
+  if (r <= 0) return local_path(B, qb, k, out_s, out_r);
+  const int ru = std::min<int>(ru_all, world * r);      // rank of the union that defines the threshold; the lists are r long
+
+  // 1-2: sampled passes, common thresholds
+  std::vector<const void*> send(nl);
+  std::vector<void*> recv(nl);
+  std::vector<float*> tau(nl);
+  for (int i = 0; i < nl; ++i) {
+    float* sample = (float*)B.alloc(i, (size_t)Q * r * 4);
+    recv[i] = B.alloc(i, (size_t)world * Q * r * 4);
+    tau[i] = (float*)B.alloc(i, (size_t)Q * 4);
+    if (!sample || !recv[i] || !tau[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
+    SH_TRY(B.begin(i, &qb[i], k, sample));
+    send[i] = sample;
+  }
+  SH_TRY(B.gather(send, recv, (size_t)Q * r * 4));
+  for (int i = 0; i < nl; ++i) SH_TRY(B.union_threshold(i, (const float*)recv[i], Q, r, ru, tau[i]));
+  // 3-4: main passes, counts, failure flags
+  const int kk = prefix_len(k, world);
+  std::vector<float*> ls(nl);
+  std::vector<int64_t*> lr(nl);
+  std::vector<int32_t*> fail_ids(nl), n_failed(nl);
+  std::vector<const void*> send_c(nl);
+  std::vector<void*> recv_c(nl);
+  for (int i = 0; i < nl; ++i) {
+    ls[i] = (float*)B.alloc(i, (size_t)Q * k * 4);
+    lr[i] = (int64_t*)B.alloc(i, (size_t)Q * k * 8);
+    int32_t* cnt = (int32_t*)B.alloc(i, (size_t)Q * 4);
+    recv_c[i] = B.alloc(i, (size_t)world * Q * 4);
+    fail_ids[i] = (int32_t*)B.alloc(i, (size_t)Q * 4);
+    n_failed[i] = (int32_t*)B.alloc(i, 256);
+    if (!ls[i] || !lr[i] || !cnt || !recv_c[i] || !fail_ids[i] || !n_failed[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
+    SH_TRY(B.finish(i, tau[i], ls[i], lr[i], cnt));
+    send_c[i] = cnt;
+  }
+  SH_TRY(B.gather(send_c, recv_c, (size_t)Q * 4));
+  // 5: list prefixes, reduce
+  std::vector<const void*> send_s(nl), send_r(nl);
+  std::vector<void*> recv_s(nl), recv_r(nl);
+  for (int i = 0; i < nl; ++i) {
+    SH_TRY(B.flag_failures(i, (const int32_t*)recv_c[i], Q, k, kk, fail_ids[i], n_failed[i]));
+    float* ps = ls[i];
+    int64_t* pr = lr[i];
+    if (kk < k) {
+      ps = (float*)B.alloc(i, (size_t)Q * kk * 4);
+      pr = (int64_t*)B.alloc(i, (size_t)Q * kk * 8);
+      if (!ps || !pr) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
+      SH_TRY(B.prefix(i, ls[i], lr[i], k, kk, Q, ps, pr));
+    }
+    recv_s[i] = B.alloc(i, (size_t)world * Q * kk * 4);
+    recv_r[i] = B.alloc(i, (size_t)world * Q * kk * 8);
+    if (!recv_s[i] || !recv_r[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
+    send_s[i] = ps; send_r[i] = pr;
+  }
+  SH_TRY(B.gather(send_s, recv_s, (size_t)Q * kk * 4));
+  SH_TRY(B.gather(send_r, recv_r, (size_t)Q * kk * 8));
+  for (int i = 0; i < nl; ++i) SH_TRY(B.merge(i, Q, kk, (const float*)recv_s[i], (const int64_t*)recv_r[i], k, out_s[i], out_r[i]));
+  // 6: the one host read; identical on every rank (it is a function of the gathered counts).  The ids come out of an atomic append on
+  // the device: sorted, so that every rank (and every local shard) holds the same order.
+  std::vector<int32_t> ids;
+  SH_TRY(B.read_failed(n_failed, fail_ids, ids));
+  const int F = (int)ids.size();
+  if (F == 0) return DHR_OK;
+  std::sort(ids.begin(), ids.end());
+  // failed queries (unrepresentative sample, skewed shards): sub-batch with local thresholds, gathered at full length, scattered into the result
+  std::vector<dhr_query_batch> sub(nl, *qb_in);
+  std::vector<float*> fs(nl);
+  std::vector<int64_t*> fr(nl);
+  std::vector<int32_t*> ids_mem(nl);
+  for (int i = 0; i < nl; ++i) {
+    SH_TRY(B.sub_batch(i, qb_in, ids, &sub[i], &ids_mem[i]));
+    fs[i] = (float*)B.alloc(i, (size_t)F * k * 4);
+    fr[i] = (int64_t*)B.alloc(i, (size_t)F * k * 8);
+    if (!fs[i] || !fr[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
+  }
+  SH_TRY(local_path(B, sub, k, fs, fr));
+  for (int i = 0; i < nl; ++i) {
+    SH_TRY(B.scatter(i, fs[i], fr[i], ids_mem[i], F, k, out_s[i], out_r[i]));
+    SH_TRY(B.sync(i));
+  }
+  return DHR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// HipBackend
 __global__ void column_kernel(const float* __restrict__ in, int ld, int col, int n, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[(int64_t)i * ld + col];
 }
-// counts [world][Q] -> fail flag per query, compact list of failed query ids, their number
+// counts [world][Q] -> compact list of failed query ids, their number
 __global__ void fail_kernel(const int32_t* __restrict__ counts, int world, int n_queries, int k, int kk, int32_t* __restrict__ fail_ids,
                             int32_t* __restrict__ n_failed) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,13 +332,46 @@ struct ShardCtx {
   Arena* arena;
 };
 
-// all-gather of `bytes` per shard: send[i] (local shard i's block) -> recv[i] = [world][bytes] on local shard i's device
-struct Gather {
-  int world, n_local, first;      // local shards are ranks [first, first + n_local)
-  dhr_comm* comm;                 // SPMD: n_local == 1
-  int run(const std::vector<ShardCtx>& sh, const std::vector<const void*>& send, const std::vector<void*>& recv, size_t bytes) const {
-    if (comm) {
+struct HipBackend : Backend {
+  std::vector<ShardCtx> sh;
+  dhr_comm* comm = nullptr;       // SPMD (n_local == 1, world > 1): RCCL or the caller's host transport; null: one process, gathers are device copies
+  std::vector<std::vector<char>> host_v, host_i;      // host sub-batches of the repair step (shared by the local shards)
+
+  void* alloc(int i, size_t bytes) override { (void)hipSetDevice(sh[i].device); return sh[i].arena->get(bytes); }
+  int set_share(int i, int share) override { return dhr_index_set_param(sh[i].ix, DHR_PARAM_SAMPLE_SHARE, share); }
+  int sample_rank(int i, int k) override { return dhr_search_sample_rank(sh[i].ix, k); }
+  int union_rank(int i, int k) override { return dhr_search_union_rank(sh[i].ix, k); }
+  int begin(int i, const dhr_query_batch* qb, int k, float* sample) override {
+    SH_HIP(hipSetDevice(sh[i].device));
+    return dhr_internal_search_begin_async(sh[i].ix, qb, k, sample, sh[i].stream);
+  }
+  int finish(int i, const float* tau, float* ls, int64_t* lr, int32_t* cnt) override {
+    SH_HIP(hipSetDevice(sh[i].device));
+    return dhr_internal_search_finish_async(sh[i].ix, tau, ls, lr, cnt, DHR_MEM_DEVICE, sh[i].stream);
+  }
+  int search(int i, const dhr_query_batch* qb, int k, float* s, int64_t* r) override {
+    SH_HIP(hipSetDevice(sh[i].device));
+    return dhr_search(sh[i].ix, qb, k, s, r, DHR_MEM_DEVICE, sh[i].stream);
+  }
+  int gather(const std::vector<const void*>& send, const std::vector<void*>& recv, size_t bytes) override {
+    if (comm && comm->comm) {
       SH_NCCL(ncclAllGather(send[0], recv[0], bytes, ncclInt8, comm->comm, sh[0].stream));
+      return DHR_OK;
+    }
+    if (comm && comm->cb) {       // the caller's transport moves HOST buffers: stage through pinned memory on this stream
+      const size_t need = bytes * (size_t)(world + 1);
+      if (comm->h_stage_bytes < need) {
+        if (comm->h_stage) (void)hipHostFree(comm->h_stage);
+        comm->h_stage = nullptr; comm->h_stage_bytes = 0;
+        SH_HIP(hipHostMalloc(&comm->h_stage, need, hipHostMallocDefault));
+        comm->h_stage_bytes = need;
+      }
+      char* hs = (char*)comm->h_stage;
+      char* hr = hs + bytes;
+      SH_HIP(hipMemcpyAsync(hs, send[0], bytes, hipMemcpyDeviceToHost, sh[0].stream));
+      SH_HIP(hipStreamSynchronize(sh[0].stream));
+      if (comm->cb(comm->cb_user, hs, hr, (int64_t)bytes) != 0) return dhr_set_error_message(DHR_ERR_INTERNAL, "the caller's all-gather callback failed");
+      SH_HIP(hipMemcpyAsync(recv[0], hr, bytes * (size_t)world, hipMemcpyHostToDevice, sh[0].stream));
       return DHR_OK;
     }
     // one process: make every block visible to every local shard (plain device copies; peer copies across devices)
@@ -134,219 +384,178 @@ struct Gather {
     for (int i = 0; i < n_local; ++i) SH_HIP(hipStreamSynchronize(sh[i].stream));
     return DHR_OK;
   }
-};
-
-int merge_gathered(const ShardCtx& c, int Q, int world, int L, const float* gs, const int64_t* gr, int k, float* os, int64_t* orow) {
-  // sorted per-shard lists in [world, Q, L] layout: rank merge in the LDS when the lists of a query fit, else the general reduce
-  if (world <= 64 && ((int64_t)world * L + k) * 12 <= 160 * 1024)
-    return dhr_merge_topk_lists(c.device, Q, world, L, gs, gr, k, os, orow, c.stream);
-  // [world, Q, L] -> [Q, world * L]
-  float* ts = (float*)c.arena->get((size_t)Q * world * L * 4);
-  int64_t* tr = (int64_t*)c.arena->get((size_t)Q * world * L * 8);
-  if (!ts || !tr) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the shard reduce");
-  for (int w = 0; w < world; ++w) {
-    SH_HIP(hipMemcpy2DAsync(ts + (size_t)w * L, (size_t)world * L * 4, gs + (size_t)w * Q * L, (size_t)L * 4, (size_t)L * 4, Q, hipMemcpyDeviceToDevice, c.stream));
-    SH_HIP(hipMemcpy2DAsync(tr + (size_t)w * L, (size_t)world * L * 8, gr + (size_t)w * Q * L, (size_t)L * 8, (size_t)L * 8, Q, hipMemcpyDeviceToDevice, c.stream));
-  }
-  return dhr_merge_topk(c.device, Q, world * L, ts, tr, k, os, orow, c.stream);
-}
-
-// local thresholds for a (sub-)batch: every shard searches with k, full lists gathered and merged.  out_* [n_q, k] per local shard.
-int local_path(const std::vector<ShardCtx>& sh, const Gather& g, const std::vector<dhr_query_batch>& qb, int k,
-               const std::vector<float*>& out_s, const std::vector<int64_t*>& out_r) {
-  const int nl = g.n_local, world = g.world, Q = qb[0].n_queries;
-  std::vector<const void*> send_s(nl), send_r(nl);
-  std::vector<void*> recv_s(nl), recv_r(nl);
-  for (int i = 0; i < nl; ++i) {
-    SH_HIP(hipSetDevice(sh[i].device));
-    float* ls = (float*)sh[i].arena->get((size_t)Q * k * 4);
-    int64_t* lr = (int64_t*)sh[i].arena->get((size_t)Q * k * 8);
-    recv_s[i] = sh[i].arena->get((size_t)world * Q * k * 4);
-    recv_r[i] = sh[i].arena->get((size_t)world * Q * k * 8);
-    if (!ls || !lr || !recv_s[i] || !recv_r[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the sharded search");
-    SH_TRY(dhr_search(sh[i].ix, &qb[i], k, ls, lr, DHR_MEM_DEVICE, sh[i].stream));
-    send_s[i] = ls; send_r[i] = lr;
-  }
-  SH_TRY(g.run(sh, send_s, recv_s, (size_t)Q * k * 4));
-  SH_TRY(g.run(sh, send_r, recv_r, (size_t)Q * k * 8));
-  for (int i = 0; i < nl; ++i) {
-    SH_HIP(hipSetDevice(sh[i].device));
-    SH_TRY(merge_gathered(sh[i], Q, world, k, (const float*)recv_s[i], (const int64_t*)recv_r[i], k, out_s[i], out_r[i]));
-  }
-  return DHR_OK;
-}
-
-int prefix_len(int k, int world) {
-  if (world <= 2) return k;
-  const int kk = ((3 * k + world - 1) / world + 64 + 63) / 64 * 64;
-  return std::min(k, kk);
-}
-
-// agree on the sample rank: all shards must report the same r > 0 (SPMD: one tiny all-reduce + host read, cached per k)
-int agree_rank(const std::vector<ShardCtx>& sh, const Gather& g, int k, int* r_out) {
-  int r = dhr_search_sample_rank(sh[0].ix, k);
-  for (int i = 1; i < g.n_local; ++i) if (dhr_search_sample_rank(sh[i].ix, k) != r) r = 0;
-  if (g.comm && g.world > 1) {
-    dhr_comm* c = g.comm;
-    // Not cached: the answer depends on every rank's shard size and sample period, a communicator outlives the index handles
-    // (a new index can reuse a freed handle's address), and a rank that hit a cache the others missed would skip a collective they
-    // issue.  The agreement costs one 8-byte all-reduce and one host read per search.
-    int32_t* d = (int32_t*)sh[0].arena->get(16);
+  int min_over_ranks(int32_t v[4]) override {
+    if (!comm || world <= 1) return DHR_OK;
+    SH_HIP(hipSetDevice(sh[0].device));
+    int32_t* d = (int32_t*)sh[0].arena->get(16 + (size_t)world * 16);
     if (!d) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory");
-    const int32_t h[2] = {r, -r};
-    SH_HIP(hipMemcpyAsync(d, h, 8, hipMemcpyHostToDevice, sh[0].stream));
-    SH_NCCL(ncclAllReduce(d, d + 2, 2, ncclInt32, ncclMin, c->comm, sh[0].stream));
-    int32_t o[2];
-    SH_HIP(hipMemcpyAsync(o, d + 2, 8, hipMemcpyDeviceToHost, sh[0].stream));
+    SH_HIP(hipMemcpyAsync(d, v, 16, hipMemcpyHostToDevice, sh[0].stream));
+    SH_TRY(gather({d}, {d + 4}, 16));
+    std::vector<int32_t> all((size_t)world * 4);
+    SH_HIP(hipMemcpyAsync(all.data(), d + 4, (size_t)world * 16, hipMemcpyDeviceToHost, sh[0].stream));
     SH_HIP(hipStreamSynchronize(sh[0].stream));
-    r = (o[0] == r && -o[1] == r) ? r : 0;
+    for (int w = 0; w < world; ++w)
+      for (int j = 0; j < 4; ++j) v[j] = std::min(v[j], all[(size_t)w * 4 + j]);
+    return DHR_OK;
   }
-  *r_out = r;
-  return DHR_OK;
-}
-
-int sharded_core(std::vector<ShardCtx>& sh, const Gather& g, const dhr_query_batch* qb_in, int k, const std::vector<float*>& out_s,
-                 const std::vector<int64_t*>& out_r) {
-  const int nl = g.n_local, world = g.world, Q = qb_in->n_queries;
-  std::vector<dhr_query_batch> qb(nl, *qb_in);
-  for (int i = 0; i < nl; ++i) SH_TRY(dhr_index_set_param(sh[i].ix, DHR_PARAM_SAMPLE_SHARE, world));      // a shard chases only its share of the union's rank
-  int r = 0;
-  SH_TRY(agree_rank(sh, g, k, &r));
-  if (r <= 0) return local_path(sh, g, qb, k, out_s, out_r);
-  const int ru = std::min<int>(dhr_search_union_rank(sh[0].ix, k), world * r);      // rank of the union that defines the threshold; the lists are r long
-
-  // 1-2: sampled passes, common thresholds
-  std::vector<const void*> send(nl);
-  std::vector<void*> recv(nl);
-  std::vector<float*> tau(nl);
-  for (int i = 0; i < nl; ++i) {
-    SH_HIP(hipSetDevice(sh[i].device));
-    float* sample = (float*)sh[i].arena->get((size_t)Q * r * 4);
-    recv[i] = sh[i].arena->get((size_t)world * Q * r * 4);
-    tau[i] = (float*)sh[i].arena->get((size_t)Q * 4);
-    if (!sample || !recv[i] || !tau[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the sharded search");
-    SH_TRY(dhr_internal_search_begin_async(sh[i].ix, &qb[i], k, sample, sh[i].stream));
-    send[i] = sample;
-  }
-  SH_TRY(g.run(sh, send, recv, (size_t)Q * r * 4));
-  for (int i = 0; i < nl; ++i) {
+  int union_threshold(int i, const float* gathered, int Q, int r, int ru, float* tau) override {
     SH_HIP(hipSetDevice(sh[i].device));
     float* merged = (float*)sh[i].arena->get((size_t)Q * ru * 4);
     if (!merged) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the sharded search");
-    SH_TRY(dhr_merge_topk_lists(sh[i].device, Q, world, r, (const float*)recv[i], nullptr, ru, merged, nullptr, sh[i].stream));
-    hipLaunchKernelGGL(column_kernel, dim3((Q + 255) / 256), dim3(256), 0, sh[i].stream, merged, ru, ru - 1, Q, tau[i]);
+    SH_TRY(dhr_merge_topk_lists(sh[i].device, Q, world, r, gathered, nullptr, ru, merged, nullptr, sh[i].stream));
+    hipLaunchKernelGGL(column_kernel, dim3((Q + 255) / 256), dim3(256), 0, sh[i].stream, merged, ru, ru - 1, Q, tau);
+    return DHR_OK;
   }
-  // 3-4: main passes, counts, failure flags
-  const int kk = prefix_len(k, world);
-  std::vector<float*> ls(nl);
-  std::vector<int64_t*> lr(nl);
-  std::vector<int32_t*> fail_ids(nl), n_failed(nl);
-  std::vector<const void*> send_c(nl);
-  std::vector<void*> recv_c(nl);
-  for (int i = 0; i < nl; ++i) {
+  int flag_failures(int i, const int32_t* counts, int Q, int k, int kk, int32_t* fail_ids, int32_t* n_failed) override {
     SH_HIP(hipSetDevice(sh[i].device));
-    ls[i] = (float*)sh[i].arena->get((size_t)Q * k * 4);
-    lr[i] = (int64_t*)sh[i].arena->get((size_t)Q * k * 8);
-    int32_t* cnt = (int32_t*)sh[i].arena->get((size_t)Q * 4);
-    recv_c[i] = sh[i].arena->get((size_t)world * Q * 4);
-    fail_ids[i] = (int32_t*)sh[i].arena->get((size_t)Q * 4);
-    n_failed[i] = (int32_t*)sh[i].arena->get(256);
-    if (!ls[i] || !lr[i] || !cnt || !recv_c[i] || !fail_ids[i] || !n_failed[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the sharded search");
-    SH_TRY(dhr_internal_search_finish_async(sh[i].ix, tau[i], ls[i], lr[i], cnt, DHR_MEM_DEVICE, sh[i].stream));
-    send_c[i] = cnt;
+    SH_HIP(hipMemsetAsync(n_failed, 0, 4, sh[i].stream));
+    hipLaunchKernelGGL(fail_kernel, dim3((Q + 255) / 256), dim3(256), 0, sh[i].stream, counts, world, Q, k, kk, fail_ids, n_failed);
+    return DHR_OK;
   }
-  SH_TRY(g.run(sh, send_c, recv_c, (size_t)Q * 4));
-  // 5: list prefixes, reduce
-  std::vector<const void*> send_s(nl), send_r(nl);
-  std::vector<void*> recv_s(nl), recv_r(nl);
-  for (int i = 0; i < nl; ++i) {
+  int prefix(int i, const float* s, const int64_t* r, int k, int kk, int Q, float* os, int64_t* orow) override {
     SH_HIP(hipSetDevice(sh[i].device));
-    SH_HIP(hipMemsetAsync(n_failed[i], 0, 4, sh[i].stream));
-    hipLaunchKernelGGL(fail_kernel, dim3((Q + 255) / 256), dim3(256), 0, sh[i].stream, (const int32_t*)recv_c[i], world, Q, k, kk, fail_ids[i], n_failed[i]);
-    float* ps = ls[i];
-    int64_t* pr = lr[i];
-    if (kk < k) {
-      ps = (float*)sh[i].arena->get((size_t)Q * kk * 4);
-      pr = (int64_t*)sh[i].arena->get((size_t)Q * kk * 8);
-      if (!ps || !pr) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the sharded search");
-      const int64_t n = (int64_t)Q * kk;
-      hipLaunchKernelGGL(prefix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sh[i].stream, ls[i], lr[i], k, kk, Q, ps, pr);
+    const int64_t n = (int64_t)Q * kk;
+    hipLaunchKernelGGL(prefix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sh[i].stream, s, r, k, kk, Q, os, orow);
+    return DHR_OK;
+  }
+  int merge(int i, int Q, int L, const float* gs, const int64_t* gr, int k, float* os, int64_t* orow) override {
+    const ShardCtx& c = sh[i];
+    SH_HIP(hipSetDevice(c.device));
+    // sorted per-shard lists in [world, Q, L] layout: rank merge in the LDS when the lists of a query fit, else the general reduce
+    if (world <= 64 && ((int64_t)world * L + k) * 12 <= 160 * 1024)
+      return dhr_merge_topk_lists(c.device, Q, world, L, gs, gr, k, os, orow, c.stream);
+    // [world, Q, L] -> [Q, world * L]
+    float* ts = (float*)c.arena->get((size_t)Q * world * L * 4);
+    int64_t* tr = (int64_t*)c.arena->get((size_t)Q * world * L * 8);
+    if (!ts || !tr) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the shard reduce");
+    for (int w = 0; w < world; ++w) {
+      SH_HIP(hipMemcpy2DAsync(ts + (size_t)w * L, (size_t)world * L * 4, gs + (size_t)w * Q * L, (size_t)L * 4, (size_t)L * 4, Q, hipMemcpyDeviceToDevice, c.stream));
+      SH_HIP(hipMemcpy2DAsync(tr + (size_t)w * L, (size_t)world * L * 8, gr + (size_t)w * Q * L, (size_t)L * 8, (size_t)L * 8, Q, hipMemcpyDeviceToDevice, c.stream));
     }
-    recv_s[i] = sh[i].arena->get((size_t)world * Q * kk * 4);
-    recv_r[i] = sh[i].arena->get((size_t)world * Q * kk * 8);
-    if (!recv_s[i] || !recv_r[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the sharded search");
-    send_s[i] = ps; send_r[i] = pr;
+    return dhr_merge_topk(c.device, Q, world * L, ts, tr, k, os, orow, c.stream);
   }
-  SH_TRY(g.run(sh, send_s, recv_s, (size_t)Q * kk * 4));
-  SH_TRY(g.run(sh, send_r, recv_r, (size_t)Q * kk * 8));
-  std::vector<int32_t> nf(nl, 0);
-  for (int i = 0; i < nl; ++i) {
+  int read_failed(const std::vector<int32_t*>& n_failed, const std::vector<int32_t*>& fail_ids, std::vector<int32_t>& ids) override {
+    int32_t nf = 0;
+    SH_HIP(hipSetDevice(sh[0].device));
+    SH_HIP(hipMemcpyAsync(&nf, n_failed[0], 4, hipMemcpyDeviceToHost, sh[0].stream));
+    for (int i = 0; i < n_local; ++i) SH_HIP(hipStreamSynchronize(sh[i].stream));
+    ids.resize((size_t)nf);
+    if (nf > 0) SH_HIP(hipMemcpy(ids.data(), fail_ids[0], (size_t)nf * 4, hipMemcpyDeviceToHost));
+    return DHR_OK;
+  }
+  int sub_batch(int i, const dhr_query_batch* in, const std::vector<int32_t>& ids, dhr_query_batch* out, int32_t** ids_mem) override {
+    const int F = (int)ids.size();
     SH_HIP(hipSetDevice(sh[i].device));
-    SH_TRY(merge_gathered(sh[i], Q, world, kk, (const float*)recv_s[i], (const int64_t*)recv_r[i], k, out_s[i], out_r[i]));
-    SH_HIP(hipMemcpyAsync(&nf[i], n_failed[i], 4, hipMemcpyDeviceToHost, sh[i].stream));
-  }
-  // 6: the one host read; identical on every rank (it is a function of the gathered counts)
-  for (int i = 0; i < nl; ++i) SH_HIP(hipStreamSynchronize(sh[i].stream));
-  const int F = nf[0];
-  if (F == 0) return DHR_OK;
-  // failed queries: sub-batch with local thresholds.  The ids come out of an atomic append: sort them so that every rank
-  // (and every local shard) holds the same order.
-  std::vector<int32_t> ids(F);
-  SH_HIP(hipSetDevice(sh[0].device));
-  SH_HIP(hipMemcpy(ids.data(), fail_ids[0], (size_t)F * 4, hipMemcpyDeviceToHost));
-  std::sort(ids.begin(), ids.end());
-  const int vsz = qb_in->value_dtype == DHR_VAL_F32 ? 4 : 2;
-  const int isz = qb_in->index_dtype == DHR_IDX_I16 ? 2 : 1;
-  std::vector<dhr_query_batch> sub(nl, *qb_in);
-  std::vector<std::vector<char>> host_v(1), host_i(1);
-  std::vector<float*> fs(nl);
-  std::vector<int64_t*> fr(nl);
-  std::vector<int32_t*> d_ids(nl);
-  const int64_t vrow = qb_in->ld_value * vsz, irow = qb_in->index ? qb_in->ld_index * isz : 0;
-  if (qb_in->mem_kind == DHR_MEM_HOST) {          // host batch: gather on the host once, shared by the local shards
-    host_v[0].resize((size_t)F * vrow);
-    for (int f = 0; f < F; ++f) memcpy(host_v[0].data() + (size_t)f * vrow, (const char*)qb_in->value + (size_t)ids[f] * vrow, vrow);
-    if (qb_in->index) {
-      host_i[0].resize((size_t)F * irow);
-      for (int f = 0; f < F; ++f) memcpy(host_i[0].data() + (size_t)f * irow, (const char*)qb_in->index + (size_t)ids[f] * irow, irow);
+    int32_t* d_ids = (int32_t*)sh[i].arena->get((size_t)F * 4);
+    if (!d_ids) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the sharded search");
+    SH_HIP(hipMemcpyAsync(d_ids, ids.data(), (size_t)F * 4, hipMemcpyHostToDevice, sh[i].stream));
+    *ids_mem = d_ids;
+    if (in->mem_kind == DHR_MEM_HOST) {          // host batch: gathered on the host once, shared by the local shards
+      if (host_v.empty()) { host_v.resize(1); host_i.resize(1); dhr_query_batch tmp; host_sub_batch(in, ids, host_v[0], host_i[0], &tmp); }
+      *out = *in;
+      out->n_queries = F;
+      out->value = host_v[0].data();
+      out->index = in->index ? host_i[0].data() : nullptr;
+      return DHR_OK;
     }
-  }
-  for (int i = 0; i < nl; ++i) {
-    SH_HIP(hipSetDevice(sh[i].device));
-    d_ids[i] = (int32_t*)sh[i].arena->get((size_t)F * 4);
-    fs[i] = (float*)sh[i].arena->get((size_t)F * k * 4);
-    fr[i] = (int64_t*)sh[i].arena->get((size_t)F * k * 8);
-    if (!d_ids[i] || !fs[i] || !fr[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the sharded search");
-    SH_HIP(hipMemcpyAsync(d_ids[i], ids.data(), (size_t)F * 4, hipMemcpyHostToDevice, sh[i].stream));
-    sub[i].n_queries = F;
-    if (qb_in->mem_kind == DHR_MEM_HOST) {
-      sub[i].value = host_v[0].data();
-      sub[i].index = qb_in->index ? host_i[0].data() : nullptr;
-    } else {
-      // device batch: the caller's arrays live on ONE device; gather there (shard 0's context must be that device for SPMD,
-      // and in the one-process form every shard on another device reads through peer access / managed mapping)
-      char* gv = (char*)sh[i].arena->get((size_t)F * vrow);
-      char* gi = qb_in->index ? (char*)sh[i].arena->get((size_t)F * irow) : nullptr;
-      if (!gv || (qb_in->index && !gi)) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the sharded search");
-      int64_t n = (int64_t)F * vrow;
-      hipLaunchKernelGGL(gather_rows_bytes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sh[i].stream, (const char*)qb_in->value, vrow, (int)vrow, d_ids[i], F, gv);
-      if (gi) {
-        n = (int64_t)F * irow;
-        hipLaunchKernelGGL(gather_rows_bytes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sh[i].stream, (const char*)qb_in->index, irow, (int)irow, d_ids[i], F, gi);
-      }
-      sub[i].value = gv;
-      sub[i].index = gi;
+    // device batch: the caller's arrays live on ONE device; gather there (shard 0's context must be that device for SPMD, and in the
+    // one-process form every shard on another device reads through peer access / managed mapping)
+    const int vsz = in->value_dtype == DHR_VAL_F32 ? 4 : 2, isz = in->index_dtype == DHR_IDX_I16 ? 2 : 1;
+    const int64_t vrow = in->ld_value * vsz, irow = in->index ? in->ld_index * isz : 0;
+    char* gv = (char*)sh[i].arena->get((size_t)F * vrow);
+    char* gi = in->index ? (char*)sh[i].arena->get((size_t)F * irow) : nullptr;
+    if (!gv || (in->index && !gi)) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the sharded search");
+    int64_t n = (int64_t)F * vrow;
+    hipLaunchKernelGGL(gather_rows_bytes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sh[i].stream, (const char*)in->value, vrow, (int)vrow, d_ids, F, gv);
+    if (gi) {
+      n = (int64_t)F * irow;
+      hipLaunchKernelGGL(gather_rows_bytes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sh[i].stream, (const char*)in->index, irow, (int)irow, d_ids, F, gi);
     }
+    *out = *in;
+    out->n_queries = F;
+    out->value = gv;
+    out->index = gi;
+    return DHR_OK;
   }
-  SH_TRY(local_path(sh, g, sub, k, fs, fr));
-  for (int i = 0; i < nl; ++i) {
+  int scatter(int i, const float* s, const int64_t* r, const int32_t* ids_mem, int F, int k, float* os, int64_t* orow) override {
     SH_HIP(hipSetDevice(sh[i].device));
     const int64_t n = (int64_t)F * k;
-    hipLaunchKernelGGL(scatter_result_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sh[i].stream, fs[i], fr[i], d_ids[i], F, k, out_s[i], out_r[i]);
-    SH_HIP(hipStreamSynchronize(sh[i].stream));
+    hipLaunchKernelGGL(scatter_result_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sh[i].stream, s, r, ids_mem, F, k, os, orow);
+    return DHR_OK;
   }
-  return DHR_OK;
-}
+  int sync(int i) override { SH_HIP(hipSetDevice(sh[i].device)); SH_HIP(hipStreamSynchronize(sh[i].stream)); return DHR_OK; }
+};
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// HostBackend: one caller-supplied shard in host memory, caller-supplied all-gather.  Test / bring-up hook (dhr_search_sharded_host).
+struct HostBackend : Backend {
+  const dhr_host_shard* shard = nullptr;
+  dhr_allgather_fn cb = nullptr;
+  void* cb_user = nullptr;
+  int share = 1;
+  std::vector<std::vector<char>> mem;
+  std::vector<char> sub_v, sub_i;
+  std::vector<int32_t> sub_ids;
+
+  void* alloc(int, size_t bytes) override { mem.emplace_back(bytes ? bytes : 16); return mem.back().data(); }
+  int set_share(int, int s) override { share = s; return DHR_OK; }
+  int sample_rank(int, int k) override { return shard->sample_rank(shard->user, k, share); }
+  int union_rank(int, int k) override { return shard->union_rank(shard->user, k); }
+  int begin(int, const dhr_query_batch* qb, int k, float* sample) override { return shard->begin(shard->user, qb, k, share, sample) == 0 ? DHR_OK : dhr_set_error_message(DHR_ERR_INTERNAL, "host shard: begin failed"); }
+  int finish(int, const float* tau, float* ls, int64_t* lr, int32_t* cnt) override { return shard->finish(shard->user, tau, ls, lr, cnt) == 0 ? DHR_OK : dhr_set_error_message(DHR_ERR_INTERNAL, "host shard: finish failed"); }
+  int search(int, const dhr_query_batch* qb, int k, float* s, int64_t* r) override { return shard->search(shard->user, qb, k, s, r) == 0 ? DHR_OK : dhr_set_error_message(DHR_ERR_INTERNAL, "host shard: search failed"); }
+  int gather(const std::vector<const void*>& send, const std::vector<void*>& recv, size_t bytes) override {
+    if (world == 1) { memcpy(recv[0], send[0], bytes); return DHR_OK; }
+    return cb(cb_user, send[0], recv[0], (int64_t)bytes) == 0 ? DHR_OK : dhr_set_error_message(DHR_ERR_INTERNAL, "the caller's all-gather callback failed");
+  }
+  int min_over_ranks(int32_t v[4]) override {
+    if (world <= 1) return DHR_OK;
+    std::vector<int32_t> all((size_t)world * 4);
+    SH_TRY(gather({v}, {all.data()}, 16));
+    for (int w = 0; w < world; ++w)
+      for (int j = 0; j < 4; ++j) v[j] = std::min(v[j], all[(size_t)w * 4 + j]);
+    return DHR_OK;
+  }
+  int union_threshold(int, const float* gathered, int Q, int r, int ru, float* tau) override {
+    std::vector<float> merged((size_t)Q * ru);
+    SH_TRY(dhr_merge_topk_lists_host(Q, world, r, gathered, nullptr, ru, merged.data(), nullptr));
+    for (int q = 0; q < Q; ++q) tau[q] = merged[(size_t)q * ru + (ru - 1)];
+    return DHR_OK;
+  }
+  int flag_failures(int, const int32_t* counts, int Q, int k, int kk, int32_t* fail_ids, int32_t* n_failed) override {
+    host_flag_failures(counts, world, Q, k, kk, fail_ids, n_failed);
+    return DHR_OK;
+  }
+  int prefix(int, const float* s, const int64_t* r, int k, int kk, int Q, float* os, int64_t* orow) override {
+    for (int q = 0; q < Q; ++q) {
+      memcpy(os + (size_t)q * kk, s + (size_t)q * k, (size_t)kk * 4);
+      memcpy(orow + (size_t)q * kk, r + (size_t)q * k, (size_t)kk * 8);
+    }
+    return DHR_OK;
+  }
+  int merge(int, int Q, int L, const float* gs, const int64_t* gr, int k, float* os, int64_t* orow) override {
+    return dhr_merge_topk_lists_host(Q, world, L, gs, gr, k, os, orow);
+  }
+  int read_failed(const std::vector<int32_t*>& n_failed, const std::vector<int32_t*>& fail_ids, std::vector<int32_t>& ids) override {
+    ids.assign(fail_ids[0], fail_ids[0] + *n_failed[0]);
+    return DHR_OK;
+  }
+  int sub_batch(int, const dhr_query_batch* in, const std::vector<int32_t>& ids, dhr_query_batch* out, int32_t** ids_mem) override {
+    if (in->mem_kind != DHR_MEM_HOST) return dhr_set_error_message(DHR_ERR_INVALID, "host shards take host query batches");
+    host_sub_batch(in, ids, sub_v, sub_i, out);
+    sub_ids = ids;
+    *ids_mem = sub_ids.data();
+    return DHR_OK;
+  }
+  int scatter(int, const float* s, const int64_t* r, const int32_t* ids_mem, int F, int k, float* os, int64_t* orow) override {
+    for (int f = 0; f < F; ++f) {
+      memcpy(os + (size_t)ids_mem[f] * k, s + (size_t)f * k, (size_t)k * 4);
+      memcpy(orow + (size_t)ids_mem[f] * k, r + (size_t)f * k, (size_t)k * 8);
+    }
+    return DHR_OK;
+  }
+  int sync(int) override { return DHR_OK; }
+};
 
 int deliver(const ShardCtx& c, int Q, int k, const float* ds, const int64_t* dr, float* out_scores, int64_t* out_rows, int mem_kind) {
   if (mem_kind == DHR_MEM_HOST) {
@@ -386,12 +595,32 @@ extern "C" int dhr_comm_wrap(void* nccl_comm, int32_t world, int32_t rank, int32
   *out = c;
   return DHR_OK;
 }
+extern "C" int dhr_comm_create_callback(int32_t world, int32_t rank, int32_t device, dhr_allgather_fn allgather, void* user, dhr_comm** out) {
+  if (!allgather || !out || world < 1 || rank < 0 || rank >= world) return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
+  dhr_comm* c = new dhr_comm();
+  c->cb = allgather; c->cb_user = user; c->world = world; c->rank = rank; c->device = device; c->owned = false;
+  *out = c;
+  return DHR_OK;
+}
 extern "C" void dhr_comm_destroy(dhr_comm* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->owned && c->comm) (void)ncclCommDestroy(c->comm);
   (void)hipFree(c->arena);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   delete c;
+}
+
+extern "C" int dhr_search_sharded_host(const dhr_host_shard* shard, int32_t world, int32_t rank, dhr_allgather_fn allgather, void* user,
+                                       const dhr_query_batch* qb, int32_t k, float* out_scores, int64_t* out_rows) {
+  if (!shard || !shard->sample_rank || !shard->union_rank || !shard->begin || !shard->finish || !shard->search || !qb || !out_scores || !out_rows ||
+      k <= 0 || world < 1 || rank < 0 || rank >= world || (world > 1 && !allgather))
+    return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
+  if (qb->mem_kind != DHR_MEM_HOST) return dhr_set_error_message(DHR_ERR_INVALID, "host shards take host query batches");
+  HostBackend B;
+  B.world = world; B.n_local = 1;
+  B.shard = shard; B.cb = allgather; B.cb_user = user;
+  return sharded_core(B, qb, k, {out_scores}, {out_rows});
 }
 
 extern "C" int dhr_search_sharded(dhr_index* shard, dhr_comm* comm, const dhr_query_batch* qb, int32_t k, float* out_scores, int64_t* out_rows,
@@ -401,9 +630,11 @@ extern "C" int dhr_search_sharded(dhr_index* shard, dhr_comm* comm, const dhr_qu
   if (device != comm->device) return dhr_set_error_message(DHR_ERR_INVALID, "the shard and the communicator live on different devices");
   SH_HIP(hipSetDevice(device));
   Arena arena{&comm->arena, &comm->arena_bytes, 0, device};
-  std::vector<ShardCtx> sh{{shard, device, (hipStream_t)stream, &arena}};
-  Gather g{comm->world, 1, comm->rank, comm->world > 1 ? comm : nullptr};
-  if (comm->world == 1) g.comm = nullptr;          // a single rank gathers by copy (n_local == world == 1)
+  HipBackend B;
+  B.sh = {{shard, device, (hipStream_t)stream, &arena}};
+  B.world = comm->world; B.n_local = 1;
+  B.comm = comm->world > 1 ? comm : nullptr;       // a single rank gathers by copy (n_local == world == 1)
+  std::vector<ShardCtx>& sh = B.sh;
   const int Q = qb->n_queries;
   float* ds = out_scores;
   int64_t* dr = out_rows;
@@ -412,7 +643,7 @@ extern "C" int dhr_search_sharded(dhr_index* shard, dhr_comm* comm, const dhr_qu
     dr = (int64_t*)arena.get((size_t)Q * k * 8);
     if (!ds || !dr) { arena.finish(); return dhr_set_error_message(DHR_ERR_HIP, "out of device memory"); }
   }
-  int rc = sharded_core(sh, g, qb, k, {ds}, {dr});
+  int rc = sharded_core(B, qb, k, {ds}, {dr});
   if (rc == DHR_OK) rc = deliver(sh[0], Q, k, ds, dr, out_scores, out_rows, out_mem_kind);
   else (void)hipStreamSynchronize((hipStream_t)stream);
   arena.finish();
@@ -427,7 +658,9 @@ extern "C" int dhr_search_sharded_local(dhr_index** shards, int32_t n_shards, co
   std::vector<LocalScratch> scratch(n_shards);
   std::vector<Arena> arenas;
   arenas.reserve(n_shards);
-  std::vector<ShardCtx> sh;
+  HipBackend B;
+  B.world = n_shards; B.n_local = n_shards;
+  std::vector<ShardCtx>& sh = B.sh;
   std::vector<hipStream_t> own(n_shards, nullptr);
   const int dev0 = dhr_index_device(shards[0]);
   for (int i = 0; i < n_shards; ++i) {
@@ -438,7 +671,6 @@ extern "C" int dhr_search_sharded_local(dhr_index** shards, int32_t n_shards, co
     if (dev != dev0) { SH_HIP(hipSetDevice(dev)); SH_HIP(hipStreamCreateWithFlags(&own[i], hipStreamNonBlocking)); s = own[i]; }
     sh.push_back({shards[i], dev, s, &arenas[i]});
   }
-  Gather g{n_shards, n_shards, 0, nullptr};
   const int Q = qb->n_queries;
   std::vector<float*> os(n_shards);
   std::vector<int64_t*> orow(n_shards);
@@ -450,7 +682,7 @@ extern "C" int dhr_search_sharded_local(dhr_index** shards, int32_t n_shards, co
     orow[i] = (int64_t*)arenas[i].get((size_t)Q * k * 8);
     if (!os[i] || !orow[i]) rc = dhr_set_error_message(DHR_ERR_HIP, "out of device memory");
   }
-  if (rc == DHR_OK) rc = sharded_core(sh, g, qb, k, os, orow);
+  if (rc == DHR_OK) rc = sharded_core(B, qb, k, os, orow);
   if (rc == DHR_OK) { (void)hipSetDevice(sh[0].device); rc = deliver(sh[0], Q, k, os[0], orow[0], out_scores, out_rows, out_mem_kind); }
   for (int i = 0; i < n_shards; ++i) {
     (void)hipSetDevice(sh[i].device);

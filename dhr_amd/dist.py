@@ -6,9 +6,11 @@ semantics of retrieval/merge.result.py:22-42 without the text-file round trip.
 The product path is the C ABI: `ShardComm` (dhr_comm_*: an RCCL communicator the library creates itself
 from a 128-byte id; the id travels over whatever torch.distributed group is up) and
 `sharded_search` -> dhr_search_sharded (sample all-gather, common thresholds, count all-gather, list
-all-gather, rank merge: dhr_amd/csrc/sharded.hip).  The same control flow written with torch.distributed
-collectives (`sharded_search_torch`) is kept as the CPU test shim: it runs under gloo, where RCCL cannot
-(tests/test_dist_gloo.py), and is what `sharded_search` uses when the process group's backend is gloo."""
+all-gather, rank merge: dhr_amd/csrc/sharded.hip).  There is ONE implementation of that control flow, in the
+library: where RCCL is not available between the ranks (a gloo group: several ranks on one GPU, CPU tests)
+the all-gathers are handed to torch.distributed through a callback communicator, and the CPU test-suite drives
+the same control flow over oracle-backed host shards (`sharded_search_host` -> dhr_search_sharded_host).  (Until
+round 4 a torch restatement of the steps lived here and was what the gloo tests exercised.)"""
 from __future__ import annotations
 
 import ctypes as C
@@ -101,17 +103,55 @@ def common_threshold(sample_scores_all, r: int):
     return merged[:, r - 1].contiguous()
 
 
-class ShardComm:
-    """dhr_comm: the library's own RCCL communicator for this rank.  Collective constructor: rank 0 draws the id
-    (dhr_comm_unique_id), it is broadcast over the torch.distributed group, every rank calls dhr_comm_create."""
+def _host_allgather(group):
+    """dhr_allgather_fn over a torch.distributed group: `bytes` from every rank -> recv = [world][bytes] (host buffers).  gloo gathers the
+    host bytes as they are; an RCCL group (which only moves device tensors) stages them through the current device."""
+    import torch
+    import torch.distributed as dist
 
-    def __init__(self, device: int, group=None):
+    def fn(_user, send, recv, nbytes):
+        try:
+            world = dist.get_world_size(group)
+            src = torch.frombuffer((C.c_char * nbytes).from_address(send), dtype=torch.uint8)
+            dst = torch.frombuffer((C.c_char * (nbytes * world)).from_address(recv), dtype=torch.uint8)
+            if dist.get_backend(group) == "nccl":
+                dev = torch.device("cuda", torch.cuda.current_device())
+                out = torch.empty(nbytes * world, dtype=torch.uint8, device=dev)
+                dist.all_gather_into_tensor(out, src.to(dev), group=group)
+                dst.copy_(out.cpu())
+            else:
+                dist.all_gather_into_tensor(dst, src.clone(), group=group)
+            return 0
+        except Exception as e:  # noqa: BLE001
+            import sys
+            print("[dhr] all-gather callback failed: %r" % (e,), file=sys.stderr)
+            return 1
+    return _lib.ALLGATHER_FN(fn)
+
+
+class ShardComm:
+    """dhr_comm for this rank.  Collective constructor.  transport "rccl": the library's own RCCL communicator (rank 0 draws the id --
+    dhr_comm_unique_id --, it is broadcast over the torch.distributed group, every rank calls dhr_comm_create); transport "host": the
+    all-gathers are done by torch.distributed on host buffers (dhr_comm_create_callback) -- what a gloo group uses (several ranks on
+    one GPU, CPU-only process groups), and what `sharded_search` falls back to when RCCL cannot be initialised.  Either way the
+    search is the library's one control flow (sharded.hip sharded_core)."""
+
+    def __init__(self, device: int, group=None, transport: str | None = None):
         import torch
         import torch.distributed as dist
         self._lib = _lib.load()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = int(device)
+        if transport is None:
+            transport = "rccl" if (self.world == 1 or dist.get_backend(group) == "nccl") else "host"
+        self.transport = transport
+        h = C.c_void_p()
+        if transport == "host":
+            self._cb = _host_allgather(group)           # keep the ctypes thunk alive as long as the communicator
+            _lib.check(self._lib.dhr_comm_create_callback(self.world, self.rank, self.device, self._cb, None, C.byref(h)), "dhr_comm_create_callback")
+            self._h = h
+            return
         uid = (C.c_char * 128)()
         if self.rank == 0:
             _lib.check(self._lib.dhr_comm_unique_id(uid, 128), "dhr_comm_unique_id")
@@ -122,7 +162,6 @@ class ShardComm:
                 t = t.to(torch.device("cuda", self.device))
             dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
-        h = C.c_void_p()
         _lib.check(self._lib.dhr_comm_create(uid, self.world, self.rank, self.device, C.byref(h)), "dhr_comm_create")
         self._h = h
 
@@ -142,9 +181,11 @@ _COMMS = {}
 
 
 def _comm_for(index, group):
-    key = (index.device, id(group))
+    import os
+    transport = "host" if os.environ.get("DHR_SHARDED_TRANSPORT") == "host" else None      # force torch.distributed gathers (A/B, bring-up)
+    key = (index.device, id(group), transport)
     if key not in _COMMS:
-        _COMMS[key] = ShardComm(index.device, group)
+        _COMMS[key] = ShardComm(index.device, group, transport)
     return _COMMS[key]
 
 
@@ -166,13 +207,9 @@ def search_sharded_local(shards, q_value, q_index, k: int):
 
 def sharded_search(index, q_value, q_index, k: int, group=None):
     """index: this rank's GipIndex (rows shard_bounds(N, world, rank), row_offset=lo).  Returns the global [Q,k] (scores, rows)
-    torch cuda tensors on every rank.  RCCL process groups (and single processes) run dhr_search_sharded; a gloo group runs the
-    torch.distributed restatement of the same steps (testing)."""
+    torch cuda tensors on every rank: dhr_search_sharded, over RCCL on an nccl process group and over torch.distributed host gathers
+    on any other (ShardComm) -- the same control flow in the library either way."""
     import torch
-    import torch.distributed as dist
-    import os
-    if dist.is_initialized() and dist.get_world_size(group) > 1 and (dist.get_backend(group) != "nccl" or os.environ.get("DHR_SHARDED_IMPL") == "torch"):
-        return sharded_search_torch(index, q_value, q_index, k, group)      # gloo (CPU tests), or forced for A/B debugging on RCCL
     comm = _comm_for(index, group)
     lib = _lib.load()
     qb, keep = index._qb(q_value, q_index)
@@ -186,52 +223,75 @@ def sharded_search(index, q_value, q_index, k: int, group=None):
     return scores, rows
 
 
-def sharded_search_torch(index, q_value, q_index, k: int, group=None):
-    """index: this rank's GipIndex (rows shard_bounds(N, world, rank), row_offset=lo).  Returns the global
-    [Q,k] (scores, rows) on every rank.
-
-    The shards agree on ONE threshold per query after their sampled runs (all-gather of [Q, r] scores,
-    r ~ 100), so a shard collects only its share of the global top-k instead of a full local top-k;
-    completeness is verified with one all-reduce of per-query counts, and the queries that fail it
-    (unrepresentative sample, list overflow) are redone with purely local thresholds."""
-    import torch
+def sharded_search_host(shard, q_value, q_index, k: int, group=None):
+    """The library's sharded control flow (sharded.hip sharded_core) over a shard implemented in PYTHON on host memory -- no GPU is
+    touched (dhr_search_sharded_host).  `shard` offers sample_rank(k, share), union_rank(k), search_begin(q, qi, k, share) ->
+    [Q, r] float32, search_finish(tau [Q]) -> (scores [Q,k] f32, rows [Q,k] i64, count [Q] i32), search(q, qi, k) -> (scores, rows),
+    all numpy.  The all-gathers run over the torch.distributed group.  The CPU test-suite drives the shipped control flow this way."""
     import torch.distributed as dist
+    lib = _lib.load()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
-        scores, rows = index.search(q_value, q_index, k, out_device=True)
-        return merge_topk(scores, rows, k)
-    index.set_param(_lib.PARAM_SAMPLE_SHARE, world)                   # a shard reports only its plausible share of the union's r best
-    r = index.sample_rank(k)
-    dev = getattr(index, "torch_device", None) or torch.device("cuda", index.device)
-    rr = torch.tensor([r, -r], dtype=torch.int32, device=dev)
-    dist.all_reduce(rr, op=dist.ReduceOp.MIN, group=group)            # (min r, -max r): shards of different size may disagree
-    rr = rr.tolist()
-    if r == 0 or rr[0] != r or -rr[1] != r:                           # not uniformly samplable: local thresholds
-        scores, rows = index.search(q_value, q_index, k, out_device=True)
-        return allgather_merge(scores, rows, k, group)
-    sample = index.search_begin(q_value, q_index, k)
-    nq = sample.shape[0]
-    gathered = torch.empty((world * nq, r), dtype=torch.float32, device=sample.device)
-    dist.all_gather_into_tensor(gathered, sample, group=group)
-    tau = common_threshold(gathered.view(world, nq, r), index.union_rank(k))
-    scores, rows, count = index.search_finish(tau)
-    # one small all-gather of the per-query counts serves the completeness check AND the useful list length
-    counts = torch.empty((world * nq,), dtype=torch.int32, device=count.device)
-    dist.all_gather_into_tensor(counts, count.to(torch.int32).contiguous(), group=group)
-    counts = counts.view(world, nq)
-    fail_mask = (counts.clamp(min=0).sum(0) < k) | (counts < 0).any(0)
-    n_failed, cmax = torch.stack([fail_mask.sum(), counts.max()]).tolist()      # one host read for both
-    failed = torch.nonzero(fail_mask).flatten() if n_failed else fail_mask[:0]
-    if failed.numel() > 0:                                             # identical on every rank
-        ids = failed.cpu().numpy()
-        sub_v = q_value[ids] if not hasattr(q_value, "index_select") else q_value.index_select(0, failed.to(q_value.device))
-        sub_i = None
-        if q_index is not None:
-            sub_i = q_index[ids] if not hasattr(q_index, "index_select") else q_index.index_select(0, failed.to(q_index.device))
-        fs, fr = index.search(sub_v, sub_i, k, out_device=True)
-        scores[failed] = fs
-        rows[failed] = fr
-        return allgather_merge(scores, rows, k, group)
-    # every global top-k row reaches tau, and a shard holds `count` of those: the tails of the lists are dead
-    kk = min(k, (int(cmax) + 63) // 64 * 64)
-    return allgather_merge(scores[:, :kk].contiguous(), rows[:, :kk].contiguous(), k, group)
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    q_value = np.ascontiguousarray(q_value)
+    q_index = None if q_index is None else np.ascontiguousarray(q_index)
+    nq, width = q_value.shape
+    state = {}
+
+    def batch_arrays(qb):
+        qb = qb.contents
+        n = int(qb.n_queries)
+        dt = np.float32 if qb.value_dtype == _lib.VAL_F32 else np.float16
+        v = np.ctypeslib.as_array(C.cast(qb.value, C.POINTER(C.c_uint8)), shape=(n * int(qb.ld_value) * np.dtype(dt).itemsize,)).view(dt).reshape(n, int(qb.ld_value))[:, :width]
+        x = None
+        if qb.index:
+            it = {_lib.IDX_U8: np.uint8, _lib.IDX_I8: np.int8, _lib.IDX_I16: np.int16}[qb.index_dtype]
+            x = np.ctypeslib.as_array(C.cast(qb.index, C.POINTER(C.c_uint8)), shape=(n * int(qb.ld_index) * np.dtype(it).itemsize,)).view(it).reshape(n, int(qb.ld_index))
+        return v, x
+
+    def out(ptr, shape, dt):
+        n = int(np.prod(shape))
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,)).view(dt).reshape(shape)
+
+    def guard(f):
+        def g(*a):
+            try:
+                return f(*a)
+            except Exception as e:  # noqa: BLE001
+                import sys, traceback
+                traceback.print_exc(file=sys.stderr)
+                return 1
+        return g
+
+    def cb_begin(_u, qb, kk, share, sample):
+        v, x = batch_arrays(qb)
+        state["n"] = v.shape[0]
+        s = np.asarray(shard.search_begin(v, x, int(kk), int(share)), np.float32)
+        out(sample, s.shape, np.float32)[...] = s
+        return 0
+
+    def cb_finish(_u, tau, ps, pr, pc):
+        n = state["n"]
+        s, r, c = shard.search_finish(out(tau, (n,), np.float32).copy())
+        out(ps, (n, k), np.float32)[...] = s
+        out(pr, (n, k), np.int64)[...] = r
+        out(pc, (n,), np.int32)[...] = c
+        return 0
+
+    def cb_search(_u, qb, kk, ps, pr):
+        v, x = batch_arrays(qb)
+        s, r = shard.search(v, x, int(kk))
+        out(ps, s.shape, np.float32)[...] = s
+        out(pr, r.shape, np.int64)[...] = r
+        return 0
+
+    hs = _lib.HostShard(None, _lib.HS_SAMPLE_RANK(lambda _u, kk, share: int(shard.sample_rank(int(kk), int(share)))),
+                        _lib.HS_UNION_RANK(lambda _u, kk: int(shard.union_rank(int(kk)))), _lib.HS_BEGIN(guard(cb_begin)),
+                        _lib.HS_FINISH(guard(cb_finish)), _lib.HS_SEARCH(guard(cb_search)))
+    gather = _host_allgather(group) if world > 1 else _lib.ALLGATHER_FN(lambda *_a: 1)
+    qb, keep = _lib.make_query_batch(q_value, q_index)
+    scores = np.empty((nq, k), np.float32)
+    rows = np.empty((nq, k), np.int64)
+    _lib.check(lib.dhr_search_sharded_host(C.byref(hs), world, rank, gather, None, C.byref(qb), int(k), scores.ctypes.data, rows.ctypes.data),
+               "dhr_search_sharded_host")
+    del keep
+    return scores, rows

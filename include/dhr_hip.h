@@ -360,7 +360,29 @@ typedef struct dhr_comm dhr_comm; /* opaque */
 int dhr_comm_unique_id(void* out128, int32_t out_bytes);
 int dhr_comm_create(const void* unique_id128, int32_t world, int32_t rank, int32_t device, dhr_comm** out);
 int dhr_comm_wrap(void* nccl_comm, int32_t world, int32_t rank, int32_t device, dhr_comm** out);
+/* A communicator whose all-gather is done by the CALLER over any transport (torch.distributed on gloo, MPI, pipes ...):
+ *   allgather(user, send, recv, bytes) gathers `bytes` from every rank into recv = [world][bytes], rank order; HOST buffers
+ *   (the library stages device blocks through pinned memory around the call); returns 0 on success.  Collective: every rank
+ *   calls it the same number of times with the same sizes.  dhr_search_sharded then runs the same control flow as over RCCL.
+ * Used where RCCL is not available between the ranks (several ranks on one GPU, CPU-only process groups). */
+typedef int (*dhr_allgather_fn)(void* user, const void* send, void* recv, int64_t bytes);
+int dhr_comm_create_callback(int32_t world, int32_t rank, int32_t device, dhr_allgather_fn allgather, void* user, dhr_comm** out);
 void dhr_comm_destroy(dhr_comm* comm);
+/* The sharded control flow over a shard the CALLER implements in host memory (no device is touched): test / bring-up hook.  The
+ * callbacks mirror the staged C ABI: sample_rank / union_rank (dhr_search_sample_rank with DHR_PARAM_SAMPLE_SHARE = share /
+ * dhr_search_union_rank), begin (writes [n_queries, sample_rank] best sample scores, best first), finish (tau [n_queries] ->
+ * [n_queries, k] sorted lists with (-inf, -1) tails + per-query counts of rows >= tau, -1 = incomplete), search (plain top-k).
+ * All return 0 on success; all arrays are host memory; rows are global.  The query batch must be a host batch. */
+typedef struct dhr_host_shard {
+  void* user;
+  int32_t (*sample_rank)(void* user, int32_t k, int32_t share);
+  int32_t (*union_rank)(void* user, int32_t k);
+  int32_t (*begin)(void* user, const dhr_query_batch* queries, int32_t k, int32_t share, float* out_sample);
+  int32_t (*finish)(void* user, const float* tau, float* out_scores, int64_t* out_rows, int32_t* out_count);
+  int32_t (*search)(void* user, const dhr_query_batch* queries, int32_t k, float* out_scores, int64_t* out_rows);
+} dhr_host_shard;
+int dhr_search_sharded_host(const dhr_host_shard* shard, int32_t world, int32_t rank, dhr_allgather_fn allgather, void* user,
+                            const dhr_query_batch* queries, int32_t k, float* out_scores, int64_t* out_rows);
 int dhr_search_sharded(dhr_index* shard, dhr_comm* comm, const dhr_query_batch* queries, int32_t k, float* out_scores,
                        int64_t* out_rows, int32_t out_mem_kind, void* stream);
 int dhr_search_sharded_local(dhr_index** shards, int32_t n_shards, const dhr_query_batch* queries, int32_t k, float* out_scores,

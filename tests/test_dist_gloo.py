@@ -64,63 +64,51 @@ def test_shard_bounds_match_reference_arithmetic():
 
 
 class _FakeShard:
-    """CPU stand-in for GipIndex with the staged-search interface, backed by the oracle (dense scores).
-    Lets the gloo test drive dist.sharded_search -- every collective of the staged path -- without a GPU."""
+    """A shard in HOST memory, backed by the oracle (dense scores), with the staged-search interface dhr_search_sharded_host binds
+    (dhr_amd/dist.py sharded_search_host).  The gloo tests drive the LIBRARY's sharded control flow (sharded.hip sharded_core: sample
+    exchange, agreed ranks, common thresholds, counts, list prefixes, rank merge, repair of failed queries) with it -- no GPU."""
 
-    def __init__(self, cv, q32, lo, period=4, r=40):
-        import torch
-        self.torch_device = torch.device("cpu")
-        self.device = 0
-        self.cv, self.lo, self.period, self.r = cv.astype(np.float64), lo, period, r
+    def __init__(self, cv, lo, period=4, r=40, r_skew=0):
+        self.cv, self.lo, self.period, self.r = cv.astype(np.float64), lo, period, r + r_skew
         self.calls = []
-
-    def set_param(self, param, value):
-        from dhr_amd import _lib
-        if param == _lib.PARAM_SAMPLE_SHARE:
-            self.share = int(value)
 
     def union_rank(self, k):
         return self.r
 
-    def sample_rank(self, k):                      # this shard's share of the union's rank (api.hip local_sample_rank)
-        share = getattr(self, "share", 1)
+    def sample_rank(self, k, share):               # this shard's share of the union's rank (api.hip local_sample_rank)
         m = self.r / share
         return self.r if share <= 1 else min(self.r, int(np.ceil(m + 5.0 * np.sqrt(m) + 4.0)))
 
     def _scores(self, q):
         return np.asarray(q, np.float64) @ self.cv.T
 
-    def search_begin(self, q, qi, k):
-        import torch
-        self.q, self.k = np.asarray(q), k
+    def search_begin(self, q, qi, k, share):
+        self.q, self.k = np.array(q), k
         s = self._scores(q)[:, ::self.period]
-        top = -np.sort(-s, axis=1)[:, : self.sample_rank(k)]
+        top = -np.sort(-s, axis=1)[:, : self.sample_rank(k, share)]
         self.calls.append("begin")
-        return torch.from_numpy(top.astype(np.float32))
+        return top.astype(np.float32)
 
     def search_finish(self, tau):
-        import torch
         s = self._scores(self.q)
         k, nq = self.k, s.shape[0]
         sc = np.full((nq, k), -np.inf, np.float32); rows = np.full((nq, k), -1, np.int64); cnt = np.zeros(nq, np.int32)
         for i in range(nq):
-            keep = np.nonzero(s[i] >= float(tau[i]))[0]
+            keep = np.nonzero(s[i].astype(np.float32) >= float(tau[i]))[0]
             keep = keep[np.lexsort((keep, -s[i][keep]))][:k]
             sc[i, : len(keep)] = s[i][keep]; rows[i, : len(keep)] = keep + self.lo; cnt[i] = len(keep)
         self.calls.append("finish")
-        return torch.from_numpy(sc), torch.from_numpy(rows), torch.from_numpy(cnt)
+        return sc, rows, cnt
 
-    def search(self, q, qi, k, out_device=True):
-        import torch
+    def search(self, q, qi, k):
         s = self._scores(np.asarray(q))
         order = np.argsort(-s, axis=1, kind="stable")[:, :k]
         self.calls.append("search%d" % len(s))
-        return torch.from_numpy(np.take_along_axis(s, order, 1).astype(np.float32)), torch.from_numpy(order + self.lo)
+        return np.take_along_axis(s, order, 1).astype(np.float32), order + self.lo
 
 
-def _staged_worker(rank, world, port, tmp, adversarial):
+def _staged_worker(rank, world, port, tmp, mode):
     sys.path.insert(0, ROOT)
-    import torch
     import torch.distributed as dist
     from dhr_amd import dist as D
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -130,27 +118,43 @@ def _staged_worker(rank, world, port, tmp, adversarial):
         n, k, nq = 4000, 60, 5
         cv = rng.standard_normal((n, 16)).astype(np.float32)
         q = rng.standard_normal((nq, 16)).astype(np.float32)
-        if adversarial:          # the best rows of query 0 all sit on sample positions of shard 0 -> threshold too high
-            cv[0:800:4] += 3.0 * q[0] / np.linalg.norm(q[0])
+        if mode == "adversarial":          # the best rows of query 0 all sit on sample positions of their shards -> threshold too high
+            for r_ in range(world):
+                lo_ = D.shard_bounds(n, world, r_)[0]
+                cv[lo_:lo_ + 400:4] += 3.0 * q[0] / np.linalg.norm(q[0])
         lo, hi = D.shard_bounds(n, world, rank)
-        shard = _FakeShard(cv[lo:hi], q, lo)
-        ms, mr = D.sharded_search(shard, q, None, k)
+        # "rank_mismatch": the last rank disagrees on the union rank -> every rank must take the local-threshold path
+        shard = _FakeShard(cv[lo:hi], lo, r_skew=(3 if mode == "rank_mismatch" and rank == world - 1 else 0))
+        ms, mr = D.sharded_search_host(shard, q, None, k)
         full = q.astype(np.float64) @ cv.astype(np.float64).T
         for i in range(nq):
             want = np.argsort(-full[i], kind="stable")[:k]
             assert set(mr[i].tolist()) == set(want.tolist()), (rank, i)
+            assert np.all(np.diff(ms[i]) <= 0)
+            np.testing.assert_allclose(ms[i], full[i][mr[i]].astype(np.float32), rtol=0, atol=0)
         np.save(os.path.join(tmp, f"calls{rank}.npy"), np.array(shard.calls))
+        np.save(os.path.join(tmp, f"rows{rank}.npy"), mr)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("adversarial", [False, True])
-def test_sharded_search_staged_gloo(tmp_path, adversarial):
-    """dist.sharded_search end to end over gloo (2 ranks): sample exchange, common threshold, count
-    all-reduce and -- in the adversarial layout -- the local-threshold fallback for the failed query."""
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("mode", ["plain", "adversarial", "rank_mismatch"])
+def test_sharded_core_over_gloo(tmp_path, mode, world):
+    """The library's sharded control flow -- dhr_search_sharded_host: the same sharded_core that dhr_search_sharded runs over RCCL -- end
+    to end with 2 and 3 ranks over gloo: sample exchange, agreement on the ranks, common threshold, count check, gathered prefixes,
+    rank merge and, in the adversarial layout, the repair of the failed query with local thresholds; a rank that disagrees on the union
+    rank sends every rank down the local-threshold path."""
     import torch.multiprocessing as mp
-    port = 29700 + (os.getpid() % 2000) + int(adversarial)
-    mp.spawn(_staged_worker, args=(2, port, str(tmp_path), adversarial), nprocs=2, join=True)
-    calls = [list(np.load(tmp_path / f"calls{r}.npy")) for r in range(2)]
-    assert calls[0][:2] == ["begin", "finish"] and calls[0] == calls[1]
-    assert (len(calls[0]) == 3) == adversarial
+    port = 29700 + (os.getpid() % 2000) + 7 * world + ["plain", "adversarial", "rank_mismatch"].index(mode)
+    mp.spawn(_staged_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
+    calls = [list(np.load(tmp_path / f"calls{r}.npy")) for r in range(world)]
+    rows = [np.load(tmp_path / f"rows{r}.npy") for r in range(world)]
+    for r in range(1, world):
+        assert calls[r] == calls[0]
+        np.testing.assert_array_equal(rows[r], rows[0])          # identical on every rank
+    if mode == "rank_mismatch":
+        assert calls[0] == ["search5"]
+    else:
+        assert calls[0][:2] == ["begin", "finish"]
+        assert (len(calls[0]) == 3) == (mode == "adversarial")

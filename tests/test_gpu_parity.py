@@ -1008,6 +1008,34 @@ def test_emb_dim_not_a_multiple_of_8(G):
         np.testing.assert_allclose(ex[i], O.gip_scores_f64(qv[i].astype(np.float32), qi[i], cv.astype(np.float32), ci), rtol=0, atol=1e-5)
 
 
+def _exhaustive_topk(ix, qv, qi, n, k, slab=1 << 20):
+    """Ground truth at any size: EVERY row of the index scored exactly for every query of the (small) batch -- dhr_score_rows over the
+    whole row range in slabs -- and the k best by (score desc, row asc) taken with torch.topk on the composite 64-bit key.  No bound, no
+    filter, no threshold is involved: what dhr_search returns must equal this bit for bit (the scores are the same exactly-rounded
+    values, exact ties break on the row)."""
+    import torch
+    dev = qv.device
+    nq = qv.shape[0]
+    best = None
+    for lo in range(0, n, slab):
+        hi = min(n, lo + slab)
+        rows = torch.arange(lo, hi, device=dev, dtype=torch.int64)[None, :].expand(nq, -1).contiguous()
+        sc = ix.score_rows_device(qv, qi, rows)
+        b = sc.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        ordered = torch.where((b >> 31) != 0, (~b) & 0xFFFFFFFF, b | 0x80000000)          # order-preserving bits of an fp32
+        key = ((ordered - (1 << 31)) << 32) + (0xFFFFFFFF - rows)                          # signed 64-bit: score desc, then row asc
+        del rows, sc, b, ordered
+        cat = key if best is None else torch.cat([best, key], dim=1)
+        best = torch.topk(cat, min(k, cat.shape[1]), dim=1).values
+        del key, cat
+    rows = 0xFFFFFFFF - (best & 0xFFFFFFFF)
+    o = (best >> 32) + (1 << 31)
+    bits = torch.where((o >> 31) != 0, o & 0x7FFFFFFF, (~o) & 0xFFFFFFFF)
+    scores = (bits & 0xFFFFFFFF).to(torch.int64)
+    scores = torch.where(scores >= (1 << 31), scores - (1 << 32), scores).to(torch.int32).view(torch.float32)
+    return scores, rows
+
+
 @pytest.mark.parametrize("kind", ["hybrid", "dense"])
 def test_full_size_properties(G, kind):
     """BASELINE config 3 (hybrid) / config 2 (dense-only) at FULL size (8 841 823 x (768+768), 6 980 queries, top-1000), where the oracle cannot run: properties
@@ -1047,6 +1075,13 @@ def test_full_size_properties(G, kind):
         kth = s1[sub, k - 1].cpu().numpy()[:, None]
         inlist = np.stack([np.isin(rnd[i], rows[i]) for i in range(len(sub))])
         assert not np.any((rs > kth) & ~inlist)                                                   # (4)
+        # (6) exhaustive ground truth for 36 queries spread over the batch (incl. its first and last): all 8 841 823 rows scored exactly,
+        # the k best taken without any bound or threshold -- the search's lists must be EQUAL (rows and score bits)
+        ex_q = torch.unique(torch.cat([torch.arange(0, nq, 200, device=dev), torch.tensor([nq - 1], device=dev)]))
+        es, er = _exhaustive_topk(ix, qv[ex_q].contiguous(), None if qi is None else qi[ex_q].contiguous(), n, k)
+        assert torch.equal(er, r1[ex_q]), "rows differ from the exhaustive top-k for queries %s" % ex_q[(er != r1[ex_q]).any(dim=1)].tolist()
+        assert torch.equal(es.view(torch.int32), s1[ex_q].view(torch.int32))
+        print("\n[%s, full size] %d queries: dhr_search == exhaustive top-%d over all %d rows" % (kind, len(ex_q), k, n))
     finally:
         ix.close()
     m = 200_000
@@ -1082,6 +1117,10 @@ def test_config4_full_size_8_shards(G):
         fs, fr = full.search(qv, qi, k, out_device=True)
     torch.cuda.synchronize(); t_full = (time.perf_counter() - t) / 3
     want = bench.result_checksum(torch, fs, fr)
+    # exhaustive ground truth for 32 queries (every row of the unsharded index scored exactly, no bound / filter / threshold): what the
+    # 8-shard search returns is compared with THIS below, not only with the unsharded search
+    ex_q = torch.arange(3, nq, 218, device=dev)
+    es, er = _exhaustive_topk(full, qv[ex_q].contiguous(), qi[ex_q].contiguous(), n, k)
     full.close()
     del full
     torch.cuda.empty_cache()
@@ -1098,6 +1137,7 @@ def test_config4_full_size_8_shards(G):
         got = bench.result_checksum(torch, ss, sr)
         assert got == want, (got, want)
         assert torch.equal(sr, fr) and torch.equal(ss, fs)
+        assert torch.equal(sr[ex_q], er) and torch.equal(ss[ex_q].view(torch.int32), es.view(torch.int32))       # 8 shards == exhaustive ground truth
         # stage times, slowest shard per stage: begin (phase 0 + sampled run) | common threshold | finish (main pass) | merge
         for ix in shards:
             ix.set_param(_lib.PARAM_SAMPLE_SHARE, ns)
