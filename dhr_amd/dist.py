@@ -295,3 +295,107 @@ def sharded_search_host(shard, q_value, q_index, k: int, group=None):
                "dhr_search_sharded_host")
     del keep
     return scores, rows
+
+
+# ----------------------------------------------------------------------------------------------- --PQIP over row shards (config 5)
+def _ordered_u32(scores):
+    """fp32 tensor -> int64 tensor of order-preserving 32-bit patterns (dhr_internal.h f32_ordered)."""
+    import torch
+    b = scores.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    return torch.where((b >> 31) != 0, (~b) & 0xFFFFFFFF, b | 0x80000000)
+
+
+def rerank_topk(index, q_value, q_index, rows, k: int):
+    """Stage 2 of --PQIP --rerank (gip_retrieval.py:205-215) on the device: exact gated inner product of each query against its candidate
+    rows [Q, m] (global rows; < 0 = no candidate), the k best by (score desc, row asc) -- deterministic on exact ties, unlike torch.topk,
+    so that the sharded and the unsharded search agree bit for bit.  -> (scores [Q,k] fp32, rows [Q,k] int64; (-inf, -1) padding)."""
+    import torch
+    s2 = index.score_rows_device(q_value, q_index, rows)
+    s2 = torch.where(rows >= 0, s2, torch.full_like(s2, float("-inf")))
+    key = ((_ordered_u32(s2) - (1 << 31)) << 32) + (0xFFFFFFFF - rows.clamp(min=0))
+    key = torch.where(rows >= 0, key, torch.full_like(key, -(1 << 63)))
+    kk = min(k, rows.shape[1])
+    best = torch.topk(key, kk, dim=1)
+    out_r = torch.gather(rows, 1, best.indices)
+    out_s = torch.gather(s2, 1, best.indices)
+    if kk < k:
+        out_r = torch.cat([out_r, torch.full((rows.shape[0], k - kk), -1, dtype=torch.int64, device=rows.device)], dim=1)
+        out_s = torch.cat([out_s, torch.full((rows.shape[0], k - kk), float("-inf"), dtype=torch.float32, device=rows.device)], dim=1)
+    return out_s, out_r
+
+
+def pq_sharded_search(pq, index, q_value, q_index, k1: int, k: int, group=None, n_total: int | None = None):
+    """--PQIP --rerank over row shards with the result of the UNSHARDED search (same codebooks; a shard's codes are its slice of the
+    corpus' codes): BASELINE config 5, "PQ-quantised index x 8 shards".
+
+    pq / index: this rank's PqIndex / GipIndex (row_offset = the shard's first global row) -- or LISTS of them, one entry per shard, for
+    the one-process form (all shards on this process' device; what the single-GPU tests drive).  Steps:
+      1. every shard: ADC scan -> its k1 best (score desc, row asc) [dhr_pq_search];
+      2. the global cut: theta_q = the k1-th best ADC score of the UNION, found exactly by bisection on the ordered 32-bit pattern of
+         the score (32 rounds of: count my scores >= v, sum over the shards) -- no list leaves its shard; ties at theta are taken
+         in global row order (shards hold ascending row ranges: an all-gather of the per-shard tie counts gives every shard its quota);
+      3. every shard reranks exactly ITS candidates inside the cut [dhr_score_rows] -> its k best;
+      4. all-gather of the [Q, k] lists + rank merge [dhr_merge_topk_lists] -> the global [Q, k], identical on every rank.
+    Parity of the PQ stage with faiss is unpinned; this function only guarantees sharded == unsharded."""
+    import torch
+    import torch.distributed as dist
+    local = isinstance(pq, (list, tuple))
+    pqs, ixs = (list(pq), list(index)) if local else ([pq], [index])
+    world = len(pqs) if local else (dist.get_world_size(group) if dist.is_initialized() else 1)
+
+    def allsum(ts):                       # list (one per local shard) of equal-shape tensors -> their sum over ALL shards
+        t = torch.stack(ts).sum(0)
+        if not local and world > 1:
+            dist.all_reduce(t, group=group)
+        return t
+
+    def allgather(ts):                    # -> [world, ...] in shard order
+        if local:
+            return torch.stack(ts)
+        if world == 1:
+            return ts[0][None]
+        out = torch.empty((world,) + tuple(ts[0].shape), dtype=ts[0].dtype, device=ts[0].device)
+        dist.all_gather_into_tensor(out.view(world * ts[0].shape[0], *ts[0].shape[1:]) if ts[0].dim() > 0 else out, ts[0].contiguous(), group=group)
+        return out
+
+    n_rows = [p.n for p in pqs]
+    if n_total is None:
+        nt = torch.tensor([sum(n_rows)], dtype=torch.int64, device=torch.device("cuda", pqs[0].device))
+        n_total = int(allsum([nt]).item()) if not local else sum(n_rows)
+    k1g = min(int(k1), int(n_total))
+    # 1. local ADC lists
+    lists = []
+    for p in pqs:
+        s1, r1 = p.search(q_value, min(k1g, p.n), out_device=True)
+        lists.append((_ordered_u32(s1), r1))
+    nq = lists[0][0].shape[0]
+    dev = lists[0][0].device
+    # 2. theta = the largest 32-bit pattern v with  #(scores >= v over all shards) >= k1g   (bisection, exact)
+    lo = torch.zeros(nq, dtype=torch.int64, device=dev)
+    hi = torch.full((nq,), 0xFFFFFFFF, dtype=torch.int64, device=dev)
+    for _ in range(33):
+        mid = (lo + hi + 1) >> 1
+        cnt = allsum([((o >= mid[:, None]) & (r >= 0)).sum(1) for o, r in lists])
+        ok = cnt >= k1g
+        lo = torch.where(ok, mid, lo)
+        hi = torch.where(ok, hi, mid - 1)
+    theta = lo
+    n_gt = [((o > theta[:, None]) & (r >= 0)).sum(1) for o, r in lists]
+    n_eq = [((o == theta[:, None]) & (r >= 0)).sum(1) for o, r in lists]
+    need = (k1g - allsum(n_gt)).clamp(min=0)                                   # ties to take, in global row order
+    eq_all = allgather(n_eq)                                                    # [world, Q]
+    before = torch.cumsum(eq_all, 0) - eq_all                                   # ties held by the shards in front
+    rank0 = 0 if local else (dist.get_rank(group) if dist.is_initialized() else 0)
+    # 3. exact rerank of the shard's candidates inside the cut
+    outs = []
+    for i, ((o, r), ix) in enumerate(zip(lists, ixs)):
+        me = i if local else rank0
+        quota = (need - before[me]).clamp(min=0)
+        take = n_gt[i] + torch.minimum(quota, n_eq[i])                          # a prefix of the sorted list (ties are in row order)
+        pos = torch.arange(r.shape[1], device=dev)[None, :]
+        cand = torch.where(pos < take[:, None], r, torch.full_like(r, -1))
+        outs.append(rerank_topk(ix, q_value, q_index, cand, k))
+    # 4. reduce
+    if local:
+        return merge_sorted_lists(torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]), k)
+    return allgather_merge(outs[0][0], outs[0][1], k, group)

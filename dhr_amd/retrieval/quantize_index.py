@@ -51,6 +51,26 @@ def train_and_encode(values, M: int = 64, n_bits: int = 8, iters: int = 25, max_
     return cb, codes, float(err.value)
 
 
+def encode(values, codebooks, n_bits: int = 8, device: int = 0):
+    """Codes of `values` under GIVEN codebooks (dhr_pq_encode: nearest centroid per sub-quantiser): what a shard of a row-sharded
+    PQ index does with the corpus-wide codebooks.  values and codebooks live in the same memory kind.  -> codes uint8 [N, M]."""
+    lib = _lib.load()
+    n, d = int(values.shape[0]), int(values.shape[1])
+    M = int(codebooks.shape[0])
+    p, ld, kind = _lib._ptr_ld(values)
+    if kind == _lib.MEM_HOST:
+        cb = np.ascontiguousarray(np.asarray(codebooks), np.float32)
+        codes = np.empty((n, M), np.uint8)
+        pcb, pcodes = cb.ctypes.data, codes.ctypes.data
+    else:
+        import torch
+        cb = codebooks.contiguous()
+        codes = torch.empty((n, M), dtype=torch.uint8, device=values.device)
+        pcb, pcodes = cb.data_ptr(), codes.data_ptr()
+    _lib.check(lib.dhr_pq_encode_nbits(device, kind, p, ld, n, d, M, int(n_bits), pcb, pcodes, None), "dhr_pq_encode")
+    return codes
+
+
 def decode(codebooks, codes, device: int = 0):
     """-> fp16 [N, d] reconstruction, same memory kind as the inputs."""
     lib = _lib.load()

@@ -1161,9 +1161,17 @@ def test_config4_full_size_8_shards(G):
             if best is None or tot < best[0]:
                 best = (tot, max(tb), tt, max(tf), tm, kk)
         assert torch.equal(mr, fr) and torch.equal(ms, fs)
+        # the collectives of dhr_search_sharded, modelled: 50 us of launch + latency each, payload / 150 GB/s (xGMI is point to point: in an
+        # all-gather every rank sends ITS block to the 7 others over 7 links at once, so the time is one block over one link);
+        # blocks: sample scores [Q, r_local] fp32, counts [Q] int32, list prefixes [Q, kk] x (fp32 + int64), kk as sharded.hip prefix_len
+        r_loc = shards[0].sample_rank(k)
+        kk_fix = min(k, ((3 * k + ns - 1) // ns + 64 + 63) // 64 * 64)
+        coll = sum(50e-6 + b / 150e9 for b in (nq * r_loc * 4, nq * 4, nq * kk_fix * 4, nq * kk_fix * 8))
         print("\n[config 4, emulated on one GPU] unsharded step %.1f ms; slowest shard per stage: begin %.2f + threshold %.2f + finish %.2f + merge %.2f "
-              "= %.2f ms (+ the all-gathers of [Q, %d] lists over xGMI, not emulated) -> %.2fx"
-              % (t_full * 1e3, best[1] * 1e3, best[2] * 1e3, best[3] * 1e3, best[4] * 1e3, best[0] * 1e3, best[5], t_full / best[0]))
+              "= %.2f ms -> %.2fx; + the 4 all-gathers modelled at 50 us + bytes / 150 GB/s each ([Q, %d] sample scores, [Q] counts, [Q, %d] x 12 B lists) "
+              "= %.2f ms -> %.2f ms = %.2fx"
+              % (t_full * 1e3, best[1] * 1e3, best[2] * 1e3, best[3] * 1e3, best[4] * 1e3, best[0] * 1e3, t_full / best[0], r_loc, kk_fix, coll * 1e3,
+                 (best[0] + coll) * 1e3, t_full / (best[0] + coll)))
     finally:
         for s in shards:
             s.close()
@@ -1793,6 +1801,44 @@ def test_pq_first_stage_beir_size(G):
         assert rec >= 0.9, rec
     finally:
         pix.close(); ix.close()
+
+
+@pytest.mark.parametrize("name,n,nq", [("fiqa", 57_638, 648), ("quora", 522_931, 512), ("arguana", 8_674, 1_406)])
+def test_config5_pq_sharded_8_equals_unsharded(G, name, n, nq):
+    """BASELINE config 5 literally -- PQ-quantised index x BEIR corpus sizes x 8 row shards (parity of the PQ stage with faiss UNPINNED):
+    the sharded --PQIP --rerank search (dist.pq_sharded_search: per-shard ADC scan, exact global agip_topk cut by bisection on the score
+    bits, per-shard exact rerank, all-gather + rank merge of the [Q, k] lists) must return the UNSHARDED search's lists bit for bit --
+    one set of codebooks, a shard's codes = its slice of the corpus' codes (gip_retrieval.py:167-231 under the shard arithmetic of
+    :292-306; merge.result.py:22-42).  arguana: agip_topk exceeds the rows of every shard AND of the corpus."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    from dhr_amd import synth, dist as D
+    from dhr_amd.retrieval import quantize_index as QI
+    dev = torch.device("cuda", 0)
+    k1, k, ns = 10_000, 1000, 8
+    seed = 5150 + n % 97
+    cv, ci = bench.gen_rows(torch, synth, dev, seed, 0, n, 768, 128, 30, 90, False)
+    qv, qi = bench.gen_rows(torch, synth, dev, seed + 999_983, 0, nq, 768, 128, 4, 12, False)
+    cb, codes, _ = QI.train_and_encode(cv, 64, 8, iters=3)
+    pix, ix = QI.PqIndex(cb, codes), G.GipIndex(cv, ci)
+    pqs, ixs = [], []
+    try:
+        s1, r1 = pix.search(qv, min(k1, n), out_device=True)
+        us, ur = D.rerank_topk(ix, qv, qi, r1, k)
+        assert bool((ur[:, : min(k, n)] >= 0).all())
+        for r in range(ns):
+            lo, hi = D.shard_bounds(n, ns, r)
+            pqs.append(QI.PqIndex(cb, QI.encode(cv[lo:hi], cb), row_offset=lo))
+            assert torch.equal(QI.encode(cv[lo:hi], cb), codes[lo:hi])               # a shard's codes are its slice of the corpus' codes
+            ixs.append(G.GipIndex(cv[lo:hi], ci[lo:hi], row_offset=lo))
+        ss, sr = D.pq_sharded_search(pqs, ixs, qv, qi, k1, k)
+        assert torch.equal(sr, ur), "rows differ for queries %s" % torch.nonzero((sr != ur).any(dim=1)).flatten()[:8].tolist()
+        assert torch.equal(ss.view(torch.int32), us.view(torch.int32))
+    finally:
+        for h in pqs + ixs + [pix, ix]:
+            h.close()
 
 
 def test_gated_image_default_by_size(G, monkeypatch):

@@ -72,7 +72,13 @@ def main():
         torch.cuda.synchronize(); t = time.perf_counter()
         ms, mr = D.merge_sorted_lists(gs, gr, k); torch.cuda.synchronize(); tm = time.perf_counter() - t
         tot = torch.stack([o[2] for o in outs]).clamp(min=0).sum(0)
-        failed = int(((tot < k) | (torch.stack([o[2] for o in outs]) < 0).any(0)).sum())
+        call = torch.stack([o[2] for o in outs])
+        fmask = (tot < k) | (call < 0).any(0)
+        failed = int(fmask.sum())
+        if it == 1 and failed:
+            for q in torch.nonzero(fmask).flatten().tolist()[:8]:
+                print("  failed query %d: counts per shard %s  sum %d  tau %.5f  own 26th-best per shard %s" %
+                      (q, call[:, q].tolist(), int(tot[q]), float(tau[q]), [round(float(sm[q, -1]), 5) for sm in samples]))
     st = shards[0].stats()
     print("shards %d rank r=%d : begin max %.1f ms  finish max %.1f ms  tau %.2f ms  merge %.2f ms  -> est. step %.1f ms (+ all-gather)  failed queries %d"
           % (a.shards, rnk, max(tb) * 1e3, max(tf) * 1e3, tt * 1e3, tm * 1e3, (max(tb) + max(tf) + tt + tm) * 1e3, failed))
