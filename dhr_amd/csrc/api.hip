@@ -540,7 +540,7 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
     ix->heavy_val = (__half*)((char*)ix->heavy_key + HEAVY * 4);
     ix->index_bytes += (int64_t)hb;
     if (launch_heavy_build(ix->vals_rm, ix->k_rm, ix->c_idx, ix->idx_dtype, d->n_rows, d->d_dlr, ix->bucket_map, ix->n_buckets,
-                           ix->heavy_key, ix->heavy_val, s) != hipSuccess)
+                           ix->heavy_key, ix->heavy_val, ix->gated_i8 ? ix->g8_inv_cs : nullptr, ix->abs_mode ? 1 : 0, s) != hipSuccess)
       return fail(set_error(DHR_ERR_HIP, "heavy_build launch failed"));
   }
   if (hipStreamSynchronize(s) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "index build failed on the device"));

@@ -256,7 +256,8 @@ __device__ __forceinline__ bool gemm_wg_tile(const GemmArgs& p, int64_t& dt, int
 inline int sparse_query_stages(int ts, bool gated, bool g8 = false) { return ts > 0 ? ((gated || g8) ? ts : 2 * ts) : 0; }
 hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s);
 hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, int idx_dtype, int64_t n_rows, int d_dlr,
-                              const uint8_t* map, int n_buckets, uint32_t* heavy_key, __half* heavy_val, hipStream_t s);
+                              const uint8_t* map, int n_buckets, uint32_t* heavy_key, __half* heavy_val,
+                              const float* g8_inv_cs /* gated_i8 indexes: the key also carries the entry's int8 level */, int abs_mode, hipStream_t s);
 struct RefineArgs {
   const uint2* cand; const uint32_t* cnt; uint32_t cap;      // bound candidates (row, U bits)
   const uint32_t* heavy_key; const __half* heavy_val;       // [n_rows][HEAVY]

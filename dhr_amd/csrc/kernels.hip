@@ -1280,7 +1280,8 @@ template <int SL>      // key registers per lane: 16 (d_dlr <= 1024) or 64 (<= 4
 __global__ void __launch_bounds__(256) heavy_build_kernel(const __half* __restrict__ vals_rm, int k_rm,
                                                           const void* __restrict__ idx, int idx_dtype, int64_t n_rows,
                                                           int d_dlr, const uint8_t* __restrict__ map, int n_buckets,
-                                                          uint32_t* __restrict__ heavy_key, __half* __restrict__ heavy_val) {
+                                                          uint32_t* __restrict__ heavy_key, __half* __restrict__ heavy_val,
+                                                          const float* __restrict__ g8_inv_cs, int abs_mode) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -1311,7 +1312,17 @@ __global__ void __launch_bounds__(256) heavy_build_kernel(const __half* __restri
       if ((j & 63) == lane) {                 // owner lane writes the entry and retires it
         const int iv = load_idx(idx, idx_dtype, row * d_dlr + j);
         const uint32_t bk = n_buckets > 1 ? (uint32_t)bucket_of(iv, j, map, n_buckets) : 0u;
-        heavy_key[row * HEAVY_KEY_STRIDE + r] = ((uint32_t)j << 20) | (bk << 16) | ((uint32_t)iv & 0xFFFFu);
+        uint32_t key_out = ((uint32_t)j << 20) | (bk << 16) | ((uint32_t)iv & 0xFFFFu);
+        if (g8_inv_cs) {
+          // gated_i8 index (two buckets: one bucket bit; the refine step compares 12 index bits): the entry's int8 operand level -- what the
+          // bound GEMM counted for it -- travels in the key's idle bits [19:17] and [15:12], so that the refine step neither looks the
+          // column's step up nor repeats the quantisation per candidate (quant_up_i8: the tile builder's expression)
+          float d = __half2float(vals_rm[row * k_rm + j]);
+          if (abs_mode) d = fabsf(d);
+          const uint32_t lvl = d > 0.f ? (uint32_t)quant_up_i8(d, g8_inv_cs[j]) : 0u;
+          key_out = ((uint32_t)j << 20) | ((lvl >> 4) << 17) | ((bk & 1u) << 16) | ((lvl & 0xFu) << 12) | ((uint32_t)iv & 0xFFFu);
+        }
+        heavy_key[row * HEAVY_KEY_STRIDE + r] = key_out;
         heavy_val[row * HEAVY_VAL_STRIDE + r] = vals_rm[row * k_rm + j];
 #pragma unroll
         for (int sl = 0; sl < SL; ++sl) if (sl == (j >> 6)) key[sl] = 0u;
@@ -1320,15 +1331,15 @@ __global__ void __launch_bounds__(256) heavy_build_kernel(const __half* __restri
   }
 }
 hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, int idx_dtype, int64_t n_rows, int d_dlr,
-                              const uint8_t* map, int n_buckets, uint32_t* heavy_key, __half* heavy_val, hipStream_t s) {
+                              const uint8_t* map, int n_buckets, uint32_t* heavy_key, __half* heavy_val, const float* g8_inv_cs, int abs_mode, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
   const int64_t blocks = (n_rows + 3) / 4;
   if (d_dlr <= 1024)
     hipLaunchKernelGGL(heavy_build_kernel<16>, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, vals_rm, k_rm,
-                       idx, idx_dtype, n_rows, d_dlr, map, n_buckets, heavy_key, heavy_val);
+                       idx, idx_dtype, n_rows, d_dlr, map, n_buckets, heavy_key, heavy_val, g8_inv_cs, abs_mode);
   else
     hipLaunchKernelGGL(heavy_build_kernel<64>, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, vals_rm, k_rm,
-                       idx, idx_dtype, n_rows, d_dlr, map, n_buckets, heavy_key, heavy_val);
+                       idx, idx_dtype, n_rows, d_dlr, map, n_buckets, heavy_key, heavy_val, g8_inv_cs, abs_mode);
   return hipGetLastError();
 }
 
@@ -1345,9 +1356,8 @@ static __device__ __forceinline__ uint2 gather8(const void* p) { return *(const 
 constexpr int REFINE_PER_WG = 256;       // candidates of ONE query per workgroup (its operand words are staged in LDS once)
 template <bool G8>
 __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
-  extern __shared__ uint32_t qw[];             // [d_dlr] query words (up to 4096 slices: the slice id has 12 bits in a heavy-list key)
-  float* ics = (float*)(qw + p.d_dlr);         // G8: [d_dlr] 1 / step of the gated corpus columns, then [d_dlr] the query's int8 operand bytes
-  uint8_t* q8 = (uint8_t*)(ics + p.d_dlr);
+  extern __shared__ uint32_t qw[];             // [d_dlr] query words (up to 4096 slices: the slice id has 12 bits in a heavy-list key);
+                                               // G8: [d_dlr] pairs {query word, the query's int8 operand level}: one 8-byte LDS read per listed entry
   int q = blockIdx.y;
   uint32_t blk = blockIdx.x;
   for (uint32_t fb = blockIdx.x;; fb += gridDim.x) {       // flat launches: grid stride over the block list (see rescore_kernel); else one pass
@@ -1358,8 +1368,8 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
   if (base >= count) { if (p.blk_off) continue; return; }
   __syncthreads();                                           // the previous block's readers are done with the staged query words
   for (int j = threadIdx.x; j < p.d_dlr; j += 256) {
-    qw[j] = p.q_pack[(int64_t)q * p.d_dlr + j];
-    if constexpr (G8) { ics[j] = p.g8_inv_cs[j]; q8[j] = p.g8_q8[(int64_t)q * p.d_dlr + j]; }
+    if constexpr (G8) { qw[2 * j] = p.q_pack[(int64_t)q * p.d_dlr + j]; qw[2 * j + 1] = p.g8_q8[(int64_t)q * p.d_dlr + j]; }
+    else qw[j] = p.q_pack[(int64_t)q * p.d_dlr + j];
   }
   __syncthreads();
   const int sub = threadIdx.x & 7;
@@ -1385,19 +1395,27 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
         const uint32_t key = keys[e];
         if (key != 0xFFFFFFFFu) {
           const uint32_t j = key >> 20;
-          const uint32_t w = qw[j];
-          const bool same_bucket = (G8 && p.ungated) || ((w >> 12) & 0xFu) == ((key >> 16) & 0xFu);
-          const bool mismatch = !(G8 && p.ungated) && (w & 0xFFFu) != (key & 0xFFFu);
-          union { uint16_t u; _Float16 h; } qv; qv.u = (uint16_t)(w >> 16);
           if constexpr (G8) {
-            if (same_bucket) {
-              const float d = p.abs_mode ? fabsf((float)hv[e]) : (float)hv[e];
-              if (d > 0.f) {
-                taken += (int)q8[j] * quant_up_i8(d, ics[j]);
-                if (!mismatch) back += (double)(float)qv.h * (double)d;
+            const uint2 wq = *(const uint2*)(qw + 2 * j);
+            const uint32_t w = wq.x;
+            const bool same_bucket = p.ungated || ((w >> 12) & 0x1u) == ((key >> 16) & 0x1u);
+            const bool mismatch = !p.ungated && (w & 0xFFFu) != (key & 0xFFFu);
+            const int lvl = (int)(((key >> 17) & 0x7u) << 4 | ((key >> 12) & 0xFu));      // the entry's int8 operand level (heavy_build_kernel)
+            if (same_bucket && lvl > 0) {
+              taken += (int)wq.y * lvl;
+              if (!mismatch) {
+                union { uint16_t u; _Float16 h; } qv; qv.u = (uint16_t)(w >> 16);
+                const float d = p.abs_mode ? fabsf((float)hv[e]) : (float)hv[e];
+                back += (double)(float)qv.h * (double)d;
               }
             }
-          } else if (same_bucket && mismatch) corr += fabsf((float)qv.h * (float)hv[e]);
+          } else {
+            const uint32_t w = qw[j];
+            const bool same_bucket = ((w >> 12) & 0xFu) == ((key >> 16) & 0xFu);
+            const bool mismatch = (w & 0xFFFu) != (key & 0xFFFu);
+            union { uint16_t u; _Float16 h; } qv; qv.u = (uint16_t)(w >> 16);
+            if (same_bucket && mismatch) corr += fabsf((float)qv.h * (float)hv[e]);
+          }
         }
       }
     }
@@ -1430,7 +1448,7 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
 hipError_t launch_refine(const RefineArgs& a, hipStream_t s) {
   if (a.max_count == 0 || a.n_queries <= 0) return hipSuccess;
   const bool g8 = a.g8_q8 != nullptr;
-  const size_t lds = (size_t)a.d_dlr * (g8 ? 9 : 4);
+  const size_t lds = (size_t)a.d_dlr * (g8 ? 8 : 4);
   const dim3 grid = a.blk_off ? dim3(std::min<uint32_t>(a.flat_blocks, FLAT_GRID_MAX)) : dim3((a.max_count + REFINE_PER_WG - 1) / REFINE_PER_WG, (unsigned)a.n_queries);
   if (a.blk_off && !a.flat_blocks) return hipSuccess;
   if (g8) hipLaunchKernelGGL(refine_kernel<true>, grid, dim3(256), lds, s, a);
@@ -1538,14 +1556,16 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
       return;
     }
   }
-  // Narrow rows (at most 128 chunks: dense-only indexes, 768 columns = 1.5 KB per row): a wave per pair leaves half of the lanes idle in its
-  // second pass and pays one 64-lane fp64 reduction per 1.5 KB -- measured 2.0 TB/s of row bytes against 5.4 TB/s on 3.8 KB hybrid rows.
-  // Instead 32 lanes per pair, two pairs per wave: lane s of a pair owns chunks s, s + 32, ... (ascending), then the xor butterfly over
-  // 32 lanes.  The summation order is fixed by the row width alone, so scores stay reproducible between searches, shards and entry points.
+  // Narrow rows (at most 128 chunks: dense-only indexes, 768 columns = 1.5 KB per row; the 768 + 128 BEIR layout): a wave per pair leaves half
+  // of the lanes idle in its second pass and pays one 64-lane fp64 reduction per 1.5 KB -- measured 2.0 TB/s of row bytes against 5.4 TB/s on
+  // 3.8 KB hybrid rows.  Instead 16 lanes per pair, four pairs per wave: lane s of a pair owns chunks s, s + 16, ... (ascending: six
+  // independent 16-byte gathers in flight per lane), then the xor butterfly over the 16 lanes.  The summation order is fixed by the row
+  // width alone, so scores stay reproducible between searches, shards and entry points.  (32 lanes per pair: 2.9-3.1 TB/s.)
   if (fast && !some_zero && nchunks <= 128) {
-    const int g = lane >> 5, sl = lane & 31;
-    static_assert(RESCORE_CANDS_PER_WG == 32, "4 waves x 2 pairs x 4 rounds");
-    for (uint32_t i0 = base + wave * 2; i0 < base + RESCORE_CANDS_PER_WG && i0 < count; i0 += 8) {
+    constexpr int L = 16, P = 64 / L;
+    const int g = lane / L, sl = lane % L;
+    static_assert(RESCORE_CANDS_PER_WG % (4 * P) == 0, "4 waves x P pairs per round");
+    for (uint32_t i0 = base + wave * P; i0 < base + RESCORE_CANDS_PER_WG && i0 < count; i0 += 4 * P) {
       const uint32_t i = i0 + g;
       const bool live = i < count;
       uint32_t row = 0u;
@@ -1557,7 +1577,7 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
       const bool valid = live && (int64_t)row < p.n_rows;
       double acc = 0.0;
       if (valid) {
-        for (int c = sl; c < nchunks; c += 32) {
+        for (int c = sl; c < nchunks; c += L) {
           const uint4 dv = gather16(p.vals_rm + (int64_t)row * p.k_rm + c * 8);
           const uint4 qv = *(const uint4*)(p.q16 + (int64_t)q * p.k_rm + c * 8);
           uint32_t d[4] = {dv.x, dv.y, dv.z, dv.w};
@@ -1577,7 +1597,7 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
         }
       }
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      for (int o = L / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
       if (sl == 0 && live) {
         const float sc = valid ? (float)acc : -INFINITY;
         if (p.out_keys) p.out_keys[(int64_t)q * p.ld_keys + i] = valid ? make_key(sc, row) : 0ull;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DHR_VERSION 100 /* 0.1.0 */
+#define DHR_VERSION 101 /* 0.1.1: dhr_comm_create_callback, dhr_search_sharded_host; dhr_search_sample_rank = the shard's share (see DHR_PARAM_SAMPLE_SHARE) */
 
 typedef enum dhr_status {
   DHR_OK = 0,
