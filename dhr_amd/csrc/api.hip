@@ -183,6 +183,7 @@ static int g_opt_gated_i8 = -1;      // int8 image of the gated half: -1 by corp
 // refine / rescoring per query), ~5 M rows with a narrow ungated half (0.35 ps per pair); a SHARD of a sharded search collects only its share
 // of the candidates, so it breaks even 8x earlier -- hence 1 M / 4 M.
 constexpr int64_t GATED_I8_MIN_ROWS = 1000000, GATED_I8_MIN_ROWS_NARROW = 4000000;
+constexpr int64_t DENSE_ONLY_I8_MIN_ROWS = 1000000;      // dense-only indexes: the int8 image by default from this many rows (if its margin is small enough, dhr_index_create)
 extern "C" int dhr_set_option(int32_t option, int64_t value) {
   if (option == DHR_OPT_DENSE_I8) { g_opt_dense_i8 = value < 0 ? -1 : (value != 0); return DHR_OK; }
   if (option == DHR_OPT_GATED_I8) { g_opt_gated_i8 = value < 0 ? -1 : (value != 0); return DHR_OK; }
@@ -362,6 +363,7 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
   // dominates the spread of the scores and the int8 margin costs few extra candidates -- DESIGN.md section 6b)
   int want_i8 = g_opt_dense_i8;
   if (const char* e = getenv("DHR_DENSE_I8")) want_i8 = atoi(e);
+  bool dense_only_trial = false;
   if (sparse_ok && (d->idx_buckets == 0 || d->idx_buckets == 2)) {
     ix->n_buckets = 2;
     ix->ts = d->d_dlr / 32;
@@ -379,7 +381,10 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
     // (idx_buckets = 1 keeps the K-step tile layout and gemm_filter_v3_kernel)
     ix->n_buckets = 1;
     ix->ts = 0;
-    ix->dense_i8 = want_i8 > 0;
+    // int8 image for a dense-only index: explicitly (option = 1), or -- default, large shards -- on trial: the margin it needs is measured
+    // below (i8_row_err pass) and the fp16 image is kept where it would be too large a share of the spread of the scores
+    dense_only_trial = want_i8 < 0 && d->n_rows >= DENSE_ONLY_I8_MIN_ROWS && d->d_cls >= 128;
+    ix->dense_i8 = want_i8 > 0 || dense_only_trial;
     ix->td = ix->dense_i8 ? 2 * ((d->d_cls + 127) / 128) : (d->d_cls + 31) / 32;
     ix->kt = ix->td * 32;
   } else {
@@ -396,14 +401,10 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
   int rc = DHR_OK;
   auto fail = [&](int code) { hipFree(stage); hipFree(d_flags); hipFree(d_hist); dhr_index_destroy(ix); return code; };
 
-  const size_t tile_bytes = ix->ts + ix->td > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * (ix->gated_i8 ? S8_STAGE_A : SP_STAGE_A) + (size_t)ix->td * SP_DENSE)
-                                       : (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2;
-  if (hipMalloc((void**)&ix->tiles, tile_bytes) != hipSuccess)
-    return fail(set_error(DHR_ERR_HIP, "hipMalloc of " + std::to_string(tile_bytes) + " bytes for the corpus tiles failed"));
   const size_t rm_bytes = (size_t)ix->n_rows * ix->k_rm * 2;
   if (hipMalloc((void**)&ix->vals_rm, rm_bytes) != hipSuccess)
     return fail(set_error(DHR_ERR_HIP, "hipMalloc of " + std::to_string(rm_bytes) + " bytes for the row-major corpus copy failed"));
-  ix->index_bytes = (int64_t)(tile_bytes + rm_bytes);
+  ix->index_bytes = (int64_t)rm_bytes;
   if (hipMalloc((void**)&d_flags, 16) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMalloc failed"));
   if (hipMemsetAsync(d_flags, 0, 16, s) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMemsetAsync failed"));
   // the index array
@@ -475,7 +476,28 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
     memcpy(&e2, &flags[0], 4); memcpy(&n2, &flags[1], 4);
     ix->i8_ec = std::sqrt(e2) * 1.001f;
     ix->i8_nc = std::sqrt(n2) * 1.001f;
+    if (dense_only_trial) {
+      // The filter margin of the int8 image is ~ ||q|| ec (+ ~60 % for the query's own rounding) while the scores of a dense-only index
+      // spread by ~ ||q|| ||d|| / sqrt(d_cls): with sqrt(d_cls) ec / ||d|| = 0.36 (the benchmark's N(0, 0.1) columns: margin 0.6 sigma) the
+      // int8 search lets ~8x the rows through the filter and is still faster (config 2: 85.1 vs 89.1 ms per step: the int8 GEMM takes half
+      // the fp16 one's time and is not held by the package power cap, the extra rescoring of 1.5 KB rows costs less than that); the
+      // candidates grow exponentially with the ratio, so anything much coarser keeps the fp16 image.
+      const float ratio = std::sqrt((float)ix->d_cls) * ix->i8_ec / std::max(ix->i8_nc, 1e-30f);
+      if (!(ratio <= 0.45f)) {
+        ix->dense_i8 = false;
+        hipFree(ix->i8_col_scale); ix->i8_col_scale = nullptr;
+        ix->i8_scale = ix->i8_ec = ix->i8_nc = 0.f;
+        ix->td = (d->d_cls + 31) / 32;
+        ix->kt = ix->td * 32;
+        ix->ksteps = (ix->kt + TILE_K - 1) / TILE_K;
+      }
+    }
   }
+  const size_t tile_bytes = ix->ts + ix->td > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * (ix->gated_i8 ? S8_STAGE_A : SP_STAGE_A) + (size_t)ix->td * SP_DENSE)
+                                       : (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2;
+  if (hipMalloc((void**)&ix->tiles, tile_bytes) != hipSuccess)
+    return fail(set_error(DHR_ERR_HIP, "hipMalloc of " + std::to_string(tile_bytes) + " bytes for the corpus tiles failed"));
+  ix->index_bytes += (int64_t)tile_bytes;
   if (ix->gated_i8) {
     // steps of the gated columns: s_ref = (largest gated |value|) / 127, column j in s_ref * (its own largest / the largest)^(3/4)
     // (the exponent splits a small column's range between a finer corpus step and a smaller query weight, as for the ungated columns)

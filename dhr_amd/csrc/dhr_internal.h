@@ -132,6 +132,7 @@ struct GemmArgs {
                               // int8 stages of the ungated columns accumulate on top; i8_mul is the final unit (score = sum * i8_mul)
   const int32_t* g8_rsum;     // gated_i8: [n_tiles * 256] 128 x (sum of the row's gated int8 values): the accumulators START there, which pays for the
                               // query operand being stored as level - 128 (8 bits of query resolution instead of 7)
+  int partial_wn;             // gemm_g8.hip: > 0 = the batch's last query tile holds real queries in its first partial_wn (1 or 2) 64-query wave columns only (set by launch_gemm_g8)
   const float* i8_mul;        // [Q_pad] or null.  Non-null: the td dense stages hold int8 columns (64 per stage); the kernel runs them
                               // FIRST on v_mfma_i32_32x32x32_i8 and turns the integer sums into fp32 with this per-query factor
                               // (corpus scale x query scale) before the gated stages accumulate on top

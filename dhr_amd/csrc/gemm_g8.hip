@@ -196,20 +196,21 @@ __device__ __forceinline__ void g8_epilogue(const GemmArgs& p, floatx16 (&acc)[4
 // the pair barrier, 1 = the next pair's first block
 __host__ __device__ constexpr int g8_dma_piece(int ph, int g) { return (ph <= 1 && (g & 1)) ? ph * 4 + (g >> 1) : -1; }
 
-template <bool DUMP>
-__global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_filter_g8_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int64_t dt;
-  int qt;
-  if (!gemm_wg_tile(p, dt, qt)) return;
-
+// One 256 x 256 tile.  PARTIAL: the batch's LAST query tile when at most 128 of its 256 queries are real (6 980 queries = 27 tiles + 68: the
+// 28th tile used to cost a full tile for 1 % of the queries, 2.6 % of the launch).  The waves are then numbered so that the wave columns that
+// hold real queries (wn < partial_wn) sit on DIFFERENT SIMDs (a workgroup's waves go to the SIMDs in cyclic order: waves w and w + 4 share
+// one), the others neither read fragments nor issue matrix instructions -- they only stream their share of the LDS-DMA and keep the
+// barriers; each SIMD then runs ONE computing wave with the matrix pipe to itself and the tile takes about half the time.
+template <bool DUMP, bool PARTIAL>
+__device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int64_t dt, const int qt) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ts = p.ts, td = p.td;
   const int nsp = ts >> 1, npairs = (ts + td) >> 1;      // the launcher selects this kernel only when ts and td are even
   const char* a_src = (const char*)p.a_tiles + dt * ((int64_t)ts * S8_STAGE_A + (int64_t)td * SP_DENSE);
   const char* b_src = (const char*)p.b_tiles + (int64_t)qt * ((int64_t)ts * SP_STAGE_B + (int64_t)td * SP_DENSE);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = PARTIAL ? (wave & 1) : (wave >> 2), wn = PARTIAL ? (wave >> 1) : (wave & 3);
+  const bool active = !PARTIAL || wn < p.partial_wn;
 
   // ---- LDS-DMA, fixed roles: wave w streams half (w & 1) of image ((w >> 1) & 1 ? query : corpus) of stage 2g + (w >> 2)
   const bool dma_b = ((wave >> 1) & 1) != 0;
@@ -279,11 +280,13 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       const int ni = g >> 2, mi = g & 3;
-      if (do_load && G8_ABL != 8) {
-        read_s8(fn, sl, g);
-        if (g < 4) read_s8(fn, sl, 8 + g);
+      if (!PARTIAL || active) {
+        if (do_load && G8_ABL != 8) {
+          read_s8(fn, sl, g);
+          if (g < 4) read_s8(fn, sl, 8 + g);
+        }
+        g8_smfmac(acc[mi][ni], fc.a[mi], fc.b[ni].v, fc.pw[mi]);
       }
-      g8_smfmac(acc[mi][ni], fc.a[mi], fc.b[ni].v, fc.pw[mi]);
       if (g8_dma_piece(PH, g) >= 0) dma_piece(g8_dma_piece(PH, g));
     }
   };
@@ -294,8 +297,10 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       const int ni = g >> 2, mi = g & 3;
-      if (do_load && G8_ABL != 8) read_dn(fn, sl, cc, g);
-      g8_mfma(acc[mi][ni], fc.a[mi], fc.b[ni].h[0]);
+      if (!PARTIAL || active) {
+        if (do_load && G8_ABL != 8) read_dn(fn, sl, cc, g);
+        g8_mfma(acc[mi][ni], fc.a[mi], fc.b[ni].h[0]);
+      }
       if (g8_dma_piece(PH, g) >= 0) dma_piece(g8_dma_piece(PH, g));
     }
   };
@@ -424,7 +429,18 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
 #if G8_ABL == 32      // timing only: no filter epilogue at all
   if (p.n_queries >= 0) { if (__float_as_int(acc[0][0][0]) == 0x7fffffff) p.cnt[0] = 1; return; }
 #endif
+  if (PARTIAL && !active) { __syncthreads(); return; }      // (the barrier g8_epilogue opens with)
   g8_epilogue(p, acc, dt, qt, wm, wn, (int)threadIdx.x, lane, smem, thr_r, mul_r);
+}
+
+template <bool DUMP>
+__global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_filter_g8_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int64_t dt;
+  int qt;
+  if (!gemm_wg_tile(p, dt, qt)) return;
+  if (!DUMP && p.partial_wn > 0 && qt == p.n_qtiles - 1) g8_tile<false, true>(p, smem, dt, qt);
+  else g8_tile<DUMP, false>(p, smem, dt, qt);
 }
 
 hipError_t launch_gemm_g8(const GemmArgs& a, dim3 grid, hipStream_t s) {
@@ -443,8 +459,12 @@ hipError_t launch_gemm_g8(const GemmArgs& a, dim3 grid, hipStream_t s) {
       attr_set = true;
     }
   }
-  if (a.dump) hipLaunchKernelGGL(gemm_filter_g8_kernel<true>, grid, dim3(G8_NT), G8_RING_LDS, s, a);
-  else hipLaunchKernelGGL(gemm_filter_g8_kernel<false>, grid, dim3(G8_NT), G8_RING_LDS, s, a);
+  if (a.dump) { hipLaunchKernelGGL(gemm_filter_g8_kernel<true>, grid, dim3(G8_NT), G8_RING_LDS, s, a); return hipGetLastError(); }
+  GemmArgs b = a;
+  static const int partial_on = getenv("DHR_G8_PARTIAL") ? atoi(getenv("DHR_G8_PARTIAL")) : 1;
+  const int valid_last = a.n_queries - (a.n_qtiles - 1) * TILE_ROWS;          // real queries of the batch's last query tile
+  b.partial_wn = (partial_on && valid_last > 0 && valid_last <= 128) ? (valid_last + 63) / 64 : 0;
+  hipLaunchKernelGGL(gemm_filter_g8_kernel<false>, grid, dim3(G8_NT), G8_RING_LDS, s, b);
   return hipGetLastError();
 }
 

@@ -122,7 +122,9 @@ typedef enum dhr_param {
 typedef enum dhr_option {
   DHR_OPT_DENSE_I8 = 1, /* int8 image of the UNGATED columns in the bound GEMM (v_mfma_i32_32x32x32_i8, twice the fp16 instruction's
                            columns per issue; the quantisation error is paid by the filter margin, results stay exact):
-                           -1 (default) = gated indexes that also carry ungated columns, 0 = never, 1 = dense-only indexes too.
+                           -1 (default) = gated indexes that also carry ungated columns, and dense-only shards of at least 1 000 000 rows whose
+                           measured quantisation error is small against the spread of their scores (sqrt(d_cls) x max row error / max row norm
+                           <= 0.45); 0 = never, 1 = every dense-only index too.
                            The environment variable DHR_DENSE_I8 overrides it. */
   DHR_OPT_GATED_I8 = 2  /* int8 image of the GATED columns too (v_smfmac_i32_32x32x64_i8: the 2:4 instruction on int8 operands, 32 slices
                            per issue; values rounded UP per column step, so the bound stays a bound and results stay exact):
