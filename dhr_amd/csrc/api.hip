@@ -556,7 +556,7 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
   // pass 2: operand tiles
   if ((rc = build_tiles(ix, s)) != DHR_OK) return fail(rc);
   if (has_idx && d->d_dlr <= 4096) {
-    const size_t hb = (size_t)d->n_rows * HEAVY_KEY_STRIDE * 4;       // one 384-byte record per row: 64 keys, then 64 values
+    const size_t hb = (size_t)d->n_rows * HEAVY_KEY_STRIDE * 4;       // one 6 x HEAVY-byte record per row: the keys, then the values
     if (hipMalloc((void**)&ix->heavy_key, hb) != hipSuccess)
       return fail(set_error(DHR_ERR_HIP, "hipMalloc of the refine lists failed"));
     ix->heavy_val = (__half*)((char*)ix->heavy_key + HEAVY * 4);

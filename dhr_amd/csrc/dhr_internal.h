@@ -41,11 +41,14 @@ constexpr int SP_SLOT = SP_STAGE_A + SP_STAGE_B;   // LDS ring slot (34 KiB): co
 //   query : [256 queries][64 bytes = 32 slices x (bucket-0 column, bucket-1 column)], 16-byte chunks swizzled like every other image.
 constexpr int S8_A_BYTES = 8192;
 constexpr int S8_STAGE_A = S8_A_BYTES + 2048;
-constexpr int HEAVY = 64;               // per-row list of the largest gated values used by the refine step
-// ... stored as ONE 384-byte record per row: 64 u32 keys, then 64 fp16 values (a candidate's refine read is one contiguous segment
-// instead of a 256-byte and a 128-byte one in two arrays): heavy_key = record base, heavy_val = base + 256 bytes
-constexpr int HEAVY_KEY_STRIDE = 96;    // u32 per record
-constexpr int HEAVY_VAL_STRIDE = 192;   // fp16 per record
+#ifndef DHR_HEAVY
+#define DHR_HEAVY 64
+#endif
+constexpr int HEAVY = DHR_HEAVY;        // per-row list of the largest gated values used by the refine step (64, or 32 in A/B builds: 8 lanes x HEAVY / 8 entries)
+// ... stored as ONE 6 x HEAVY-byte record per row (384 B): HEAVY u32 keys, then HEAVY fp16 values (a candidate's refine read is one contiguous
+// segment instead of a 256-byte and a 128-byte one in two arrays): heavy_key = record base, heavy_val = base + 4 x HEAVY bytes
+constexpr int HEAVY_KEY_STRIDE = HEAVY * 6 / 4;    // u32 per record
+constexpr int HEAVY_VAL_STRIDE = HEAVY * 6 / 2;    // fp16 per record
 constexpr int DOC_GROUP = 4;                               // doc tiles that share one XCD sweep
 
 __host__ __device__ inline int64_t tiled_chunk_offset(int64_t row, int chunk, int ksteps) {

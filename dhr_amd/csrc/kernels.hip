@@ -1384,14 +1384,23 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
     uint2 c = make_uint2(0u, 0u);
     if (i < count) {
       c = p.cand[(int64_t)q * p.cap + i];
-      const uint32_t* hk = p.heavy_key + (int64_t)c.x * HEAVY_KEY_STRIDE + sub * 8;
-      const uint4 k0 = gather16(hk), k1 = gather16(hk + 4);
+      constexpr int EPL = HEAVY / 8;              // entries per lane: 8 (two 16-byte key loads + one 16-byte value load) or 4 (one + an 8-byte one)
+      static_assert(EPL == 8 || EPL == 4, "8 lanes per candidate read 8 or 4 entries each");
+      const uint32_t* hk = p.heavy_key + (int64_t)c.x * HEAVY_KEY_STRIDE + sub * EPL;
+      const uint4 k0 = gather16(hk);
+      uint4 k1 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
       union { uint4 u; half8 h; } hvu;
-      hvu.u = gather16(p.heavy_val + (int64_t)c.x * HEAVY_VAL_STRIDE + sub * 8);
+      if constexpr (EPL == 8) {
+        k1 = gather16(hk + 4);
+        hvu.u = gather16(p.heavy_val + (int64_t)c.x * HEAVY_VAL_STRIDE + sub * 8);
+      } else {
+        const uint2 v2 = gather8(p.heavy_val + (int64_t)c.x * HEAVY_VAL_STRIDE + sub * 4);
+        hvu.u = make_uint4(v2.x, v2.y, 0u, 0u);
+      }
       const half8 hv = hvu.h;
       const uint32_t keys[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < EPL; ++e) {
         const uint32_t key = keys[e];
         if (key != 0xFFFFFFFFu) {
           const uint32_t j = key >> 20;
