@@ -21,6 +21,9 @@
 #include <type_traits>
 #include <climits>
 
+#ifndef G8_TRACE
+#define G8_TRACE 0    // 1: thread 0 of every workgroup records clock values at the tile's phase boundaries (tools/g8_trace.py; timing only)
+#endif
 #ifndef G8_ABL
 #define G8_ABL 0      // timing ablations (wrong results): 4 = no DMA pieces in the loop, 8 = 4 + no fragment reads in the loop, 16 = no list flush, 32 = no epilogue
 #endif
@@ -34,6 +37,15 @@ constexpr int G8_SLOT = 32768;
 constexpr int G8_META = 4 * G8_SLOT;           // behind the ring: 4 x 1 KiB = the tile's 256 row sums, and unit / threshold / shift of its 256 queries
 constexpr int G8_RING_LDS = 4 * G8_SLOT + 4096 + 64;
 constexpr int G8_NT = 512;
+
+#if G8_TRACE
+constexpr int G8_TRACE_SLOTS = 1 << 18;
+__device__ unsigned long long g8_trace_buf[G8_TRACE_SLOTS * 8];
+__device__ unsigned int g8_trace_n;
+#define G8_T(i) do { if (threadIdx.x == 0 && tslot < G8_TRACE_SLOTS) g8_trace_buf[(size_t)tslot * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define G8_T(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ void g8_smfmac(floatx16& c, const intx4& a, const intx8& b, uint32_t idx) {
   asm("v_smfmac_i32_32x32x64_i8 %0, %1, %2, %3" : "+v"(c) : "v"(a), "v"(b), "v"(idx));
@@ -202,7 +214,7 @@ __host__ __device__ constexpr int g8_dma_piece(int ph, int g) { return (ph <= 1 
 // one), the others neither read fragments nor issue matrix instructions -- they only stream their share of the LDS-DMA and keep the
 // barriers; each SIMD then runs ONE computing wave with the matrix pipe to itself and the tile takes about half the time.
 template <bool DUMP, bool PARTIAL>
-__device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int64_t dt, const int qt) {
+__device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int64_t dt, const int qt, const unsigned tslot = 0) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ts = p.ts, td = p.td;
@@ -322,6 +334,7 @@ __device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int
     if (dma_n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  G8_T(2);
   // The query's gated operand has 8 bits: level L in [0, 255] is stored as L - 128 (a column that carries nothing as -128), so
   //   sum_cols (stored + 128) * d8 = sum_cols stored * d8 + 128 * (sum of the row's gated int8 values),
   // and the second term is a constant of the ROW: the accumulators start there (g8_rsum, built with the index).
@@ -374,6 +387,7 @@ __device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int
     dma_commit();
     blk_s8(f1, f0, 2 * g + 2, false, PH0);
   }
+  G8_T(3);
   if (td > 0) {
     // gated sums -> ungated units: every accumulator shifted left by its query's shift, then the first ungated fragments
     __builtin_amdgcn_sched_barrier(0);
@@ -418,7 +432,9 @@ __device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int
       blk_dn(f1, f0, t0 + 4, false, PH0);
     }
   }
+  G8_T(4);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // the last matrix results are in the accumulators
+  G8_T(5);
   if (DUMP) { g8_dump_tile(p, acc, dt, qt, wm, wn, lane, mul_r); return; }
   int thr_r[2];                // thresholds in accumulator units: a division per query, off the start-up path
 #pragma unroll
@@ -439,9 +455,42 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
   int64_t dt;
   int qt;
   if (!gemm_wg_tile(p, dt, qt)) return;
+#if G8_TRACE
+  unsigned tslot = 0;
+  if (threadIdx.x == 0) tslot = atomicAdd(&g8_trace_n, 1u);
+  tslot = __builtin_amdgcn_readfirstlane(tslot);
+  if (threadIdx.x == 0 && tslot < G8_TRACE_SLOTS) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g8_trace_buf[(size_t)tslot * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+    g8_trace_buf[(size_t)tslot * 8 + 7] = (unsigned long long)hw | ((unsigned long long)(xcc & 0xf) << 32) | ((unsigned long long)qt << 40) | ((unsigned long long)(dt & 0xffff) << 48);
+  }
+  G8_T(1);
+  if (!DUMP && p.partial_wn > 0 && qt == p.n_qtiles - 1) g8_tile<false, true>(p, smem, dt, qt, tslot);
+  else g8_tile<DUMP, false>(p, smem, dt, qt, tslot);
+  G8_T(6);
+#else
   if (!DUMP && p.partial_wn > 0 && qt == p.n_qtiles - 1) g8_tile<false, true>(p, smem, dt, qt);
   else g8_tile<DUMP, false>(p, smem, dt, qt);
+#endif
 }
+#if G8_TRACE
+}  // namespace dhr
+// tuning hook of the trace build: copies the first `max_slots` trace records (8 x u64 each) to the host and resets the record counter
+extern "C" int dhr_debug_g8_trace(unsigned long long* out, int max_slots, unsigned* n_out) {
+  unsigned n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(dhr::g8_trace_n), 4) != hipSuccess) return -1;
+  if (n_out) *n_out = n;
+  const unsigned m = n < (unsigned)max_slots ? n : (unsigned)max_slots;
+  const unsigned mm = m < (unsigned)dhr::G8_TRACE_SLOTS ? m : (unsigned)dhr::G8_TRACE_SLOTS;
+  if (out && mm && hipMemcpyFromSymbol(out, HIP_SYMBOL(dhr::g8_trace_buf), (size_t)mm * 64) != hipSuccess) return -1;
+  const unsigned zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(dhr::g8_trace_n), &zero, 4) != hipSuccess) return -1;
+  return 0;
+}
+namespace dhr {
+#endif
 
 hipError_t launch_gemm_g8(const GemmArgs& a, dim3 grid, hipStream_t s) {
   static std::mutex attr_mu;                       // per-device, under a lock (handles on different devices / host threads)
