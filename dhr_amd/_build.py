@@ -14,8 +14,8 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdhr_hip.so")
 OBJDIR = os.path.join(CSRC, "build")
-SOURCES = ["kernels.hip", "gemm_w4.hip", "gemm_g8.hip", "api.hip", "sharded.hip", "pq_adc.hip", "select_global.hip", "host_io.hip"]
-HEADERS = ["dhr_internal.h", "gemm_common.h", os.path.join("..", "..", "include", "dhr_hip.h")]
+SOURCES = ["kernels.hip", "gemm_w4.hip", "gemm_g8.hip", "gemm_g8p.hip", "api.hip", "sharded.hip", "pq_adc.hip", "select_global.hip", "host_io.hip"]
+HEADERS = ["dhr_internal.h", "gemm_common.h", "gemm_g8.h", os.path.join("..", "..", "include", "dhr_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 

@@ -36,8 +36,8 @@ constexpr int SP_STAGE_B = 16384;      // query bytes per sparse stage: 256 rows
 constexpr int SP_DENSE = 16384;        // 2:4 layout, ungated columns: 32-column stages, 256 rows x 64 bytes, for corpus and queries
 constexpr int SP_SLOT = SP_STAGE_A + SP_STAGE_B;   // LDS ring slot (34 KiB): corpus part at +0, query part at +SP_STAGE_A
 // gated_i8 indexes (gemm_g8.hip): the gated half as int8 on v_smfmac_i32_32x32x64_i8.  A stage is still 32 slices:
-//   corpus: [8 blocks of 32 rows][lane half h][32 rows][16 stored bytes = slices 16h .. 16h+15] + [8 blocks][h][32 rows] u32 position
-//           words (2 bits per stored value: 2 * (slice & 1) + bucket) = 8 + 2 KiB;
+//   corpus: [8 blocks of 32 rows][lane half h][32 rows][16 stored bytes = slices 16h .. 16h+15] + [2 groups of 128 rows][h][32 rows][4 blocks]
+//           u32 position words (2 bits per stored value: 2 * (slice & 1) + bucket) = 8 + 2 KiB;
 //   query : [256 queries][64 bytes = 32 slices x (bucket-0 column, bucket-1 column)], 16-byte chunks swizzled like every other image.
 constexpr int S8_A_BYTES = 8192;
 constexpr int S8_STAGE_A = S8_A_BYTES + 2048;
@@ -136,6 +136,8 @@ struct GemmArgs {
   const int32_t* g8_rsum;     // gated_i8: [n_tiles * 256] 128 x (sum of the row's gated int8 values): the accumulators START there, which pays for the
                               // query operand being stored as level - 128 (8 bits of query resolution instead of 7)
   int partial_wn;             // gemm_g8.hip: > 0 = the batch's last query tile holds real queries in its first partial_wn (1 or 2) 64-query wave columns only (set by launch_gemm_g8)
+  uint32_t* p_ctr;            // gemm_g8p.hip (persistent workgroups): this launch's 8 per-XCD tile counters, zeroed on the stream before the launch (set by launch_gemm_g8p)
+  int64_t p_groups;           //   corpus tile groups of the launch, ceil((seq_hi - seq_lo) / DOC_GROUP)
   const float* i8_mul;        // [Q_pad] or null.  Non-null: the td dense stages hold int8 columns (64 per stage); the kernel runs them
                               // FIRST on v_mfma_i32_32x32x32_i8 and turns the integer sums into fp32 with this per-query factor
                               // (corpus scale x query scale) before the gated stages accumulate on top

@@ -16,10 +16,9 @@
 // the query's 64-byte stage row in natural order -- no register expansion at all.
 // Structure: the 8-wave form of gemm_w4.hip (every wave computes and issues its share of the LDS-DMA, stages handed over in
 // pairs, one workgroup barrier per pair); a gated stage is ONE block of 8 matrix instructions per wave (K = 64 logical columns).
-#include "gemm_common.h"
+#include "gemm_g8.h"
 #include <mutex>
 #include <type_traits>
-#include <climits>
 
 #ifndef G8_TRACE
 #define G8_TRACE 0    // 1: thread 0 of every workgroup records clock values at the tile's phase boundaries (tools/g8_trace.py; timing only)
@@ -29,15 +28,6 @@
 #endif
 namespace dhr {
 
-typedef int intx4 __attribute__((ext_vector_type(4)));
-typedef int intx8 __attribute__((ext_vector_type(8)));
-
-constexpr int G8_QOFF = 16384;                 // query part of a ring slot (the corpus part is 10 KiB gated / 16 KiB ungated)
-constexpr int G8_SLOT = 32768;
-constexpr int G8_META = 4 * G8_SLOT;           // behind the ring: 4 x 1 KiB = the tile's 256 row sums, and unit / threshold / shift of its 256 queries
-constexpr int G8_RING_LDS = 4 * G8_SLOT + 4096 + 64;
-constexpr int G8_NT = 512;
-
 #if G8_TRACE
 constexpr int G8_TRACE_SLOTS = 1 << 18;
 __device__ unsigned long long g8_trace_buf[G8_TRACE_SLOTS * 8];
@@ -46,32 +36,6 @@ __device__ unsigned int g8_trace_n;
 #else
 #define G8_T(i) do { } while (0)
 #endif
-
-__device__ __forceinline__ void g8_smfmac(floatx16& c, const intx4& a, const intx8& b, uint32_t idx) {
-  asm("v_smfmac_i32_32x32x64_i8 %0, %1, %2, %3" : "+v"(c) : "v"(a), "v"(b), "v"(idx));
-}
-__device__ __forceinline__ void g8_mfma(floatx16& c, const intx4& a, const intx4& b) {
-  asm("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
-
-struct G8Frag {
-  intx4 a[4];                       // corpus fragments of the block's four 32-row blocks
-  uint32_t pw[4];                   // gated blocks: their position words
-  union { intx8 v; intx4 h[2]; } b[2];   // query fragments (ungated blocks use h[0])
-};
-
-// filter threshold of a query in accumulator units, rounded DOWN (a row is kept when sum >= thr)
-__device__ __forceinline__ int g8_thr_units(float thr, float mul) {
-  const float x = thr / mul;
-  if (!(x < 2.1e9f)) return INT_MAX;          // +inf (padded query), NaN, mul == 0
-  if (x < -2.1e9f) return INT_MIN;
-  return (int)floorf(x - fabsf(x) * 1e-6f) - 1;
-}
-__device__ __forceinline__ float g8_score(int sum, float mul) {      // accumulator units -> score units, rounded up
-  const float x = (float)sum * mul;
-  return x + fabsf(x) * 2.4e-7f;
-}
-
 __device__ __forceinline__ void g8_dump_tile(const GemmArgs& p, floatx16 (&acc)[4][2], int64_t dt, int qt, int wm, int wn, int lane,
                                              const float (&mul_r)[2]) {
   const int fhalf = lane >> 5;
@@ -206,7 +170,16 @@ __device__ __forceinline__ void g8_epilogue(const GemmArgs& p, floatx16 (&acc)[4
 
 // DMA piece (of this wave's <= 8 per stage pair) issued behind matrix instruction g of the block in phase ph: 0 = the block behind
 // the pair barrier, 1 = the next pair's first block
+#ifndef G8_DMA_SCHED
+#define G8_DMA_SCHED 1    // 0 = the schedule of rounds 3-4a (four pieces behind the barrier, four in the next block)
+#endif
+#if G8_DMA_SCHED == 1      // every piece of the next pair right behind the pair barrier (one per matrix instruction of that block)
+__host__ __device__ constexpr int g8_dma_piece(int ph, int g) { return ph == 0 ? g : -1; }
+#elif G8_DMA_SCHED == 2    // pieces 0-5 behind the barrier, 6-7 in the following block
+__host__ __device__ constexpr int g8_dma_piece(int ph, int g) { return ph == 0 ? (g >= 2 ? g - 2 : -1) : (ph == 1 && g < 2) ? 6 + g : -1; }
+#else
 __host__ __device__ constexpr int g8_dma_piece(int ph, int g) { return (ph <= 1 && (g & 1)) ? ph * 4 + (g >> 1) : -1; }
+#endif
 
 // One 256 x 256 tile.  PARTIAL: the batch's LAST query tile when at most 128 of its 256 queries are real (6 980 queries = 27 tiles + 68: the
 // 28th tile used to cost a full tile for 1 % of the queries, 2.6 % of the launch).  The waves are then numbered so that the wave columns that
@@ -270,15 +243,15 @@ __device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int
   const int swz4 = (frow >> 2) & 3;
   const int c0 = (fhalf ^ swz4) << 4, c1 = ((2 + fhalf) ^ swz4) << 4;
   const int a8_off = ((wm * 8 + fhalf) * 32 + frow) * 16;                     // gated corpus values, + mi * 1024
-  const int p8_off = S8_A_BYTES + ((wm * 8 + fhalf) * 32 + frow) * 4;         // position words, + mi * 256
+  const int p8_off = S8_A_BYTES + ((wm * 2 + fhalf) * 32 + frow) * 16;        // the lane's four position words
   const int ad_row = (wm * 128 + frow) * 64;                                  // ungated corpus rows, + mi * 2048
   const int q_row = G8_QOFF + (wn * 64 + frow) * 64;                          // query rows (both kinds), + ni * 2048
 
-  // fragment read number g (0..11) of the gated stage in ring slot sl: 4 corpus value reads, 4 position words, 2 x 2 query chunks
+  // fragment read number g (0..8) of the gated stage in ring slot sl: 2 x 2 query chunks, 4 corpus value reads, the 4 position words
   auto read_s8 = [&](G8Frag& f, const char* sl, int g) __attribute__((always_inline)) {
     if (g < 4) f.b[g >> 1].h[g & 1] = *(const intx4*)(sl + q_row + (g >> 1) * 2048 + ((g & 1) ? c1 : c0));
     else if (g < 8) f.a[g - 4] = *(const intx4*)(sl + a8_off + (g - 4) * 1024);
-    else if (g < 12) f.pw[g - 8] = *(const uint32_t*)(sl + p8_off + (g - 8) * 256);
+    else if (g == 8) f.pw = *(const intx4*)(sl + p8_off);
   };
   // fragment read number g (0..5) of ungated block t (stage t >> 1 of the ungated part, 32-column half t & 1)
   auto read_dn = [&](G8Frag& f, const char* sl, int cc, int g) __attribute__((always_inline)) {
@@ -295,11 +268,12 @@ __device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int
       if (!PARTIAL || active) {
         if (do_load && G8_ABL != 8) {
           read_s8(fn, sl, g);
-          if (g < 4) read_s8(fn, sl, 8 + g);
+          if (g == 0) read_s8(fn, sl, 8);
         }
-        g8_smfmac(acc[mi][ni], fc.a[mi], fc.b[ni].v, fc.pw[mi]);
+        g8_smfmac(acc[mi][ni], fc.a[mi], fc.b[ni].v, (uint32_t)fc.pw[mi]);
       }
       if (g8_dma_piece(PH, g) >= 0) dma_piece(g8_dma_piece(PH, g));
+      __builtin_amdgcn_sched_barrier(0);       // keep the reads between the matrix instructions (blocks without DMA pieces were clustered: 9 reads, one wait, 8 instructions)
     }
   };
   auto blk_dn = [&](const G8Frag& fc, G8Frag& fn, int tn, bool do_load, auto ph_c) __attribute__((always_inline)) {
@@ -314,6 +288,7 @@ __device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int
         g8_mfma(acc[mi][ni], fc.a[mi], fc.b[ni].h[0]);
       }
       if (g8_dma_piece(PH, g) >= 0) dma_piece(g8_dma_piece(PH, g));
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -361,7 +336,7 @@ __device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int
   }
   G8Frag f0, f1;
 #pragma unroll
-  for (int g = 0; g < 12; ++g) read_s8(f0, smem, g);
+  for (int g = 0; g < 9; ++g) read_s8(f0, smem, g);
   if (G8_ABL == 8) f1 = f0;
   constexpr std::integral_constant<int, 0> PH0{};
   constexpr std::integral_constant<int, 1> PH1{};

@@ -293,7 +293,8 @@ __global__ void __launch_bounds__(256) tile_rows_sparse_kernel(const __half* __r
       char* stg = tile + (int64_t)st * S8_STAGE_A;
       const int slot = ((r >> 5) * 2 + h) * 32 + (r & 31);
       *(half8*)(stg + slot * 16) = o.h8;
-      *(uint32_t*)(stg + S8_A_BYTES + slot * 4) = bits;
+      // position words: the four 32-row blocks of a 128-row wave tile side by side, so that a lane reads its four words with ONE ds_read_b128
+      *(uint32_t*)(stg + S8_A_BYTES + ((((r >> 7) * 2 + h) * 32 + (r & 31)) * 4 + ((r >> 5) & 3)) * 4) = bits;
     } else if (c < sp_chunks) {
       const int st = c >> 2, cc = c & 3, j0 = c * 8;
       uint32_t bits = 0;
@@ -1175,6 +1176,9 @@ hipError_t launch_gemm_filter(const GemmArgs& a_in, hipStream_t s) {
   // proper message, the others cannot be reached through the C ABI (n_rows < 2^32, sample period <= 256)
   if ((int64_t)DOC_GROUP * a_in.n_qtiles > 65535 || a_in.perm_n >= (1 << 24) || a_in.period > (1 << 20)) return hipErrorInvalidValue;
   if (a_in.map_mode >= 2 && a_in.period < 2) return hipErrorInvalidValue;      // "everything but the sample" needs a sample: divmod24 by period - 1
+  // gated_i8 indexes: persistent workgroups over the whole launch (gemm_g8p.hip) with DHR_G8_PERSIST=1; experimental, see docs/experiments.md
+  static const int g8_persist = getenv("DHR_G8_PERSIST") ? atoi(getenv("DHR_G8_PERSIST")) : 0;
+  if (a_in.g8_shift && g8_persist && gemm_g8p_ok(a_in)) return launch_gemm_g8p(a_in, s);
   GemmArgs a = a_in;
   a.inv_perm_n = 1.0 / (double)(a.perm_n > 0 ? a.perm_n : 1);
   a.inv_pm1 = 1.0 / (double)(a.period > 1 ? a.period - 1 : 1);

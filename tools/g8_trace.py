@@ -35,20 +35,37 @@ def main():
     del cv
     lib = ix._lib
     tr = getattr(lib, "dhr_debug_g8_trace", None)
-    if tr is None:
+    trp = getattr(lib, "dhr_debug_g8p_trace", None)
+    if tr is None or trp is None:
         raise SystemExit("this library was not built with -DG8_TRACE=1")
     tr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint)]
+    trp.argtypes = [C.c_void_p, C.c_int]
     qb, keep = _lib.make_query_batch(qv, qi)
     ms, fl = C.c_double(), C.c_double()
     n = C.c_uint()
-    _lib.check(lib.dhr_debug_gemm_time(ix._h, C.byref(qb), 1, C.byref(ms), C.byref(fl), None), "gemm_time")
     torch.cuda.synchronize()
     cap = 1 << 18
-    buf = np.zeros((cap, 8), dtype=np.uint64)
-    assert tr(buf.ctypes.data, cap, C.byref(n)) == 0
-    m = min(n.value, cap)
-    print("launch %.3f ms, %d records (2 launches: warm-up + timed)" % (ms.value, n.value))
-    r = buf[:m].astype(np.int64)
+    persistent = os.environ.get("DHR_G8_PERSIST", "1") != "0"
+    if persistent:
+        # persistent workgroups (gemm_g8p.hip): one record per tile at slot xcc * 32768 + the tile's index on its XCD; the warm-up launch
+        # of dhr_debug_gemm_time writes the same slots first, the timed launch overwrites them
+        assert trp(None, 0) == 0
+        _lib.check(lib.dhr_debug_gemm_time(ix._h, C.byref(qb), 1, C.byref(ms), C.byref(fl), None), "gemm_time")
+        torch.cuda.synchronize()
+        buf = np.zeros((cap, 8), dtype=np.uint64)
+        assert trp(buf.ctypes.data, cap) == 0
+        r = buf[buf[:, 1] != 0].astype(np.int64)
+        print("launch %.3f ms, %d tile records of the timed launch (persistent workgroups)" % (ms.value, len(r)))
+    else:
+        assert tr(None, 0, C.byref(n)) == 0              # drop the records of the search above
+        _lib.check(lib.dhr_debug_gemm_time(ix._h, C.byref(qb), 1, C.byref(ms), C.byref(fl), None), "gemm_time")
+        torch.cuda.synchronize()
+        buf = np.zeros((cap, 8), dtype=np.uint64)
+        assert tr(buf.ctypes.data, cap, C.byref(n)) == 0
+        m = min(n.value, cap)
+        print("launch %.3f ms, %d records (2 launches: warm-up + timed)" % (ms.value, n.value))
+        r = buf[:m].astype(np.int64)
+        r = r[np.argsort(r[:, 0])][-(len(r) // 2):]          # the timed launch
     if a.save:
         np.save(a.save, r)
     analyse(r)
@@ -56,42 +73,37 @@ def main():
 
 
 def analyse(r):
-    half = len(r) // 2
-    r = r[half:]                                   # the timed launch
+    """r: [records][8] = s_memrealtime at entry (100 MHz), s_memtime at entry / first pair landed / end of the gated stages / end of the
+    ungated stages / accumulators final / exit, HW_ID | XCC_ID << 32 | qt << 40 | dt << 48.  s_memtime counts shader clocks with a
+    base of its own on every XCD: only differences inside a workgroup or a CU mean anything."""
+    r = r[np.argsort(r[:, 0])]
     rt0, t1, t2, t3, t4, t5, t6, meta = [r[:, i] for i in range(8)]
-    # s_memtime ticks per microsecond (s_memrealtime counts 100 MHz)
-    o = np.argsort(t1)
-    tick_us = (t1[o[-1]] - t1[o[0]]) / max(1, (rt0[o[-1]] - rt0[o[0]])) * 100.0
-    print("s_memtime ticks per us: %.2f; launch spans %.3f ms" % (tick_us, (t6.max() - t1.min()) / tick_us / 1e3))
-    ok = (t2 > 0) & (t6 > 0)
-    def us(x):
-        return x / tick_us
-    names = ["prologue (entry -> first pair landed)", "gated stages", "ungated stages", "last wait", "epilogue", "whole tile"]
-    segs = [t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t6 - t1]
-    for nm, s in zip(names, segs):
-        s = us(s[ok])
-        print("  %-40s mean %7.3f us  median %7.3f  p10 %7.3f  p90 %7.3f" % (nm, s.mean(), np.median(s), np.percentile(s, 10), np.percentile(s, 90)))
-    cu = (meta & 0xffffffffff) >> 8                # cu / sh / se bits of HW_ID + the XCC id
     cu = ((meta >> 32) & 0xf) * 4096 + ((meta >> 8) & 0xff)
-    gaps = []
-    busy = []
+    rates, gaps, spans = [], [], []
     for c in np.unique(cu):
         i = np.where(cu == c)[0]
         i = i[np.argsort(t1[i])]
-        g = t1[i][1:] - t6[i][:-1]
-        gaps.append(g)
-        busy.append(((t6[i] - t1[i]).sum(), t6[i].max() - t1[i].min(), len(i)))
-    g = us(np.concatenate(gaps))
-    print("  CUs seen %d; workgroups per CU %.1f" % (len(busy), np.mean([b[2] for b in busy])))
-    print("  gap between two workgroups on a CU: mean %.3f us  median %.3f  p10 %.3f  p90 %.3f  (negative = two workgroups overlapped)" % (g.mean(), np.median(g), np.percentile(g, 10), np.percentile(g, 90)))
-    b = np.array([(x[0] / x[1]) for x in busy])
+        if len(i) < 3:
+            continue
+        rates.append((t1[i][-1] - t1[i][0]) / ((rt0[i][-1] - rt0[i][0]) / 100.0))
+        gaps.append(t1[i][1:] - t6[i][:-1])
+        spans.append(((t6[i] - t1[i]).sum(), t6[i][-1] - t1[i][0], len(i)))
+    mhz = float(np.median(rates))
+    print("shader clock %.0f MHz; launch spans %.3f ms; %d CUs, %.1f workgroups per CU" % (mhz, (rt0.max() - rt0.min()) / 1e5, len(spans), np.mean([x[2] for x in spans])))
+    names = ["prologue (entry -> first pair landed)", "gated stages", "ungated stages", "last wait", "epilogue", "whole tile"]
+    segs = [t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t6 - t1]
+    g = np.concatenate(gaps)
+    names.append("gap to the CU's next workgroup")
+    segs.append(g)
+    for nm, s in zip(names, segs):
+        print("  %-40s mean %7.0f cycles = %6.3f us   median %7.0f  p10 %7.0f  p90 %7.0f" % (nm, s.mean(), s.mean() / mhz, np.median(s), np.percentile(s, 10), np.percentile(s, 90)))
+    b = np.array([x[0] / x[1] for x in spans])
     print("  fraction of a CU's span inside some tile: mean %.3f min %.3f" % (b.mean(), b.min()))
-    sp = us(np.array([x[1] for x in busy]))
-    print("  CU span: mean %.1f us min %.1f max %.1f" % (sp.mean(), sp.min(), sp.max()))
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--load":
-        analyse(np.load(sys.argv[2]))
+        r_ = np.load(sys.argv[2])
+        analyse(r_ if len(sys.argv) > 3 else r_[np.argsort(r_[:, 0])][-(len(r_) // 2):])
     else:
         main()
