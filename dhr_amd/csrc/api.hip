@@ -231,7 +231,7 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
     case DHR_PARAM_GEMM_EXCLUSIVE: ix->gemm_exclusive = value != 0; return DHR_OK;
     case DHR_PARAM_OVERLAP_AUX: ix->overlap_aux = value < 0 ? -1 : value != 0; return DHR_OK;
     case DHR_PARAM_GEMM_VARIANT:
-      if (value < 3 || value > 5) return set_error(DHR_ERR_INVALID, "gemm_variant: 3 (12-wave producer / consumer kernel), 4 (4 waves, 128 x 128 wave tiles) or 5 (8 waves, 128 x 64 wave tiles)");
+      if (value < 3 || value > 6) return set_error(DHR_ERR_INVALID, "gemm_variant: 3 (12-wave producer / consumer kernel), 4 (4 waves, 128 x 128 wave tiles), 5 (8 waves, 128 x 64 wave tiles) or 6 (5 with persistent workgroups on gated_i8 indexes)");
       ix->gemm_variant = (int)value; return DHR_OK;
     case DHR_PARAM_MAX_GROWTH:
       if (value < 1 || value > 1024) return set_error(DHR_ERR_INVALID, "max_growth must be in [1,1024] sixteenths");

@@ -29,9 +29,10 @@
 #endif
 namespace dhr {
 
-constexpr int G8P_DEPTH = 5;                              // private hit-stack slots per thread (+ one slot that takes the pushes of a full stack)
-constexpr int G8P_QUEUE = G8_META + 4096;                 // the stacks: slot j of thread t at G8P_QUEUE + (j * 512 + t) * 8, behind the ring
-constexpr int G8P_MAIL = G8P_QUEUE + (G8P_DEPTH + 1) * G8_NT * 8;    // one word: the tile index published for the tile after next
+constexpr int G8P_DEPTH = 12;                             // private hit-stack slots per thread (+ one slot that takes the pushes of a full stack); over a
+                                                          // search of 2 M rows 3 % of the (wave, tile) scans hold a lane with more hits (33 % with 5)
+constexpr int G8P_QUEUE = G8_META + 4096;                 // the stacks: slot j of thread t = the dword at G8P_QUEUE + (j * 512 + t) * 4, behind the ring
+constexpr int G8P_MAIL = G8P_QUEUE + (G8P_DEPTH + 1) * G8_NT * 4;    // one word: the tile index published for the tile after next
 constexpr int G8P_LDS = G8P_MAIL + 64;
 static_assert(G8P_LDS <= 163840, "LDS of a CU");
 constexpr int G8P_CTR_SLOTS = 4096;                       // launches in flight share nothing: each takes the next slot of 8 counters
@@ -60,10 +61,12 @@ __device__ __forceinline__ KArgs g8p_kargs() {
 // One query column (NI_) of the lane's accumulators against its threshold (two levels: the maximum of a group of four, then the four
 // elements -- gemm_g8.hip).  A hit pushes (local row, integer sum) onto the thread's private stack; a full stack (G8P_DEPTH hits of one
 // thread in one tile: hot queries only) just counts on, and its surplus goes straight to the query's list in a second, cold scan that only
-// waves with such a lane run (SURPLUS).
+// waves with such a lane run (SURPLUS).  A stack entry is ONE dword: the local row in the low byte, the sum rounded UP to a multiple of 256
+// above it (the list carries an upper bound of the bound: 256 units are ~1e-5 of a candidate's sum) -- twice the depth in the same LDS.
+__device__ __forceinline__ uint32_t g8p_entry(int v, int rl) { return ((uint32_t)(v + 255) & 0xffffff00u) | (uint32_t)rl; }
 template <bool SURPLUS, int NI_, bool CHECK_ROWS>
 __device__ __forceinline__ void g8p_scan_half(KArgs kp, floatx16 (&acc)[4][2], const int rbase, const int rows_valid, const uint32_t row0, const int q,
-                                              uint2* stack, const int t, const float mul, uint32_t& j) {
+                                              uint32_t* stack, const int t, const float mul, uint32_t& j) {
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     const floatx16& a = acc[mi][NI_];
@@ -80,7 +83,7 @@ __device__ __forceinline__ void g8p_scan_half(KArgs kp, floatx16 (&acc)[4][2], c
             const int v = __float_as_int(a[e]);
             const int rl = rbase + mi * 32 + (e & 3) + 8 * (e >> 2);
             const uint32_t slot = j < (uint32_t)G8P_DEPTH ? j : (uint32_t)G8P_DEPTH;
-            stack[slot * G8_NT] = make_uint2((uint32_t)rl, (uint32_t)v);
+            stack[slot * G8_NT] = g8p_entry(v, rl);
             j += v >= t ? 1u : 0u;
           }
         } else
@@ -96,7 +99,7 @@ __device__ __forceinline__ void g8p_scan_half(KArgs kp, floatx16 (&acc)[4][2], c
                 const uint32_t slot = atomicAdd(kp->cnt + q, 1u);
                 if (slot < cap) kp->cand[(int64_t)q * cap + slot] = make_uint2(row0 + (uint32_t)rl, __float_as_uint(g8_score(v, mul)));
               }
-            } else if (j < (uint32_t)G8P_DEPTH) stack[j * G8_NT] = make_uint2((uint32_t)rl, (uint32_t)v);
+            } else if (j < (uint32_t)G8P_DEPTH) stack[j * G8_NT] = g8p_entry(v, rl);
             ++j;
           }
         }
@@ -115,18 +118,18 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 7u;
-  const int64_t groups_x = p.p_groups > (int64_t)xcc ? (p.p_groups - (int64_t)xcc + 7) >> 3 : 0;
   const uint32_t per_group = (uint32_t)(DOC_GROUP * nq);
-  const uint32_t limit = (uint32_t)groups_x * per_group;          // < 2^31 (launcher)
+  uint32_t fv = xcc;                              // the XCD whose sweep this workgroup is taking tiles from: its own, then -- when that is used up -- the next ones
 
-  // linear index of the XCD's sweep -> tile: group z of the XCD = group 8 z + xcc of the launch; inside a group the query tile moves slowest
-  // over DOC_GROUP corpus tiles (the launch's last group may hold fewer).  The first index that is not a tile ends the XCD's stream.
-  auto decode = [&](uint32_t L, int64_t& dt_o, int& qt_o, bool& ok_o, bool& dead_o) __attribute__((always_inline)) {
+  // linear index L of XCD v's sweep -> tile: group z of the XCD = group 8 z + v of the launch; inside a group the query tile moves slowest
+  // over DOC_GROUP corpus tiles (the launch's last group may hold fewer).  The first index that is not a tile means the sweep is used up.
+  auto decode = [&](uint32_t L, uint32_t v, int64_t& dt_o, int& qt_o, bool& ok_o, bool& dead_o) __attribute__((always_inline)) {
     int64_t dt = 0;
     int qt = 0, ok = 0, dead = 0;
-    if (L < limit) {
+    const int64_t groups_v = p.p_groups > (int64_t)v ? (p.p_groups - (int64_t)v + 7) >> 3 : 0;
+    if ((int64_t)L < groups_v * (int64_t)per_group) {          // < 2^31 (launcher)
       const uint32_t z = L / per_group, r = L - z * per_group;
-      const int64_t grp = (int64_t)z * 8 + (int64_t)xcc;
+      const int64_t grp = (int64_t)z * 8 + (int64_t)v;
       KArgs k = g8p_kargs();
       const int64_t left = (k->seq_hi - k->seq_lo) - grp * DOC_GROUP;
       uint32_t dl;
@@ -147,19 +150,32 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
     ok_o = __builtin_amdgcn_readfirstlane(ok) != 0;
     dead_o = __builtin_amdgcn_readfirstlane(dead) != 0;
   };
+  // Which workgroup runs on which XCD is the hardware's business (a launch of three workgroups need not touch XCD 0 at all), so the XCD is an
+  // affinity, not a partition: a workgroup whose own sweep is used up goes on with the other XCDs' sweeps, one after the other -- every tile
+  // of the launch is taken by somebody whatever the placement.  Taking a tile from a new sweep is synchronous (one atomic round trip; it
+  // happens at most eight times in a workgroup's life).
+#define G8P_ACQUIRE_SYNC(dt_, qt_, ok_, dead_)                                                                                        \
+  do {                                                                                                                               \
+    for (int tries_ = 0; !(ok_) && tries_ < 8; ++tries_) {                                                                          \
+      __syncthreads();                                                                                                               \
+      if (threadIdx.x == 0)                                                                                                          \
+        *(volatile __attribute__((address_space(3))) uint32_t*)LDS_PTR(smem + G8P_MAIL) = atomicAdd(g8p_kargs()->p_ctr + fv, 1u);   \
+      __syncthreads();                                                                                                               \
+      const uint32_t La_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile __attribute__((address_space(3))) uint32_t*)LDS_PTR(smem + G8P_MAIL)); \
+      decode(La_, fv, dt_, qt_, ok_, dead_);                                                                                         \
+      if (!(ok_)) fv = (fv + 1u) & 7u;                                                                                               \
+    }                                                                                                                                \
+  } while (0)
 
-  // ---- first two tile indices of this workgroup
-  if (threadIdx.x == 0) *(volatile __attribute__((address_space(3))) uint32_t*)LDS_PTR(smem + G8P_MAIL) = atomicAdd(p.p_ctr + xcc, 2u);
-  __syncthreads();
-  const uint32_t L0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile __attribute__((address_space(3))) uint32_t*)LDS_PTR(smem + G8P_MAIL));
-  int64_t cur_dt, nxt_dt;
-  int cur_qt, nxt_qt;
-  bool cur_ok, nxt_ok, cur_dead, nxt_dead;
-  decode(L0, cur_dt, cur_qt, cur_ok, cur_dead);
-  decode(L0 + 1u, nxt_dt, nxt_qt, nxt_ok, nxt_dead);
+  // ---- first two tiles of this workgroup
+  int64_t cur_dt = 0, nxt_dt = 0;
+  int cur_qt = 0, nxt_qt = 0;
+  bool cur_ok = false, nxt_ok = false, cur_dead = false, nxt_dead = false;
+  G8P_ACQUIRE_SYNC(cur_dt, cur_qt, cur_ok, cur_dead);
   if (!cur_ok) return;
+  G8P_ACQUIRE_SYNC(nxt_dt, nxt_qt, nxt_ok, nxt_dead);
 #if G8_TRACE
-  uint32_t Lcur = L0, Lnxt = L0 + 1u;
+  uint32_t wg_tile = 0;                           // trace slot of a tile: 1024 x the workgroup + its tile count
 #endif
 
   // ---- LDS-DMA, fixed roles: wave w streams half (w & 1) of image ((w >> 1) & 1 ? query : corpus) of stage 2g + (w >> 2) of every pair g
@@ -235,7 +251,7 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
 
   // ---- flush of a tile's hit stacks, inside the NEXT tile's stage loops: behind its first pair barrier every lane reserves its hits in
   // its two queries' lists (returning atomics), behind the second one it stores them -- both round trips run under matrix instructions
-  uint2* const stack = (uint2*)(smem + G8P_QUEUE) + threadIdx.x;
+  uint32_t* const stack = (uint32_t*)(smem + G8P_QUEUE) + threadIdx.x;
   int fl_stage = 0;                               // 0 nothing, 1 reservations to issue, 2 stores to issue (wave-uniform)
   bool mail_pending = false;
   uint32_t fl_row0 = 0, fl_s = 0;                 // fl_s = hits of the lane's first query column | hits of both << 8
@@ -252,12 +268,22 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
       const uint32_t cap = k->cap;
       uint2* const cand = k->cand;
       const uint32_t s0 = fl_s & 255u, s1 = fl_s >> 8;
-      for (uint32_t i = 0; i < s1; ++i) {
-        const uint2 en = stack[i * G8_NT];
-        const bool first = i < s0;
-        const uint32_t slot = first ? fl_base0 + i : fl_base1 + (i - s0);
-        const int q = first ? fl_q : fl_q + 32;
-        if (slot < cap) cand[(int64_t)q * cap + slot] = make_uint2(fl_row0 + en.x, __float_as_uint(g8_score((int)en.y, first ? fl_mul0 : fl_mul1)));
+      // four entries per round: their LDS reads go out together, one wait, then the stores (few lanes hold more than four hits)
+      for (uint32_t i0 = 0; __builtin_amdgcn_ballot_w64(i0 < s1) != 0; i0 += 4) {
+        uint32_t en[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) en[u] = stack[(i0 + u < (uint32_t)G8P_DEPTH ? i0 + u : (uint32_t)G8P_DEPTH) * G8_NT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t i = i0 + u;
+          if (i < s1) {
+            const bool first = i < s0;
+            const uint32_t slot = first ? fl_base0 + i : fl_base1 + (i - s0);
+            const int q = first ? fl_q : fl_q + 32;
+            if (slot < cap)
+              cand[(int64_t)q * cap + slot] = make_uint2(fl_row0 + (en[u] & 255u), __float_as_uint(g8_score((int)(en[u] & 0xffffff00u), first ? fl_mul0 : fl_mul1)));
+          }
+        }
       }
       fl_stage = 0;
     } else if (fl_stage == 1) {
@@ -292,8 +318,9 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
   for (;;) {
     const bool PARTIAL = p.partial_wn > 0 && cur_qt == nq - 1;
 #if G8_TRACE
-    const unsigned tslot = xcc * (unsigned)(G8P_TRACE_SLOTS / 8) + Lcur;
-    if (threadIdx.x == 0 && Lcur < (unsigned)(G8P_TRACE_SLOTS / 8)) {
+    const unsigned tslot = wg_tile < 1024u && blockIdx.x < (unsigned)(G8P_TRACE_SLOTS / 1024) ? blockIdx.x * 1024u + wg_tile : (unsigned)G8P_TRACE_SLOTS;
+    ++wg_tile;
+    if (threadIdx.x == 0 && tslot < (unsigned)G8P_TRACE_SLOTS) {
       unsigned hw;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       g8p_trace_buf[(size_t)tslot * 8 + 0] = __builtin_amdgcn_s_memrealtime();
@@ -381,7 +408,7 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     G8P_T(2);
-    if (threadIdx.x == 0) pend = atomicAdd(g8p_kargs()->p_ctr + xcc, 1u);      // the tile after next
+    if (threadIdx.x == 0) pend = atomicAdd(g8p_kargs()->p_ctr + fv, 1u);      // the tile after next (from the sweep in use)
     mail_pending = true;
     {
       const int32_t* rs = (const int32_t*)(smem + G8_META) + wm * 128 + 4 * (lane >> 5);
@@ -519,10 +546,11 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
     G8P_T(6);
     // ---- on to the next tile of the stream
     cur_dt = nxt_dt; cur_qt = nxt_qt; cur_ok = nxt_ok; cur_dead = nxt_dead;
-    decode(Lnn, nxt_dt, nxt_qt, nxt_ok, nxt_dead);
-#if G8_TRACE
-    Lcur = Lnxt; Lnxt = Lnn;
-#endif
+    decode(Lnn, fv, nxt_dt, nxt_qt, nxt_ok, nxt_dead);
+    if (!nxt_ok && cur_ok) {                     // that sweep is used up: on to the next XCD's (the barriers inside are the tile's only extra ones)
+      fv = (fv + 1u) & 7u;
+      G8P_ACQUIRE_SYNC(nxt_dt, nxt_qt, nxt_ok, nxt_dead);
+    }
     base_cur = base_nxt;
     base_nxt = role_base(nxt_dt, nxt_qt);
     soff = (soff + 2 * npairs) & 3;
@@ -585,7 +613,7 @@ bool gemm_g8p_ok(const GemmArgs& a) {
 }  // namespace dhr
 
 #if G8_TRACE
-// tuning hook of the trace build: copies the trace records (8 x u64 per tile, slot = xcc * 32768 + the tile's index on its XCD) to the host
+// tuning hook of the trace build: copies the trace records (8 x u64 per tile, slot = 1024 x workgroup + the workgroup's tile count) to the host
 extern "C" int dhr_debug_g8p_stat(unsigned long long* out16) {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(dhr::g8p_stat), 128) != hipSuccess) return -1;
   unsigned long long z[16] = {};

@@ -1176,9 +1176,11 @@ hipError_t launch_gemm_filter(const GemmArgs& a_in, hipStream_t s) {
   // proper message, the others cannot be reached through the C ABI (n_rows < 2^32, sample period <= 256)
   if ((int64_t)DOC_GROUP * a_in.n_qtiles > 65535 || a_in.perm_n >= (1 << 24) || a_in.period > (1 << 20)) return hipErrorInvalidValue;
   if (a_in.map_mode >= 2 && a_in.period < 2) return hipErrorInvalidValue;      // "everything but the sample" needs a sample: divmod24 by period - 1
-  // gated_i8 indexes: persistent workgroups over the whole launch (gemm_g8p.hip) with DHR_G8_PERSIST=1; experimental, see docs/experiments.md
+  // gated_i8 indexes: persistent workgroups over the whole launch (gemm_g8p.hip) for DHR_PARAM_GEMM_VARIANT = 6 (or DHR_G8_PERSIST=1, tuning).
+  // Not the default: the kernel runs at the package power cap, where the ~10 % of cycles the persistent form saves come back as a lower
+  // clock, not as time, and a workgroup that never leaves its CU keeps refine / rescoring of the previous chunk from interleaving
   static const int g8_persist = getenv("DHR_G8_PERSIST") ? atoi(getenv("DHR_G8_PERSIST")) : 0;
-  if (a_in.g8_shift && g8_persist && gemm_g8p_ok(a_in)) return launch_gemm_g8p(a_in, s);
+  if (a_in.g8_shift && (g8_persist || a_in.variant == 6) && gemm_g8p_ok(a_in)) return launch_gemm_g8p(a_in, s);
   GemmArgs a = a_in;
   a.inv_perm_n = 1.0 / (double)(a.perm_n > 0 ? a.perm_n : 1);
   a.inv_pm1 = 1.0 / (double)(a.period > 1 ? a.period - 1 : 1);
@@ -1212,7 +1214,7 @@ static hipError_t launch_gemm_filter_grid(const GemmArgs& a, dim3 grid, hipStrea
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int variant = a.variant ? a.variant : g_gemm_variant;        // per handle (dhr_index_set_param), else the library default
+  const int variant = a.variant == 6 ? 5 : a.variant ? a.variant : g_gemm_variant;        // per handle (dhr_index_set_param), else the library default
   if (a.g8_shift) return (a.ts > 0 && !(a.ts & 1) && !(a.td & 1) && a.ts_q == a.ts) ? launch_gemm_g8(a, grid, s) : hipErrorInvalidValue;
   if (a.i8_mul)      // int8 dense stages exist in the every-wave-computes kernels only (dhr_index_create enables them only where those run)
     return (a.ts + a.td > 0 && !(a.ts_q & 1) && !(a.td & 1)) ? launch_gemm_wx(a, grid, variant == 4 ? 4 : 5, s) : hipErrorInvalidValue;

@@ -106,7 +106,7 @@ typedef enum dhr_param {
   DHR_PARAM_GEMM_EXCLUSIVE = 10, /* with AUX_CUS: 1 = run the bound GEMM on the other CUs only */
   DHR_PARAM_OVERLAP_AUX = 11,  /* 0: refine / rescoring / select of a chunk run after its GEMM on the same stream; 1: beside the GEMM of the next chunk on a CU-masked stream; -1 (default): 1 */
   DHR_PARAM_PROGRESSIVE_THR = 8, /* later main-pass chunks filter with 1: the running exact k-th best; 2 (default): additionally the rank extrapolated from the scattered fraction of the corpus seen so far (main pass in a scattered tile order; a query whose extrapolation was too high fails the final verification and is redone); 0: the sampled threshold only */
-  DHR_PARAM_GEMM_VARIANT = 6, /* bound-GEMM kernel of the 2:4 layout: 3 = 12 waves (producer / consumer), 4 = 4 waves with 128 x 128 wave tiles, 5 = 8 waves with 128 x 64 wave tiles (default) */
+  DHR_PARAM_GEMM_VARIANT = 6, /* bound-GEMM kernel of the 2:4 layout: 3 = 12 waves (producer / consumer), 4 = 4 waves with 128 x 128 wave tiles, 5 = 8 waves with 128 x 64 wave tiles (default), 6 = 5, and on gated_i8 indexes persistent workgroups (gemm_g8p.hip: the same results and, the kernel being held by the package power cap, the same time in fewer cycles -- DESIGN.md section 4b) */
   DHR_PARAM_ASYNC_CONTROLLER = 13, /* the first attempt of a sampled search ENQUEUES its phases without reading list lengths back between them.
                                      2 (default): one 32-byte read after the sampled run (the fullest lists: how many chunks the main pass
                                      needs) + ONE at the end (the number of queries whose verification failed); 1: the final read only (fixed

@@ -1859,3 +1859,42 @@ def test_gated_image_default_by_size(G, monkeypatch):
     for setting in ("0", "1"):
         np.testing.assert_array_equal(out[setting][1], out["-1"][1])
         np.testing.assert_array_equal(out[setting][0], out["-1"][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nq,d_dlr,d_cls,k", [(70_001, 300, 768, 768, 1000), (20_000, 70, 128, 64, 100), (131_072, 520, 256, 0, 50)])
+def test_persistent_workgroup_gemm(G, force_gated_i8, n, nq, d_dlr, d_cls, k):
+    """DHR_PARAM_GEMM_VARIANT = 6: the bound GEMM of a gated_i8 index with persistent workgroups (gemm_g8p.hip: LDS-DMA stream across tiles,
+    private hit stacks behind the ring flushed inside the next tile's stage loops, tiles from per-XCD counters).  Same search, same
+    lists: results equal the default kernel's bit for bit and the oracle's top-k; shapes with a ragged last corpus tile, a last query tile
+    that computes on half of its waves, no ungated half, and (cand_cap 1024) lists that overflow and are redone."""
+    from dhr_amd import _lib, synth
+    cv, ci, qv, qi = synth.make_pair(21, n, nq, d_dlr, max(d_cls, 8))
+    if d_cls == 0:
+        cv, qv = cv[:, :d_dlr].copy(), qv[:, :d_dlr].copy()
+    q32 = qv.astype(np.float32)
+    # a few hot queries: their thresholds sit low, a lane holds more hits per tile than its private stack (the surplus path)
+    q32[:3] = np.abs(q32[:3]) * 0.05
+    out = {}
+    for variant in (5, 6):
+        ix = G.GipIndex(cv, ci)
+        try:
+            ix.set_param(_lib.PARAM_GEMM_VARIANT, variant)
+            sc, rows = ix.search(q32, qi, k)
+            out[variant] = (sc.copy(), rows.copy(), ix.stats())
+            if variant == 6 and n <= 70_001:
+                ix.set_param(_lib.PARAM_CAND_CAP, 1024)
+                sc2, rows2 = ix.search(q32, qi, k)
+                np.testing.assert_array_equal(rows2, rows)
+                np.testing.assert_array_equal(sc2, sc)
+        finally:
+            ix.close()
+    np.testing.assert_array_equal(out[5][1], out[6][1])
+    np.testing.assert_array_equal(out[5][0], out[6][0])
+    # (the count of bound candidates is not reproducible to the last row even for ONE kernel: a chunk's thresholds are raised by the previous
+    # chunk's select while its GEMM already runs; the persistent kernel's lists carry the bound rounded up to a multiple of 256 units)
+    assert abs(out[5][2]["candidates_bound"] - out[6][2]["candidates_bound"]) <= 1e-3 * out[5][2]["candidates_bound"], (out[5][2], out[6][2])
+    c32 = cv.astype(np.float32)
+    for i in (0, 1, 2, nq // 2, nq - 1):
+        ex = O.gip_scores_f64(q32[i], qi[i], c32, ci)
+        O.check_topk(out[6][1][i], out[6][0][i], ex, k)
