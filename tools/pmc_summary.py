@@ -18,7 +18,7 @@ for run in sorted(os.listdir(root)):
                 k = row.get("Kernel_Name", "")
                 if "gemm_filter" not in k:
                     continue
-                name = "g8" if "_g8_" in k else "wx" if "_wx_" in k else ("sparse" if "sparse" in k else "v3")
+                name = "g8p" if "_g8p_" in k else "g8" if "_g8_" in k else "wx" if "_wx_" in k else ("sparse" if "sparse" in k else "v3")
                 a = acc[(name, row["Counter_Name"])]
                 a[0] += float(row["Counter_Value"])
                 a[1] += 1

@@ -41,24 +41,26 @@ if [ $PART = trace ] || [ $PART = all ]; then
   DB=$(ls $O/trace_serial/*/*_results.db 2>/dev/null | head -1)
   [ -n "$DB" ] && python tools/rocpd_summary.py $DB $O/${TAG}_kernel_stats_serial.txt | head -14
   tail -1 $O/trace_bench.log | cut -c1-400; tail -1 $O/trace_serial_bench.log | cut -c1-400
+  rm -rf $O/trace $O/trace_serial          # the databases are large: gpurun copies back at most 64 MiB
 fi
 if [ $PART = pmc ] || [ $PART = all ]; then
   cd /tmp && export TMPDIR=/tmp
   SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
   SQ2="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_MFMA"
-  for cfg in "g8 768 1 -1" "dense 0 1 0" "densei8 0 1 1"; do
+  for cfg in "g8 768 1 -1 0" "g8p 768 1 -1 1" "dense 0 1 0 0" "densei8 0 1 1 0"; do
     set -- $cfg
-    export DHR_GATED_I8=$3 DHR_DENSE_I8=$4
+    export DHR_GATED_I8=$3 DHR_DENSE_I8=$4 DHR_G8_PERSIST=$5
     timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_$1_f -- $R/tools/probe/_bin/gemm_pmc 500000 6980 $2 > $O/pmc_$1_f.log 2>&1
     timeout 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $O/pmc_$1_t -- $R/tools/probe/_bin/gemm_pmc 500000 6980 $2 > $O/pmc_$1_t.log 2>&1
     timeout 200 rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $O/pmc_$1_s -- $R/tools/probe/_bin/gemm_pmc 500000 6980 $2 > $O/pmc_$1_s.log 2>&1
     timeout 200 rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d $O/pmc_$1_l -- $R/tools/probe/_bin/gemm_pmc 500000 6980 $2 > $O/pmc_$1_l.log 2>&1
   done
-  unset DHR_GATED_I8 DHR_DENSE_I8
+  unset DHR_GATED_I8 DHR_DENSE_I8 DHR_G8_PERSIST
   cd $R
   python3 tools/pmc_summary.py $O > $O/${TAG}_gemm_pmc_raw.txt
   cat $O/${TAG}_gemm_pmc_raw.txt
-  tail -1 $O/pmc_g8_f.log; tail -1 $O/pmc_dense_f.log; tail -1 $O/pmc_densei8_f.log
+  for d in $O/pmc_*_?; do [ -d $d ] && rm -rf $d; done
+  tail -1 $O/pmc_g8_f.log; tail -1 $O/pmc_g8p_f.log; tail -1 $O/pmc_dense_f.log; tail -1 $O/pmc_densei8_f.log
 fi
 if [ $PART = beir ] || [ $PART = all ]; then
   timeout 1500 python bench.py --workload beir --no-cpu-baseline --steps 10 --warmup 3 > $O/bench_${TAG}_beir_exact.jsonl 2> $O/bench_beir_exact.err
