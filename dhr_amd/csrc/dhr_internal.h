@@ -45,16 +45,10 @@ constexpr int S8_STAGE_A = S8_A_BYTES + 2048;
 #define DHR_HEAVY 64
 #endif
 constexpr int HEAVY = DHR_HEAVY;        // per-row list of the largest gated values used by the refine step (64, or 32 in A/B builds: 8 lanes x HEAVY / 8 entries)
-// ... stored as ONE 6 x HEAVY-byte record per row (384 B), largest magnitude first, in FOUR blocks of HEAVY / 4 entries, each block its u32
-// keys followed by its fp16 values (96 B): the refine step reads block 0 -- the 16 heaviest entries, inside the record's first 128-byte
-// line -- re-tests the candidate, and reads the other three only for the survivors (round 4; the keys-then-values record of round 3 cost
-// three lines per candidate).  heavy_key = record base of row 0; entry r of a row: key at heavy_key_off(r), value at heavy_val_off(r) bytes.
+// ... stored as ONE 6 x HEAVY-byte record per row (384 B): HEAVY u32 keys, then HEAVY fp16 values (a candidate's refine read is one contiguous
+// segment instead of a 256-byte and a 128-byte one in two arrays): heavy_key = record base, heavy_val = base + 4 x HEAVY bytes
 constexpr int HEAVY_KEY_STRIDE = HEAVY * 6 / 4;    // u32 per record
 constexpr int HEAVY_VAL_STRIDE = HEAVY * 6 / 2;    // fp16 per record
-constexpr int HEAVY_BLK = HEAVY / 4;               // entries per block
-constexpr int HEAVY_BLK_BYTES = HEAVY_BLK * 6;
-__host__ __device__ inline int heavy_key_off(int r) { return (r / HEAVY_BLK) * HEAVY_BLK_BYTES + (r % HEAVY_BLK) * 4; }
-__host__ __device__ inline int heavy_val_off(int r) { return (r / HEAVY_BLK) * HEAVY_BLK_BYTES + HEAVY_BLK * 4 + (r % HEAVY_BLK) * 2; }
 constexpr int DOC_GROUP = 4;                               // doc tiles that share one XCD sweep
 
 __host__ __device__ inline int64_t tiled_chunk_offset(int64_t row, int chunk, int ksteps) {

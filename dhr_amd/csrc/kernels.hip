@@ -1311,10 +1311,7 @@ __global__ void __launch_bounds__(256) heavy_build_kernel(const __half* __restri
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { const uint32_t ob = __shfl_xor(best, o, 64); best = ob > best ? ob : best; }
       if (best == 0u) {                       // fewer than HEAVY non-zero entries: pad
-        if (lane == 0) for (int rr = r; rr < HEAVY; ++rr) {
-          char* rec = (char*)(heavy_key + row * HEAVY_KEY_STRIDE);
-          *(uint32_t*)(rec + heavy_key_off(rr)) = 0xFFFFFFFFu; *(__half*)(rec + heavy_val_off(rr)) = __float2half(0.f);
-        }
+        if (lane == 0) for (int rr = r; rr < HEAVY; ++rr) { heavy_key[row * HEAVY_KEY_STRIDE + rr] = 0xFFFFFFFFu; heavy_val[row * HEAVY_VAL_STRIDE + rr] = __float2half(0.f); }
         break;
       }
       const int j = MAXJ - (int)(best & 0xFFFFu);
@@ -1331,9 +1328,8 @@ __global__ void __launch_bounds__(256) heavy_build_kernel(const __half* __restri
           const uint32_t lvl = d > 0.f ? (uint32_t)quant_up_i8(d, g8_inv_cs[j]) : 0u;
           key_out = ((uint32_t)j << 20) | ((lvl >> 4) << 17) | ((bk & 1u) << 16) | ((lvl & 0xFu) << 12) | ((uint32_t)iv & 0xFFFu);
         }
-        char* rec = (char*)(heavy_key + row * HEAVY_KEY_STRIDE);
-        *(uint32_t*)(rec + heavy_key_off(r)) = key_out;
-        *(__half*)(rec + heavy_val_off(r)) = vals_rm[row * k_rm + j];
+        heavy_key[row * HEAVY_KEY_STRIDE + r] = key_out;
+        heavy_val[row * HEAVY_VAL_STRIDE + r] = vals_rm[row * k_rm + j];
 #pragma unroll
         for (int sl = 0; sl < SL; ++sl) if (sl == (j >> 6)) key[sl] = 0u;
       }
@@ -1363,6 +1359,11 @@ hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, 
 // 12.0 -> 14.1 ms, rescoring 15.8 -> 16.6 ms per config-3 step, step 121.7 -> 124.5 ms.  Plain loads stay.)
 static __device__ __forceinline__ uint4 gather16(const void* p) { return *(const uint4*)p; }
 static __device__ __forceinline__ uint2 gather8(const void* p) { return *(const uint2*)p; }
+// (Round 4: refine in two levels -- the record as four blocks of 16 entries, each its keys then its values; the candidate's first two lanes
+// read block 0 = the 16 heaviest entries = one 128-byte line, the candidate is re-tested, and only the survivors' other six lanes read blocks
+// 1-3 -- prunes 60 % of the candidates after one line instead of three, and was SLOWER: refine 11.3 -> 15.9 ms per config-3 step.  The kernel
+// is bound by the round trips a wave waits for, not by bytes: nearly every wave holds a survivor among its 8 candidates and then pays two
+// dependent gathers per iteration.  It would take a compacting pass between the levels (a third list set); not built.)
 constexpr int REFINE_PER_WG = 256;       // candidates of ONE query per workgroup (its operand words are staged in LDS once)
 template <bool G8>
 __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
@@ -1387,30 +1388,24 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
   const double unit = G8 ? (double)p.g8_unit[q] : 0.0;
   // (A variant that issued the loads of all 8 candidates of a lane group up front ran 30 % SLOWER: 4x the gathers
   // in flight per CU only thrash the memory system; the dependent chain below at 8 waves per SIMD is the sweet spot.)
-  constexpr int EPL = HEAVY / 8;              // entries per lane: 8 (two 16-byte key loads + one 16-byte value load) or 4 (one + an 8-byte one)
-  static_assert(EPL == 8 || EPL == 4, "8 lanes per candidate read 8 or 4 entries each");
-  // lane `sub` of a candidate's 8 owns entries sub * EPL ..: half (sub & 1) of block sub >> 1 of the row's record
-  const int my_key_off = (sub >> 1) * HEAVY_BLK_BYTES + (sub & 1) * EPL * 4;
-  const int my_val_off = (sub >> 1) * HEAVY_BLK_BYTES + HEAVY_BLK * 4 + (sub & 1) * EPL * 2;
   for (uint32_t i = base + (threadIdx.x >> 3); i < base + REFINE_PER_WG; i += 32) {
+    float corr = 0.f;
+    int taken = 0;              // G8: operand products (integer units) of the listed same-bucket entries
+    double back = 0.0;          // G8: real-valued products of those whose index values agree
     uint2 c = make_uint2(0u, 0u);
-    const char* rec = nullptr;
     if (i < count) {
       c = p.cand[(int64_t)q * p.cap + i];
-      rec = (const char*)(p.heavy_key + (int64_t)c.x * HEAVY_KEY_STRIDE);
-    }
-    // this lane's entries -> corr (fp16-gated image) or taken / back (gated_i8: operand products (integer units) of the listed same-bucket
-    // entries, real-valued products of those whose index values agree)
-    auto my_entries = [&](float& corr, int& taken, double& back) __attribute__((always_inline)) {
-      const uint32_t* hk = (const uint32_t*)(rec + my_key_off);
+      constexpr int EPL = HEAVY / 8;              // entries per lane: 8 (two 16-byte key loads + one 16-byte value load) or 4 (one + an 8-byte one)
+      static_assert(EPL == 8 || EPL == 4, "8 lanes per candidate read 8 or 4 entries each");
+      const uint32_t* hk = p.heavy_key + (int64_t)c.x * HEAVY_KEY_STRIDE + sub * EPL;
       const uint4 k0 = gather16(hk);
       uint4 k1 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
       union { uint4 u; half8 h; } hvu;
       if constexpr (EPL == 8) {
         k1 = gather16(hk + 4);
-        hvu.u = gather16(rec + my_val_off);
+        hvu.u = gather16(p.heavy_val + (int64_t)c.x * HEAVY_VAL_STRIDE + sub * 8);
       } else {
-        const uint2 v2 = gather8(rec + my_val_off);
+        const uint2 v2 = gather8(p.heavy_val + (int64_t)c.x * HEAVY_VAL_STRIDE + sub * 4);
         hvu.u = make_uint4(v2.x, v2.y, 0u, 0u);
       }
       const half8 hv = hvu.h;
@@ -1443,41 +1438,24 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
           }
         }
       }
-    };
-    // U counted `taken` units for the listed same-bucket entries; the entries whose index values agree contribute their real product, the
-    // others nothing.  fp64: exact up to 2^-53 relative; the result is rounded UP to fp32.  (Every listed entry can only lower the bound --
-    // its operand product was rounded up on both sides -- so the value after ANY subset of the entries is still an upper bound.)
-    auto bound_now = [&](float corr, int taken, double back) __attribute__((always_inline)) -> float {
+    }
+    if constexpr (G8) {
+      taken += __shfl_xor(taken, 1, 64); taken += __shfl_xor(taken, 2, 64); taken += __shfl_xor(taken, 4, 64);
+      back += __shfl_xor(back, 1, 64); back += __shfl_xor(back, 2, 64); back += __shfl_xor(back, 4, 64);
+    } else {
+      corr += __shfl_xor(corr, 1, 64);
+      corr += __shfl_xor(corr, 2, 64);
+      corr += __shfl_xor(corr, 4, 64);
+    }
+    if (sub == 0 && i < count) {
+      float u2;
       if constexpr (G8) {
+        // U counted `taken` units for the listed same-bucket entries; the entries whose index values agree contribute their real
+        // product, the others nothing.  fp64: exact up to 2^-53 relative; the result is rounded UP to fp32.
         const double v = (double)__uint_as_float(c.y) - (double)taken * unit + back;
-        float u2 = (float)v;
+        u2 = (float)v;
         if ((double)u2 < v) u2 = nextafterf(u2, INFINITY);
-        return u2;
-      } else return __uint_as_float(c.y) - corr;
-    };
-    auto reduce8 = [&](float& corr, int& taken, double& back) __attribute__((always_inline)) {
-      if constexpr (G8) {
-        taken += __shfl_xor(taken, 1, 64); taken += __shfl_xor(taken, 2, 64); taken += __shfl_xor(taken, 4, 64);
-        back += __shfl_xor(back, 1, 64); back += __shfl_xor(back, 2, 64); back += __shfl_xor(back, 4, 64);
-      } else {
-        corr += __shfl_xor(corr, 1, 64); corr += __shfl_xor(corr, 2, 64); corr += __shfl_xor(corr, 4, 64);
-      }
-    };
-    // level 1: the record's first block (its HEAVY / 4 heaviest entries: one 128-byte line), read by the candidate's first two lanes
-    float corr = 0.f;
-    int taken = 0;
-    double back = 0.0;
-    if (i < count && sub < 2) my_entries(corr, taken, back);
-    reduce8(corr, taken, back);
-    const bool alive = i < count && bound_now(corr, taken, back) >= t;
-    // level 2: the other three blocks, for the candidates the first block did not take below the threshold
-    float corr2 = 0.f;
-    int taken2 = 0;
-    double back2 = 0.0;
-    if (alive && sub >= 2) my_entries(corr2, taken2, back2);
-    reduce8(corr2, taken2, back2);
-    if (sub == 0 && alive) {
-      const float u2 = bound_now(corr + corr2, taken + taken2, back + back2);
+      } else u2 = __uint_as_float(c.y) - corr;
       if (u2 >= t) {
         const uint32_t slot = atomicAdd(p.out_cnt + q, 1u);
         if (slot < p.out_cap) p.out[(int64_t)q * p.out_cap + slot] = make_uint2(c.x, __float_as_uint(u2));
