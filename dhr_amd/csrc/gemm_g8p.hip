@@ -1,24 +1,31 @@
-// Bound GEMM + filter of a gated_i8 index with PERSISTENT workgroups (round 4).  Same tile, same arithmetic and the same operand images as
-// gemm_g8.hip; what changes is everything around the stage loops, because a per-tile timeline of that kernel (tools/g8_trace.py, -DG8_TRACE=1)
-// showed where a 256 x 256 tile's ~58 k cycles went with an open filter: 24.6 k of matrix instructions, and
-//   * 2.0 k between a workgroup's exit and its successor's start on the CU (3.5 k with an open filter), 1.9-2.1 k of prologue (the first
+// Bound GEMM + filter of a gated_i8 index with PERSISTENT workgroups (round 4; DHR_PARAM_GEMM_VARIANT = 6).  Same tile, same arithmetic and
+// the same operand images as gemm_g8.hip; what changes is everything around the stage loops, because a per-tile timeline of that kernel
+// (tools/g8_trace.py, -DG8_TRACE=1; profiles/r04_gemm_timeline.txt) showed where a 256 x 256 tile's ~58 k cycles go with an open filter: 24.6 k of
+// matrix instructions, and
+//   * 2.0 k between a workgroup's exit and its successor's start on the CU (3.7 k with an open filter), 1.9-2.1 k of prologue (the first
 //     stage pair's round trip to L2) -- 160 KiB of LDS and 2 x 248 registers per SIMD allow ONE workgroup per CU, so nothing hides either;
-//   * 12.8 k of filter epilogue (3.0 k with a closed filter): private hit stacks that fill the whole staging ring, two list reservations
+//   * 13.0 k of filter epilogue (3.0 k with a closed filter): private hit stacks that fill the whole staging ring, two list reservations
 //     (returning global atomics) per lane and their round trips, per-lane flush loops;
 //   * ~4 k of waiting at the gated pairs' barriers for LDS-DMA pieces issued one block (~500 cycles) earlier -- less than an L2 round trip.
-// Here a workgroup takes tile after tile from a per-XCD counter, and
+// Here a workgroup takes tile after tile from per-XCD counters, and
 //   1. the LDS-DMA stream never stops: the ring is free from a tile's LAST pair barrier on (its last fragments are in registers by then), so
 //      pair 0 / pair 1 (+ the constants) of the NEXT tile are simply virtual pairs npairs / npairs + 1 of the current one.  They land during
 //      the epilogue; the next tile's "prologue" is one barrier;
 //   2. every piece of a pair is issued in the block right behind the pair barrier (a whole block of slack before the next barrier);
-//   3. the epilogue leaves the ring alone: a hit goes to a small WAVE-PRIVATE queue (376 entries of (row, query, integer sum) behind the ring;
-//      position = the wave's count + the lane's rank among the hits of that compare: v_cmp -> s_bcnt1 / v_mbcnt, no atomics, no branches on
-//      the push) and the queue is flushed to the queries' lists INSIDE THE NEXT TILE'S STAGE LOOPS: one entry per lane, the list
-//      reservation (+ the query's unit) issued behind one pair barrier, the store behind the next -- both round trips under matrix work;
+//   3. the epilogue leaves the ring alone: a hit goes to the thread's private stack BEHIND the ring (12 four-byte entries: the local row + the
+//      sum rounded up to a multiple of 256; the branch-free push of gemm_g8.hip) and the stacks are flushed to the queries' lists INSIDE THE
+//      NEXT TILE'S STAGE LOOPS: the list reservations (returning atomics) behind its first pair barrier, the stores behind the second -- both
+//      round trips run under matrix work.  (A wave-private queue filled with v_cmp -> s_bcnt1 / v_mbcnt ranks was tried first: ~100 cycles per
+//      pushed element, the scan went from 13 k to 22 k cycles.  Stacks of 5 eight-byte entries overflow in 33 % of the (wave, tile) scans of a
+//      real search, 12 in 3 %: tools/g8p_stat.py.  A thread with more hits sends its surplus straight to the lists in a second, cold scan.)
 //   4. tile indices come from the counter two tiles ahead (one returning atomic per tile by one lane, published through the LDS).
-// The XCD a workgroup runs on is read from HW_REG_XCC_ID; every XCD owns the corpus tile groups g = xcc (mod 8) and sweeps them against all
-// query tiles in the order of gemm_wg_tile (dhr_internal.h), so the L2 behaviour is that of the 3-D grid.  Results do not depend on which
-// workgroup computes which tile: the lists are unordered sets.
+// The XCD a workgroup runs on is read from HW_REG_XCC_ID and is an AFFINITY: XCD v's sweep is the corpus tile groups g = v (mod 8) against all
+// query tiles in the order of gemm_wg_tile (dhr_internal.h), so the L2 behaviour is that of the 3-D grid -- and a workgroup whose own sweep is
+// used up goes on with the other XCDs', so every tile is computed whatever the placement (a 3-workgroup launch need not touch XCD 0).
+// Results do not depend on which workgroup computes which tile: the lists are unordered sets.
+// MEASURED: ~10 % fewer cycles per tile and the SAME time as gemm_g8.hip (closed filter 18.7 / 18.8 ms per 2 M rows, open 21.1 / 21.2; bench step
+// 124.6 / 126.7 ms): the launch runs at the 1 400 W package cap with either kernel and the clock is what the power budget leaves (DESIGN.md
+// section 4b).  Not the default; kept because it is the measurement that shows the bound.
 #include "gemm_g8.h"
 #include <atomic>
 #include <mutex>
