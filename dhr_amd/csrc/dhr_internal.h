@@ -49,7 +49,10 @@ constexpr int HEAVY = DHR_HEAVY;        // per-row list of the largest gated val
 // segment instead of a 256-byte and a 128-byte one in two arrays): heavy_key = record base, heavy_val = base + 4 x HEAVY bytes
 constexpr int HEAVY_KEY_STRIDE = HEAVY * 6 / 4;    // u32 per record
 constexpr int HEAVY_VAL_STRIDE = HEAVY * 6 / 2;    // fp16 per record
-constexpr int DOC_GROUP = 4;                               // doc tiles that share one XCD sweep
+#ifndef DHR_DOC_GROUP
+#define DHR_DOC_GROUP 4
+#endif
+constexpr int DOC_GROUP = DHR_DOC_GROUP;                   // doc tiles that share one XCD sweep (A/B builds: -DDHR_DOC_GROUP=n; 3 / 4 / 6 / 8 measure alike)
 
 __host__ __device__ inline int64_t tiled_chunk_offset(int64_t row, int chunk, int ksteps) {
   const int64_t tile = row >> 8;
