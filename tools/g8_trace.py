@@ -47,8 +47,9 @@ def main():
     cap = 1 << 18
     persistent = os.environ.get("DHR_G8_PERSIST", "1") != "0"
     if persistent:
-        # persistent workgroups (gemm_g8p.hip): one record per tile at slot xcc * 32768 + the tile's index on its XCD; the warm-up launch
-        # of dhr_debug_gemm_time writes the same slots first, the timed launch overwrites them
+        # persistent workgroups (gemm_g8p.hip): one record per tile at slot 1024 x workgroup + the workgroup's tile count; the warm-up launch
+        # of dhr_debug_gemm_time writes the same slots first, the timed launch overwrites them.  (The trace build of THAT kernel spills 131
+        # registers: its phase times are not the product's; the hit-stack statistics of tools/g8p_stat.py are unaffected.)
         assert trp(None, 0) == 0
         _lib.check(lib.dhr_debug_gemm_time(ix._h, C.byref(qb), 1, C.byref(ms), C.byref(fl), None), "gemm_time")
         torch.cuda.synchronize()
