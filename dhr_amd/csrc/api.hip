@@ -65,6 +65,7 @@ struct Workspace {
   float* thr_hat = nullptr;              // frozen main-pass threshold (tau_hat - margin)
   uint32_t* fail_flags = nullptr;
   uint32_t* q_pack = nullptr;            // [q_pad][d_dlr] refine operand words
+  float* thr_raise = nullptr;            // [q_pad] dense-only int8 index with a residual image: what its refine level adds to the filter threshold
   uint2* cand_r = nullptr;               // refine survivors
   uint32_t* cnt_r = nullptr;
   uint32_t* blk_off = nullptr;           // 2 x (q_pad + 1): block offsets of the flat refine / rescoring launches
@@ -108,6 +109,9 @@ struct dhr_index {
   // maxima of ||d - scale*d8|| and ||scale*d8|| over the ungated part of a row (the filter margin pays for them, query_prep_kernel)
   bool dense_i8 = false;
   float i8_scale = 0.f, i8_ec = 0.f, i8_nc = 0.f;
+  uint8_t* resid8 = nullptr;               // dense-only int8 index: [n_rows][resid_ld] residual image (what the int8 image lost, in 1/254 steps, + 128): the refine level
+  int resid_ld = 0;
+  float resid_ec2 = 0.f;                   //   >= the norm of what the residual image itself loses (weighted space of i8_ec)
   float* i8_col_scale = nullptr;           // [d_cls] int8 step of every ungated column (its largest |value| / 127): outlier columns do not cost the others their resolution
   // gated_i8: the gated stages are int8 2:4 images too (gemm_g8.hip): column j in units of its own step, rounded up; the query
   // side carries w_j = step_j / g8_sref as a weight (query_prep_kernel)
@@ -143,7 +147,7 @@ struct dhr_index {
 
 static void free_ws(Workspace& w) {
   hipFree(w.q_tiles); hipFree(w.q32); hipFree(w.q_idx); hipFree(w.q16); hipFree(w.q_idx8); hipFree(w.q_inexact); hipFree(w.margin); hipFree(w.i8_mul); hipFree(w.g8_q8); hipFree(w.g8_shift); hipFree(w.g8_unit); hipFree(w.tau); hipFree(w.thr);
-  hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2); hipFree(w.q_pack); hipFree(w.cand_r); hipFree(w.cnt_r); hipFree(w.blk_off);
+  hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2); hipFree(w.q_pack); hipFree(w.cand_r); hipFree(w.cnt_r); hipFree(w.thr_raise); hipFree(w.blk_off);
   if (w.h_pinned) hipHostFree(w.h_pinned);
   if (w.h_pinned2) hipHostFree(w.h_pinned2);
   hipFree(w.d_max2); hipFree(w.d_ref); hipFree(w.d_stats);
@@ -169,7 +173,7 @@ extern "C" void dhr_index_destroy(dhr_index* ix) {
   free_ws(ix->ws_fb[1]);
   if (ix->s_aux) hipStreamDestroy(ix->s_aux);
   if (ix->s_gemm) hipStreamDestroy(ix->s_gemm);
-  hipFree(ix->i8_col_scale); hipFree(ix->g8_inv_cs); hipFree(ix->g8_w); hipFree(ix->g8_rsum); hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map); hipFree(ix->heavy_key);      // (heavy_val points into the heavy_key records)
+  hipFree(ix->resid8); hipFree(ix->i8_col_scale); hipFree(ix->g8_inv_cs); hipFree(ix->g8_w); hipFree(ix->g8_rsum); hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map); hipFree(ix->heavy_key);      // (heavy_val points into the heavy_key records)
   delete ix;
 }
 
@@ -493,6 +497,23 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
       }
     }
   }
+  // dense-only int8 index: residual image = the refine level between the filter and the exact rescoring (DHR_DENSE_RESID=0 switches it off).
+  // The int8 margin is  ||q'|| ec (corpus rounding) + ||q' - q8'|| nc (query rounding); with the residuals the first term is MEASURED per
+  // candidate from 768 bytes instead of bounded, and the candidates that only the corpus half of the margin let through never reach the
+  // 1.5 KB rows of the exact rescoring.
+  {
+    static const int env_resid = getenv("DHR_DENSE_RESID") ? atoi(getenv("DHR_DENSE_RESID")) : 1;
+    const int ld = (int)round_up(ix->d_cls, 256);
+    if (env_resid != 0 && ix->dense_i8 && ix->d_dlr == 0 && ld <= 1024 && ix->i8_ec > 0.f) {
+      const size_t rb = (size_t)ix->n_rows * ld;
+      if (hipMalloc((void**)&ix->resid8, rb) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMalloc of the residual image failed"));
+      ix->index_bytes += (int64_t)rb;
+      ix->resid_ld = ld;
+      if (launch_resid_build(ix->vals_rm, ix->k_rm, ix->n_rows, ix->d_dlr, ix->d_cls, ix->i8_col_scale, ix->resid8, ld, s) != hipSuccess)
+        return fail(set_error(DHR_ERR_HIP, "residual image launch failed"));
+      ix->resid_ec2 = std::sqrt((float)ix->d_cls) * ix->i8_scale / 508.f;      // every residual is within half of 1/254 of its column's step: scale / 508 in the weighted space
+    }
+  }
   const size_t tile_bytes = ix->ts + ix->td > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * (ix->gated_i8 ? S8_STAGE_A : SP_STAGE_A) + (size_t)ix->td * SP_DENSE)
                                        : (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2;
   if (hipMalloc((void**)&ix->tiles, tile_bytes) != hipSuccess)
@@ -729,7 +750,7 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   int kp = 1;
   while (kp < k) kp <<= 1;
   if (kp < 64) kp = 64;
-  const bool refine = ix->heavy_key != nullptr && use_refine;
+  const bool refine = (ix->heavy_key != nullptr || ix->resid8 != nullptr) && use_refine;
   // default list depth: 262144 (refine) / 65536, but never more than ~32 GiB for the two bound-list sets of a big batch
   int64_t base_cap = refine ? 262144 : 65536;
   // ... sized by the SHARD: a list cannot hold more rows than the shard has, and the chunk planner of the main pass cuts the pass
@@ -777,8 +798,9 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.fail_flags, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.thr_hat, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.blk_off, (size_t)2 * (q_pad + 1) * 4, tot));
+  if (ix->resid8) HIP_TRY(re_malloc(w.thr_raise, (size_t)q_pad * 4, tot));
   if (refine) {
-    HIP_TRY(re_malloc(w.q_pack, (size_t)q_pad * ix->d_dlr * 4, tot));
+    HIP_TRY(re_malloc(w.q_pack, (size_t)q_pad * std::max(ix->d_dlr, 8) * 4, tot));
     HIP_TRY(re_malloc(w.cand_r, (size_t)q_pad * cap_r * 8, tot));
     HIP_TRY(re_malloc(w.cnt_r, (size_t)q_pad * 4, tot));
   }
@@ -868,6 +890,7 @@ static int prep_queries(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, 
   w.ts_q = sparse_query_stages(ix->ts, ix->d_dlr > 0 && qb->index, ix->gated_i8);
   G8Prep g8{};
   if (ix->gated_i8) { g8.inv_cs = ix->g8_inv_cs; g8.w = ix->g8_w; g8.s_ref = ix->g8_sref; g8.max_shift = ix->g8_max_shift; g8.q8 = w.g8_q8; g8.shift = w.g8_shift; g8.unit = w.g8_unit; }
+  if (ix->resid8) { g8.thr_raise = w.thr_raise; g8.resid_ec2 = ix->resid_ec2; }
   HIP_TRY(hipMemsetAsync(w.q_inexact, 0, 8, s));      // [0] some query is not fp16-representable, [1] some query has an all-zero chunk
   HIP_TRY(launch_query_prep(v, qb->value_dtype == DHR_VAL_F32, ldv, (ix->d_dlr > 0 && qb->index) ? qi : nullptr, qb->index_dtype, ldi,
                             qb->n_queries, w.q_pad, ix->d_dlr, ix->d_cls, ix->k_rm, ix->n_buckets, ix->kt, ix->bucket_map,
@@ -896,7 +919,7 @@ enum { T_GEMM = 0, T_REFINE = 1, T_RESCORE = 2, T_SELECT = 3, T_PREP = 4 };
 
 // The refine step serves gated batches, and -- on gated_i8 indexes -- ungated ones too (--IP stage 1): there it takes the int8
 // products of a row's listed entries off the bound and puts their real products back, whatever the index values (RefineArgs::ungated).
-static inline bool uses_refine(const dhr_index* ix, bool gate) { return ix->heavy_key != nullptr && (gate || ix->gated_i8); }
+static inline bool uses_refine(const dhr_index* ix, bool gate) { return (ix->heavy_key != nullptr && (gate || ix->gated_i8)) || ix->resid8 != nullptr; }
 static RescoreArgs base_rescore_args(const dhr_index* ix, const Workspace& w, int n_queries, bool gate) {
   RescoreArgs r{};
   r.vals_rm = ix->vals_rm; r.c_idx = ix->c_idx; r.c_idx_dtype = ix->idx_dtype;
@@ -964,6 +987,7 @@ static int rescore_select_async(dhr_index* ix, Workspace& w, int Q, bool gate, S
     f.q_pack = w.q_pack; f.d_dlr = ix->d_dlr; f.thr = thr; f.out = w.cand_r; f.out_cnt = w.cnt_r; f.out_cap = (uint32_t)w.cap_r;
     f.n_queries = Q; f.max_count = 1;
     if (ix->gated_i8) { f.g8_q8 = w.g8_q8; f.g8_inv_cs = ix->g8_inv_cs; f.g8_unit = w.g8_unit; f.abs_mode = ix->abs_mode ? 1 : 0; f.ungated = gate ? 0 : 1; }
+    if (ix->resid8) { f.resid8 = ix->resid8; f.resid_ld = ix->resid_ld; f.q32 = w.q32; f.q32_ld = ix->k_rm; f.col_scale = ix->i8_col_scale; f.d_cls = ix->d_cls; f.thr_raise = w.thr_raise; }
     HIP_TRY(launch_block_offsets(cnt, (uint32_t)w.cap, Q, 256, w.blk_off, s));
     f.blk_off = w.blk_off; f.flat_blocks = async_grid();
     HIP_TRY(hipMemsetAsync(w.cnt_r, 0, (size_t)w.q_pad * 4, s));
@@ -999,6 +1023,7 @@ static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectA
     f.q_pack = w.q_pack; f.d_dlr = ix->d_dlr; f.thr = thr; f.out = w.cand_r; f.out_cnt = w.cnt_r; f.out_cap = (uint32_t)w.cap_r;
     f.n_queries = Q; f.max_count = maxr;
     if (ix->gated_i8) { f.g8_q8 = w.g8_q8; f.g8_inv_cs = ix->g8_inv_cs; f.g8_unit = w.g8_unit; f.abs_mode = ix->abs_mode ? 1 : 0; f.ungated = gate ? 0 : 1; }
+    if (ix->resid8) { f.resid8 = ix->resid8; f.resid_ld = ix->resid_ld; f.q32 = w.q32; f.q32_ld = ix->k_rm; f.col_scale = ix->i8_col_scale; f.d_cls = ix->d_cls; f.thr_raise = w.thr_raise; }
     // flat launch: one workgroup per REAL block of 256 candidates (bound_sum / 256 + Q is an upper bound of their number)
     HIP_TRY(launch_block_offsets(cnt, (uint32_t)w.cap, Q, 256, w.blk_off, s));
     f.blk_off = w.blk_off; f.flat_blocks = (uint32_t)std::min<int64_t>(bound_sum / 256 + Q, (int64_t)0x7fffffff);
@@ -1161,7 +1186,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   int64_t first = ix->first_rows > 0 ? std::max<int64_t>(ix->first_rows, 2 * (int64_t)r_eff) : std::max<int64_t>(S >= 2 ? 256 : 512, 2 * (int64_t)r_eff);
   first = std::min(round_up(first, TILE_ROWS), round_up(n, TILE_ROWS));
   const int64_t first_valid = std::min(first, n);
-  if ((rc = ensure_ws(ix, w, Q, k, first_valid, depth == 0 ? 1 : 16, gate || ix->gated_i8)) != DHR_OK) return rc;
+  if ((rc = ensure_ws(ix, w, Q, k, first_valid, depth == 0 ? 1 : 16, gate || ix->gated_i8 || ix->resid8 != nullptr)) != DHR_OK) return rc;
 
   // first attempt of a sampled search: the controller only enqueues (no host read-backs); DHR_ASYNC=0 / DHR_PARAM_ASYNC_CONTROLLER 0 keep the
   // host-driven controller (and the fallback depths always use it: it is the one that is exact for any input)

@@ -239,6 +239,9 @@ struct G8Prep {
   uint8_t* q8;           // [Q_pad][d_dlr] out: the query's gated int8 operand values (refine step)
   int32_t* shift;        // [Q_pad] out
   float* unit;           // [Q_pad] out: score units of one gated product (= i8_mul * 2^shift)
+  // dense-only int8 index with a residual image (RefineArgs::resid8): by how much the refine level may raise the filter threshold
+  float* thr_raise;      // [Q_pad] out, or null
+  float resid_ec2;       // >= || what the residual image itself loses ||  in the weighted space of i8_ec
 };
 hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const void* idx, int idx_dtype, int64_t ld_idx,
                              int n_queries, int q_pad, int d_dlr, int d_cls, int k_rm, int n_buckets, int kt,
@@ -282,7 +285,15 @@ struct RefineArgs {
   const float* g8_unit;                                      // [Q_pad] score units of one gated operand product
   int abs_mode;
   int ungated;                                               // gated_i8, plain inner product batch: every listed entry counts in both directions (no bucket / index test)
+  // dense-only int8 index (round 4): the refine level is the RESIDUAL image of the corpus -- resid8[row][c] = 128 + rint((d - cs_c d8) * 254 / cs_c),
+  // what the int8 image of column c lost, in 1/254 of its step -- so that  U + sum_c q_c (cs_c / 254) (resid8 - 128)  leaves only the QUERY's
+  // rounding (and 1/254 of the corpus') to the margin: the threshold of this level is thr + thr_raise (query_prep_kernel)
+  const uint8_t* resid8; int resid_ld;                       // [n_rows][resid_ld] or null
+  const float* q32; int64_t q32_ld;                          // fp32 queries (row-major copies of the batch)
+  const float* col_scale; int d_cls;                         // cs_c
+  const float* thr_raise;                                    // [Q_pad]
 };
+hipError_t launch_resid_build(const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls, const float* col_scale, uint8_t* resid8, int resid_ld, hipStream_t s);
 hipError_t launch_refine(const RefineArgs& a, hipStream_t s);
 hipError_t launch_rescore(const RescoreArgs& a, hipStream_t s);
 hipError_t launch_select(const SelectArgs& a, hipStream_t s);

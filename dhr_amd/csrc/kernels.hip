@@ -693,6 +693,15 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
       m += 1.001f * (i8_qn * i8_ec + i8_qe * i8_nc) + 1.2e-6f * (i8_qn + i8_qe) * i8_nc + 4.f * (float)(2 * (idx ? ts : 2 * ts) + 8) * mul;
       if (!(m >= 0.f)) m = INFINITY;                     // NaN somewhere: filter with -inf thresholds (everything is rescored exactly)
       i8_mul[q] = real ? mul : 0.f;
+      if (g8.thr_raise) {
+        // residual refine level: the corpus term ||q'|| ec of the margin is replaced by the measured  <q, d - sc*d8>  (up to what the
+        // residual image loses, ||q'|| ec2, the fp32 rounding of that sum and of the residuals themselves): the level's threshold is
+        // thr + (what the margin no longer has to pay)
+        const float gone = 1.001f * i8_qn * i8_ec;
+        const float left = 1.01f * i8_qn * g8.resid_ec2 + 1e-3f * gone + 4e-6f * (i8_qn + i8_qe) * i8_nc;
+        const float up = gone - left;
+        g8.thr_raise[q] = (up > 0.f && m < INFINITY) ? up : 0.f;
+      }
     }
     margin[q] = m;
     tau[q] = -INFINITY;
@@ -1465,8 +1474,132 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
   if (!p.blk_off) return;
   }
 }
+// ---- dense-only int8 index: residual image and its refine level (RefineArgs::resid8)
+__global__ void __launch_bounds__(256) resid_build_kernel(const __half* __restrict__ vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls,
+                                                          const float* __restrict__ col_scale, uint8_t* __restrict__ resid8, int ld) {
+  const int64_t total = n_rows * (ld / 16);
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = g / (ld / 16);
+    const int c0 = (int)(g - row * (ld / 16)) * 16;
+    union { uint4 u; uint8_t b[16]; } o;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int c = c0 + e;
+      int r8 = 0;
+      if (c < d_cls) {
+        const float cs = col_scale[c];
+        const float f = __half2float(vals_rm[row * k_rm + d_dlr + c]);
+        const float rho = f - cs * (float)quant_i8(f, 1.f / cs);         // |rho| <= cs / 2 (a value beyond 127 steps does not occur: cs >= column maximum / 127)
+        float t = rintf(rho * (254.f / cs));
+        t = t < -127.f ? -127.f : (t > 127.f ? 127.f : t);               // NaN / inf values: the margin of such an index is infinite anyway
+        r8 = (int)t;
+      }
+      o.b[e] = (uint8_t)(r8 + 128);
+    }
+    *(uint4*)(resid8 + row * ld + c0) = o.u;
+  }
+}
+hipError_t launch_resid_build(const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls, const float* col_scale, uint8_t* resid8, int resid_ld, hipStream_t s) {
+  if (n_rows <= 0) return hipSuccess;
+  const int64_t blocks = (n_rows * (resid_ld / 16) + 255) / 256;
+  hipLaunchKernelGGL(resid_build_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, vals_rm, k_rm, n_rows, d_dlr, d_cls, col_scale, resid8, resid_ld);
+  return hipGetLastError();
+}
+// 16 lanes per candidate, CH bytes of its residual row each (768 columns: 48); the lane's CH query factors q_c cs_c / 254 stay in registers
+// for the workgroup's 256 candidates of one query
+template <int CH>
+__global__ void __launch_bounds__(256) dense_refine_kernel(RefineArgs p) {
+  __shared__ float a_s[1024];
+  __shared__ float part[256];
+  int q = blockIdx.y;
+  uint32_t blk = blockIdx.x;
+  const int sub = threadIdx.x & 15;
+  for (uint32_t fb = blockIdx.x;; fb += gridDim.x) {       // flat launches: grid stride over the block list (see rescore_kernel); else one pass
+  if (p.blk_off && !flat_block(p.blk_off, p.n_queries, fb, q, blk)) return;
+  uint32_t count = p.cnt[q];
+  if (count > p.cap) count = p.cap;
+  const uint32_t base = blk * REFINE_PER_WG;
+  if (base >= count) { if (p.blk_off) continue; return; }
+  __syncthreads();                                           // the previous block's readers are done with the staged factors
+  float ps = 0.f;
+  for (int j = threadIdx.x; j < CH * 16; j += 256) {
+    const float a = j < p.d_cls ? p.q32[(int64_t)q * p.q32_ld + j] * p.col_scale[j] * (1.f / 254.f) : 0.f;
+    a_s[j] = a;
+    ps += a;
+  }
+  part[threadIdx.x] = ps;
+  __syncthreads();
+  // lane `sub` owns the 16-byte pieces sub, 16 + sub, ... of a row (one load instruction of the candidate's 16 lanes = 256 contiguous bytes)
+  constexpr int U = CH / 16;
+  float a[CH];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a[u * 16 + e] = a_s[u * 256 + sub * 16 + e];
+  float off = part[threadIdx.x & 63] + part[64 + (threadIdx.x & 63)] + part[128 + (threadIdx.x & 63)] + part[192 + (threadIdx.x & 63)];
+  off = wave_sum(off) * 128.f;                               // 128 * sum of the factors: the residuals are stored with an offset of 128
+  const float t = p.thr[q] + p.thr_raise[q];
+  // the loads of the NEXT 16 candidates go out before the current ones are summed (the kernel waits for round trips, not for bytes)
+  auto fetch = [&](uint32_t i, uint2& c, uint4 (&v)[U]) __attribute__((always_inline)) {
+    c = make_uint2(0u, 0u);
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+    if (i < count) {
+      c = p.cand[(int64_t)q * p.cap + i];
+      const uint8_t* r = p.resid8 + (int64_t)c.x * p.resid_ld + sub * 16;
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = gather16(r + u * 256);
+    }
+  };
+  uint2 c;
+  uint4 v[U];
+  fetch(base + (threadIdx.x >> 4), c, v);
+  for (uint32_t i = base + (threadIdx.x >> 4); i < base + REFINE_PER_WG; i += 16) {
+    uint2 cn;
+    uint4 vn[U];
+    fetch(i + 16 < base + REFINE_PER_WG ? i + 16 : 0xffffffffu, cn, vn);
+    float dot = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+      for (int d4 = 0; d4 < 4; ++d4) {
+        dot += a[u * 16 + d4 * 4 + 0] * (float)(w[d4] & 0xffu);
+        dot += a[u * 16 + d4 * 4 + 1] * (float)((w[d4] >> 8) & 0xffu);
+        dot += a[u * 16 + d4 * 4 + 2] * (float)((w[d4] >> 16) & 0xffu);
+        dot += a[u * 16 + d4 * 4 + 3] * (float)(w[d4] >> 24);
+      }
+    }
+    dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64); dot += __shfl_xor(dot, 8, 64);
+    if (sub == 0 && i < count) {
+      float u2 = __uint_as_float(c.y) + (dot - off);
+      u2 += fabsf(u2) * 2.4e-7f;                             // the sum of the two rounded up (the fp32 error of the dot product is in thr_raise's slack)
+      if (u2 >= t) {
+        const uint32_t slot = atomicAdd(p.out_cnt + q, 1u);
+        if (slot < p.out_cap) p.out[(int64_t)q * p.out_cap + slot] = make_uint2(c.x, __float_as_uint(u2));
+      }
+    }
+    c = cn;
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = vn[u];
+  }
+  if (!p.blk_off) return;
+  }
+}
 hipError_t launch_refine(const RefineArgs& a, hipStream_t s) {
   if (a.max_count == 0 || a.n_queries <= 0) return hipSuccess;
+  if (a.resid8) {
+    const dim3 grid = a.blk_off ? dim3(std::min<uint32_t>(a.flat_blocks, FLAT_GRID_MAX)) : dim3((a.max_count + REFINE_PER_WG - 1) / REFINE_PER_WG, (unsigned)a.n_queries);
+    if (a.blk_off && !a.flat_blocks) return hipSuccess;
+    switch (a.resid_ld / 16) {
+      case 16: hipLaunchKernelGGL(dense_refine_kernel<16>, grid, dim3(256), 0, s, a); break;
+      case 32: hipLaunchKernelGGL(dense_refine_kernel<32>, grid, dim3(256), 0, s, a); break;
+      case 48: hipLaunchKernelGGL(dense_refine_kernel<48>, grid, dim3(256), 0, s, a); break;
+      case 64: hipLaunchKernelGGL(dense_refine_kernel<64>, grid, dim3(256), 0, s, a); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   const bool g8 = a.g8_q8 != nullptr;
   const size_t lds = (size_t)a.d_dlr * (g8 ? 8 : 4);
   const dim3 grid = a.blk_off ? dim3(std::min<uint32_t>(a.flat_blocks, FLAT_GRID_MAX)) : dim3((a.max_count + REFINE_PER_WG - 1) / REFINE_PER_WG, (unsigned)a.n_queries);

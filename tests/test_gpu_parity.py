@@ -1898,3 +1898,35 @@ def test_persistent_workgroup_gemm(G, force_gated_i8, n, nq, d_dlr, d_cls, k):
     for i in (0, 1, 2, nq // 2, nq - 1):
         ex = O.gip_scores_f64(q32[i], qi[i], c32, ci)
         O.check_topk(out[6][1][i], out[6][0][i], ex, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["gauss", "outlier_columns", "spiky_rows", "tiny", "fp32_queries", "one_hot_queries"])
+def test_dense_only_residual_refine(G, kind):
+    """Dense-only int8 index (`dhr_set_option(DHR_OPT_DENSE_I8, 1)`): between the filter and the exact rescoring sits the RESIDUAL level --
+    768 bytes per candidate that hold what the int8 image lost (in 1/254 of a column's step), so that the corpus half of the margin is
+    measured instead of bounded.  Results equal the fp16 index's bit for bit and the oracle's top-k on inputs that stress both roundings;
+    on plain Gaussian columns the level removes most of the bound candidates."""
+    from dhr_amd import _lib
+    rng = np.random.default_rng(zlib.crc32(kind.encode()) % 997)
+    n, nq, d, k = 60_000, 24, 768, 100
+    cv = (rng.standard_normal((n, d)) * 0.1).astype(np.float32)
+    qv = (rng.standard_normal((nq, d)) * 0.1).astype(np.float32)
+    if kind == "outlier_columns":
+        cv[:, ::97] *= 30.0
+        qv[:, ::97] *= 0.2
+    elif kind == "spiky_rows":
+        cv[::11] = 0
+        cv[np.arange(0, n, 11), rng.integers(0, d, len(range(0, n, 11)))] = 6.0
+    elif kind == "tiny":
+        cv *= 1e-3
+    elif kind == "fp32_queries":
+        qv = qv * np.float32(1.0001) + np.float32(1e-5)
+    elif kind == "one_hot_queries":
+        qv[:] = 0
+        qv[np.arange(nq), rng.integers(0, d, nq)] = 1.5
+    cv = cv.astype(np.float16)
+    qv = qv.astype(np.float32)
+    st0, st1, _, _ = _i8_pair(G, cv, None, qv, None, k)
+    if kind == "gauss":
+        assert st1["candidates_exact"] - 256 * nq < 0.6 * st1["candidates_bound"], st1      # the residual level did prune (`exact` also counts the 256 head rows of every query)
