@@ -109,7 +109,7 @@ struct dhr_index {
   // maxima of ||d - scale*d8|| and ||scale*d8|| over the ungated part of a row (the filter margin pays for them, query_prep_kernel)
   bool dense_i8 = false;
   float i8_scale = 0.f, i8_ec = 0.f, i8_nc = 0.f;
-  uint8_t* resid8 = nullptr;               // dense-only int8 index: [n_rows][resid_ld] residual image (what the int8 image lost, in 1/254 steps, + 128): the refine level
+  uint8_t* resid8 = nullptr;               // dense-only int8 index: [n_rows][resid_ld] residual image (what the int8 image lost, four bits per value in 1/14 steps, + 8): the refine level
   int resid_ld = 0;
   float resid_ec2 = 0.f;                   //   >= the norm of what the residual image itself loses (weighted space of i8_ec)
   float* i8_col_scale = nullptr;           // [d_cls] int8 step of every ungated column (its largest |value| / 127): outlier columns do not cost the others their resolution
@@ -499,19 +499,19 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
   }
   // dense-only int8 index: residual image = the refine level between the filter and the exact rescoring (DHR_DENSE_RESID=0 switches it off).
   // The int8 margin is  ||q'|| ec (corpus rounding) + ||q' - q8'|| nc (query rounding); with the residuals the first term is MEASURED per
-  // candidate from 768 bytes instead of bounded, and the candidates that only the corpus half of the margin let through never reach the
-  // 1.5 KB rows of the exact rescoring.
+  // candidate from 384 bytes (four bits per value) instead of bounded, and the candidates that only the corpus half of the margin let through
+  // never reach the 1.5 KB rows of the exact rescoring.
   {
     static const int env_resid = getenv("DHR_DENSE_RESID") ? atoi(getenv("DHR_DENSE_RESID")) : 1;
-    const int ld = (int)round_up(ix->d_cls, 256);
-    if (env_resid != 0 && ix->dense_i8 && ix->d_dlr == 0 && ld <= 1024 && ix->i8_ec > 0.f) {
+    const int ld = (int)round_up(ix->d_cls, 256) / 2;           // four bits per value
+    if (env_resid != 0 && ix->dense_i8 && ix->d_dlr == 0 && ld <= 512 && ix->i8_ec > 0.f) {
       const size_t rb = (size_t)ix->n_rows * ld;
       if (hipMalloc((void**)&ix->resid8, rb) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMalloc of the residual image failed"));
       ix->index_bytes += (int64_t)rb;
       ix->resid_ld = ld;
       if (launch_resid_build(ix->vals_rm, ix->k_rm, ix->n_rows, ix->d_dlr, ix->d_cls, ix->i8_col_scale, ix->resid8, ld, s) != hipSuccess)
         return fail(set_error(DHR_ERR_HIP, "residual image launch failed"));
-      ix->resid_ec2 = std::sqrt((float)ix->d_cls) * ix->i8_scale / 508.f;      // every residual is within half of 1/254 of its column's step: scale / 508 in the weighted space
+      ix->resid_ec2 = std::sqrt((float)ix->d_cls) * ix->i8_scale / 28.f;       // every residual is within half of 1/14 of its column's step: scale / 28 in the weighted space
     }
   }
   const size_t tile_bytes = ix->ts + ix->td > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * (ix->gated_i8 ? S8_STAGE_A : SP_STAGE_A) + (size_t)ix->td * SP_DENSE)

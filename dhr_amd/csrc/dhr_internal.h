@@ -285,9 +285,9 @@ struct RefineArgs {
   const float* g8_unit;                                      // [Q_pad] score units of one gated operand product
   int abs_mode;
   int ungated;                                               // gated_i8, plain inner product batch: every listed entry counts in both directions (no bucket / index test)
-  // dense-only int8 index (round 4): the refine level is the RESIDUAL image of the corpus -- resid8[row][c] = 128 + rint((d - cs_c d8) * 254 / cs_c),
-  // what the int8 image of column c lost, in 1/254 of its step -- so that  U + sum_c q_c (cs_c / 254) (resid8 - 128)  leaves only the QUERY's
-  // rounding (and 1/254 of the corpus') to the margin: the threshold of this level is thr + thr_raise (query_prep_kernel)
+  // dense-only int8 index (round 4): the refine level is the RESIDUAL image of the corpus -- nibble c of a row = 8 + rint((d - cs_c d8) * 14 / cs_c),
+  // what the int8 image of column c lost, in 1/14 of its step -- so that  U + sum_c q_c (cs_c / 14) (nibble - 8)  leaves only the QUERY's
+  // rounding (and 1/15 of the corpus') to the margin: the threshold of this level is thr + thr_raise (query_prep_kernel)
   const uint8_t* resid8; int resid_ld;                       // [n_rows][resid_ld] or null
   const float* q32; int64_t q32_ld;                          // fp32 queries (row-major copies of the batch)
   const float* col_scale; int d_cls;                         // cs_c

@@ -1475,45 +1475,53 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
   }
 }
 // ---- dense-only int8 index: residual image and its refine level (RefineArgs::resid8)
+// FOUR bits per value: nibble = 8 + rint((d - cs d8) * 14 / cs) in [1, 15] (what the int8 image lost, in 1/14 of the column's step; columns 2b and
+// 2b + 1 in the low and high nibble of byte b).  A 768-column row is 384 bytes = three 128-byte lines: the level costs half the lines of an 8-bit
+// residual and leaves 1/15 of the corpus term to the margin instead of 1/255 (+7 % survivors).
 __global__ void __launch_bounds__(256) resid_build_kernel(const __half* __restrict__ vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls,
                                                           const float* __restrict__ col_scale, uint8_t* __restrict__ resid8, int ld) {
-  const int64_t total = n_rows * (ld / 16);
+  const int64_t total = n_rows * (ld / 8);
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = g / (ld / 16);
-    const int c0 = (int)(g - row * (ld / 16)) * 16;
-    union { uint4 u; uint8_t b[16]; } o;
+    const int64_t row = g / (ld / 8);
+    const int c0 = (int)(g - row * (ld / 8)) * 16;                       // 16 columns = 8 bytes per thread
+    uint32_t w[2] = {0u, 0u};
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int c = c0 + e;
-      int r8 = 0;
+      int r4 = 0;
       if (c < d_cls) {
         const float cs = col_scale[c];
         const float f = __half2float(vals_rm[row * k_rm + d_dlr + c]);
         const float rho = f - cs * (float)quant_i8(f, 1.f / cs);         // |rho| <= cs / 2 (a value beyond 127 steps does not occur: cs >= column maximum / 127)
-        float t = rintf(rho * (254.f / cs));
-        t = t < -127.f ? -127.f : (t > 127.f ? 127.f : t);               // NaN / inf values: the margin of such an index is infinite anyway
-        r8 = (int)t;
+        float t = rintf(rho * (14.f / cs));
+        t = t < -7.f ? -7.f : (t > 7.f ? 7.f : t);                       // NaN / inf values: the margin of such an index is infinite anyway
+        r4 = (int)t;
       }
-      o.b[e] = (uint8_t)(r8 + 128);
+      w[e >> 3] |= (uint32_t)(r4 + 8) << (4 * (e & 7));
     }
-    *(uint4*)(resid8 + row * ld + c0) = o.u;
+    *(uint2*)(resid8 + row * ld + c0 / 2) = make_uint2(w[0], w[1]);
   }
 }
 hipError_t launch_resid_build(const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls, const float* col_scale, uint8_t* resid8, int resid_ld, hipStream_t s) {
   if (n_rows <= 0) return hipSuccess;
-  const int64_t blocks = (n_rows * (resid_ld / 16) + 255) / 256;
+  const int64_t blocks = (n_rows * (resid_ld / 8) + 255) / 256;
   hipLaunchKernelGGL(resid_build_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, vals_rm, k_rm, n_rows, d_dlr, d_cls, col_scale, resid8, resid_ld);
   return hipGetLastError();
 }
-// 16 lanes per candidate, CH bytes of its residual row each (768 columns: 48); the lane's CH query factors q_c cs_c / 254 stay in registers
-// for the workgroup's 256 candidates of one query
+// 16 lanes per candidate, CH columns of its residual row each (768 columns: 48 = three 8-byte loads; one load instruction of the candidate's
+// 16 lanes = 128 contiguous bytes = one line).  The query factors a_c = q_c cs_c / 14 are quantised ONCE per workgroup to int8 (a_c = sa a8_c +
+// da_c; what that loses is at most 7 sum_c |da_c|, summed exactly here and taken off the level's threshold) so that eight columns cost
+// two v_dot4_i32_i8 and two mask operations instead of 32 vector instructions -- the first cut (fp32 factors, one shift + mask + convert +
+// multiply-add per nibble) spent more time on its arithmetic than on its gathers.  Integer sums: nothing is rounded before the final conversion.
 template <int CH>
 __global__ void __launch_bounds__(256) dense_refine_kernel(RefineArgs p) {
   __shared__ float a_s[1024];
-  __shared__ float part[256];
+  __shared__ uint32_t f_s[2 * 128];        // packed int8 factors: [0, 128) even columns of every group of eight, [128, 256) odd columns
+  __shared__ float red[3 * 4];             // per wave: max |a|, then sum a8 and sum |da| (as floats: both are below 2^24 in magnitude / harmlessly rounded UP below)
   int q = blockIdx.y;
   uint32_t blk = blockIdx.x;
-  const int sub = threadIdx.x & 15;
+  const int sub = threadIdx.x & 15, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NCOL = CH * 16;
   for (uint32_t fb = blockIdx.x;; fb += gridDim.x) {       // flat launches: grid stride over the block list (see rescore_kernel); else one pass
   if (p.blk_off && !flat_block(p.blk_off, p.n_queries, fb, q, blk)) return;
   uint32_t count = p.cnt[q];
@@ -1521,59 +1529,81 @@ __global__ void __launch_bounds__(256) dense_refine_kernel(RefineArgs p) {
   const uint32_t base = blk * REFINE_PER_WG;
   if (base >= count) { if (p.blk_off) continue; return; }
   __syncthreads();                                           // the previous block's readers are done with the staged factors
-  float ps = 0.f;
-  for (int j = threadIdx.x; j < CH * 16; j += 256) {
-    const float a = j < p.d_cls ? p.q32[(int64_t)q * p.q32_ld + j] * p.col_scale[j] * (1.f / 254.f) : 0.f;
+  float mx = 0.f;
+  for (int j = threadIdx.x; j < NCOL; j += 256) {
+    const float a = j < p.d_cls ? p.q32[(int64_t)q * p.q32_ld + j] * p.col_scale[j] * (1.f / 14.f) : 0.f;
     a_s[j] = a;
-    ps += a;
+    mx = fmaxf(mx, fabsf(a));
   }
-  part[threadIdx.x] = ps;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (lane == 0) red[wave] = mx;
   __syncthreads();
-  // lane `sub` owns the 16-byte pieces sub, 16 + sub, ... of a row (one load instruction of the candidate's 16 lanes = 256 contiguous bytes)
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sa = mx > 0.f && mx < INFINITY ? mx * (1.f / 127.f) : 1.f, inv_sa = 1.f / sa;
+  float s8 = 0.f, sd = 0.f;
+  for (int g8 = threadIdx.x; g8 < NCOL / 8; g8 += 256) {     // one group of eight columns per thread: its two packed factor words
+    uint32_t fe = 0u, fo = 0u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = a_s[g8 * 8 + e];
+      float r = rintf(a * inv_sa);
+      r = r < -127.f ? -127.f : (r > 127.f ? 127.f : r);     // (NaN: the index's margin is infinite anyway)
+      s8 += r;
+      sd += fabsf(a - sa * r);
+      const uint32_t b = (uint32_t)(int)r & 0xffu;
+      if (e & 1) fo |= b << (8 * (e >> 1)); else fe |= b << (8 * (e >> 1));
+    }
+    f_s[g8] = fe;
+    f_s[128 + g8] = fo;
+  }
+  s8 = wave_sum(s8); sd = wave_sum(sd);
+  if (lane == 0) { red[4 + wave] = s8; red[8 + wave] = sd; }
+  __syncthreads();
+  s8 = red[4] + red[5] + red[6] + red[7];
+  sd = (red[8] + red[9] + red[10] + red[11]) * 1.0001f;
+  // lane `sub` owns the 8-byte pieces sub, 16 + sub, ... of a row = columns 256 u + 16 sub ..: groups of eight 32 u + 2 sub, 32 u + 2 sub + 1
   constexpr int U = CH / 16;
-  float a[CH];
+  uint32_t fe[2 * U], fo[2 * U];
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) a[u * 16 + e] = a_s[u * 256 + sub * 16 + e];
-  float off = part[threadIdx.x & 63] + part[64 + (threadIdx.x & 63)] + part[128 + (threadIdx.x & 63)] + part[192 + (threadIdx.x & 63)];
-  off = wave_sum(off) * 128.f;                               // 128 * sum of the factors: the residuals are stored with an offset of 128
-  const float t = p.thr[q] + p.thr_raise[q];
+    for (int h = 0; h < 2; ++h) { fe[2 * u + h] = f_s[32 * u + 2 * sub + h]; fo[2 * u + h] = f_s[128 + 32 * u + 2 * sub + h]; }
+  const int off = 8 * (int)s8;                               // the residuals are stored with an offset of 8 (s8 is an integer below 2^17: exact)
+  const float t = p.thr[q] + p.thr_raise[q] - 7.f * sd;      // 7 sum |da|: what the int8 factors can be off by over a row's residuals
   // the loads of the NEXT 16 candidates go out before the current ones are summed (the kernel waits for round trips, not for bytes)
-  auto fetch = [&](uint32_t i, uint2& c, uint4 (&v)[U]) __attribute__((always_inline)) {
+  auto fetch = [&](uint32_t i, uint2& c, uint2 (&v)[U]) __attribute__((always_inline)) {
     c = make_uint2(0u, 0u);
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+    for (int u = 0; u < U; ++u) v[u] = make_uint2(0x88888888u, 0x88888888u);
     if (i < count) {
       c = p.cand[(int64_t)q * p.cap + i];
-      const uint8_t* r = p.resid8 + (int64_t)c.x * p.resid_ld + sub * 16;
+      const uint8_t* r = p.resid8 + (int64_t)c.x * p.resid_ld + sub * 8;
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = gather16(r + u * 256);
+      for (int u = 0; u < U; ++u) v[u] = gather8(r + u * 128);
     }
   };
   uint2 c;
-  uint4 v[U];
+  uint2 v[U];
   fetch(base + (threadIdx.x >> 4), c, v);
   for (uint32_t i = base + (threadIdx.x >> 4); i < base + REFINE_PER_WG; i += 16) {
     uint2 cn;
-    uint4 vn[U];
+    uint2 vn[U];
     fetch(i + 16 < base + REFINE_PER_WG ? i + 16 : 0xffffffffu, cn, vn);
-    float dot = 0.f;
+    int isum = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      const uint32_t w[2] = {v[u].x, v[u].y};
 #pragma unroll
-      for (int d4 = 0; d4 < 4; ++d4) {
-        dot += a[u * 16 + d4 * 4 + 0] * (float)(w[d4] & 0xffu);
-        dot += a[u * 16 + d4 * 4 + 1] * (float)((w[d4] >> 8) & 0xffu);
-        dot += a[u * 16 + d4 * 4 + 2] * (float)((w[d4] >> 16) & 0xffu);
-        dot += a[u * 16 + d4 * 4 + 3] * (float)(w[d4] >> 24);
+      for (int h = 0; h < 2; ++h) {
+        isum = __builtin_amdgcn_sdot4((int)fe[2 * u + h], (int)(w[h] & 0x0f0f0f0fu), isum, false);
+        isum = __builtin_amdgcn_sdot4((int)fo[2 * u + h], (int)((w[h] >> 4) & 0x0f0f0f0fu), isum, false);
       }
     }
-    dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64); dot += __shfl_xor(dot, 8, 64);
+    isum += __shfl_xor(isum, 1, 64); isum += __shfl_xor(isum, 2, 64); isum += __shfl_xor(isum, 4, 64); isum += __shfl_xor(isum, 8, 64);
     if (sub == 0 && i < count) {
-      float u2 = __uint_as_float(c.y) + (dot - off);
-      u2 += fabsf(u2) * 2.4e-7f;                             // the sum of the two rounded up (the fp32 error of the dot product is in thr_raise's slack)
+      float u2 = __uint_as_float(c.y) + sa * (float)(isum - off);
+      u2 += fabsf(u2) * 4.8e-7f;                             // the product and the sum rounded up
       if (u2 >= t) {
         const uint32_t slot = atomicAdd(p.out_cnt + q, 1u);
         if (slot < p.out_cap) p.out[(int64_t)q * p.out_cap + slot] = make_uint2(c.x, __float_as_uint(u2));
@@ -1591,7 +1621,7 @@ hipError_t launch_refine(const RefineArgs& a, hipStream_t s) {
   if (a.resid8) {
     const dim3 grid = a.blk_off ? dim3(std::min<uint32_t>(a.flat_blocks, FLAT_GRID_MAX)) : dim3((a.max_count + REFINE_PER_WG - 1) / REFINE_PER_WG, (unsigned)a.n_queries);
     if (a.blk_off && !a.flat_blocks) return hipSuccess;
-    switch (a.resid_ld / 16) {
+    switch (a.resid_ld / 8) {            // columns per lane = 2 x row bytes / 16 lanes
       case 16: hipLaunchKernelGGL(dense_refine_kernel<16>, grid, dim3(256), 0, s, a); break;
       case 32: hipLaunchKernelGGL(dense_refine_kernel<32>, grid, dim3(256), 0, s, a); break;
       case 48: hipLaunchKernelGGL(dense_refine_kernel<48>, grid, dim3(256), 0, s, a); break;
