@@ -961,16 +961,14 @@ static uint32_t async_grid() {
   return g ? g : FLAT_GRID_ASYNC;
 }
 static int gemm_phase_async(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi, int map_mode, int period, int64_t head,
-                            Timer& tm, dhr_search_stats& st, hipStream_t s, uint32_t* d_fullest = nullptr) {
+                            Timer& tm, dhr_search_stats& st, hipStream_t s) {
   GemmArgs g{};
   g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr; g.g8_rsum = ix->g8_rsum;
   g.seq_lo = lo; g.seq_hi = hi; g.map_mode = map_mode; g.period = period; g.head = head; g.n_tiles = ix->n_tiles;
   g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt;
   g.cap = (uint32_t)w.cap; g.n_queries = Q;
   HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));
-  tm.begin(T_GEMM); HIP_TRY(launch_gemm_filter(g, s)); tm.end();
-  HIP_TRY(launch_max_u32(w.cnt, Q, d_fullest ? d_fullest : w.d_max, w.d_stats + 0, s));
-  HIP_TRY(launch_mark_overflow(w.cnt, (uint32_t)w.cap, Q, w.fail_flags, s));
+  tm.begin(T_GEMM); HIP_TRY(launch_gemm_filter(g, s)); tm.end();      // (list statistics + overflow marks: rescore_select_async, one launch)
   const double rows = (double)(hi - lo) * TILE_ROWS;
   st.phases++;
   st.gemm_rows += (int64_t)rows;
@@ -978,29 +976,32 @@ static int gemm_phase_async(dhr_index* ix, Workspace& w, int Q, int64_t lo, int6
   st.gemm_flops_alg += 2.0 * (double)Q * rows * (double)ix->k;
   return DHR_OK;
 }
+// (d_fullest_bound / d_fullest: where the length of the fullest bound / survivor list of this phase is stored, or nullptr)
 static int rescore_select_async(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, const uint2* cand, const uint32_t* cnt,
-                                const float* thr, Timer& tm, hipStream_t s, uint32_t* d_fullest = nullptr) {
+                                const float* thr, Timer& tm, hipStream_t s, uint32_t* d_fullest_bound = nullptr, uint32_t* d_fullest = nullptr) {
   uint32_t list_cap = (uint32_t)w.cap;
-  if (uses_refine(ix, gate)) {
+  const bool refine = uses_refine(ix, gate);
+  // the bound lists: statistics, overflow marks, block offsets of the kernel that walks them and (refine) the survivor counters cleared
+  HIP_TRY(launch_lists_ready(cnt, (uint32_t)w.cap, Q, refine ? 256u : (uint32_t)RESCORE_CANDS_PER_WG, refine ? w.blk_off : w.blk_off + w.q_pad + 1,
+                             d_fullest_bound, refine ? nullptr : d_fullest, w.d_stats + 0, refine ? nullptr : w.d_stats + 1, w.fail_flags,
+                             refine ? w.cnt_r : nullptr, refine ? (int)w.q_pad : 0, s));
+  if (refine) {
     RefineArgs f{};
     f.cand = cand; f.cnt = cnt; f.cap = (uint32_t)w.cap; f.heavy_key = ix->heavy_key; f.heavy_val = ix->heavy_val;
     f.q_pack = w.q_pack; f.d_dlr = ix->d_dlr; f.thr = thr; f.out = w.cand_r; f.out_cnt = w.cnt_r; f.out_cap = (uint32_t)w.cap_r;
     f.n_queries = Q; f.max_count = 1;
     if (ix->gated_i8) { f.g8_q8 = w.g8_q8; f.g8_inv_cs = ix->g8_inv_cs; f.g8_unit = w.g8_unit; f.abs_mode = ix->abs_mode ? 1 : 0; f.ungated = gate ? 0 : 1; }
     if (ix->resid8) { f.resid8 = ix->resid8; f.resid_ld = ix->resid_ld; f.q32 = w.q32; f.q32_ld = ix->k_rm; f.col_scale = ix->i8_col_scale; f.d_cls = ix->d_cls; f.thr_raise = w.thr_raise; }
-    HIP_TRY(launch_block_offsets(cnt, (uint32_t)w.cap, Q, 256, w.blk_off, s));
     f.blk_off = w.blk_off; f.flat_blocks = async_grid();
-    HIP_TRY(hipMemsetAsync(w.cnt_r, 0, (size_t)w.q_pad * 4, s));
     tm.begin_on(T_REFINE, s); HIP_TRY(launch_refine(f, s)); tm.end_on(s);
-    HIP_TRY(launch_mark_overflow(w.cnt_r, (uint32_t)w.cap_r, Q, w.fail_flags, s));
     list_cap = (uint32_t)w.cap_r;
     cand = w.cand_r; cnt = w.cnt_r;
+    HIP_TRY(launch_lists_ready(cnt, list_cap, Q, (uint32_t)RESCORE_CANDS_PER_WG, w.blk_off + w.q_pad + 1, d_fullest, nullptr, w.d_stats + 1,
+                               nullptr, w.fail_flags, nullptr, 0, s));
   }
-  HIP_TRY(launch_max_u32(cnt, Q, d_fullest ? d_fullest : w.d_max, w.d_stats + 1, s));
   RescoreArgs r = base_rescore_args(ix, w, Q, gate);
   r.cand = cand; r.cnt = cnt; r.cap = list_cap; r.max_count = 1;
   r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
-  HIP_TRY(launch_block_offsets(cnt, list_cap, Q, RESCORE_CANDS_PER_WG, w.blk_off + w.q_pad + 1, s));
   r.blk_off = w.blk_off + w.q_pad + 1; r.flat_blocks = async_grid();
   tm.begin_on(T_RESCORE, s); HIP_TRY(launch_rescore(r, s)); tm.end_on(s);
   sel.cnt = cnt; sel.count_all = 0; sel.cap = list_cap;
@@ -1092,10 +1093,9 @@ static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectAr
     }
     if (async_ctl) {          // enqueue only: an overflowing list flags its query instead of halving the chunk
       // (d_max2: {fullest bound list, -, -, -, fullest survivor list} of the latest phase -- what the chunk plan of the main pass reads)
-      HIP_TRY(hipMemsetAsync(w.d_max2, 0, 32, s));
-      int rc = gemm_phase_async(ix, w, Q, pos, hi, map_mode, period, head, tm, st, s, w.d_max2);
+      int rc = gemm_phase_async(ix, w, Q, pos, hi, map_mode, period, head, tm, st, s);
       if (rc) return rc;
-      if ((rc = rescore_select_async(ix, w, Q, gate, sel, w.cand, w.cnt, w.thr, tm, s, w.d_max2 + 4)) != DHR_OK) return rc;
+      if ((rc = rescore_select_async(ix, w, Q, gate, sel, w.cand, w.cnt, w.thr, tm, s, w.d_max2, w.d_max2 + 4)) != DHR_OK) return rc;
       if (last_rows) *last_rows = (hi - pos) * TILE_ROWS;
       seen_rows += (hi - pos) * TILE_ROWS;
       pos = hi;
@@ -1390,10 +1390,12 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr_hat; g.cand = cand; g.cnt = cnt;
       g.cap = (uint32_t)w.cap; g.n_queries = Q;
       HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)w.q_pad * 4, sg));
-      HIP_TRY(hipMemsetAsync(w.d_max2 + 4 * (i & 1), 0, 16, sg));
+      if (!async_ctl) HIP_TRY(hipMemsetAsync(w.d_max2 + 4 * (i & 1), 0, 16, sg));
       tm.begin_on(T_GEMM, sg); HIP_TRY(launch_gemm_filter(g, sg)); tm.end_on(sg);
-      HIP_TRY(launch_max_u32(cnt, Q, w.d_max2 + 4 * (i & 1), (unsigned long long*)(w.d_max2 + 4 * (i & 1) + 2), sg));
-      HIP_TRY(hipMemcpyAsync(w.h_pinned2 + 16 * (i & 1), w.d_max2 + 4 * (i & 1), 16, hipMemcpyDeviceToHost, sg));
+      if (!async_ctl) {       // the host-driven controller sizes the per-candidate launches from the list lengths; the enqueue-only one leaves them on the device
+        HIP_TRY(launch_max_u32(cnt, Q, w.d_max2 + 4 * (i & 1), (unsigned long long*)(w.d_max2 + 4 * (i & 1) + 2), sg));
+        HIP_TRY(hipMemcpyAsync(w.h_pinned2 + 16 * (i & 1), w.d_max2 + 4 * (i & 1), 16, hipMemcpyDeviceToHost, sg));
+      }
       HIP_TRY(hipEventRecord(ev_gemm[i], sg));
       const double rows = (double)(hi - lo) * TILE_ROWS;
       st.phases++;
@@ -1410,8 +1412,6 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
         uint2* cand_a = (i & 1) ? w.cand2 : w.cand;
         uint32_t* cnt_a = (i & 1) ? w.cnt2 : w.cnt;
         if (sb != sg) HIP_TRY(hipStreamWaitEvent(sb, ev_gemm[i], 0));
-        HIP_TRY(launch_max_u32(cnt_a, Q, w.d_max, w.d_stats + 0, sb));
-        HIP_TRY(launch_mark_overflow(cnt_a, (uint32_t)w.cap, Q, w.fail_flags, sb));
         if ((rc = rescore_select_async(ix, w, Q, gate, sel, cand_a, cnt_a, w.thr_hat, tm, sb)) != DHR_OK) return rc;
         if (ix->progressive_thr) HIP_TRY(launch_raise_thr(w.thr_hat, sel.thr, Q, sb));
         if (extrapolate && i + 1 < M) {

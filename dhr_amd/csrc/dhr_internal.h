@@ -314,6 +314,9 @@ hipError_t launch_pq_decode(const uint8_t* codes, int64_t ld_codes, int64_t n, i
 // exclusive scan of ceil(min(cnt[q], cap) / per) over the queries -> offs[0 .. n_queries] (one workgroup)
 hipError_t launch_block_offsets(const uint32_t* cnt, uint32_t cap, int n_queries, uint32_t per, uint32_t* offs, hipStream_t s);
 hipError_t launch_max_u32(const uint32_t* v, int n, uint32_t* out_max, unsigned long long* out_sum, hipStream_t s);
+hipError_t launch_lists_ready(const uint32_t* cnt, uint32_t cap, int n_queries, uint32_t per, uint32_t* offs, uint32_t* out_max, uint32_t* out_max2,
+                              unsigned long long* out_sum, unsigned long long* out_sum2, uint32_t* fail_flags, uint32_t* zero, int n_zero,
+                              hipStream_t s);
 hipError_t launch_rows_to_local(const int64_t* rows, int64_t n, int64_t row_offset, int64_t n_rows, uint32_t* out,
                                 hipStream_t s);
 hipError_t launch_mark_overflow(const uint32_t* cnt, uint32_t cap, int n_queries, uint32_t* fail_flags, hipStream_t s);

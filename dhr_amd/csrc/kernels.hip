@@ -1276,6 +1276,64 @@ hipError_t launch_block_offsets(const uint32_t* cnt, uint32_t cap, int n_queries
   hipLaunchKernelGGL(block_offsets_kernel, dim3(1), dim3(1024), 0, s, cnt, cap, n_queries, per, offs);
   return hipGetLastError();
 }
+// The same scan with the rest of the bookkeeping a list set needs before a per-candidate kernel walks it, in ONE launch (the controller
+// without read-backs used four: max_u32 + mark_overflow + block_offsets + a fill; at ~8 us each they were ~40 us of every phase of a
+// sampled run and of every chunk of a shard's main pass): fullest list -> out_max / out_max2 (stored: one list set per launch), entries ->
+// atomicAdd(out_sum / out_sum2) (accumulated over the phases of a search), overflowed lists flag their query, and `zero` (the next level's
+// counters) is cleared.
+__global__ void __launch_bounds__(1024) lists_ready_kernel(const uint32_t* __restrict__ cnt, uint32_t cap, int n_queries, uint32_t per,
+                                                           uint32_t* __restrict__ offs, uint32_t* __restrict__ out_max, uint32_t* __restrict__ out_max2,
+                                                           unsigned long long* __restrict__ out_sum, unsigned long long* __restrict__ out_sum2,
+                                                           uint32_t* __restrict__ fail_flags, uint32_t* __restrict__ zero, int n_zero) {
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t wmax[16];
+  __shared__ unsigned long long wsum[16];
+  const int tid = threadIdx.x;
+  const int chunk = (n_queries + 1023) / 1024;
+  const int lo = tid * chunk, hi = min(lo + chunk, n_queries);
+  uint32_t s = 0, m = 0;
+  unsigned long long tot = 0;
+  for (int q = lo; q < hi; ++q) {
+    uint32_t c = cnt[q];
+    m = c > m ? c : m;
+    tot += c;
+    if (c > cap) { c = cap; if (fail_flags) fail_flags[q] = 1u; }
+    s += (c + per - 1) / per;
+  }
+  part[tid] = s;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t om = __shfl_xor(m, o, 64);
+    m = om > m ? om : m;
+    tot += __shfl_xor(tot, o, 64);
+  }
+  if ((tid & 63) == 0) { wmax[tid >> 6] = m; wsum[tid >> 6] = tot; }
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint32_t v = tid >= d ? part[tid - d] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = tid ? part[tid - 1] : 0u;
+  for (int q = lo; q < hi; ++q) { offs[q] = run; uint32_t c = cnt[q]; if (c > cap) c = cap; run += (c + per - 1) / per; }
+  if (tid == 1023) offs[n_queries] = part[1023];
+  if (tid == 0) {
+    for (int i = 1; i < 16; ++i) { m = wmax[i] > m ? wmax[i] : m; tot += wsum[i]; }
+    if (out_max) *out_max = m;
+    if (out_max2) *out_max2 = m;
+    if (out_sum) atomicAdd(out_sum, tot);
+    if (out_sum2) atomicAdd(out_sum2, tot);
+  }
+  for (int j = tid; j < n_zero; j += 1024) zero[j] = 0u;
+}
+hipError_t launch_lists_ready(const uint32_t* cnt, uint32_t cap, int n_queries, uint32_t per, uint32_t* offs, uint32_t* out_max, uint32_t* out_max2,
+                              unsigned long long* out_sum, unsigned long long* out_sum2, uint32_t* fail_flags, uint32_t* zero, int n_zero,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(lists_ready_kernel, dim3(1), dim3(1024), 0, s, cnt, cap, n_queries, per, offs, out_max, out_max2, out_sum, out_sum2, fail_flags,
+                     zero, n_zero);
+  return hipGetLastError();
+}
 __device__ __forceinline__ bool flat_block(const uint32_t* __restrict__ offs, int n_queries, uint32_t b, int& q, uint32_t& blk) {
   if (b >= offs[n_queries]) return false;
   int lo = 0, hi = n_queries;              // largest q with offs[q] <= b (offs[q+1] > b picks the non-empty one)
@@ -2549,30 +2607,69 @@ __global__ void __launch_bounds__(1024) merge_lists_kernel(int n_lists, int L, i
     osc[j] = -INFINITY;
     if (in_rows) orow[j] = -1;
   }
-  for (int e = tid; e < n_tot; e += nthr) {
-    const int l = e / L, j = e - l * L;
-    const int64_t src = ((int64_t)l * n_queries + q) * L + j;
-    uint32_t key = f32_ordered(in_scores[src]);
-    if (in_rows) {
-      const int64_t row = in_rows[src];
-      if (row < 0) key = 0u;
-      rw[e] = row < 0 ? INT64_MAX : row;
+  // eight lists' loads in flight per thread (one at a time they were serial HBM round trips; a flat index costs a division per entry and the
+  // kernel is bound by instruction issue)
+  for (int l0 = 0; l0 < n_lists; l0 += 8)
+    for (int j = tid; j < L; j += nthr) {
+      float sc[8];
+      int64_t rr[8];
+      const int64_t src0 = ((int64_t)l0 * n_queries + q) * L + j;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        sc[u] = 0.f; rr[u] = 0;
+        if (l0 + u < n_lists) {
+          sc[u] = in_scores[src0 + (int64_t)u * n_queries * L];
+          if (in_rows) rr[u] = in_rows[src0 + (int64_t)u * n_queries * L];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (l0 + u < n_lists) {
+          const int e = (l0 + u) * L + j;
+          uint32_t key = f32_ordered(sc[u]);
+          if (in_rows) {
+            if (rr[u] < 0) key = 0u;
+            rw[e] = rr[u] < 0 ? INT64_MAX : rr[u];
+          }
+          sk[e] = key;
+        }
     }
-    sk[e] = key;
+  __syncthreads();
+  // Entries that cannot reach the output are cut first: with P = ceil(k_out / n_lists), every list holds P entries >= the SMALLEST of the
+  // lists' P-th keys, so k_out entries reach that key and nothing below it is wanted.  At 8 lists of 448 for k = 1000 that leaves ~1 100 of
+  // 3 584 entries, spread over all threads (until round 4 a thread owned a fixed run of one list: the lanes on the lists' tails searched
+  // seven lists each only to find a rank beyond k_out: 0.85 -> 0.52 ms for 6 980 queries x 8 lists of 448).
+  __shared__ int act[64];
+  __shared__ uint32_t t_min;
+  if (tid == 0) t_min = 0xFFFFFFFFu;
+  __syncthreads();
+  const int P = (k_out + n_lists - 1) / n_lists;
+  if (tid < n_lists) atomicMin(&t_min, P <= L ? sk[tid * L + P - 1] : 0u);
+  __syncthreads();
+  if (tid < n_lists) {
+    const uint32_t t = t_min;
+    int lo = 0, hi = L;
+    while (lo < hi) {                                      // first entry below t
+      const int mid = (lo + hi) >> 1;
+      if (sk[tid * L + mid] >= t) lo = mid + 1; else hi = mid;
+    }
+    act[tid] = lo;
   }
   __syncthreads();
-  // A thread owns a run of consecutive entries of ONE list.  Its first entry finds its place in every other list by
-  // binary search; the next entries only advance from there (the places are monotone along a sorted run: ~2 probes
-  // per list instead of log2 L).  The kernel is bound by instruction issue, not by LDS latency or bandwidth.
-  const int tpl = nthr / n_lists;                         // threads per list
-  const int run = (L + tpl - 1) / tpl;
-  const int l = tid / tpl;
-  if (l < n_lists) {
-    const int j0 = (tid - l * tpl) * run, j1 = min(L, j0 + run);
+  int n_act = 0;
+  for (int m = 0; m < n_lists; ++m) n_act += act[m];
+  // A thread owns a run of consecutive live entries (list-major).  The first entry of a list in its run finds its place in every other
+  // list by binary search; the next ones only advance from there (the places are monotone along a sorted list).
+  const int run = (n_act + nthr - 1) / nthr;
+  const int f0 = tid * run, f1 = min(n_act, f0 + run);
+  if (f0 < f1) {
+    int l = 0, base = 0;
+    while (f0 >= base + act[l]) { base += act[l]; ++l; }
+    int j = f0 - base;
+    bool fresh = true;
     int pos[NL];
-#pragma unroll
-    for (int m = 0; m < NL; ++m) pos[m] = 0;
-    for (int j = j0; j < j1; ++j) {
+    for (int f = f0; f < f1; ++f, ++j) {
+      while (j >= act[l]) { ++l; j = 0; fresh = true; }
       const int e = l * L + j;
       const uint32_t key = sk[e];
       const int64_t row = in_rows ? rw[e] : 0;
@@ -2587,21 +2684,27 @@ __global__ void __launch_bounds__(1024) merge_lists_kernel(int n_lists, int L, i
 #pragma unroll
       for (int m = 0; m < NL; ++m) {
         if (m < n_lists && m != l) {
-          int p = pos[m];
-          if (j == j0) {
-            int hi = L;
+          const int am = act[m];
+          int p = fresh ? 0 : pos[m];
+          if (fresh) {
+            int hi = am;
             while (p < hi) {
               const int mid = (p + hi) >> 1;
               if (before(m, mid)) p = mid + 1; else hi = mid;
             }
           } else {
-            while (p < L && before(m, p)) ++p;
+            while (p < am && before(m, p)) ++p;
           }
           pos[m] = p;
           rank += p;
         }
       }
-      if (rank >= k_out) break;                            // ranks only grow along the run
+      fresh = false;
+      if (rank >= k_out) {                                 // ranks only grow along a list: the rest of this list in the run is not wanted
+        f += act[l] - 1 - j;
+        j = act[l] - 1;
+        continue;
+      }
       if (in_rows && row == INT64_MAX) continue;           // padding: the slot keeps (-inf, -1)
       osc[rank] = ordered_f32(key);
       if (in_rows) orow[rank] = row;

@@ -1153,10 +1153,16 @@ def test_config4_full_size_8_shards(G):
             for ix in shards:
                 torch.cuda.synchronize(); t = time.perf_counter()
                 outs.append(ix.search_finish(tau)); torch.cuda.synchronize(); tf.append(time.perf_counter() - t)
-            cnts = torch.stack([o[2] for o in outs]); kk = min(k, (int(cnts.max()) + 63) // 64 * 64)
+            # the merge as sharded.hip runs it: list prefixes of the fixed length prefix_len(k, world) (a shard holding more than that of
+            # a query's top-k flags the query for the repair path; none does here).  Timed: ONE shard's prefix cut + the rank merge of the
+            # gathered block (stacking the eight prefixes here stands for the all-gather, which is modelled below).
+            cnts = torch.stack([o[2] for o in outs]); kk = min(k, ((3 * k + ns - 1) // ns + 64 + 63) // 64 * 64)
+            assert int(cnts.max()) <= kk and int(cnts.min()) >= 0
             gs = torch.stack([o[0][:, :kk] for o in outs]); gr = torch.stack([o[1][:, :kk] for o in outs])
             torch.cuda.synchronize(); t = time.perf_counter()
+            cut = (outs[0][0][:, :kk].contiguous(), outs[0][1][:, :kk].contiguous())
             ms, mr = D.merge_sorted_lists(gs, gr, k); torch.cuda.synchronize(); tm = time.perf_counter() - t
+            del cut
             tot = max(tb) + tt + max(tf) + tm
             if best is None or tot < best[0]:
                 best = (tot, max(tb), tt, max(tf), tm, kk)

@@ -21,7 +21,8 @@ def timeit(fn, n=20):
 def main():
     q, k = 6980, 1000
     lib = _lib.load()
-    for n_lists, ll in [(8, 192), (8, 256), (8, 384), (8, 512), (4, 384), (2, 640), (8, 1000), (4, 1000), (2, 1000), (8, 58), (8, 99)]:
+    shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]          # e.g. 8x448: only these shapes
+    for n_lists, ll in shapes or [(8, 192), (8, 256), (8, 384), (8, 448), (8, 512), (4, 384), (2, 640), (8, 1000), (4, 1000), (2, 1000), (8, 58), (8, 99)]:
         s = torch.randn(n_lists, q, ll, device="cuda").sort(dim=2, descending=True).values
         r = torch.randint(0, 8_000_000, (n_lists, q, ll), device="cuda", dtype=torch.int64)
         cs = s.permute(1, 0, 2).reshape(q, -1).contiguous(); cr = r.permute(1, 0, 2).reshape(q, -1).contiguous()
