@@ -1,8 +1,7 @@
 #!/bin/bash
 O=gpurun_out/ab2; mkdir -p $O
-for i in 1 2; do
-timeout 900 python bench.py --workload dense --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/dense_$i.json
-python -c "import json; d=json.load(open('$O/dense_$i.json')); print('dense', d['ms_per_step'], d['value'], d['result_checksum'], d['phase_ms_per_step'], d['candidates_per_query'])"
-DHR_HIP_LIB=$PWD/dhr_amd/csrc/_ab/libdhr_hip_base.so timeout 900 python bench.py --workload dense --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/dense_base_$i.json
-python -c "import json; d=json.load(open('$O/dense_base_$i.json')); print('dense base', d['ms_per_step'], d['value'], d['result_checksum'], d['phase_ms_per_step'])"
-done
+timeout 900 python tools/stress.py 300 77 2>&1 | tail -2 > $O/stress.txt
+timeout 900 python tools/stress_sampled.py 2>&1 | tail -3 >> $O/stress.txt
+cat $O/stress.txt
+bash tools/prof_r04.sh bench 2>&1 | tail -9
+bash tools/prof_r04.sh trace 2>&1 | tail -32
