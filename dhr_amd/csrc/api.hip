@@ -140,7 +140,7 @@ struct dhr_index {
   hipStream_t s_gemm = nullptr;         // main-pass GEMM stream when CU masks are in use
   hipStream_t s_aux = nullptr;          // non-blocking stream for rescoring/select overlapped with the main-pass GEMM
   // staged search (dhr_search_begin / dhr_search_finish): state carried between the two calls
-  struct { bool valid = false, done = false, gate = false; int Q = 0, k = 0; double rate = 0.0, rate_r = 0.0; int64_t dev_bound = 0, dev_exact = 0; } pend;
+  struct { bool valid = false, done = false, gate = false, mid = false; int Q = 0, k = 0; double rate = 0.0, rate_r = 0.0; int64_t dev_bound = 0, dev_exact = 0; } pend;   // mid: dhr_search_mid ran the first slice of the main pass
   Workspace ws, ws_fb[2];              // ws_fb[d]: workspace of fallback depth d+1 (16x candidate capacity)
   dhr_search_stats stats{};
 };
@@ -1134,6 +1134,8 @@ static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectAr
 }
 
 // Leaves the sorted top-k keys of every query in w.topk_keys.  qb must already be validated.
+// stage 3 (dhr_search_mid): the first slice of the main pass with the caller's thresholds, then stop -- dhr_search_finish resumes behind it with
+// the thresholds the shards agree on from what they have seen by then.
 // stage 0: whole search.  stage 1 (dhr_search_begin): stop after the sampled run.  stage 2 (dhr_search_finish):
 // resume at the main pass with the caller's thresholds tau_ext (device [Q]); no local verification.
 // Conservative rank of the sampled threshold: the k/S top rows a 1/S sample holds on average + 5 sigma + 4 (4 sigma until round 2:
@@ -1165,11 +1167,17 @@ static int local_sample_rank(const dhr_index* ix, int r) {
   return std::min(r, (int)std::ceil(m + 5.0 * std::sqrt(m) + 4.0));
 }
 
+// Share of the main pass that dhr_search_mid runs before the shards agree on thresholds a second time, in 1/16ths (default 2 = 1/8: with the
+// 1/32 sample the shards have then seen ~15 % of their rows)
+static int mid_share16() {
+  static const int v = getenv("DHR_MID_SHARE16") ? std::max(1, std::min(12, atoi(getenv("DHR_MID_SHARE16")))) : 2;
+  return v;
+}
 static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, int k, int depth, Timer& tm,
                        dhr_search_stats& st, hipStream_t s, int stage = 0, const float* tau_ext = nullptr) {
   int rc;
-  const int Q = stage == 2 ? ix->pend.Q : qb->n_queries;
-  const bool gate = stage == 2 ? ix->pend.gate
+  const int Q = stage >= 2 ? ix->pend.Q : qb->n_queries;
+  const bool gate = stage >= 2 ? ix->pend.gate
                                : (ix->d_dlr > 0 && qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE);   // else plain IP
   const int64_t n = ix->n_rows;
   const int64_t group_rows = (int64_t)DOC_GROUP * TILE_ROWS;
@@ -1193,7 +1201,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   static const int env_async = getenv("DHR_ASYNC") ? atoi(getenv("DHR_ASYNC")) : -1;
   const bool async_ctl = depth == 0 && S >= 2 && (env_async < 0 ? ix->async_ctl != 0 : env_async != 0) && !getenv("DHR_DEBUG_PLAN");
   const bool plan_read = (env_async < 0 ? ix->async_ctl : env_async) >= 2;      // 2: the chunk plan of the main pass reads the sampled run's list lengths back
-  if (stage != 2) {
+  if (stage < 2) {
     tm.begin(T_PREP);
     if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
     HIP_TRY(hipMemsetAsync(w.topk_keys, 0, (size_t)w.q_pad * w.kp * 8, s));
@@ -1213,7 +1221,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   sel.n_queries = Q;
 
   // ---- phase 0: exhaustive exact scoring of rows [0, first_valid)
-  if (stage != 2) {
+  if (stage < 2) {
     RescoreArgs r = base_rescore_args(ix, w, Q, gate);
     r.row0 = 0; r.count_all = (uint32_t)first_valid; r.max_count = (uint32_t)first_valid;
     r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
@@ -1227,7 +1235,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     tm.begin(T_SELECT); HIP_TRY(launch_select(sel, s)); tm.end();
     st.candidates_exact += (int64_t)first_valid * Q;
   }
-  if (stage == 2 && ix->pend.done) return DHR_OK;              // the begin call already finished the search
+  if (stage >= 2 && ix->pend.done) return DHR_OK;              // the begin call already finished the search
   if (rest <= 0 || S < 2) {
     // plain streaming over all remaining tiles
     if (rest > 0 && (rc = stream_phases(ix, w, Q, gate, sel, rest, 1, 1, head, head, first_valid, tm, st, s)) != DHR_OK) return rc;
@@ -1238,7 +1246,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   // ---- sampled run: top-r_eff of {head rows} + {every S-th tile}  ->  tau_hat
   const int64_t n_sample = (rest + S - 1) / S;
   double rate = 0.0, rate_r = 0.0;
-  if (stage != 2) {
+  if (stage < 2) {
     int64_t last_rows = 0;
     if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, std::max<int64_t>(head, DOC_GROUP), first_valid, tm, st, s, &rate, &rate_r, async_ctl, &last_rows,
                             r_eff, first_valid + n_sample * TILE_ROWS)) != DHR_OK) return rc;
@@ -1254,15 +1262,22 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       rate_r = uses_refine(ix, gate) ? (double)hp[4] / (double)last_rows : 0.0;
     }
     if (stage == 1) {
-      ix->pend.valid = true; ix->pend.done = false; ix->pend.gate = gate; ix->pend.Q = Q; ix->pend.k = k; ix->pend.rate = rate; ix->pend.rate_r = rate_r;
+      ix->pend.valid = true; ix->pend.done = false; ix->pend.mid = false; ix->pend.gate = gate; ix->pend.Q = Q; ix->pend.k = k; ix->pend.rate = rate; ix->pend.rate_r = rate_r;
       return DHR_OK;
     }
   } else {
     rate = ix->pend.rate; rate_r = ix->pend.rate_r;
-    // thresholds agreed between the shards: tau_ext >= this shard's own tau_hat in general
-    HIP_TRY(hipMemcpyAsync(w.tau_hat, tau_ext, (size_t)Q * 4, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(launch_flag_tau_above(w.tau, w.tau_hat, Q, w.fail_flags, s));      // sample rows this shard dropped below its own (higher) threshold
-    HIP_TRY(launch_make_thr(w.tau_hat, w.margin, Q, w.q_pad, w.thr, s));
+    if (stage == 2 && ix->pend.mid) {
+      // second agreement (after dhr_search_mid): thresholds only ever rise
+      HIP_TRY(launch_raise_thr(w.tau_hat, tau_ext, Q, s));
+      HIP_TRY(launch_make_thr(w.tau_hat, w.margin, Q, w.q_pad, w.thr, s));
+      HIP_TRY(launch_raise_thr(w.thr_hat, w.thr, Q, s));
+    } else {
+      // thresholds agreed between the shards: tau_ext >= this shard's own tau_hat in general
+      HIP_TRY(hipMemcpyAsync(w.tau_hat, tau_ext, (size_t)Q * 4, hipMemcpyDeviceToDevice, s));
+      HIP_TRY(launch_flag_tau_above(w.tau, w.tau_hat, Q, w.fail_flags, s));      // sample rows this shard dropped below its own (higher) threshold
+      HIP_TRY(launch_make_thr(w.tau_hat, w.margin, Q, w.q_pad, w.thr, s));
+    }
   }
 
   // ---- main pass: all other tiles with the FROZEN threshold tau_hat - margin, in a few chunks; the
@@ -1273,14 +1288,16 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   // order (i -> i * perm_mul mod n_main, perm_mul ~ 0.618 n_main and coprime), so that what has been seen after any chunk is a
   // scattered fraction of the corpus whatever the order of the rows, and the thresholds are extrapolated from it (raise_thr_rank_kernel)
   const bool extrapolate = ix->progressive_thr >= 2 && stage == 0 && depth == 0 && n_main >= 64 && k >= 16;
+  const bool mid_proto = stage == 3 || (stage == 2 && ix->pend.mid);       // the shards agree a second time after a first slice: it must be a scattered one
+  const bool scatter = extrapolate || (mid_proto && n_main >= 64);
   int64_t perm_mul = 1;
-  if (extrapolate) {
+  if (scatter) {
     perm_mul = (int64_t)(0.6180339887 * (double)n_main) | 1;
     auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
     while (gcd(perm_mul, n_main) != 1) perm_mul += 2;
   }
   {
-    HIP_TRY(hipMemcpyAsync(w.thr_hat, w.thr, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
+    if (!(stage == 2 && ix->pend.mid)) HIP_TRY(hipMemcpyAsync(w.thr_hat, w.thr, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
     if (!w.cand2) {
       int64_t tot = 0;
       HIP_TRY(re_malloc(w.cand2, (size_t)w.q_pad * w.cap * 8, tot));
@@ -1351,13 +1368,15 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     // 10 000 queries) that is a fifth of the rows of a chunk, and with 2 chunks 195 queries per step overflowed their 65 536-entry lists and
     // were redone (60 ms per step instead of 28).  The first chunk is 3 / (2 M) of the pass.  (A shard chases its share of k.)
     {
-      const double k_eff = (double)k / (double)std::max(1, stage == 2 ? ix->sample_share : 1);
+      const double k_eff = (double)k / (double)std::max(1, stage >= 2 ? ix->sample_share : 1);
       const int64_t by_hot = (int64_t)std::ceil(300.0 * k_eff / (double)w.cap);
       const int64_t by_hot_r = (int64_t)std::ceil(65.0 * k_eff / (double)w.cap_r);
       by_size = std::max(by_size, std::min<int64_t>(24, std::max(by_hot, by_hot_r)));
     }
     const int64_t want = async_ctl ? std::max<int64_t>(std::max<int64_t>(ix->main_chunks, by_size), (plan_read && stage == 0) ? need : 0) : std::max<int64_t>(ix->main_chunks, need);
-    const int M = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, 64), n_main / (16 * DOC_GROUP)));
+    const int M_plain = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, 64), n_main / (16 * DOC_GROUP)));
+    // mid protocol: chunk 0 is the slice dhr_search_mid runs (mid_share16 / 16 of the pass), the plain plan covers the rest
+    const int M = mid_proto ? M_plain + 1 : M_plain;
     if (getenv("DHR_DEBUG_PLAN"))
       fprintf(stderr, "[dhr] main pass: rate %.3e (x n_main rows = %.0f of cap %lld), rate_r %.3e (%.0f of cap_r %lld), need %lld, chunks %d, n_main %lld tiles\n", rate,
               rate * (double)n_main * TILE_ROWS, (long long)w.cap, rate_r, rate_r * (double)n_main * TILE_ROWS, (long long)w.cap_r, (long long)need, M, (long long)n_main);
@@ -1365,14 +1384,18 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     // share) so that the refine/rescoring tail that cannot overlap a GEMM (the last chunk's) is short
     std::vector<int64_t> bound(M + 1, 0);
     {
+      const int first = mid_proto ? 1 : 0;
+      const int64_t off = mid_proto ? std::min<int64_t>(n_main, round_up(n_main * mid_share16() / 16, DOC_GROUP)) : 0;
+      bound[first] = off;
       double acc = 0.0, tot = 0.0;
-      for (int i = 0; i < M; ++i) tot += 1.0 + 2.0 * (M - 1 - i) / std::max(1, M - 1);
-      for (int i = 0; i < M; ++i) {
-        acc += 1.0 + 2.0 * (M - 1 - i) / std::max(1, M - 1);
-        bound[i + 1] = std::min<int64_t>(n_main, round_up((int64_t)(n_main * acc / tot), DOC_GROUP));
+      for (int i = 0; i < M_plain; ++i) tot += 1.0 + 2.0 * (M_plain - 1 - i) / std::max(1, M_plain - 1);
+      for (int i = 0; i < M_plain; ++i) {
+        acc += 1.0 + 2.0 * (M_plain - 1 - i) / std::max(1, M_plain - 1);
+        bound[first + i + 1] = std::min<int64_t>(n_main, off + round_up((int64_t)((n_main - off) * acc / tot), DOC_GROUP));
       }
       bound[M] = n_main;
     }
+    const int c_lo = (stage == 2 && ix->pend.mid) ? 1 : 0, c_hi = stage == 3 ? 1 : M;      // the chunks THIS call runs
     std::vector<hipEvent_t> ev_gemm(M), ev_done(M);
     for (int i = 0; i < M; ++i) {
       HIP_TRY(hipEventCreateWithFlags(&ev_gemm[i], hipEventDisableTiming));
@@ -1383,10 +1406,10 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       uint2* cand = (i & 1) ? w.cand2 : w.cand;
       uint32_t* cnt = (i & 1) ? w.cnt2 : w.cnt;
       const int64_t lo = bound[i], hi = bound[i + 1];
-      if (i >= 2) HIP_TRY(hipStreamWaitEvent(sg, ev_done[i - 2], 0));      // list set is free again
+      if (i >= c_lo + 2) HIP_TRY(hipStreamWaitEvent(sg, ev_done[i - 2], 0));      // list set is free again
       GemmArgs g{};
       g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr; g.g8_rsum = ix->g8_rsum;
-      g.seq_lo = lo; g.seq_hi = hi; g.map_mode = extrapolate ? 3 : 2; g.period = S; g.head = head; g.n_tiles = ix->n_tiles; g.perm_mul = perm_mul; g.perm_n = n_main;
+      g.seq_lo = lo; g.seq_hi = hi; g.map_mode = scatter ? 3 : 2; g.period = S; g.head = head; g.n_tiles = ix->n_tiles; g.perm_mul = perm_mul; g.perm_n = n_main;
       g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr_hat; g.cand = cand; g.cnt = cnt;
       g.cap = (uint32_t)w.cap; g.n_queries = Q;
       HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)w.q_pad * 4, sg));
@@ -1405,9 +1428,9 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       return DHR_OK;
     };
     (void)h;
-    if ((rc = enqueue_gemm(0)) != DHR_OK) return rc;
-    for (int i = 0; i < M; ++i) {
-      if (i + 1 < M && (rc = enqueue_gemm(i + 1)) != DHR_OK) return rc;
+    if ((rc = enqueue_gemm(c_lo)) != DHR_OK) return rc;
+    for (int i = c_lo; i < c_hi; ++i) {
+      if (i + 1 < c_hi && (rc = enqueue_gemm(i + 1)) != DHR_OK) return rc;
       if (async_ctl) {
         uint2* cand_a = (i & 1) ? w.cand2 : w.cand;
         uint32_t* cnt_a = (i & 1) ? w.cnt2 : w.cnt;
@@ -1440,11 +1463,12 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       }
       HIP_TRY(hipEventRecord(ev_done[i], sb));
     }
-    HIP_TRY(hipStreamWaitEvent(s, ev_done[M - 1], 0));
+    HIP_TRY(hipStreamWaitEvent(s, ev_done[c_hi - 1], 0));
     for (int i = 0; i < M; ++i) { hipEventDestroy(ev_gemm[i]); hipEventDestroy(ev_done[i]); }
     if (ev_enter) hipEventDestroy(ev_enter);
   }
-  if (stage == 2) return DHR_OK;                                // the caller verifies across shards
+  if (stage == 3) ix->pend.mid = true;
+  if (stage >= 2) return DHR_OK;                                // the caller verifies across shards
   // ---- verify; queries whose list overflowed or that found < k rows above tau_hat are redone exactly
   if (getenv("DHR_DEBUG_FAIL")) {        // diagnostics: which queries are about to be redone, and why
     std::vector<uint32_t> ff(Q); std::vector<float> th(Q);
@@ -1644,6 +1668,69 @@ extern "C" int32_t dhr_search_union_rank(const dhr_index* ix, int32_t k) {
   int S = 0, r = k;
   plan_sampling(ix, k, S, r);
   return S >= 2 ? r : 0;
+}
+
+// Ranks of the second agreement (dhr_search_mid): after the head, the sample and the first slice of the main pass a shard has seen the
+// fraction f of its rows, scattered; the union of what the shards have seen holds k f +- sqrt(k f (1 - f)) of the final top-k, so its
+// (k f + 6 sigma + 4)-th best score lies below the final k-th best (the counts verify it; a failure is repaired like any other).  A shard
+// reports its share of that rank (local_sample_rank's rule).
+extern "C" int32_t dhr_search_mid_ranks(const dhr_index* ix, int32_t k, int32_t* out_local, int32_t* out_union) {
+  if (out_local) *out_local = 0;
+  if (out_union) *out_union = 0;
+  if (!ix || k <= 0) return 0;
+  int S = 0, r = k;
+  plan_sampling(ix, k, S, r);
+  if (S < 2) return 0;
+  const int r_eff = local_sample_rank(ix, r);
+  int64_t first = ix->first_rows > 0 ? std::max<int64_t>(ix->first_rows, 2 * (int64_t)r_eff) : std::max<int64_t>(256, 2 * (int64_t)r_eff);
+  first = std::min(round_up(first, TILE_ROWS), round_up(ix->n_rows, TILE_ROWS));
+  const int64_t head = first / TILE_ROWS, rest = ix->n_tiles - head;
+  if (rest <= 0) return 0;
+  const int64_t n_sample = (rest + S - 1) / S, n_main = rest - n_sample;
+  if (n_main < 64) return 0;
+  const int64_t off = std::min<int64_t>(n_main, round_up(n_main * mid_share16() / 16, DOC_GROUP));
+  const double f = (double)(head + n_sample + off) / (double)ix->n_tiles;
+  const int ru = (int)std::min<double>(k, std::ceil((double)k * f + 6.0 * std::sqrt((double)k * f * (1.0 - f)) + 4.0));
+  const double m = (double)ru / std::max(1, ix->sample_share);
+  const int rl = ix->sample_share <= 1 ? ru : std::min(ru, (int)std::ceil(m + 5.0 * std::sqrt(m) + 4.0));
+  if (out_local) *out_local = rl;
+  if (out_union) *out_union = ru;
+  return rl;
+}
+// The first slice of the main pass with the thresholds of the first agreement; leaves the shard's r_local best scores seen so far in
+// out_scores_dev [Q, r_local] (r_local: dhr_search_mid_ranks, or what the shards agreed on).  dhr_search_finish then takes the thresholds of the
+// second agreement.
+static int search_mid_impl(dhr_index* ix, const float* tau_hat_dev, int32_t r_local, float* out_scores_dev, void* stream) {
+  if (!ix || !ix->pend.valid) return set_error(DHR_ERR_INVALID, "dhr_search_mid without a matching dhr_search_begin");
+  if (ix->pend.done) return DHR_OK;                   // the shard was not sampled: its search is complete already
+  if (ix->pend.mid) return set_error(DHR_ERR_INVALID, "dhr_search_mid called twice");
+  if (!tau_hat_dev || !out_scores_dev) return set_error(DHR_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = (hipStream_t)stream;
+  if (dhr_search_mid_ranks(ix, ix->pend.k, nullptr, nullptr) <= 0) return set_error(DHR_ERR_INVALID, "this index has no mid step (dhr_search_mid_ranks returned 0)");
+  if (r_local <= 0 || r_local > ix->pend.k) return set_error(DHR_ERR_INVALID, "r_local must be in [1, k]");
+  const int32_t rl = r_local;
+  Timer tm{ix->profile != 0, s, {}, {}};
+  dhr_search_stats st = ix->stats;
+  int rc;
+  if ((rc = search_core(ix, ix->ws, nullptr, ix->pend.k, 0, tm, st, s, 3, tau_hat_dev)) != DHR_OK) return rc;
+  HIP_TRY(launch_emit_scores(ix->ws.topk_keys, ix->ws.kp, ix->pend.Q, rl, out_scores_dev, s));
+  if (ix->profile) {
+    HIP_TRY(hipStreamSynchronize(s));
+    double ms[5] = {0, 0, 0, 0, 0};
+    tm.collect(ms);
+    st.gemm_ms += ms[T_GEMM]; st.refine_ms += ms[T_REFINE]; st.rescore_ms += ms[T_RESCORE]; st.select_ms += ms[T_SELECT];
+  }
+  ix->stats = st;
+  return DHR_OK;
+}
+extern "C" int dhr_search_mid(dhr_index* ix, const float* tau_hat_dev, int32_t r_local, float* out_scores_dev, void* stream) {
+  int rc = search_mid_impl(ix, tau_hat_dev, r_local, out_scores_dev, stream);
+  if (rc == DHR_OK && ix) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return rc;
+}
+extern "C" int dhr_internal_search_mid_async(dhr_index* ix, const float* tau_hat_dev, int32_t r_local, float* out_scores_dev, void* stream) {
+  return search_mid_impl(ix, tau_hat_dev, r_local, out_scores_dev, stream);
 }
 
 // sync = false (dhr_search_sharded*): only enqueues when the controller runs without read-backs -- the shards of a one-process search then

@@ -284,9 +284,23 @@ def sharded_search_host(shard, q_value, q_index, k: int, group=None):
         out(pr, r.shape, np.int64)[...] = r
         return 0
 
+    def cb_mid_ranks(_u, kk, share, p_local, p_union):
+        rl, ru = shard.mid_ranks(int(kk), int(share))
+        p_local[0], p_union[0] = int(rl), int(ru)
+        return int(rl)
+
+    def cb_mid(_u, tau, r_local, ps):
+        n = state["n"]
+        s = np.asarray(shard.search_mid(out(tau, (n,), np.float32).copy(), int(r_local)), np.float32)
+        out(ps, (n, int(r_local)), np.float32)[...] = s
+        return 0
+
+    has_mid = hasattr(shard, "search_mid")          # optional: the second threshold agreement (dhr_search_mid)
     hs = _lib.HostShard(None, _lib.HS_SAMPLE_RANK(lambda _u, kk, share: int(shard.sample_rank(int(kk), int(share)))),
                         _lib.HS_UNION_RANK(lambda _u, kk: int(shard.union_rank(int(kk)))), _lib.HS_BEGIN(guard(cb_begin)),
-                        _lib.HS_FINISH(guard(cb_finish)), _lib.HS_SEARCH(guard(cb_search)))
+                        _lib.HS_FINISH(guard(cb_finish)), _lib.HS_SEARCH(guard(cb_search)),
+                        _lib.HS_MID_RANKS(guard(cb_mid_ranks)) if has_mid else _lib.HS_MID_RANKS(),
+                        _lib.HS_MID(guard(cb_mid)) if has_mid else _lib.HS_MID())
     gather = _host_allgather(group) if world > 1 else _lib.ALLGATHER_FN(lambda *_a: 1)
     qb, keep = _lib.make_query_batch(q_value, q_index)
     scores = np.empty((nq, k), np.float32)

@@ -174,6 +174,24 @@ class GipIndex:
         del keep
         return out
 
+    def mid_ranks(self, k: int):
+        """(local, union) ranks of the second threshold agreement (dhr_search_mid_ranks); (0, 0): this index has no mid step."""
+        lo, un = C.c_int32(), C.c_int32()
+        self._lib.dhr_search_mid_ranks(self._h, int(k), C.byref(lo), C.byref(un))
+        return int(lo.value), int(un.value)
+
+    def search_mid(self, tau_hat, r_local: int = 0, stream: int = 0):
+        """First slice of the main pass with the common thresholds tau_hat [Q]; -> torch cuda tensor [Q, r_local]: this shard's best
+        scores seen so far (dhr_search_mid).  search_finish then takes the thresholds of the second agreement."""
+        import torch
+        nq, k = self._pending
+        dev = torch.device("cuda", self.device)
+        rl = int(r_local) or self.mid_ranks(k)[0]
+        out = torch.empty((nq, rl), dtype=torch.float32, device=dev)
+        tau_hat = tau_hat.to(device=dev, dtype=torch.float32).contiguous()
+        _lib.check(self._lib.dhr_search_mid(self._h, tau_hat.data_ptr(), rl, out.data_ptr(), stream), "dhr_search_mid")
+        return out
+
     def search_finish(self, tau_hat, stream: int = 0):
         """tau_hat: torch cuda tensor [Q] (or None after a non-sampled begin).  -> (scores [Q,k], rows [Q,k],
         count [Q] int32 rows reaching tau_hat, -1 = list overflow), all torch cuda tensors."""

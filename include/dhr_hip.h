@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DHR_VERSION 101 /* 0.1.1: dhr_comm_create_callback, dhr_search_sharded_host; dhr_search_sample_rank = the shard's share (see DHR_PARAM_SAMPLE_SHARE) */
+#define DHR_VERSION 102 /* 0.1.2: dhr_search_mid / dhr_search_mid_ranks (second threshold agreement of the sharded search), dhr_host_shard::mid_ranks / mid */
 
 typedef enum dhr_status {
   DHR_OK = 0,
@@ -219,6 +219,16 @@ int32_t dhr_search_union_rank(const dhr_index* index, int32_t k);
 int dhr_search_begin(dhr_index* index, const dhr_query_batch* queries, int32_t k, float* out_sample_scores_dev, void* stream);
 int dhr_search_finish(dhr_index* index, const float* tau_hat_dev, float* out_scores, int64_t* out_rows,
                       int32_t* out_count_dev, int32_t out_mem_kind, void* stream);
+/* Optional step between the two: a SECOND agreement on the thresholds.  dhr_search_mid runs the first slice of the main pass (1/8 of it,
+ * in scattered order) with the thresholds of the first agreement and leaves the shard's r_local best scores seen so far -- head, sample and
+ * slice -- in out_scores_dev [n_queries, r_local] (r_local: dhr_search_mid_ranks, or the largest over the shards where their sizes differ).
+ * The shards have then seen the fraction f of their rows; the caller gathers the blocks and
+ * takes the r_union-th best of the union per query (r_union = k f + 6 sigma + 4: it lies below the final k-th best), and hands
+ * max(first threshold, that) to dhr_search_finish, which runs the rest of the pass with it and counts against it.  A 1/8 shard of the 8.8 M-row
+ * benchmark then rescores ~360 instead of ~490 rows per query in its main pass.  dhr_search_mid_ranks returns r_local (also through
+ * out_local; 0: this index has no such step -- it is too small -- and dhr_search_finish follows dhr_search_begin directly). */
+int32_t dhr_search_mid_ranks(const dhr_index* index, int32_t k, int32_t* out_local, int32_t* out_union);
+int dhr_search_mid(dhr_index* index, const float* tau_hat_dev, int32_t r_local, float* out_scores_dev, void* stream);
 
 /* Exact gated inner product of each query against m given rows (stage 2 of --rerank,
  * gip_retrieval.py:144-146 / :207-208).  rows [n_queries, m] int64 GLOBAL rows (row < 0 -> -inf).
@@ -382,6 +392,9 @@ typedef struct dhr_host_shard {
   int32_t (*begin)(void* user, const dhr_query_batch* queries, int32_t k, int32_t share, float* out_sample);
   int32_t (*finish)(void* user, const float* tau, float* out_scores, int64_t* out_rows, int32_t* out_count);
   int32_t (*search)(void* user, const dhr_query_batch* queries, int32_t k, float* out_scores, int64_t* out_rows);
+  /* optional (both NULL: no second agreement): dhr_search_mid_ranks / dhr_search_mid of the shard */
+  int32_t (*mid_ranks)(void* user, int32_t k, int32_t share, int32_t* out_local, int32_t* out_union);
+  int32_t (*mid)(void* user, const float* tau, int32_t r_local, float* out_scores);
 } dhr_host_shard;
 int dhr_search_sharded_host(const dhr_host_shard* shard, int32_t world, int32_t rank, dhr_allgather_fn allgather, void* user,
                             const dhr_query_batch* queries, int32_t k, float* out_scores, int64_t* out_rows);

@@ -107,6 +107,38 @@ class _FakeShard:
         return np.take_along_axis(s, order, 1).astype(np.float32), order + self.lo
 
 
+class _FakeShardMid(_FakeShard):
+    """The same with the optional second agreement (dhr_host_shard::mid_ranks / mid; dhr_search_mid of a device shard): after the sample the
+    shard also looks at every row whose position is 1 mod 8 (a scattered eighth) and reports its best scores among everything seen."""
+
+    def _seen(self):
+        n = self.cv.shape[0]
+        m = np.zeros(n, bool)
+        m[::self.period] = True
+        m[1::8] = True
+        return m
+
+    def mid_ranks(self, k, share):
+        f = float(self._seen().mean())
+        ru = int(min(k, np.ceil(k * f + 6.0 * np.sqrt(k * f * (1.0 - f)) + 4.0)))
+        m = ru / max(share, 1)
+        rl = ru if share <= 1 else min(ru, int(np.ceil(m + 5.0 * np.sqrt(m) + 4.0)))
+        return rl, ru
+
+    def search_mid(self, tau, r_local):
+        s = self._scores(self.q)[:, self._seen()]
+        top = -np.sort(-s, axis=1)[:, :r_local]
+        if top.shape[1] < r_local:
+            top = np.concatenate([top, np.full((top.shape[0], r_local - top.shape[1]), -np.inf)], axis=1)
+        self.tau1 = np.array(tau)
+        self.calls.append("mid")
+        return top.astype(np.float32)
+
+    def search_finish(self, tau):
+        assert np.all(np.asarray(tau) >= self.tau1)            # the second agreement never lowers a threshold
+        return super().search_finish(tau)
+
+
 def _staged_worker(rank, world, port, tmp, mode):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -124,7 +156,12 @@ def _staged_worker(rank, world, port, tmp, mode):
                 cv[lo_:lo_ + 400:4] += 3.0 * q[0] / np.linalg.norm(q[0])
         lo, hi = D.shard_bounds(n, world, rank)
         # "rank_mismatch": the last rank disagrees on the union rank -> every rank must take the local-threshold path
-        shard = _FakeShard(cv[lo:hi], lo, r_skew=(3 if mode == "rank_mismatch" and rank == world - 1 else 0))
+        cls = _FakeShardMid if mode.startswith("mid") else _FakeShard
+        if mode == "mid_adversarial":      # the best rows of query 0 all sit on positions the shards have seen by the second agreement -> threshold too high
+            for r_ in range(world):
+                lo_ = D.shard_bounds(n, world, r_)[0]
+                cv[lo_ + 1:lo_ + 801:8] += 3.0 * q[0] / np.linalg.norm(q[0])
+        shard = cls(cv[lo:hi], lo, r_skew=(3 if mode == "rank_mismatch" and rank == world - 1 else 0))
         ms, mr = D.sharded_search_host(shard, q, None, k)
         full = q.astype(np.float64) @ cv.astype(np.float64).T
         for i in range(nq):
@@ -139,14 +176,16 @@ def _staged_worker(rank, world, port, tmp, mode):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("mode", ["plain", "adversarial", "rank_mismatch"])
+@pytest.mark.parametrize("mode", ["plain", "adversarial", "rank_mismatch", "mid", "mid_adversarial"])
 def test_sharded_core_over_gloo(tmp_path, mode, world):
     """The library's sharded control flow -- dhr_search_sharded_host: the same sharded_core that dhr_search_sharded runs over RCCL -- end
     to end with 2 and 3 ranks over gloo: sample exchange, agreement on the ranks, common threshold, count check, gathered prefixes,
     rank merge and, in the adversarial layout, the repair of the failed query with local thresholds; a rank that disagrees on the union
-    rank sends every rank down the local-threshold path."""
+    rank sends every rank down the local-threshold path.  "mid": shards that offer the second threshold agreement (dhr_search_mid) -- one
+    more exchange between begin and finish, thresholds that only rise; "mid_adversarial": the best rows of a query sit where the shards have
+    looked by then, the second threshold comes out too high, the counts catch it and the query is repaired."""
     import torch.multiprocessing as mp
-    port = 29700 + (os.getpid() % 2000) + 7 * world + ["plain", "adversarial", "rank_mismatch"].index(mode)
+    port = 29700 + (os.getpid() % 2000) + 7 * world + ["plain", "adversarial", "rank_mismatch", "mid", "mid_adversarial"].index(mode)
     mp.spawn(_staged_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     calls = [list(np.load(tmp_path / f"calls{r}.npy")) for r in range(world)]
     rows = [np.load(tmp_path / f"rows{r}.npy") for r in range(world)]
@@ -156,5 +195,5 @@ def test_sharded_core_over_gloo(tmp_path, mode, world):
     if mode == "rank_mismatch":
         assert calls[0] == ["search5"]
     else:
-        assert calls[0][:2] == ["begin", "finish"]
-        assert (len(calls[0]) == 3) == (mode == "adversarial")
+        assert calls[0][:3] == ["begin", "mid", "finish"] if mode.startswith("mid") else calls[0][:2] == ["begin", "finish"]
+        assert (len(calls[0]) == (4 if mode.startswith("mid") else 3)) == (mode in ("adversarial", "mid_adversarial"))

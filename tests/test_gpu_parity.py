@@ -661,8 +661,9 @@ def test_negative_query_values_on_nonneg_corpus(G, nb):
     _search_check(G, cv, ci, qv.astype(np.float32), qi, 100, idx_buckets=nb)
 
 
-def _fake_world_search(G, shards, q32, qi, k):
-    """dist.sharded_search with the collectives replaced by in-process tensor ops (one GPU, S shards)."""
+def _fake_world_search(G, shards, q32, qi, k, mid=False):
+    """dist.sharded_search with the collectives replaced by in-process tensor ops (one GPU, S shards); mid: with the second threshold
+    agreement (dhr_search_mid) between begin and finish."""
     import torch
     from dhr_amd import dist as D
     from dhr_amd import _lib
@@ -672,6 +673,13 @@ def _fake_world_search(G, shards, q32, qi, k):
     assert r > 0 and all(s.sample_rank(k) == r for s in shards)
     samples = [s.search_begin(q32, qi, k) for s in shards]
     tau = D.common_threshold(torch.stack(samples), shards[0].union_rank(k))
+    if mid:
+        ranks = [s.mid_ranks(k) for s in shards]
+        assert all(a > 0 and b > 0 for a, b in ranks), ranks
+        rl, ru = max(a for a, _ in ranks), max(b for _, b in ranks)
+        seen = [s.search_mid(tau, rl) for s in shards]
+        tau2 = D.common_threshold(torch.stack(seen), min(ru, len(shards) * rl))
+        tau = torch.maximum(tau, tau2)
     outs = [s.search_finish(tau) for s in shards]
     count = torch.stack([o[2] for o in outs])
     tot = count.clamp(min=0).sum(0)
@@ -688,8 +696,9 @@ def _fake_world_search(G, shards, q32, qi, k):
     return ms.cpu().numpy(), mr.cpu().numpy(), int(failed.numel()), [int(x) for x in tot[:4]]
 
 
+@pytest.mark.parametrize("mid", [False, True])
 @pytest.mark.parametrize("kind", ["hybrid", "dense"])
-def test_staged_sharded_search_common_threshold(G, kind, gated_image):
+def test_staged_sharded_search_common_threshold(G, kind, gated_image, mid):
     """Shards exchange their sample scores, agree on one threshold per query, and the union of their
     (now much shorter) lists still equals the unsharded exact result."""
     from dhr_amd import synth, _lib
@@ -707,16 +716,17 @@ def test_staged_sharded_search_common_threshold(G, kind, gated_image):
         lo, hi = G.shard_bounds(n, ns, sh)
         shards.append(G.GipIndex(cv[lo:hi], None if ci is None else ci[lo:hi], row_offset=lo))
         shards[-1].set_param(_lib.PARAM_SAMPLE_PERIOD, 4)          # 100k-row shards: sample every 4th tile
-    ms, mr, n_failed, tot = _fake_world_search(G, shards, q32, qi, k)
+    ms, mr, n_failed, tot = _fake_world_search(G, shards, q32, qi, k, mid=mid)
     exact_per_shard = [s.stats()["candidates_exact"] for s in shards]
     for s in shards:
         s.close()
     np.testing.assert_array_equal(mr, fr)
     np.testing.assert_array_equal(ms, fs)
-    print(kind, "failed", n_failed, "counts>=tau", tot, "rows rescored per shard and query", [e // 12 for e in exact_per_shard])
+    print(kind, "mid" if mid else "plain", "failed", n_failed, "counts>=tau", tot, "rows rescored per shard and query", [e // 12 for e in exact_per_shard])
 
 
-def test_staged_sharded_search_failure_path(G):
+@pytest.mark.parametrize("mid", [False, True])
+def test_staged_sharded_search_failure_path(G, mid):
     """All high-scoring rows sit in sample tiles of shard 0: the common threshold is too high for the
     union to reach k rows, the count check must catch it and the local fallback must repair it."""
     from dhr_amd import _lib
@@ -731,7 +741,7 @@ def test_staged_sharded_search_failure_path(G):
         lo, hi = G.shard_bounds(n, ns, sh)
         shards.append(G.GipIndex(cv[lo:hi], None, row_offset=lo))
         shards[-1].set_param(_lib.PARAM_SAMPLE_PERIOD, 16)         # the period the corpus is structured for
-    ms, mr, n_failed, tot = _fake_world_search(G, shards, q32, None, k)
+    ms, mr, n_failed, tot = _fake_world_search(G, shards, q32, None, k, mid=mid)
     for s in shards:
         s.close()
     assert n_failed == 5
@@ -1142,6 +1152,8 @@ def test_config4_full_size_8_shards(G):
         for ix in shards:
             ix.set_param(_lib.PARAM_SAMPLE_SHARE, ns)
         rnk = shards[0].union_rank(k)
+        rl_mid, ru_mid = max(s.mid_ranks(k)[0] for s in shards), max(s.mid_ranks(k)[1] for s in shards)
+        assert rl_mid > 0
         best = None
         for it in range(3):
             tb, tf, samples, outs = [], [], [], []
@@ -1150,9 +1162,17 @@ def test_config4_full_size_8_shards(G):
                 samples.append(ix.search_begin(qv, qi, k)); torch.cuda.synchronize(); tb.append(time.perf_counter() - t)
             torch.cuda.synchronize(); t = time.perf_counter()
             tau = D.common_threshold(torch.stack(samples), rnk); torch.cuda.synchronize(); tt = time.perf_counter() - t
+            # second agreement (sharded.hip step 2b): first slice of the main pass, the shards' best scores seen so far, tau raised
+            seen, tmid = [], []
+            for ix in shards:
+                torch.cuda.synchronize(); t = time.perf_counter()
+                seen.append(ix.search_mid(tau, rl_mid)); torch.cuda.synchronize(); tmid.append(time.perf_counter() - t)
+            torch.cuda.synchronize(); t = time.perf_counter()
+            tau = torch.maximum(tau, D.common_threshold(torch.stack(seen), min(ru_mid, ns * rl_mid))); torch.cuda.synchronize(); tt += time.perf_counter() - t
             for ix in shards:
                 torch.cuda.synchronize(); t = time.perf_counter()
                 outs.append(ix.search_finish(tau)); torch.cuda.synchronize(); tf.append(time.perf_counter() - t)
+            tf = [a_ + b_ for a_, b_ in zip(tf, tmid)]                  # "finish" = both parts of the main pass
             # the merge as sharded.hip runs it: list prefixes of the fixed length prefix_len(k, world) (a shard holding more than that of
             # a query's top-k flags the query for the repair path; none does here).  Timed: ONE shard's prefix cut + the rank merge of the
             # gathered block (stacking the eight prefixes here stands for the all-gather, which is modelled below).
@@ -1172,11 +1192,11 @@ def test_config4_full_size_8_shards(G):
         # blocks: sample scores [Q, r_local] fp32, counts [Q] int32, list prefixes [Q, kk] x (fp32 + int64), kk as sharded.hip prefix_len
         r_loc = shards[0].sample_rank(k)
         kk_fix = min(k, ((3 * k + ns - 1) // ns + 64 + 63) // 64 * 64)
-        coll = sum(50e-6 + b / 150e9 for b in (nq * r_loc * 4, nq * 4, nq * kk_fix * 4, nq * kk_fix * 8))
-        print("\n[config 4, emulated on one GPU] unsharded step %.1f ms; slowest shard per stage: begin %.2f + threshold %.2f + finish %.2f + merge %.2f "
-              "= %.2f ms -> %.2fx; + the 4 all-gathers modelled at 50 us + bytes / 150 GB/s each ([Q, %d] sample scores, [Q] counts, [Q, %d] x 12 B lists) "
+        coll = sum(50e-6 + b / 150e9 for b in (nq * r_loc * 4, nq * rl_mid * 4, nq * 4, nq * kk_fix * 4, nq * kk_fix * 8))
+        print("\n[config 4, emulated on one GPU] unsharded step %.1f ms; slowest shard per stage: begin %.2f + thresholds (two agreements) %.2f + main pass (first slice + rest) %.2f + merge %.2f "
+              "= %.2f ms -> %.2fx; + the 5 all-gathers modelled at 50 us + bytes / 150 GB/s each ([Q, %d] sample scores, [Q, %d] seen scores, [Q] counts, [Q, %d] x 12 B lists) "
               "= %.2f ms -> %.2f ms = %.2fx"
-              % (t_full * 1e3, best[1] * 1e3, best[2] * 1e3, best[3] * 1e3, best[4] * 1e3, best[0] * 1e3, t_full / best[0], r_loc, kk_fix, coll * 1e3,
+              % (t_full * 1e3, best[1] * 1e3, best[2] * 1e3, best[3] * 1e3, best[4] * 1e3, best[0] * 1e3, t_full / best[0], r_loc, rl_mid, kk_fix, coll * 1e3,
                  (best[0] + coll) * 1e3, t_full / (best[0] + coll)))
     finally:
         for s in shards:

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--sample-period", type=int, default=-1)
     ap.add_argument("--overlap-aux", type=int, default=-1)
     ap.add_argument("--aux-cus", type=int, default=-1)
+    ap.add_argument("--mid", type=int, default=0, help="1: second threshold agreement after the first slice of the main pass (dhr_search_mid)")
     a = ap.parse_args()
     import torch
     import bench
@@ -56,32 +57,49 @@ def main():
     for ix in shards:
         ix.set_param(_lib.PARAM_SAMPLE_SHARE, a.shards)
     rnk = shards[0].union_rank(k)
-    for it in range(2):
-        tb, tf, samples, outs = [], [], [], []
-        for ix in shards:
+    results = {}
+    for mid in ([0, 1] if a.mid else [0]):
+        for it in range(2):
+            tb, tf, samples, outs = [], [], [], []
+            for ix in shards:
+                torch.cuda.synchronize(); t = time.perf_counter()
+                samples.append(ix.search_begin(qv, qi, k)); torch.cuda.synchronize(); tb.append(time.perf_counter() - t)
+            st_begin = shards[0].stats()
+            t = time.perf_counter(); tau = D.common_threshold(torch.stack(samples), rnk); torch.cuda.synchronize(); tt = time.perf_counter() - t
+            tmid, tt2 = [0.0], 0.0
+            if mid:
+                rl, ru = shards[0].mid_ranks(k)
+                mids, tmid = [], []
+                for ix in shards:
+                    torch.cuda.synchronize(); t = time.perf_counter()
+                    mids.append(ix.search_mid(tau)); torch.cuda.synchronize(); tmid.append(time.perf_counter() - t)
+                t = time.perf_counter(); tau = torch.maximum(tau, D.common_threshold(torch.stack(mids), ru)); torch.cuda.synchronize(); tt2 = time.perf_counter() - t
+            for ix in shards:
+                torch.cuda.synchronize(); t = time.perf_counter()
+                outs.append(ix.search_finish(tau)); torch.cuda.synchronize(); tf.append(time.perf_counter() - t)
+            t = time.perf_counter()
+            cnts = torch.stack([o[2] for o in outs]); kk = min(k, (int(cnts.max()) + 63) // 64 * 64)
+            gs = torch.stack([o[0][:, :kk] for o in outs]); gr = torch.stack([o[1][:, :kk] for o in outs])     # what the all-gather leaves
             torch.cuda.synchronize(); t = time.perf_counter()
-            samples.append(ix.search_begin(qv, qi, k)); torch.cuda.synchronize(); tb.append(time.perf_counter() - t)
-        st_begin = shards[0].stats()
-        t = time.perf_counter(); tau = D.common_threshold(torch.stack(samples), rnk); torch.cuda.synchronize(); tt = time.perf_counter() - t
-        for ix in shards:
-            torch.cuda.synchronize(); t = time.perf_counter()
-            outs.append(ix.search_finish(tau)); torch.cuda.synchronize(); tf.append(time.perf_counter() - t)
-        t = time.perf_counter()
-        cnts = torch.stack([o[2] for o in outs]); kk = min(k, (int(cnts.max()) + 63) // 64 * 64)
-        gs = torch.stack([o[0][:, :kk] for o in outs]); gr = torch.stack([o[1][:, :kk] for o in outs])     # what the all-gather leaves
-        torch.cuda.synchronize(); t = time.perf_counter()
-        ms, mr = D.merge_sorted_lists(gs, gr, k); torch.cuda.synchronize(); tm = time.perf_counter() - t
-        tot = torch.stack([o[2] for o in outs]).clamp(min=0).sum(0)
-        call = torch.stack([o[2] for o in outs])
-        fmask = (tot < k) | (call < 0).any(0)
-        failed = int(fmask.sum())
-        if it == 1 and failed:
-            for q in torch.nonzero(fmask).flatten().tolist()[:8]:
-                print("  failed query %d: counts per shard %s  sum %d  tau %.5f  own 26th-best per shard %s" %
-                      (q, call[:, q].tolist(), int(tot[q]), float(tau[q]), [round(float(sm[q, -1]), 5) for sm in samples]))
-    st = shards[0].stats()
-    print("shards %d rank r=%d : begin max %.1f ms  finish max %.1f ms  tau %.2f ms  merge %.2f ms  -> est. step %.1f ms (+ all-gather)  failed queries %d"
-          % (a.shards, rnk, max(tb) * 1e3, max(tf) * 1e3, tt * 1e3, tm * 1e3, (max(tb) + max(tf) + tt + tm) * 1e3, failed))
+            ms, mr = D.merge_sorted_lists(gs, gr, k); torch.cuda.synchronize(); tm = time.perf_counter() - t
+            tot = torch.stack([o[2] for o in outs]).clamp(min=0).sum(0)
+            call = torch.stack([o[2] for o in outs])
+            fmask = (tot < k) | (call < 0).any(0)
+            failed = int(fmask.sum())
+            if it == 1 and failed:
+                for q in torch.nonzero(fmask).flatten().tolist()[:8]:
+                    print("  failed query %d: counts per shard %s  sum %d  tau %.5f  own 26th-best per shard %s" %
+                          (q, call[:, q].tolist(), int(tot[q]), float(tau[q]), [round(float(sm[q, -1]), 5) for sm in samples]))
+        st = shards[0].stats()
+        print("shards %d rank r=%d : begin max %.2f ms  mid max %.2f ms + tau2 %.2f ms  finish max %.2f ms  tau %.2f ms  merge %.2f ms  -> est. step %.2f ms (+ all-gather)  failed queries %d"
+              % (a.shards, rnk, max(tb) * 1e3, max(tmid) * 1e3, tt2 * 1e3, max(tf) * 1e3, tt * 1e3, tm * 1e3, (max(tb) + max(tmid) + tt2 + max(tf) + tt + tm) * 1e3, failed))
+        if mid:
+            print("mid ranks (local, union):", shards[0].mid_ranks(k))
+        results[mid] = (ms, mr, fmask)
+    if a.mid:
+        ok = ~(results[0][2] | results[1][2])
+        print("mid == plain on the %d queries neither protocol flagged: rows %s scores %s" % (int(ok.sum()), bool((results[0][1][ok] == results[1][1][ok]).all()),
+              bool((results[0][0][ok] == results[1][0][ok]).all())))
     print("shard0 stats after begin:", {k_: (round(v, 2) if isinstance(v, float) else v) for k_, v in st_begin.items()})
     print("shard0 stats:", {k_: (round(v, 2) if isinstance(v, float) else v) for k_, v in st.items()})
 
