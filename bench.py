@@ -332,27 +332,36 @@ def run_workload(args, spec, ctx):
             gr.record_stream(copy_stream)
         return gs, gr
 
+    # N > 1: the kernel timers of a sharded step cost it a host synchronisation between its stages (begin | exchange | first slice | exchange |
+    # rest), so the timed steps run WITHOUT them and the same number of extra, untimed steps below collects the kernel times and list statistics
+    stats_in_timed = world == 1 or pq is not None
+    if not stats_in_timed:
+        index.set_param(_lib.PARAM_PROFILE, 0)
     for _ in range(args.warmup):
         step_d2h()
-    gemm_ms = gemm_flops_alg = 0.0
-    launches = 0
+    acc = {"gemm_ms": 0.0, "gemm_flops_alg": 0.0, "launches": 0}
     stats_acc = {}
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gs, gr = step_d2h()
+
+    def collect():
         st = index.stats() if pq is None else dict.fromkeys(("gemm_ms", "phases", "gemm_flops_alg", "refine_ms", "rescore_ms", "select_ms", "prep_ms", "total_ms",
                                                               "candidates_bound", "candidates_exact", "overflow_retries", "gemm_rows", "sample_fallback_queries"), 0)
         if pq is not None:
             ms_scan, by_scan = pq.last_scan()
             stats_acc["adc_scan_ms"] = stats_acc.get("adc_scan_ms", 0) + ms_scan
             stats_acc["adc_code_bytes"] = stats_acc.get("adc_code_bytes", 0) + by_scan
-        gemm_ms += st["gemm_ms"]
-        launches += st["phases"]
-        gemm_flops_alg += st["gemm_flops_alg"]                  # algorithmic: real Q and K of every launch
+        acc["gemm_ms"] += st["gemm_ms"]
+        acc["launches"] += st["phases"]
+        acc["gemm_flops_alg"] += st["gemm_flops_alg"]           # algorithmic: real Q and K of every launch
         for key in ("refine_ms", "rescore_ms", "select_ms", "prep_ms", "total_ms", "candidates_bound", "candidates_exact",
                     "overflow_retries", "gemm_rows", "sample_fallback_queries"):
             stats_acc[key] = stats_acc.get(key, 0) + st[key]
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gs, gr = step_d2h()
+        if stats_in_timed:
+            collect()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -371,6 +380,13 @@ def run_workload(args, spec, ctx):
         step()
     barrier()
     ms_device_resident = (time.perf_counter() - t1) * 1e3 / args.steps
+    if not stats_in_timed:
+        index.set_param(_lib.PARAM_PROFILE, 1)
+        for _ in range(args.steps):
+            step()
+            collect()
+        barrier()
+    gemm_ms, gemm_flops_alg, launches = acc["gemm_ms"], acc["gemm_flops_alg"], acc["launches"]
 
     # side figure 2 (N = 1): the bound GEMM ALONE.  In the timed steps refine / rescoring / select of a chunk run beside the next chunk's GEMM
     # (library default since round 4), so the GEMM's launch durations there include what it loses to the gathers; two extra steps with
@@ -473,6 +489,8 @@ def run_workload(args, spec, ctx):
                          "achieved_note": ("kernel alone: hipEvent durations of the same %d launches per step in 3 extra steps with refine / rescoring / select serialised behind each "
                                            "launch (DHR_PARAM_OVERLAP_AUX = 0, %.1f ms per step); inside the timed region the launches share the chip with the gathers of the previous "
                                            "chunk: achieved_in_timed_region" % (serial["launches"] // 3, serial["ms_per_step"])) if serial else
+                                          ("hipEvent durations of rank 0's launches in %d extra, untimed steps of the same sharded search (the timers cost a sharded step a host "
+                                           "synchronisation between its stages, so the timed steps run without them)" % args.steps) if not stats_in_timed else
                                           "hipEvent durations of the launches inside the timed region",
                          "achieved_in_timed_region": round(ach_tf, 1), "frac_in_timed_region": round(ach_tf / peak, 4),
                          "peak_note": "dense fp16 / bf16 matrix peak (MI355X_MICROARCH.md): the roofline BASELINE.json prices this metric against; algorithmic flops 2 x Q x rows x (d_dlr + d_cls)",

@@ -41,6 +41,7 @@ static inline int idx_esize(int dt) { return dt == DHR_IDX_I16 ? 2 : 1; }
 
 struct Workspace {
   int q_pad = 0, kp = 0;
+  int q_alloc = 0;       // query rows the buffers were allocated for (>= q_pad: a smaller batch re-uses them)
   int64_t cap = 0;       // capacity of the bound-candidate lists (cand, cand2)
   uint32_t last_maxr = 0;   // fullest survivor list of the latest refine step (before clamping to cap_r): the chunk planner sizes the main pass by it too
   int64_t cap_r = 0;     // capacity of the lists that reach the exact rescoring (refine survivors; == cap without refine)
@@ -745,33 +746,44 @@ static hipError_t re_malloc(T*& p, size_t bytes, int64_t& total) {
 // the multi-GB lists every time (hipFree synchronises the device).
 static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t keys_ld_min, int64_t cap_mult = 1, bool use_refine = true,
                      bool queries_only = false) {
-  if (queries_only && w.q_pad >= (int)round_up(n_queries, TILE_ROWS) && w.kt == ix->kt && w.q32 != nullptr) return DHR_OK;
+  if (queries_only && w.q_alloc >= (int)round_up(n_queries, TILE_ROWS) && w.kt == ix->kt && w.q32 != nullptr) return DHR_OK;
   const int q_pad = (int)round_up(n_queries, TILE_ROWS);
   int kp = 1;
   while (kp < k) kp <<= 1;
   if (kp < 64) kp = 64;
   const bool refine = (ix->heavy_key != nullptr || ix->resid8 != nullptr) && use_refine;
   // default list depth: 262144 (refine) / 65536, but never more than ~32 GiB for the two bound-list sets of a big batch
-  int64_t base_cap = refine ? 262144 : 65536;
-  // ... sized by the SHARD: a list cannot hold more rows than the shard has, and the chunk planner of the main pass cuts the pass
-  // so that the fullest list fits, so a 1/8 shard gets 1/8 of the depth (floor: 32768 / 16384) instead of the full-corpus workspace
-  // (measured at config 3: depth 262 144 / 131 072 / 65 536 = 195.2 / 196.5 / 196.2 ms per step, 100.2 / 85.2 / 77.7 GB)
-  // (gated_i8 indexes: the int8 bound passes ~1.5x the rows of the fp16 one, and far more for the few queries with two or three
-  // dominant terms -- the fullest list decides the chunk count of the main pass, so these get 4x the depth: 32 -> 8 chunks at config 3)
-  // Round 3: n_rows / 8, capped at 262 144 -- a 1/8 shard of config 4 planned 22 chunks at n_rows / 32 (its fullest list is as long as
-  // the whole corpus's in proportion, but the floor of the depth is not), each with its own host round trips.
-  const int64_t by_rows = ix->gated_i8 ? std::min<int64_t>(std::max<int64_t>(ix->n_rows / 8, 32768), 262144)
-                                       : std::max<int64_t>(ix->n_rows / 128, refine ? 32768 : 16384);
-  while (base_cap > by_rows && base_cap > 4096) base_cap >>= 1;          // power-of-two floor of n_rows / 128 (65 536 at 8.84 M rows)
-  while (base_cap > 4096 && (int64_t)q_pad * base_cap * 16 > ((int64_t)32 << 30)) base_cap >>= 1;
-  if (ix->cand_cap > 0) base_cap = ix->cand_cap;
-  // fallback depths serve a handful of queries: 16x deeper lists there cost little memory
-  const int64_t cap = std::min<int64_t>(base_cap * cap_mult, (int64_t)1 << 22);
-  // survivor lists: 32 768 entries, and at least 4 x the padded k (agip_topk 10 000: a chunk of the main pass must be able to bring
-  // a hot query's share of its 10 000 best -- 12 queries per step overflowed 32 768 and were redone)
-  const int64_t cap_r = refine ? std::min<int64_t>(cap, std::max<int64_t>(32768, 4 * (int64_t)kp) * cap_mult) : cap;
-  const int64_t keys_ld = std::max<int64_t>(cap_r, keys_ld_min);
-  if (w.q_pad == q_pad && w.kp == kp && w.cap == cap && w.cap_r == cap_r && w.keys_ld >= keys_ld && w.kt == ix->kt) return DHR_OK;
+  int64_t cap = 0, cap_r = 0, keys_ld = 0;
+  auto plan_depths = [&](int q_for_cap) {
+    int64_t base_cap = refine ? 262144 : 65536;
+    // ... sized by the SHARD: a list cannot hold more rows than the shard has, and the chunk planner of the main pass cuts the pass
+    // so that the fullest list fits, so a 1/8 shard gets 1/8 of the depth (floor: 32768 / 16384) instead of the full-corpus workspace
+    // (measured at config 3: depth 262 144 / 131 072 / 65 536 = 195.2 / 196.5 / 196.2 ms per step, 100.2 / 85.2 / 77.7 GB)
+    // (gated_i8 indexes: the int8 bound passes ~1.5x the rows of the fp16 one, and far more for the few queries with two or three
+    // dominant terms -- the fullest list decides the chunk count of the main pass, so these get 4x the depth: 32 -> 8 chunks at config 3)
+    // Round 3: n_rows / 8, capped at 262 144 -- a 1/8 shard of config 4 planned 22 chunks at n_rows / 32 (its fullest list is as long as
+    // the whole corpus's in proportion, but the floor of the depth is not), each with its own host round trips.
+    const int64_t by_rows = ix->gated_i8 ? std::min<int64_t>(std::max<int64_t>(ix->n_rows / 8, 32768), 262144)
+                                         : std::max<int64_t>(ix->n_rows / 128, refine ? 32768 : 16384);
+    while (base_cap > by_rows && base_cap > 4096) base_cap >>= 1;          // power-of-two floor of n_rows / 128 (65 536 at 8.84 M rows)
+    while (base_cap > 4096 && (int64_t)q_for_cap * base_cap * 16 > ((int64_t)32 << 30)) base_cap >>= 1;
+    if (ix->cand_cap > 0) base_cap = ix->cand_cap;
+    // fallback depths serve a handful of queries: 16x deeper lists there cost little memory
+    cap = std::min<int64_t>(base_cap * cap_mult, (int64_t)1 << 22);
+    // survivor lists: 32 768 entries, and at least 4 x the padded k (agip_topk 10 000: a chunk of the main pass must be able to bring
+    // a hot query's share of its 10 000 best -- 12 queries per step overflowed 32 768 and were redone)
+    cap_r = refine ? std::min<int64_t>(cap, std::max<int64_t>(32768, 4 * (int64_t)kp) * cap_mult) : cap;
+    keys_ld = std::max<int64_t>(cap_r, keys_ld_min);
+  };
+  // A SMALLER batch re-uses the buffers of a larger one (same list depths and strides; q_pad is the ACTIVE padded query count).  Until round 4
+  // any other batch size freed and re-allocated the whole workspace -- tens of GB, and hipFree synchronises the device: the repair of ONE
+  // failed query of a sharded step (dhr_search on a sub-batch, then the next full batch) cost 0.7 s.
+  // (the list depths of the LARGER batch: beyond ~8 000 queries they are halved to bound the memory)
+  if (w.q_alloc >= q_pad && w.kt == ix->kt) {
+    plan_depths(w.q_alloc);
+    if (w.kp == kp && w.cap == cap && w.cap_r == cap_r && w.keys_ld >= keys_ld) { w.q_pad = q_pad; return DHR_OK; }
+  }
+  plan_depths(q_pad);
   free_ws(w);
   int64_t tot = 0;
   HIP_TRY(re_malloc(w.q_tiles, (size_t)q_pad * ix->kt * 2, tot));
@@ -811,7 +823,7 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(hipHostMalloc(&w.h_ref, 16, hipHostMallocDefault));
   HIP_TRY(re_malloc(w.d_stats, 32, tot));
   HIP_TRY(hipHostMalloc(&w.h_stats, 32, hipHostMallocDefault));
-  w.q_pad = q_pad; w.kp = kp; w.cap = cap; w.cap_r = cap_r; w.keys_ld = keys_ld; w.kt = ix->kt; w.d_dlr = ix->d_dlr;
+  w.q_pad = w.q_alloc = q_pad; w.kp = kp; w.cap = cap; w.cap_r = cap_r; w.keys_ld = keys_ld; w.kt = ix->kt; w.d_dlr = ix->d_dlr;
   w.bytes = tot;
   return DHR_OK;
 }
@@ -1300,8 +1312,8 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     if (!(stage == 2 && ix->pend.mid)) HIP_TRY(hipMemcpyAsync(w.thr_hat, w.thr, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
     if (!w.cand2) {
       int64_t tot = 0;
-      HIP_TRY(re_malloc(w.cand2, (size_t)w.q_pad * w.cap * 8, tot));
-      HIP_TRY(re_malloc(w.cnt2, (size_t)w.q_pad * 4, tot));
+      HIP_TRY(re_malloc(w.cand2, (size_t)w.q_alloc * w.cap * 8, tot));
+      HIP_TRY(re_malloc(w.cnt2, (size_t)w.q_alloc * 4, tot));
       w.bytes += tot;
     }
     // Streams of the main pass.  Default: the bound GEMM on the caller's stream, refine/rescoring/select on a

@@ -696,6 +696,34 @@ def _fake_world_search(G, shards, q32, qi, k, mid=False):
     return ms.cpu().numpy(), mr.cpu().numpy(), int(failed.numel()), [int(x) for x in tot[:4]]
 
 
+def test_smaller_batch_reuses_the_workspace(G):
+    """A batch with fewer queries runs in the buffers of the larger one before it (ensure_ws: until round 4 every change of the batch size freed
+    and re-allocated the workspace -- 0.7 s for the one-query repair step of a sharded search at full size): the device footprint does not move,
+    the padded query rows of the smaller batch (stale rows of the larger one) stay out of the results, and the larger batch still answers the same."""
+    from dhr_amd import synth
+    cv, ci, qv, qi = synth.make_pair(41, 60_000, 300, 768, 64)
+    q = qv.astype(np.float32)
+    ix = G.GipIndex(cv, ci)
+    try:
+        s_all, r_all = ix.search(q, qi, 100)
+        bytes_all = ix.device_bytes()
+        for sub in (np.array([7]), np.arange(250, 263), np.arange(0, 300, 7)):
+            s_sub, r_sub = ix.search(q[sub], qi[sub], 100)
+            assert ix.device_bytes() == bytes_all
+            np.testing.assert_array_equal(r_sub, r_all[sub])
+            np.testing.assert_array_equal(s_sub, s_all[sub])
+        s2, r2 = ix.search(q, qi, 100)
+        assert ix.device_bytes() == bytes_all
+        np.testing.assert_array_equal(r2, r_all)
+        np.testing.assert_array_equal(s2, s_all)
+        for i in (0, 150, 299):
+            ex = O.gip_scores_f64(q[i], qi[i], cv.astype(np.float32), ci)
+            order = np.lexsort((np.arange(len(ex)), -ex))[:100]
+            np.testing.assert_array_equal(r_all[i], order)
+    finally:
+        ix.close()
+
+
 @pytest.mark.parametrize("mid", [False, True])
 @pytest.mark.parametrize("kind", ["hybrid", "dense"])
 def test_staged_sharded_search_common_threshold(G, kind, gated_image, mid):
