@@ -1367,7 +1367,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     // do not tighten fills them first
     const int64_t need = std::max((int64_t)std::ceil(1.5 * rate * (double)n_main * TILE_ROWS / (double)w.cap),
                                   (int64_t)std::ceil(1.5 * rate_r * (double)n_main * TILE_ROWS / (double)w.cap_r));
-    // (without read-backs the sampled run's rates are not known here: a fixed 8 chunks, which the deep lists of round 3 cover at config 3 --
+    // (without read-backs the sampled run's rates are not known here: a fixed 8 chunks (12 where the thresholds are extrapolated, below), which the deep lists of round 3 cover at config 3 --
     // 203 k entries in the fullest list of the first chunk against 262 144 slots; a list that overflows anyway flags its query)
     // ... scaled with the shard: one chunk per ~4 200 tiles, 2 to 8 (a 1/8 shard of config 4: 2 chunks; 8 cost it 7 ms of launches)
     // ... and, where that takes at most 12 chunks, so many that the FIRST (largest: 3 / (2 M) of the pass) chunk has no more rows than a list has
@@ -1385,6 +1385,11 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       const int64_t by_hot_r = (int64_t)std::ceil(65.0 * k_eff / (double)w.cap_r);
       by_size = std::max(by_size, std::min<int64_t>(24, std::max(by_hot, by_hot_r)));
     }
+    // ... and, where the thresholds are extrapolated between the chunks (unsharded search), one chunk per ~2 800 tiles up to 12: every chunk
+    // boundary is a chance to raise them.  Config 3: 8 -> 12 chunks rescores 3.29 k instead of 3.37 k rows per query, -0.4 ms; config 2 (whose
+    // refine level is the larger share of its step): 78.0 -> 75.5 ms.  16 measure the same, 24 / 32 / 48 lose it again to launch boundaries
+    // (config 3: 121.9 / 123.2 / 126.6 ms against 121.2-121.6 at 16 and 121.9 at 8 on one box).
+    if (extrapolate) by_size = std::max(by_size, std::min<int64_t>(12, (n_main + 2799) / 2800));
     const int64_t want = async_ctl ? std::max<int64_t>(std::max<int64_t>(ix->main_chunks, by_size), (plan_read && stage == 0) ? need : 0) : std::max<int64_t>(ix->main_chunks, need);
     const int M_plain = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, 64), n_main / (16 * DOC_GROUP)));
     // mid protocol: chunk 0 is the slice dhr_search_mid runs (mid_share16 / 16 of the pass), the plain plan covers the rest
