@@ -8,9 +8,20 @@ One "step" = one pass of the hot path over one batch: ALL queries of the batch (
 dev.small) searched against the whole corpus (8 841 823 synthetic passages, 768 densified-lexical +
 768 dense columns = BASELINE.json config 3, "DeLADE-CLS 768+768 dense-hybrid, 1xMI355X"), exact
 top-1000.  With N>1 the corpus is row-sharded over the ranks (gip_retrieval.py:292-306 arithmetic),
-every rank searches its shard and ONE RCCL all-gather + k-way reduce produces the global top-k on
-every rank (total work fixed -> "strong" scaling).  Corpus and queries are resident in HBM before
-the timed region (the reference also times only its query loop, gip_retrieval.py:107,161-163).
+every rank searches its shard inside ONE library call (dhr_search_sharded) whose five small exchanges
+run over RCCL: the ranks agree on the sample ranks (32 bytes), all-gather their sample scores
+[Q, r] -> common thresholds, all-gather their best scores after the first eighth of the main pass
+[Q, r2] -> raised thresholds, all-gather the per-query counts [Q], and all-gather the list prefixes
+[Q, kk] (scores + rows) for the rank merge that leaves the global top-k on every rank (total work
+fixed -> "strong" scaling).  The communicator is brought up under a watchdog (dhr_amd.dist.bring_up):
+if RCCL fails or hangs on ANY rank, every rank degrades to torch.distributed gloo gathers on host
+buffers -- the same control flow -- and the JSON line says so (`n_ranks_seen_by_rccl` = ncclCommCount
+of the communicator the timed steps used, 0 for the host transport).  Corpus and queries are resident
+in HBM before the timed region (the reference also times only its query loop,
+gip_retrieval.py:107,161-163).
+
+The default invocation (N=1, config 3) also times 5 steps each of config 2 (dense-only) and config 1
+(BM25, 100 k rows) and attaches them as `other_configs` to the same JSON line.
 
 Prints ONE JSON line (rank 0).  See DESIGN.md section "Measurement" for the field definitions.
 """
@@ -43,7 +54,7 @@ BEIR = [("trec-covid", 171_332, 50), ("nfcorpus", 3_633, 323), ("nq", 2_681_468,
         ("climate-fever", 5_416_593, 1_535), ("scifact", 5_183, 300)]
 
 
-def gen_rows(torch, synth, device, seed, row_lo, row_hi, d_dlr, d_cls, lmin, lmax, uniform_idx):
+def gen_rows(torch, synth, device, seed, row_lo, row_hi, d_dlr, d_cls, lmin, lmax, uniform_idx, clustered=None, hot_frac=0.0, dup=False):
     """Rows [row_lo, row_hi) of the synthetic matrix with this seed, on the GPU (SURVEY.md section 8(d) recipe).  Every global
     GEN_CHUNK-row chunk has its own generator seed, so the rows do not depend on how the corpus is sharded.
     -> (value fp16 [n,K], index u8 [n,d_dlr]|None)"""
@@ -61,9 +72,16 @@ def gen_rows(torch, synth, device, seed, row_lo, row_hi, d_dlr, d_cls, lmin, lma
             index[a - row_lo:b - row_lo] = i[a - c_lo:b - c_lo]
             del v, i
         if d_cls:
-            d = (torch.randn((GEN_CHUNK, d_cls), generator=gen, device=device) * 0.1).to(torch.float16)
+            if clustered is not None:      # --data clustered: clustered / anisotropic dense columns (dhr_amd/synth.py), the same chunk seeding
+                d = synth.torch_make_dense_clustered(gen, GEN_CHUNK, d_cls, clustered, device, hot_frac=hot_frac)
+            else:
+                d = (torch.randn((GEN_CHUNK, d_cls), generator=gen, device=device) * 0.1).to(torch.float16)
             value[a - row_lo:b - row_lo, d_dlr:] = d[a - c_lo:b - c_lo]
             del d
+        if dup and clustered is not None and c_lo >= row_lo and c_lo + GEN_CHUNK <= row_hi:
+            # near-duplicate rows inside whole chunks of this shard (a chunk cut by a shard boundary is left alone: the duplicates of a
+            # chunk are drawn over the whole chunk, and a shard must stay a slice of the same corpus)
+            synth.torch_near_duplicates(gen, value[c_lo - row_lo:c_lo - row_lo + GEN_CHUNK], None if index is None else index[c_lo - row_lo:c_lo - row_lo + GEN_CHUNK], d_dlr)
     return value, index
 
 
@@ -94,7 +112,7 @@ def cpu_baseline_legs(sample, k, n_full, q_one, q_all):
     cores = usable
     s1, _ = OT.gip_loop(q32[:q_one], None if sqi is None else sqi[:q_one], c32, sci, k, 1)
     sa, _ = OT.gip_loop(q32[:q_all], None if sqi is None else sqi[:q_all], c32, sci, k, cores)
-    threads_seen = torch.get_num_threads()
+    threads_seen = int(getattr(OT, "LAST_THREADS", 0)) or cores        # what torch reported INSIDE the loop (gip_loop restores the setting on its way out)
     torch.set_num_threads(max(1, min(cores, 64)))
     scale = n_full / c32.shape[0]
     what = "torch-CPU restatement of gip_retrieval.py:115-126 (mask * corpus -> einsum -> topk, one query at a time, fp32)"
@@ -147,6 +165,9 @@ def main():
     ap.add_argument("--parity-rows", type=int, default=200_000)
     ap.add_argument("--parity-queries", type=int, default=24)
     ap.add_argument("--seed", type=int, default=1237)
+    ap.add_argument("--rccl-timeout", type=float, default=300.0, help="N > 1: seconds the bring-up of the library's RCCL communicator (incl. one untimed sharded step) may take before every rank degrades to the host transport")
+    ap.add_argument("--other-configs", type=int, default=-1, help="1: after the headline workload also time 5 steps each of config 2 (dense) and config 1 (bm25) and attach them as other_configs (default: on for the plain N=1 hybrid invocation)")
+    ap.add_argument("--data", default="iid", choices=["iid", "clustered"], help="dense columns: iid Gaussian (SURVEY 8d) or the structured variant (2 000 clusters, decaying spectrum, 1 %% near-duplicate rows, 5 %% hot queries)")
     ap.add_argument("--dist-backend", default="nccl", help="testing only: 'gloo' lets several ranks share ONE GPU (with DHR_BENCH_SINGLE_DEVICE=1)")
     args = ap.parse_args()
 
@@ -180,15 +201,33 @@ def main():
             if rank == 0:
                 print(json.dumps(out), flush=True)
     else:
-        spec = {"hybrid": dict(name="hybrid", n=N_MSMARCO, nq=Q_DEV, d_dlr=768, d_cls=768, kind="encoder",
-                               baseline_config="config 3: DeLADE-CLS 768+768 dense-hybrid" if world == 1 else "config 4: 768+768 dense-hybrid, corpus row-sharded across %d GPUs" % world),
-                "dense": dict(name="dense", n=N_MSMARCO, nq=Q_DEV, d_dlr=0, d_cls=768, kind="dense", baseline_config="config 2: Aggretriever 768-d dense-only"),
-                "bm25": dict(name="bm25", n=100_000, nq=Q_DEV, d_dlr=768, d_cls=0, kind="bm25",
-                             baseline_config="config 1: BM25 densified (DLR only), 100k-passage toy corpus")}[args.workload]
+        specs = {"hybrid": dict(name="hybrid", n=N_MSMARCO, nq=Q_DEV, d_dlr=768, d_cls=768, kind="encoder",
+                                baseline_config="config 3: DeLADE-CLS 768+768 dense-hybrid" if world == 1 else "config 4: 768+768 dense-hybrid, corpus row-sharded across %d GPUs" % world),
+                 "dense": dict(name="dense", n=N_MSMARCO, nq=Q_DEV, d_dlr=0, d_cls=768, kind="dense", baseline_config="config 2: Aggretriever 768-d dense-only"),
+                 "bm25": dict(name="bm25", n=100_000, nq=Q_DEV, d_dlr=768, d_cls=0, kind="bm25",
+                              baseline_config="config 1: BM25 densified (DLR only), 100k-passage toy corpus")}
+        for sp in specs.values():
+            sp["seed"] = args.seed
+        spec = specs[args.workload]
         spec["n"] = args.n_docs or spec["n"]
         spec["nq"] = args.n_queries or spec["nq"]
-        spec["seed"] = args.seed
         out = run_workload(args, spec, ctx)
+        # configs 1 and 2 on the same clock: the plain default invocation (N = 1, config 3 at full size) also times 5 steps each of the
+        # dense-only and the BM25 workload -- same code path, same seed rule, their own roofline and checksum -- and attaches them to the line
+        plain = (args.workload == "hybrid" and world == 1 and not args.n_docs and not args.n_queries and not args.uniform_idx and args.data == "iid"
+                 and not args.pq and args.topk == 1000)
+        if (args.other_configs == 1 or (args.other_configs < 0 and plain)) and world == 1 and args.workload == "hybrid":
+            import copy
+            other = {}
+            for wl, tag in (("dense", "config2"), ("bm25", "config1")):
+                a2 = copy.copy(args)
+                a2.workload, a2.steps, a2.warmup, a2.no_cpu_baseline, a2.n_docs, a2.n_queries = wl, 5, 2, True, 0, 0
+                o = run_workload(a2, specs[wl], ctx)
+                if rank == 0:
+                    other[tag] = {key: o[key] for key in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "whole_job_frac_of_gemm_roofline",
+                                                          "result_checksum", "phase_ms_per_step", "candidates_per_query", "parity_check", "index_device_gb") if key in o}
+            if rank == 0:
+                out["other_configs"] = other
         if rank == 0:
             print(json.dumps(out), flush=True)
     if world > 1:
@@ -215,8 +254,10 @@ def run_workload(args, spec, ctx):
         qv, qi = torch.from_numpy(qvh).to(device), torch.from_numpy(qih).to(device)
         del cvh, cih, qvh, qih
     else:
-        cv, ci = gen_rows(torch, synth, device, seed, lo, hi, d_dlr, d_cls, 30, 90, args.uniform_idx)
-        qv, qi = gen_rows(torch, synth, device, seed + 999_983, 0, nq, d_dlr, d_cls, 4, 12, args.uniform_idx)
+        cm = synth.torch_cluster_model(seed, d_cls, device) if (args.data == "clustered" and d_cls) else None
+        cv, ci = gen_rows(torch, synth, device, seed, lo, hi, d_dlr, d_cls, 30, 90, args.uniform_idx, clustered=cm, dup=True)
+        qv, qi = gen_rows(torch, synth, device, seed + 999_983, 0, nq, d_dlr, d_cls, 4, 12, args.uniform_idx, clustered=cm, hot_frac=synth.HOT_FRAC)
+        del cm
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
     t_build = time.perf_counter()
@@ -289,28 +330,24 @@ def run_workload(args, spec, ctx):
             dist.barrier()
         torch.cuda.synchronize()
 
-    # N > 1 over RCCL: one untimed trial of dhr_search_sharded on the library's own RCCL communicator.  If it raises on any rank, EVERY rank
-    # switches the communicator's transport to torch.distributed all-gathers on host buffers (dhr_comm_create_callback: the SAME control
-    # flow in the library, only the gathers change) and the JSON line says so -- the scaling run is the first time this path meets more
-    # than one GPU.
+    # N > 1: the communicator is brought up under a watchdog (dhr_amd.dist.bring_up): RCCL id + ncclCommInitRank + ONE untimed sharded
+    # step run in a worker thread; this thread waits at most --rccl-timeout seconds, then the ranks vote over a gloo control group.  One
+    # "no" (an exception, or a rank still blocked because a peer never arrived) and EVERY rank drops RCCL and takes torch.distributed
+    # all-gathers on host buffers (dhr_comm_create_callback: the SAME control flow in the library, only the gathers change); the JSON line
+    # says which transport the timed steps used and how many ranks RCCL itself reports (ncclCommCount).
     sharded_impl = None
+    comm = None
     if world > 1 and pq is None:
         import torch.distributed as dist
-        host_tr = dist.get_backend() != "nccl" or os.environ.get("DHR_SHARDED_TRANSPORT") == "host"
-        sharded_impl = "dhr_search_sharded, all-gathers by torch.distributed on host buffers (callback communicator)" if host_tr \
-            else "dhr_search_sharded (RCCL inside the library)"
-        if not host_tr:
-            ok, why = 1, ""
-            try:
-                step()
-            except Exception as e:      # noqa: BLE001
-                ok, why = 0, str(e)[:200]
-            flag = torch.tensor([ok], dtype=torch.int32, device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                os.environ["DHR_SHARDED_TRANSPORT"] = "host"
-                sharded_impl = "dhr_search_sharded, all-gathers by torch.distributed on host buffers; the library's RCCL communicator failed in the trial: %s" % (why or "on another rank")
-                print("[bench] rank %d: %s" % (rank, sharded_impl), file=sys.stderr)
+        want = "host" if (dist.get_backend() != "nccl" and os.environ.get("DHR_BENCH_FORCE_RCCL_TRIAL") != "1") or os.environ.get("DHR_SHARDED_TRANSPORT") == "host" else "rccl"
+
+        def trial(c):
+            D.sharded_search(index, qv, qi, k, comm=c)
+            torch.cuda.synchronize(device)
+        comm = D.checked_comm(index, None, trial, args.rccl_timeout, want)
+        sharded_impl = "dhr_search_sharded: " + comm.note
+        if comm.transport != "rccl" and want == "rccl":
+            print("[bench] rank %d: %s" % (rank, sharded_impl), file=sys.stderr)
     kk = min(k, n)
     host_s = torch.empty((nq, kk), dtype=torch.float32).pin_memory()
     host_r = torch.empty((nq, kk), dtype=torch.int64).pin_memory()
@@ -479,22 +516,25 @@ def run_workload(args, spec, ctx):
                                     % (spec["name"], n, d_dlr, d_cls,
                                        (" + int16 slice index" if spec["kind"] == "bm25" else " + uint8 slice index") if d_dlr else "", nq, k,
                                        "uniform slice index (adversarial)" if args.uniform_idx else
-                                       "whole-word vocabulary, no background" if spec["kind"] == "bm25" else "densify-rule slice index")),
+                                       "whole-word vocabulary, no background" if spec["kind"] == "bm25" else "densify-rule slice index"))
+                                   + ("; dense columns CLUSTERED (2 000 clusters, sigma_within 0.3, decaying spectrum, 1 % near-duplicate rows, 5 % hot queries)" if args.data == "clustered" and d_cls else ""),
                        "baseline_config": spec["baseline_config"],
                        "parallelism": "rowshard%d+allgather" % world if world > 1 else "1gpu",
                        **({"collectives": sharded_impl} if sharded_impl else {})},
+            **({"n_ranks_seen_by_rccl": (comm.ranks_seen() if comm.transport == "rccl" else 0), "sharded_transport": comm.transport} if comm is not None else {}),
             "roofline": {"bound": "mfma", "kernel": kernel,
-                         "achieved": round(ach_k, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(ach_k / peak, 4),
-                         "achieved_note": ("kernel alone: hipEvent durations of the same %d launches per step in 3 extra steps with refine / rescoring / select serialised behind each "
-                                           "launch (DHR_PARAM_OVERLAP_AUX = 0, %.1f ms per step); inside the timed region the launches share the chip with the gathers of the previous "
-                                           "chunk: achieved_in_timed_region" % (serial["launches"] // 3, serial["ms_per_step"])) if serial else
-                                          ("hipEvent durations of rank 0's launches in %d extra, untimed steps of the same sharded search (the timers cost a sharded step a host "
+                         "achieved": round(ach_tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(ach_tf / peak, 4),
+                         "achieved_note": ("hipEvent durations of rank 0's launches in %d extra, untimed steps of the same sharded search (the timers cost a sharded step a host "
                                            "synchronisation between its stages, so the timed steps run without them)" % args.steps) if not stats_in_timed else
-                                          "hipEvent durations of the launches inside the timed region",
-                         "achieved_in_timed_region": round(ach_tf, 1), "frac_in_timed_region": round(ach_tf / peak, 4),
+                                          "algorithmic flops / hipEvent durations of the kernel's launches INSIDE the timed region (where they share the chip with the previous "
+                                          "chunk's refine / rescoring / select)",
+                         "achieved_kernel_alone": round(ach_k, 1) if serial else None, "frac_kernel_alone": round(ach_k / peak, 4) if serial else None,
+                         "kernel_alone_note": ("hipEvent durations of the same %d launches per step in 3 extra steps with refine / rescoring / select serialised behind each "
+                                               "launch (DHR_PARAM_OVERLAP_AUX = 0, %.1f ms per step)" % (serial["launches"] // 3, serial["ms_per_step"])) if serial else None,
                          "peak_note": "dense fp16 / bf16 matrix peak (MI355X_MICROARCH.md): the roofline BASELINE.json prices this metric against; algorithmic flops 2 x Q x rows x (d_dlr + d_cls)",
-                         "peak_instruction_mix": round(peak_mix, 1), "frac_of_instruction_mix_peak": round(ach_k / peak_mix, 4),
+                         "peak_instruction_mix": round(peak_mix, 1), "frac_of_instruction_mix_peak": round(ach_tf / peak_mix, 4),
+                         "frac_of_instruction_mix_peak_kernel_alone": round(ach_k / peak_mix, 4) if serial else None,
                          "traffic": None if traffic_per_row is None else round(traffic_per_row * rows_per_launch, 0),
                          "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE, gfx950-corrected; profiles/r04_gemm_pmc.txt; fp16-gated hybrid images: r02_gemm_pmc.txt)",
                          "algorithmic_bytes_per_launch": round(alg_bytes_per_row * rows_per_launch, 0),

@@ -746,8 +746,10 @@ static hipError_t re_malloc(T*& p, size_t bytes, int64_t& total) {
 // the multi-GB lists every time (hipFree synchronises the device).
 static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t keys_ld_min, int64_t cap_mult = 1, bool use_refine = true,
                      bool queries_only = false) {
-  if (queries_only && w.q_alloc >= (int)round_up(n_queries, TILE_ROWS) && w.kt == ix->kt && w.q32 != nullptr) return DHR_OK;
   const int q_pad = (int)round_up(n_queries, TILE_ROWS);
+  // (q_pad is the ACTIVE padded query count: query_prep_kernel prepares rows < q_pad only, so the re-use must set it -- a batch that
+  // followed a smaller one through this return kept the smaller count and scored its later queries against stale operand rows)
+  if (queries_only && w.q_alloc >= q_pad && w.kt == ix->kt && w.q32 != nullptr) { w.q_pad = q_pad; return DHR_OK; }
   int kp = 1;
   while (kp < k) kp <<= 1;
   if (kp < 64) kp = 64;
@@ -1556,6 +1558,7 @@ extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, f
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = (hipStream_t)stream;
   const int Q = qb->n_queries;
+  ix->pend.valid = false;          // a plain search overwrites the workspace of any staged search left open on this handle
   hipEvent_t ev0, ev1;
   HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
   HIP_TRY(hipEventRecord(ev0, s));
@@ -1783,6 +1786,9 @@ static int search_begin_impl(dhr_index* ix, const dhr_query_batch* qb, int32_t k
   }
   ix->stats = st;
   return DHR_OK;
+}
+extern "C" void dhr_internal_search_abort(dhr_index* ix) {
+  if (ix) ix->pend.valid = false;
 }
 extern "C" int dhr_search_begin(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_sample_scores_dev, void* stream) {
   return search_begin_impl(ix, qb, k, out_sample_scores_dev, stream, true);

@@ -13,6 +13,7 @@ extern "C" int dhr_index_device(const dhr_index* ix);
 // dhr_search_begin / dhr_search_finish without their final stream synchronisation (sharded.hip: the shards of a one-process search work
 // concurrently until the collective layer synchronises; over RCCL the whole call enqueues up to its one host read)
 extern "C" int dhr_internal_search_begin_async(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_sample_scores_dev, void* stream);
+extern "C" void dhr_internal_search_abort(dhr_index* ix);      // drops the state a dhr_search_begin left behind (error exits of the sharded step)
 extern "C" int dhr_internal_search_mid_async(dhr_index* ix, const float* tau_hat_dev, int32_t r_local, float* out_scores_dev, void* stream);
 extern "C" int dhr_internal_search_finish_async(dhr_index* ix, const float* tau_hat_dev, float* out_scores, int64_t* out_rows, int32_t* out_count_dev,
                                                 int32_t out_mem_kind, void* stream);

@@ -72,6 +72,7 @@ struct Backend {
   virtual ~Backend() {}
   virtual void* alloc(int i, size_t bytes) = 0;                 // scratch in local shard i's memory, released when the call ends
   virtual int set_share(int i, int share) = 0;                  // DHR_PARAM_SAMPLE_SHARE
+  virtual void abort(int) {}                                    // forget a staged search that did not reach its finish call
   virtual int sample_rank(int i, int k) = 0;
   virtual int union_rank(int i, int k) = 0;
   virtual int begin(int i, const dhr_query_batch* qb, int k, float* sample) = 0;
@@ -185,7 +186,9 @@ int agree_rank(Backend& B, int k, int* r_out, int* ru_out, int* rl_mid_out, int*
 // that a later dhr_search_begin / finish on the same handle (another shard count, or none) does not inherit a stale share
 struct ShareGuard {
   Backend& B;
-  ~ShareGuard() { for (int i = 0; i < B.n_local; ++i) (void)B.set_share(i, 1); }
+  // (and a step that failed between begin and finish -- arena out of memory, a transport error, a failed mid step -- must not leave the
+  // handle "pending": dhr_score_rows refuses a pending handle; after a completed step this is a no-op)
+  ~ShareGuard() { for (int i = 0; i < B.n_local; ++i) { (void)B.set_share(i, 1); B.abort(i); } }
 };
 
 int sharded_core(Backend& B, const dhr_query_batch* qb_in, int k, const std::vector<float*>& out_s, const std::vector<int64_t*>& out_r) {
@@ -378,6 +381,7 @@ struct HipBackend : Backend {
 
   void* alloc(int i, size_t bytes) override { (void)hipSetDevice(sh[i].device); return sh[i].arena->get(bytes); }
   int set_share(int i, int share) override { return dhr_index_set_param(sh[i].ix, DHR_PARAM_SAMPLE_SHARE, share); }
+  void abort(int i) override { dhr_internal_search_abort(sh[i].ix); }
   int sample_rank(int i, int k) override { return dhr_search_sample_rank(sh[i].ix, k); }
   int union_rank(int i, int k) override { return dhr_search_union_rank(sh[i].ix, k); }
   int begin(int i, const dhr_query_batch* qb, int k, float* sample) override {
@@ -679,6 +683,24 @@ extern "C" void dhr_comm_destroy(dhr_comm* c) {
   (void)hipFree(c->arena);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   delete c;
+}
+
+extern "C" int dhr_comm_info(const dhr_comm* c, int32_t what) {
+  if (!c) return dhr_set_error_message(DHR_ERR_INVALID, "null communicator");
+  int v = 0;
+  switch (what) {
+    case DHR_COMM_TRANSPORT: return c->comm ? 0 : 1;
+    case DHR_COMM_WORLD: if (!c->comm) return c->world; SH_NCCL(ncclCommCount(c->comm, &v)); return v;
+    case DHR_COMM_RANK: if (!c->comm) return c->rank; SH_NCCL(ncclCommUserRank(c->comm, &v)); return v;
+    case DHR_COMM_DEVICE: if (!c->comm) return c->device; SH_NCCL(ncclCommCuDevice(c->comm, &v)); return v;
+    default: return dhr_set_error_message(DHR_ERR_INVALID, "unknown dhr_comm_info field");
+  }
+}
+extern "C" void dhr_comm_abort(dhr_comm* c) {
+  if (!c) return;
+  if (c->owned && c->comm) (void)ncclCommAbort(c->comm);
+  c->comm = nullptr;
+  dhr_comm_destroy(c);
 }
 
 extern "C" int dhr_search_sharded_host(const dhr_host_shard* shard, int32_t world, int32_t rank, dhr_allgather_fn allgather, void* user,

@@ -103,9 +103,9 @@ def common_threshold(sample_scores_all, r: int):
     return merged[:, r - 1].contiguous()
 
 
-def _host_allgather(group):
+def _host_allgather(group, device=None):
     """dhr_allgather_fn over a torch.distributed group: `bytes` from every rank -> recv = [world][bytes] (host buffers).  gloo gathers the
-    host bytes as they are; an RCCL group (which only moves device tensors) stages them through the current device."""
+    host bytes as they are; an RCCL group (which only moves device tensors) stages them through `device` (the communicator's)."""
     import torch
     import torch.distributed as dist
 
@@ -115,7 +115,7 @@ def _host_allgather(group):
             src = torch.frombuffer((C.c_char * nbytes).from_address(send), dtype=torch.uint8)
             dst = torch.frombuffer((C.c_char * (nbytes * world)).from_address(recv), dtype=torch.uint8)
             if dist.get_backend(group) == "nccl":
-                dev = torch.device("cuda", torch.cuda.current_device())
+                dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
                 out = torch.empty(nbytes * world, dtype=torch.uint8, device=dev)
                 dist.all_gather_into_tensor(out, src.to(dev), group=group)
                 dst.copy_(out.cpu())
@@ -133,41 +133,66 @@ class ShardComm:
     """dhr_comm for this rank.  Collective constructor.  transport "rccl": the library's own RCCL communicator (rank 0 draws the id --
     dhr_comm_unique_id --, it is broadcast over the torch.distributed group, every rank calls dhr_comm_create); transport "host": the
     all-gathers are done by torch.distributed on host buffers (dhr_comm_create_callback) -- what a gloo group uses (several ranks on
-    one GPU, CPU-only process groups), and what `sharded_search` falls back to when RCCL cannot be initialised.  Either way the
-    search is the library's one control flow (sharded.hip sharded_core)."""
+    one GPU, CPU-only process groups).  Either way the search is the library's one control flow (sharded.hip sharded_core).
 
-    def __init__(self, device: int, group=None, transport: str | None = None):
+    This constructor does NOT fall back: a dhr_comm_create that fails raises, and one that never returns (a peer that did not reach
+    ncclCommInitRank) blocks.  `bring_up` below is the constructor with a watchdog and a collective fallback to the host transport.
+    The host transport is a bring-up / test transport: a step has 5-7 gathers, each a device -> host copy, a stream synchronisation
+    and a blocking callback, and a failure on ONE rank between two gathers leaves the others waiting in the next one until the
+    torch.distributed group's own timeout fires (give the group a short timeout: bring_up's control group has one)."""
+
+    def __init__(self, device: int, group=None, transport: str | None = None, uid: bytes | None = None):
         import torch
         import torch.distributed as dist
         self._lib = _lib.load()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = int(device)
+        self.note = ""
         if transport is None:
             transport = "rccl" if (self.world == 1 or dist.get_backend(group) == "nccl") else "host"
         self.transport = transport
         h = C.c_void_p()
         if transport == "host":
-            self._cb = _host_allgather(group)           # keep the ctypes thunk alive as long as the communicator
+            self._cb = _host_allgather(group, self.device)           # keep the ctypes thunk alive as long as the communicator
             _lib.check(self._lib.dhr_comm_create_callback(self.world, self.rank, self.device, self._cb, None, C.byref(h)), "dhr_comm_create_callback")
             self._h = h
             return
-        uid = (C.c_char * 128)()
-        if self.rank == 0:
-            _lib.check(self._lib.dhr_comm_unique_id(uid, 128), "dhr_comm_unique_id")
-        if self.world > 1:
-            backend = dist.get_backend(group)
-            t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
-            if backend == "nccl":
-                t = t.to(torch.device("cuda", self.device))
-            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
-        _lib.check(self._lib.dhr_comm_create(uid, self.world, self.rank, self.device, C.byref(h)), "dhr_comm_create")
+        if uid is None:
+            buf = (C.c_char * 128)()
+            if self.rank == 0:
+                _lib.check(self._lib.dhr_comm_unique_id(buf, 128), "dhr_comm_unique_id")
+            if self.world > 1:
+                backend = dist.get_backend(group)
+                t = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+                if backend == "nccl":
+                    t = t.to(torch.device("cuda", self.device))
+                dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                uid = bytes(t.cpu().numpy().tobytes())
+            else:
+                uid = bytes(buf)
+        _lib.check(self._lib.dhr_comm_create((C.c_char * 128).from_buffer_copy(uid), self.world, self.rank, self.device, C.byref(h)), "dhr_comm_create")
         self._h = h
+
+    def info(self, what: int) -> int:
+        """dhr_comm_info: what the transport itself reports (RCCL: ncclCommCount / ncclCommUserRank / ncclCommCuDevice)."""
+        v = int(self._lib.dhr_comm_info(self._h, int(what)))
+        if v < 0:
+            _lib.check(v, "dhr_comm_info")
+        return v
+
+    def ranks_seen(self) -> int:
+        return self.info(_lib.COMM_WORLD)
 
     def close(self):
         if getattr(self, "_h", None):
             self._lib.dhr_comm_destroy(self._h)
+            self._h = None
+
+    def abort(self):
+        """ncclCommAbort: callable while another thread of this process is blocked in one of the communicator's collectives."""
+        if getattr(self, "_h", None):
+            self._lib.dhr_comm_abort(self._h)
             self._h = None
 
     def __del__(self):
@@ -178,14 +203,127 @@ class ShardComm:
 
 
 _COMMS = {}
+_CTL_GROUPS = {}
+
+
+def control_group(group=None, timeout_s: float = 120.0):
+    """A gloo group over the same ranks, with a timeout: votes and the host transport run on it, so that nothing the bring-up of RCCL
+    does (or fails to do) on one rank can leave the others waiting forever.  Collective; cached per parent group."""
+    import datetime
+    import torch.distributed as dist
+    if dist.get_backend(group) == "gloo":
+        return group
+    key = id(group)
+    if key not in _CTL_GROUPS:
+        ranks = dist.get_process_group_ranks(group) if group is not None else None
+        _CTL_GROUPS[key] = dist.new_group(ranks=ranks, backend="gloo", timeout=datetime.timedelta(seconds=timeout_s))
+    return _CTL_GROUPS[key]
+
+
+def bring_up(device: int, group=None, trial=None, timeout_s: float = 120.0, want: str = "rccl"):
+    """ShardComm with a watchdog and a COLLECTIVE fallback.  Every rank calls it; every rank returns a communicator of the same
+    transport.  RCCL is brought up (id from rank 0 over the control group, dhr_comm_create, then `trial(comm)` -- one untimed sharded
+    step, synchronised) in a worker thread; the calling thread waits at most `timeout_s`, then the ranks vote over the gloo control
+    group (MIN of "my bring-up finished without an exception").  One "no" -- an exception on one rank, or a rank still blocked in
+    ncclCommInitRank / a collective because a peer never arrived -- and EVERY rank drops RCCL (ncclCommAbort if the handle exists; a
+    thread still inside ncclCommInitRank is left behind as a daemon) and returns the host transport over the control group: the same
+    control flow in the library, only the gathers change.  The calling thread itself only ever blocks in gloo collectives with a
+    timeout.  `comm.note` says what happened.  (Test hooks: DHR_TEST_COMM_FAIL_RANK=r raises on rank r before dhr_comm_create,
+    DHR_TEST_COMM_HANG_RANK=r blocks rank r's bring-up thread -- the shape of a peer that never reaches the collective.)"""
+    import os
+    import threading
+    import time
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world == 1:
+        comm = ShardComm(device, group, "rccl")
+        if trial is not None:
+            trial(comm)
+        return comm
+    ctl = control_group(group, timeout_s)
+    if want != "rccl" or os.environ.get("DHR_SHARDED_TRANSPORT") == "host":
+        comm = ShardComm(device, ctl, "host")
+        comm.note = "host transport requested"
+        if trial is not None:
+            trial(comm)
+        return comm
+    lib = _lib.load()
+    # the id travels over the control group, with a status byte: a rank 0 that cannot draw one must not leave the others in a broadcast
+    t = torch.zeros(129, dtype=torch.uint8)
+    if rank == 0:
+        try:
+            buf = (C.c_char * 128)()
+            _lib.check(lib.dhr_comm_unique_id(buf, 128), "dhr_comm_unique_id")
+            t[0] = 1
+            t[1:] = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8)
+        except Exception as e:  # noqa: BLE001
+            print("[dhr] rank 0 could not draw an RCCL id: %r" % (e,))
+    dist.broadcast(t, src=dist.get_global_rank(ctl, 0) if ctl is not None else 0, group=ctl)
+    state = {"comm": None, "err": None, "done": False}
+    if int(t[0]) == 1:
+        uid = bytes(t[1:].numpy().tobytes())
+
+        def work():
+            try:
+                if torch.cuda.is_available():
+                    torch.cuda.set_device(device)
+                if os.environ.get("DHR_TEST_COMM_FAIL_RANK", "") == str(rank):
+                    raise _lib.DhrError("injected failure before dhr_comm_create (DHR_TEST_COMM_FAIL_RANK)")
+                if os.environ.get("DHR_TEST_COMM_HANG_RANK", "") == str(rank):
+                    time.sleep(1e6)
+                state["comm"] = ShardComm(device, group, "rccl", uid=uid)
+                if trial is not None:
+                    trial(state["comm"])
+                state["done"] = True
+            except Exception as e:  # noqa: BLE001
+                state["err"] = e
+        th = threading.Thread(target=work, daemon=True, name="dhr-rccl-bring-up")
+        th.start()
+        th.join(timeout_s)
+        hung = th.is_alive()
+    else:
+        hung = False
+        state["err"] = _lib.DhrError("rank 0 could not draw an RCCL id")
+    ok = state["done"] and not hung and state["err"] is None
+    vote = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=ctl)
+    if int(vote.item()) == 1:
+        comm = state["comm"]
+        comm.note = "RCCL communicator of the library; ncclCommCount = %d" % comm.ranks_seen()
+        return comm
+    why = ("bring-up still blocked after %.0f s (a peer never arrived)" % timeout_s) if hung else \
+        ("%s" % (state["err"],))[:200] if state["err"] is not None else "another rank failed"
+    c = state["comm"]
+    if c is not None:
+        try:
+            c.abort()              # also unblocks a worker thread parked in one of this communicator's collectives
+        except Exception:  # noqa: BLE001
+            pass
+    comm = ShardComm(device, ctl, "host")
+    comm.note = "host transport (torch.distributed gloo all-gathers on host buffers); the library's RCCL communicator was dropped on every rank: rank %d: %s" % (rank, why)
+    if trial is not None:
+        trial(comm)
+    return comm
 
 
 def _comm_for(index, group):
     import os
     transport = "host" if os.environ.get("DHR_SHARDED_TRANSPORT") == "host" else None      # force torch.distributed gathers (A/B, bring-up)
+    for key in ((index.device, id(group), "checked"), (index.device, id(group), transport)):
+        if key in _COMMS:
+            return _COMMS[key]
     key = (index.device, id(group), transport)
+    _COMMS[key] = ShardComm(index.device, group, transport)
+    return _COMMS[key]
+
+
+def checked_comm(index, group=None, trial=None, timeout_s: float = 120.0, want: str = "rccl"):
+    """bring_up for `sharded_search`: the communicator every later sharded_search(index, ..., group) uses.  Collective."""
+    key = (index.device, id(group), "checked")
     if key not in _COMMS:
-        _COMMS[key] = ShardComm(index.device, group, transport)
+        _COMMS[key] = bring_up(index.device, group, trial, timeout_s, want)
     return _COMMS[key]
 
 
@@ -205,12 +343,12 @@ def search_sharded_local(shards, q_value, q_index, k: int):
     return scores, rows
 
 
-def sharded_search(index, q_value, q_index, k: int, group=None):
+def sharded_search(index, q_value, q_index, k: int, group=None, comm=None):
     """index: this rank's GipIndex (rows shard_bounds(N, world, rank), row_offset=lo).  Returns the global [Q,k] (scores, rows)
     torch cuda tensors on every rank: dhr_search_sharded, over RCCL on an nccl process group and over torch.distributed host gathers
     on any other (ShardComm) -- the same control flow in the library either way."""
     import torch
-    comm = _comm_for(index, group)
+    comm = comm if comm is not None else _comm_for(index, group)
     lib = _lib.load()
     qb, keep = index._qb(q_value, q_index)
     dev = torch.device("cuda", index.device)

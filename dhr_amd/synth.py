@@ -120,3 +120,71 @@ def torch_make_dlr(gen, n: int, d_dlr: int, lmin: int, lmax: int, device, *, uni
     val = torch.where(has, hv, val)
     idx = torch.where(has, hi, idx)
     return val.to(torch.float16), idx.to(torch.uint8)
+
+
+# ----------------------------------------------------------------------------- structured dense columns ("--data clustered")
+# SURVEY.md 8(d) specifies i.i.d. Gaussian dense columns; real encoder output is not: it clusters, its spectrum decays, corpora hold
+# near-duplicate passages, and some queries sit on a cluster centre.  The filter of this design is data-dependent, so the
+# bench can also be run on this variant: N_CLUSTERS Gaussian clusters with a skewed size distribution (p_i ~ (1 + i)^-0.7), sigma_within =
+# 0.3 sigma_between, per-dimension standard deviation ~ (1 + d / 32)^-1/2 (the overall scale keeps the mean per-column std at 0.1),
+# DUP_FRAC of the rows near-duplicates of another row (the WHOLE row: gated values, indices, dense part + 1 % noise), HOT_FRAC of the queries
+# on a cluster centre (+ 5 % noise).
+N_CLUSTERS = 2000
+SIGMA_WITHIN = 0.3
+DUP_FRAC = 0.01
+HOT_FRAC = 0.05
+
+
+def cluster_model(seed: int, d: int):
+    """-> (centres [N_CLUSTERS, d] fp32 in units of the final scale, per-dimension std of the within-cluster noise [d], cluster cdf)."""
+    rng = np.random.Generator(np.random.PCG64(seed * 7919 + 17))
+    spec = (1.0 + np.arange(d) / 32.0) ** -0.5
+    scale = 0.1 / np.sqrt((1.0 + SIGMA_WITHIN ** 2) * np.mean(spec ** 2))
+    centres = (rng.standard_normal((N_CLUSTERS, d)) * spec * scale).astype(np.float32)
+    p = (1.0 + np.arange(N_CLUSTERS)) ** -0.7
+    return centres, (SIGMA_WITHIN * spec * scale).astype(np.float32), np.cumsum(p / p.sum())
+
+
+def make_dense_clustered(rng: np.random.Generator, n: int, d: int, model, *, hot_frac: float = 0.0) -> np.ndarray:
+    centres, sw, cdf = model
+    c = np.minimum(np.searchsorted(cdf, rng.random(n)), N_CLUSTERS - 1)
+    noise = rng.standard_normal((n, d)).astype(np.float32) * sw
+    hot = rng.random(n) < hot_frac
+    noise[hot] *= 0.05 / SIGMA_WITHIN
+    return (centres[c] + noise).astype(np.float16)
+
+
+def torch_make_dense_clustered(gen, n: int, d: int, model_t, device, *, hot_frac: float = 0.0):
+    """torch form on `device`; model_t = (centres, sw, cdf) as device tensors (torch_cluster_model)."""
+    import torch
+    centres, sw, cdf = model_t
+    c = torch.bucketize(torch.rand((n,), generator=gen, device=device), cdf).clamp_(max=N_CLUSTERS - 1)
+    noise = torch.randn((n, d), generator=gen, device=device) * sw
+    if hot_frac > 0:
+        hot = torch.rand((n, 1), generator=gen, device=device) < hot_frac
+        noise = torch.where(hot, noise * (0.05 / SIGMA_WITHIN), noise)
+    return (centres[c] + noise).to(torch.float16)
+
+
+def torch_cluster_model(seed: int, d: int, device):
+    import torch
+    centres, sw, cdf = cluster_model(seed, d)
+    return (torch.from_numpy(centres).to(device), torch.from_numpy(sw).to(device), torch.tensor(cdf, device=device, dtype=torch.float32))
+
+
+def torch_near_duplicates(gen, value, index, d_dlr: int, frac: float = DUP_FRAC):
+    """In place: a fraction `frac` of the rows become copies of another row of the block (gated values and indices exactly, dense part
+    times (1 + 1 % noise))."""
+    import torch
+    n = value.shape[0]
+    m = int(n * frac)
+    if m <= 0:
+        return
+    dst = torch.randint(0, n, (m,), generator=gen, device=value.device)
+    src = torch.randint(0, n, (m,), generator=gen, device=value.device)
+    value[dst] = value[src]
+    if index is not None:
+        index[dst] = index[src]
+    if value.shape[1] > d_dlr:
+        jit = 1.0 + 0.01 * torch.randn((m, value.shape[1] - d_dlr), generator=gen, device=value.device)
+        value[dst, d_dlr:] = (value[dst, d_dlr:].float() * jit).to(torch.float16)

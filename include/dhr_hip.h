@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DHR_VERSION 102 /* 0.1.2: dhr_search_mid / dhr_search_mid_ranks (second threshold agreement of the sharded search), dhr_host_shard::mid_ranks / mid */
+#define DHR_VERSION 103 /* 0.1.3: dhr_comm_info / dhr_comm_abort (what the communicator really spans; a way out of a hung bring-up) */
 
 typedef enum dhr_status {
   DHR_OK = 0,
@@ -380,6 +380,15 @@ int dhr_comm_wrap(void* nccl_comm, int32_t world, int32_t rank, int32_t device, 
 typedef int (*dhr_allgather_fn)(void* user, const void* send, void* recv, int64_t bytes);
 int dhr_comm_create_callback(int32_t world, int32_t rank, int32_t device, dhr_allgather_fn allgather, void* user, dhr_comm** out);
 void dhr_comm_destroy(dhr_comm* comm);
+/* What the communicator really is, asked of the transport itself (a scaling record can then show that RCCL spanned N ranks):
+ *   DHR_COMM_TRANSPORT 0 = RCCL, 1 = caller-supplied host transport;  DHR_COMM_WORLD / DHR_COMM_RANK / DHR_COMM_DEVICE: for an RCCL
+ *   communicator ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the ncclComm_t, else the values given at creation.
+ * Returns the value, or a negative status. */
+enum { DHR_COMM_TRANSPORT = 0, DHR_COMM_WORLD = 1, DHR_COMM_RANK = 2, DHR_COMM_DEVICE = 3 };
+int dhr_comm_info(const dhr_comm* comm, int32_t what);
+/* Way out of a bring-up that hangs (a peer never reached ncclCommInitRank / a collective): ncclCommAbort instead of ncclCommDestroy --
+ * may be called from another host thread than the one blocked in the collective; the handle is gone afterwards. */
+void dhr_comm_abort(dhr_comm* comm);
 /* The sharded control flow over a shard the CALLER implements in host memory (no device is touched): test / bring-up hook.  The
  * callbacks mirror the staged C ABI: sample_rank / union_rank (dhr_search_sample_rank with DHR_PARAM_SAMPLE_SHARE = share /
  * dhr_search_union_rank), begin (writes [n_queries, sample_rank] best sample scores, best first), finish (tau [n_queries] ->

@@ -12,12 +12,16 @@ import time
 
 import numpy as np
 
+LAST_THREADS = 0          # torch.get_num_threads() as read INSIDE the last gip_loop (the setting is restored on the way out)
+
 
 def gip_loop(q32: np.ndarray, qi, c32: np.ndarray, ci, k: int, threads: int):
     """-> (seconds per query, rows [Q, k]).  q32 / c32 fp32 (the reference's CPU dtype), qi / ci unpadded index arrays or None."""
     import torch
     old = torch.get_num_threads()
     torch.set_num_threads(max(1, threads))
+    global LAST_THREADS
+    LAST_THREADS = torch.get_num_threads()
     try:
         c = torch.from_numpy(c32)
         q = torch.from_numpy(q32)

@@ -197,3 +197,45 @@ def test_sharded_core_over_gloo(tmp_path, mode, world):
     else:
         assert calls[0][:3] == ["begin", "mid", "finish"] if mode.startswith("mid") else calls[0][:2] == ["begin", "finish"]
         assert (len(calls[0]) == (4 if mode.startswith("mid") else 3)) == (mode in ("adversarial", "mid_adversarial"))
+
+
+# ---- bring-up of the library's RCCL communicator under a watchdog (dhr_amd.dist.bring_up): a failure or a hang on ONE rank must degrade
+# EVERY rank to the host transport instead of leaving the others in a collective.  On this CPU box dhr_comm_create itself cannot
+# succeed (no device), which is one more failure the vote has to survive; the real RCCL leg runs in the -m gpu suite.
+def _bringup_worker(rank, world, port, tmp, env):
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import time
+    import torch.distributed as dist
+    from dhr_amd import dist as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t0 = time.time()
+        comm = D.bring_up(0, None, None, timeout_s=4.0)
+        dt = time.time() - t0
+        assert comm.transport == "host" and comm.info(0) == 1 and comm.ranks_seen() == world and comm.info(2) == rank
+        assert "dropped on every rank" in comm.note, comm.note
+        assert dt < 60.0, dt
+        # the communicator's gather is the control group's: every rank's block arrives in rank order
+        send = np.full(16, rank + 1, np.uint8)
+        recv = np.zeros(16 * world, np.uint8)
+        assert comm._cb(None, send.ctypes.data, recv.ctypes.data, 16) == 0
+        np.testing.assert_array_equal(recv, np.repeat(np.arange(1, world + 1, dtype=np.uint8), 16))
+        comm.close()
+        open(os.path.join(tmp, f"ok{rank}"), "w").write(comm.note)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("env", [{"DHR_TEST_COMM_FAIL_RANK": "1"}, {"DHR_TEST_COMM_HANG_RANK": "0"}, {}], ids=["one_rank_raises", "one_rank_hangs", "no_device"])
+def test_bring_up_degrades_collectively(tmp_path, env):
+    import torch.multiprocessing as mp
+    world = 2
+    port = 29500 + (os.getpid() % 2000) + 17 + len(env) + (7 if "DHR_TEST_COMM_HANG_RANK" in env else 0)
+    mp.spawn(_bringup_worker, args=(world, port, str(tmp_path), env), nprocs=world, join=True)
+    notes = [open(tmp_path / f"ok{r}").read() for r in range(world)]
+    if "DHR_TEST_COMM_HANG_RANK" in env:
+        assert "still blocked" in notes[0]
+    if "DHR_TEST_COMM_FAIL_RANK" in env:
+        assert "injected failure" in notes[1]
