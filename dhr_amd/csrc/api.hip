@@ -1344,7 +1344,15 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
           if (ix->s_gemm) { hipStreamDestroy(ix->s_gemm); ix->s_gemm = nullptr; }
         }
       }
-      if (!ix->s_aux) HIP_TRY(hipStreamCreateWithFlags(&ix->s_aux, hipStreamNonBlocking));
+      if (!ix->s_aux) {
+        // DHR_AUX_PRIO=1: the refine / rescoring stream at the LOWEST queue priority, so that a CU that a bound-GEMM workgroup has just left
+        // takes the next GEMM workgroup first and the gathers fill what is left (co-residence instead of time slices)
+        static const int aux_prio = getenv("DHR_AUX_PRIO") ? atoi(getenv("DHR_AUX_PRIO")) : 0;
+        int least = 0, greatest = 0;
+        if (aux_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+          HIP_TRY(hipStreamCreateWithPriority(&ix->s_aux, hipStreamNonBlocking, least));
+        else HIP_TRY(hipStreamCreateWithFlags(&ix->s_aux, hipStreamNonBlocking));
+      }
       ix->aux_cus_made = aux_cus; ix->gemm_excl_made = ix->gemm_exclusive;
     }
     hipStream_t sg = ix->s_gemm ? ix->s_gemm : s;

@@ -424,8 +424,18 @@ __device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int
   g8_epilogue(p, acc, dt, qt, wm, wn, (int)threadIdx.x, lane, smem, thr_r, mul_r);
 }
 
+// G8_VGPR_CAP (build flag, architectural registers = HALF the cap on the unified file): 116 = 232 registers per wave -- two waves leave 48
+// of a SIMD's 512 registers to a co-resident refine / rescoring wave; 0 = no cap (243)
+#ifndef G8_VGPR_CAP
+#define G8_VGPR_CAP 0
+#endif
+#if G8_VGPR_CAP > 0
+#define G8_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(2, 2), amdgpu_num_vgpr(G8_VGPR_CAP)))
+#else
+#define G8_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 template <bool DUMP>
-__global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_filter_g8_kernel(GemmArgs p) {
+__global__ void __launch_bounds__(G8_NT) G8_KERNEL_ATTR gemm_filter_g8_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int64_t dt;
   int qt;

@@ -1922,7 +1922,10 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
 }
 // Flat launches walk the block list with a grid stride: the grid is the exact block count when the host knows it, and a fixed one when the
 // controller runs without host read-backs (the list lengths then exist in device memory only).
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7))) rescore_kernel(RescoreArgs p) {
+#ifndef RESCORE_WPE
+#define RESCORE_WPE 7          // waves per SIMD the register allocation aims at (7 = 72 registers, 8 = 64)
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RESCORE_WPE))) rescore_kernel(RescoreArgs p) {
   if (!p.blk_off) { rescore_block(p, (int)blockIdx.y, blockIdx.x); return; }
   for (uint32_t b = blockIdx.x;; b += gridDim.x) {
     int q; uint32_t blk;
