@@ -1129,6 +1129,58 @@ def test_full_size_properties(G, kind):
     _search_check(G, cvs, cis, qs[:6], None if qis is None else qis[:6], 100)                     # (5)
 
 
+@pytest.mark.parametrize("kind", ["hybrid", "dense"])
+def test_clustered_data_exhaustive(G, kind):
+    """Structure-bearing dense columns (bench.py --data clustered: 2 000 Gaussian clusters with a skewed size distribution, sigma_within =
+    0.3 sigma_between, decaying per-dimension spectrum, 1 % near-duplicate rows, 5 % hot queries on cluster centres) -- the filter's speed is
+    data-dependent, its RESULT must not be.  1 M rows (whole generator chunks, so the near-duplicates are in), 1 024 queries, top-1000:
+    (a) 40 queries spread over the batch -- every hot query among them -- equal the exhaustive top-k over all rows (rows and score bits);
+    (b) sorted, distinct, idempotent; (c) a 100 000-row slice against the float64 oracle under the tie rule; (d) no query fell back."""
+    import sys, os
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    from dhr_amd import synth, _lib
+    dev = torch.device("cuda", 0)
+    n, nq, k = 4 * bench.GEN_CHUNK, 1024, 1000
+    d_dlr = 768 if kind == "hybrid" else 0
+    cm = synth.torch_cluster_model(1237, 768, dev)
+    cv, ci = bench.gen_rows(torch, synth, dev, 1237, 0, n, d_dlr, 768, 30, 90, False, clustered=cm, dup=True)
+    qv, qi = bench.gen_rows(torch, synth, dev, 1237 + 999_983, 0, nq, d_dlr, 768, 4, 12, False, clustered=cm, hot_frac=synth.HOT_FRAC)
+    # the data really is what the docstring says: near-duplicate rows exist, and some queries sit on a centre
+    centres = cm[0]
+    qd = qv[:, d_dlr:].float()
+    dist = torch.cdist(qd, centres).min(dim=1).values
+    hot = torch.nonzero(dist < 0.25 * dist.median()).flatten()
+    assert 20 <= len(hot) <= 100, len(hot)
+    ix = G.GipIndex(cv, ci)
+    ix.set_param(_lib.PARAM_PROFILE, 1)
+    try:
+        s1, r1 = ix.search(qv, qi, k, out_device=True)
+        st = ix.stats()
+        s2, r2 = ix.search(qv, qi, k, out_device=True)
+        assert torch.equal(r1, r2) and torch.equal(s1, s2)
+        ds = s1[:, 1:] - s1[:, :-1]
+        assert bool((ds <= 0).all()) and bool((r1[:, 1:][ds == 0] > r1[:, :-1][ds == 0]).all())
+        assert int(torch.sort(r1, dim=1).values.diff(dim=1).eq(0).sum()) == 0
+        ex_q = torch.unique(torch.cat([torch.arange(0, nq, 64, device=dev), hot[:24], torch.tensor([nq - 1], device=dev)]))
+        es, er = _exhaustive_topk(ix, qv[ex_q].contiguous(), None if qi is None else qi[ex_q].contiguous(), n, k)
+        assert torch.equal(er, r1[ex_q]), "rows differ from the exhaustive top-k for queries %s" % ex_q[(er != r1[ex_q]).any(dim=1)].tolist()
+        assert torch.equal(es.view(torch.int32), s1[ex_q].view(torch.int32))
+        assert st["sample_fallback_queries"] == 0, st
+        print("\n[clustered %s, %d rows] %d queries (%d hot) == exhaustive top-%d; bound %.0f -> exact %.0f rows per query, %d launches"
+              % (kind, n, len(ex_q), min(24, len(hot)), k, st["candidates_bound"] / nq, st["candidates_exact"] / nq, st["phases"]))
+    finally:
+        ix.close()
+    m = 100_000
+    qs = qv[hot[:3].tolist() + [0, 1, 2]].cpu().numpy().astype(np.float32)
+    qis = None if qi is None else qi[hot[:3].tolist() + [0, 1, 2]].cpu().numpy()
+    cvs, cis = cv[:m].cpu().numpy(), (None if ci is None else ci[:m].cpu().numpy())
+    del cv, ci
+    torch.cuda.empty_cache()
+    _search_check(G, cvs, cis, qs, qis, 100)
+
+
 def test_config4_full_size_8_shards(G):
     """BASELINE config 4 at FULL size on one GPU: the bench corpus (seed 1237, bench.gen_rows) as the reference's 8 row shards
     (gip_retrieval.py:292-306: per = N // S, the last shard takes the remainder) through dhr_search_sharded_local -- the same
