@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--gemm-variant", type=int, default=-1, help="tuning: bound-GEMM kernel of the 2:4 layout (3 = 12-wave producer / consumer, 4 = 4 waves, 5 = 8 waves)")
     ap.add_argument("--no-progressive-thr", action="store_true", help="A/B: keep the sampled thresholds frozen over the main pass")
     ap.add_argument("--first-rows", type=int, default=0)
+    ap.add_argument("--list-stride", type=int, default=0, help="tuning: DHR_PARAM_LIST_STRIDE (uniform slots per query of the bound lists; 262144 = the uniform lists of rounds 3-4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline slice (SURVEY.md section 8d: 1 M)")
     ap.add_argument("--cpu-queries", type=int, default=8, help="queries of the all-cores CPU leg (~3.3 s per query and M rows on the 256-thread host; section 8d's 32 with --cpu-queries 32)")
@@ -269,7 +270,7 @@ def run_workload(args, spec, ctx):
     t_build = time.perf_counter() - t_build
     index.set_param(_lib.PARAM_PROFILE, 1)
     for flag, prm in ((args.cand_cap, _lib.PARAM_CAND_CAP), (args.max_growth, _lib.PARAM_MAX_GROWTH), (args.main_chunks, _lib.PARAM_MAIN_CHUNKS),
-                      (args.first_rows, _lib.PARAM_FIRST_ROWS)):
+                      (args.first_rows, _lib.PARAM_FIRST_ROWS), (args.list_stride, _lib.PARAM_LIST_STRIDE)):
         if flag:
             index.set_param(prm, flag)
     for flag, prm in ((args.sample_period, _lib.PARAM_SAMPLE_PERIOD), (args.aux_cus, _lib.PARAM_AUX_CUS), (args.overlap_aux, _lib.PARAM_OVERLAP_AUX),

@@ -13,7 +13,7 @@ DHR_OK = 0
 IDX_NONE, IDX_U8, IDX_I8, IDX_I16 = 0, 1, 2, 3
 VAL_F16, VAL_F32 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
-PARAM_CAND_CAP, PARAM_FIRST_ROWS, PARAM_PROFILE, PARAM_MAX_GROWTH, PARAM_SAMPLE_PERIOD, PARAM_GEMM_VARIANT, PARAM_MAIN_CHUNKS, PARAM_PROGRESSIVE_THR, PARAM_AUX_CUS, PARAM_GEMM_EXCLUSIVE, PARAM_OVERLAP_AUX, PARAM_SAMPLE_SHARE, PARAM_ASYNC_CONTROLLER = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
+PARAM_CAND_CAP, PARAM_FIRST_ROWS, PARAM_PROFILE, PARAM_MAX_GROWTH, PARAM_SAMPLE_PERIOD, PARAM_GEMM_VARIANT, PARAM_MAIN_CHUNKS, PARAM_PROGRESSIVE_THR, PARAM_AUX_CUS, PARAM_GEMM_EXCLUSIVE, PARAM_OVERLAP_AUX, PARAM_SAMPLE_SHARE, PARAM_ASYNC_CONTROLLER, PARAM_LIST_STRIDE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14
 OPT_DENSE_I8, OPT_GATED_I8 = 1, 2
 COMM_TRANSPORT, COMM_WORLD, COMM_RANK, COMM_DEVICE = 0, 1, 2, 3
 INFO_DENSE_I8, INFO_I8_SCALE, INFO_I8_ROW_ERR, INFO_I8_ROW_NORM, INFO_ROW_NORM_MAX, INFO_TILE_BYTES, INFO_GATED_I8 = 1, 2, 3, 4, 5, 6, 7

@@ -42,7 +42,15 @@ static inline int idx_esize(int dt) { return dt == DHR_IDX_I16 ? 2 : 1; }
 struct Workspace {
   int q_pad = 0, kp = 0;
   int q_alloc = 0;       // query rows the buffers were allocated for (>= q_pad: a smaller batch re-uses them)
-  int64_t cap = 0;       // capacity of the bound-candidate lists (cand, cand2)
+  int64_t cap = 0;       // entries every query owns in the bound-candidate lists (cand, cand2): the stride of the uniform arrays
+  int64_t cap_deep = 0;  // what ONE query's list may grow to: cap, or (two-tier lists) cap + its segment of the arena, at most this -- the depth the chunk plans assume
+  int64_t arena = 0;     // two-tier lists: entries of each overflow arena (0: uniform lists only)
+  uint2 *ovf = nullptr, *ovf2 = nullptr;          // the arenas of the two list sets
+  uint32_t *ovf_off = nullptr, *ovf_cap = nullptr;   // [q_pad] a query's segment (plan_overflow_kernel); planned before every sampled phase and once for the main pass
+  bool keys_alias = false;                        // rs_keys IS cand_r (see ensure_ws)
+  ListTier* tier_dev = nullptr;                   // device copy of {ovf, ovf_off, ovf_cap} and {ovf2, ovf_off, ovf_cap}: what GemmArgs::tier points at
+  uint32_t* cnt_plan = nullptr;                   // [q_pad] bound-list lengths of the last sampled phase, kept for the plan of the main pass (a staged search resumes in another call)
+  int64_t plan_rows = 0;                          // ... and the rows that phase covered
   uint32_t last_maxr = 0;   // fullest survivor list of the latest refine step (before clamping to cap_r): the chunk planner sizes the main pass by it too
   int64_t cap_r = 0;     // capacity of the lists that reach the exact rescoring (refine survivors; == cap without refine)
   int64_t keys_ld = 0, kt = 0, d_dlr = 0;
@@ -125,6 +133,7 @@ struct dhr_index {
   int64_t index_bytes = 0;
   // params
   int64_t cand_cap = 0, first_rows = 0;   // 0 = default (262144 with refine lists, else 65536)
+  int64_t list_stride = 0;                // DHR_PARAM_LIST_STRIDE (0 = 32768)
   int profile = 0, max_growth16 = 32;
   int sample_period = 32;
   int async_ctl = 2;                       // (2: + one 32-byte read after the sampled run for the chunk plan of the main pass) first attempt of a sampled search: the controller only ENQUEUES (no host read-backs between the phases; list
@@ -148,7 +157,7 @@ struct dhr_index {
 
 static void free_ws(Workspace& w) {
   hipFree(w.q_tiles); hipFree(w.q32); hipFree(w.q_idx); hipFree(w.q16); hipFree(w.q_idx8); hipFree(w.q_inexact); hipFree(w.margin); hipFree(w.i8_mul); hipFree(w.g8_q8); hipFree(w.g8_shift); hipFree(w.g8_unit); hipFree(w.tau); hipFree(w.thr);
-  hipFree(w.cnt); hipFree(w.cand); hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2); hipFree(w.q_pack); hipFree(w.cand_r); hipFree(w.cnt_r); hipFree(w.thr_raise); hipFree(w.blk_off);
+  hipFree(w.cnt); hipFree(w.cand); if (!w.keys_alias) hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2); hipFree(w.q_pack); hipFree(w.cand_r); hipFree(w.cnt_r); hipFree(w.thr_raise); hipFree(w.blk_off); hipFree(w.ovf); hipFree(w.ovf2); hipFree(w.ovf_off); hipFree(w.ovf_cap); hipFree(w.cnt_plan); hipFree(w.tier_dev);
   if (w.h_pinned) hipHostFree(w.h_pinned);
   if (w.h_pinned2) hipHostFree(w.h_pinned2);
   hipFree(w.d_max2); hipFree(w.d_ref); hipFree(w.d_stats);
@@ -223,6 +232,9 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
       if (value < 0 || value > 256) return set_error(DHR_ERR_INVALID, "sample_period must be in [0,256] (0/1 = off)");
       ix->sample_period = (int)value; return DHR_OK;
     case DHR_PARAM_ASYNC_CONTROLLER: ix->async_ctl = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return DHR_OK;
+    case DHR_PARAM_LIST_STRIDE:
+      if (value != 0 && (value < 256 || value > (1 << 22) || value % 256)) return set_error(DHR_ERR_INVALID, "list_stride must be 0 (default) or a multiple of 256 in [256, 4194304]");
+      ix->list_stride = value; return DHR_OK;
     case DHR_PARAM_SAMPLE_SHARE:
       if (value < 1 || value > 4096) return set_error(DHR_ERR_INVALID, "sample_share must be in [1,4096]");
       ix->sample_share = (int)value; return DHR_OK;
@@ -755,7 +767,7 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   if (kp < 64) kp = 64;
   const bool refine = (ix->heavy_key != nullptr || ix->resid8 != nullptr) && use_refine;
   // default list depth: 262144 (refine) / 65536, but never more than ~32 GiB for the two bound-list sets of a big batch
-  int64_t cap = 0, cap_r = 0, keys_ld = 0;
+  int64_t cap = 0, cap_r = 0, keys_ld = 0, cap_deep = 0, arena = 0;
   auto plan_depths = [&](int q_for_cap) {
     int64_t base_cap = refine ? 262144 : 65536;
     // ... sized by the SHARD: a list cannot hold more rows than the shard has, and the chunk planner of the main pass cuts the pass
@@ -772,9 +784,25 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
     if (ix->cand_cap > 0) base_cap = ix->cand_cap;
     // fallback depths serve a handful of queries: 16x deeper lists there cost little memory
     cap = std::min<int64_t>(base_cap * cap_mult, (int64_t)1 << 22);
+    cap_deep = cap;
+    // Two-tier lists (round 5).  The depth above is what the HOTTEST query of a batch needs (a few per cent of the queries pass 10-100 x the
+    // average through the filter); as the stride of [q_pad][cap] arrays it cost config 3 two 15 GB list sets of which a step fills 0.1 GB.
+    // Now every query owns `stride` slots and a hot one gets the rest of its depth from an arena shared by the batch, planned on the device
+    // from the previous launch's list lengths (plan_overflow_kernel).  Only where the bound lists are read by a refine level (the rescoring
+    // kernel and the key buffer keep their uniform stride), for the first attempt (the fallback depths serve a handful of queries), and not
+    // when the caller fixed the depth (DHR_PARAM_CAND_CAP).
+    const int64_t stride = ix->list_stride > 0 ? ix->list_stride : 32768;
+    arena = 0;
+    const int variant = ix->gemm_variant ? ix->gemm_variant : g_gemm_variant;
+    const bool kernel_writes_tier = ix->gated_i8 || variant != 4;      // (the 4-wave kernel writes the uniform part only: dhr_internal.h cand_store)
+    if (refine && cap_mult == 1 && ix->cand_cap <= 0 && cap > stride && kernel_writes_tier) {
+      cap = stride;
+      arena = std::max<int64_t>((int64_t)4 << 20, std::min<int64_t>((int64_t)q_for_cap * 4096, (int64_t)64 << 20));
+      arena = std::max(arena, 2 * (cap_deep - cap));
+    }
     // survivor lists: 32 768 entries, and at least 4 x the padded k (agip_topk 10 000: a chunk of the main pass must be able to bring
     // a hot query's share of its 10 000 best -- 12 queries per step overflowed 32 768 and were redone)
-    cap_r = refine ? std::min<int64_t>(cap, std::max<int64_t>(32768, 4 * (int64_t)kp) * cap_mult) : cap;
+    cap_r = refine ? std::min<int64_t>(cap_deep, std::max<int64_t>(32768, 4 * (int64_t)kp) * cap_mult) : cap;
     keys_ld = std::max<int64_t>(cap_r, keys_ld_min);
   };
   // A SMALLER batch re-uses the buffers of a larger one (same list depths and strides; q_pad is the ACTIVE padded query count).  Until round 4
@@ -783,7 +811,7 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   // (the list depths of the LARGER batch: beyond ~8 000 queries they are halved to bound the memory)
   if (w.q_alloc >= q_pad && w.kt == ix->kt) {
     plan_depths(w.q_alloc);
-    if (w.kp == kp && w.cap == cap && w.cap_r == cap_r && w.keys_ld >= keys_ld) { w.q_pad = q_pad; return DHR_OK; }
+    if (w.kp == kp && w.cap == cap && w.cap_deep == cap_deep && w.arena == arena && w.cap_r == cap_r && w.keys_ld >= keys_ld) { w.q_pad = q_pad; return DHR_OK; }
   }
   plan_depths(q_pad);
   free_ws(w);
@@ -805,7 +833,11 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.thr, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.cnt, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.cand, (size_t)q_pad * cap * 8, tot));
-  HIP_TRY(re_malloc(w.rs_keys, (size_t)q_pad * keys_ld * 8, tot));
+  // The keys of the exact rescoring (score bits | row) overwrite the survivor entries they were computed from: entry i of a query is read
+  // (its row) and written (its key) by the same wave of rescore_kernel, nothing reads the survivor lists afterwards, and both are 8 bytes
+  // -- with a refine level and equal strides the key buffer IS the survivor array (1.9 GB of a config-3 workspace).
+  const bool alias = refine && keys_ld == cap_r;
+  if (!alias) HIP_TRY(re_malloc(w.rs_keys, (size_t)q_pad * keys_ld * 8, tot));
   HIP_TRY(re_malloc(w.topk_keys, (size_t)q_pad * kp * 8, tot));
   HIP_TRY(re_malloc(w.d_max, 16, tot));
   HIP_TRY(re_malloc(w.tau_hat, (size_t)q_pad * 4, tot));
@@ -813,10 +845,22 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.thr_hat, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.blk_off, (size_t)2 * (q_pad + 1) * 4, tot));
   if (ix->resid8) HIP_TRY(re_malloc(w.thr_raise, (size_t)q_pad * 4, tot));
+  if (arena > 0) {
+    HIP_TRY(re_malloc(w.ovf, (size_t)arena * 8, tot));
+    HIP_TRY(re_malloc(w.ovf_off, (size_t)q_pad * 4, tot));
+    HIP_TRY(re_malloc(w.ovf_cap, (size_t)q_pad * 4, tot));
+    HIP_TRY(re_malloc(w.cnt_plan, (size_t)q_pad * 4, tot));
+    HIP_TRY(re_malloc(w.tier_dev, 2 * sizeof(ListTier), tot));
+    { const ListTier t0{w.ovf, w.ovf_off, w.ovf_cap}; HIP_TRY(hipMemcpy(w.tier_dev, &t0, sizeof t0, hipMemcpyHostToDevice)); }
+    HIP_TRY(hipMemset(w.cnt_plan, 0, (size_t)q_pad * 4));
+    HIP_TRY(hipMemset(w.ovf_off, 0, (size_t)q_pad * 4));
+    HIP_TRY(hipMemset(w.ovf_cap, 0, (size_t)q_pad * 4));
+  }
   if (refine) {
     HIP_TRY(re_malloc(w.q_pack, (size_t)q_pad * std::max(ix->d_dlr, 8) * 4, tot));
     HIP_TRY(re_malloc(w.cand_r, (size_t)q_pad * cap_r * 8, tot));
     HIP_TRY(re_malloc(w.cnt_r, (size_t)q_pad * 4, tot));
+    if (alias) { w.rs_keys = (uint64_t*)w.cand_r; w.keys_alias = true; }
   }
   HIP_TRY(hipHostMalloc(&w.h_pinned, 16, hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&w.h_pinned2, 32, hipHostMallocDefault));
@@ -825,7 +869,7 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(hipHostMalloc(&w.h_ref, 16, hipHostMallocDefault));
   HIP_TRY(re_malloc(w.d_stats, 32, tot));
   HIP_TRY(hipHostMalloc(&w.h_stats, 32, hipHostMallocDefault));
-  w.q_pad = w.q_alloc = q_pad; w.kp = kp; w.cap = cap; w.cap_r = cap_r; w.keys_ld = keys_ld; w.kt = ix->kt; w.d_dlr = ix->d_dlr;
+  w.q_pad = w.q_alloc = q_pad; w.kp = kp; w.cap = cap; w.cap_deep = cap_deep; w.arena = arena; w.cap_r = cap_r; w.keys_ld = keys_ld; w.kt = ix->kt; w.d_dlr = ix->d_dlr;
   w.bytes = tot;
   return DHR_OK;
 }
@@ -977,6 +1021,7 @@ static uint32_t async_grid() {
 static int gemm_phase_async(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi, int map_mode, int period, int64_t head,
                             Timer& tm, dhr_search_stats& st, hipStream_t s) {
   GemmArgs g{};
+  if (w.arena > 0) g.tier = w.tier_dev;      // two-tier lists: planned by the caller (stream_phases)
   g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr; g.g8_rsum = ix->g8_rsum;
   g.seq_lo = lo; g.seq_hi = hi; g.map_mode = map_mode; g.period = period; g.head = head; g.n_tiles = ix->n_tiles;
   g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt;
@@ -992,15 +1037,19 @@ static int gemm_phase_async(dhr_index* ix, Workspace& w, int Q, int64_t lo, int6
 }
 // (d_fullest_bound / d_fullest: where the length of the fullest bound / survivor list of this phase is stored, or nullptr)
 static int rescore_select_async(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, const uint2* cand, const uint32_t* cnt,
-                                const float* thr, Timer& tm, hipStream_t s, uint32_t* d_fullest_bound = nullptr, uint32_t* d_fullest = nullptr) {
+                                const float* thr, Timer& tm, hipStream_t s, uint32_t* d_fullest_bound = nullptr, uint32_t* d_fullest = nullptr,
+                                const uint2* ovf = nullptr) {
   uint32_t list_cap = (uint32_t)w.cap;
   const bool refine = uses_refine(ix, gate);
+  if (!refine) ovf = nullptr;                    // (the second tier exists for lists a refine level reads, ensure_ws)
+  const uint32_t* ovf_cap = ovf ? w.ovf_cap : nullptr;
   // the bound lists: statistics, overflow marks, block offsets of the kernel that walks them and (refine) the survivor counters cleared
   HIP_TRY(launch_lists_ready(cnt, (uint32_t)w.cap, Q, refine ? 256u : (uint32_t)RESCORE_CANDS_PER_WG, refine ? w.blk_off : w.blk_off + w.q_pad + 1,
                              d_fullest_bound, refine ? nullptr : d_fullest, w.d_stats + 0, refine ? nullptr : w.d_stats + 1, w.fail_flags,
-                             refine ? w.cnt_r : nullptr, refine ? (int)w.q_pad : 0, s));
+                             refine ? w.cnt_r : nullptr, refine ? (int)w.q_pad : 0, s, ovf_cap));
   if (refine) {
     RefineArgs f{};
+    f.ovf = ovf; f.ovf_off = ovf ? w.ovf_off : nullptr; f.ovf_cap = ovf_cap;
     f.cand = cand; f.cnt = cnt; f.cap = (uint32_t)w.cap; f.heavy_key = ix->heavy_key; f.heavy_val = ix->heavy_val;
     f.q_pack = w.q_pack; f.d_dlr = ix->d_dlr; f.thr = thr; f.out = w.cand_r; f.out_cnt = w.cnt_r; f.out_cap = (uint32_t)w.cap_r;
     f.n_queries = Q; f.max_count = 1;
@@ -1097,6 +1146,7 @@ static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectAr
                          hipStream_t s, double* last_rate = nullptr, double* last_rate_r = nullptr, bool async_ctl = false,
                          int64_t* last_rows = nullptr, int rank_target = 0, int64_t rank_rows = 0) {
   int64_t pos = 0;
+  int64_t prev_rows = 0;
   int64_t chunk = std::max<int64_t>(DOC_GROUP, first_chunk);
   while (pos < n_seq) {
     chunk = std::min(chunk, round_up(n_seq - pos, DOC_GROUP));
@@ -1106,10 +1156,15 @@ static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectAr
       sel.monotone = 1;
     }
     if (async_ctl) {          // enqueue only: an overflowing list flags its query instead of halving the chunk
+      // two-tier lists: the second tier of this phase from the list lengths of the previous one (w.cnt still holds them; none for the first)
+      if (w.arena > 0)
+        HIP_TRY(launch_plan_overflow(prev_rows > 0 ? w.cnt : nullptr, prev_rows > 0 ? (double)((hi - pos) * TILE_ROWS) / (double)prev_rows : 0.0, (uint32_t)w.cap,
+                                     (uint32_t)(w.cap_deep - w.cap), (uint32_t)w.arena, Q, w.ovf_off, w.ovf_cap, s));
       // (d_max2: {fullest bound list, -, -, -, fullest survivor list} of the latest phase -- what the chunk plan of the main pass reads)
       int rc = gemm_phase_async(ix, w, Q, pos, hi, map_mode, period, head, tm, st, s);
       if (rc) return rc;
-      if ((rc = rescore_select_async(ix, w, Q, gate, sel, w.cand, w.cnt, w.thr, tm, s, w.d_max2, w.d_max2 + 4)) != DHR_OK) return rc;
+      if ((rc = rescore_select_async(ix, w, Q, gate, sel, w.cand, w.cnt, w.thr, tm, s, w.d_max2, w.d_max2 + 4, w.arena > 0 ? w.ovf : nullptr)) != DHR_OK) return rc;
+      prev_rows = (hi - pos) * TILE_ROWS;
       if (last_rows) *last_rows = (hi - pos) * TILE_ROWS;
       seen_rows += (hi - pos) * TILE_ROWS;
       pos = hi;
@@ -1265,6 +1320,10 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, std::max<int64_t>(head, DOC_GROUP), first_valid, tm, st, s, &rate, &rate_r, async_ctl, &last_rows,
                             r_eff, first_valid + n_sample * TILE_ROWS)) != DHR_OK) return rc;
     HIP_TRY(hipMemcpyAsync(w.tau_hat, w.tau, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
+    if (async_ctl && w.arena > 0) {          // the main pass plans its second list tier from these (possibly in a later call: staged search)
+      HIP_TRY(hipMemcpyAsync(w.cnt_plan, w.cnt, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
+      w.plan_rows = last_rows;
+    }
     if (async_ctl && plan_read && stage == 0 && last_rows > 0) {
       // the ONE read-back besides the final one: 32 bytes, the fullest bound / survivor list of the last sampled phase -> how many chunks
       // the main pass needs for the hottest query's lists to fit (a list that overflows costs its query tile an extra pass over the corpus:
@@ -1316,6 +1375,11 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       int64_t tot = 0;
       HIP_TRY(re_malloc(w.cand2, (size_t)w.q_alloc * w.cap * 8, tot));
       HIP_TRY(re_malloc(w.cnt2, (size_t)w.q_alloc * 4, tot));
+      if (w.arena > 0) {
+        HIP_TRY(re_malloc(w.ovf2, (size_t)w.arena * 8, tot));
+        const ListTier t1{w.ovf2, w.ovf_off, w.ovf_cap};
+        HIP_TRY(hipMemcpy(w.tier_dev + 1, &t1, sizeof t1, hipMemcpyHostToDevice));
+      }
       w.bytes += tot;
     }
     // Streams of the main pass.  Default: the bound GEMM on the caller's stream, refine/rescoring/select on a
@@ -1375,7 +1439,10 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     // (rate = bound candidates per corpus row of the fullest query at the final sample thresholds, 1.5x headroom)
     // ... and the same for the survivor lists of the refine step, which are shallower (cap_r): a query whose bound the heavy lists
     // do not tighten fills them first
-    const int64_t need = std::max((int64_t)std::ceil(1.5 * rate * (double)n_main * TILE_ROWS / (double)w.cap),
+    // (two-tier lists: a hot query's list may grow to cap_deep; the host-driven controller only has the uniform stride)
+    const bool two_tier = async_ctl && w.arena > 0;
+    const int64_t plan_cap = two_tier ? w.cap_deep : w.cap;
+    const int64_t need = std::max((int64_t)std::ceil(1.5 * rate * (double)n_main * TILE_ROWS / (double)plan_cap),
                                   (int64_t)std::ceil(1.5 * rate_r * (double)n_main * TILE_ROWS / (double)w.cap_r));
     // (without read-backs the sampled run's rates are not known here: a fixed 8 chunks (12 where the thresholds are extrapolated, below), which the deep lists of round 3 cover at config 3 --
     // 203 k entries in the fullest list of the first chunk against 262 144 slots; a list that overflows anyway flags its query)
@@ -1383,7 +1450,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     // ... and, where that takes at most 12 chunks, so many that the FIRST (largest: 3 / (2 M) of the pass) chunk has no more rows than a list has
     // slots: a small corpus then cannot overflow a list whatever its scores are (queries with fewer than k matching rows filter at 0)
     int64_t by_size = std::min<int64_t>(8, std::max<int64_t>(2, (n_main + 4199) / 4200));
-    const int64_t no_overflow = (3 * n_main * TILE_ROWS + 2 * std::min(w.cap, w.cap_r) - 1) / (2 * std::min(w.cap, w.cap_r));
+    const int64_t no_overflow = (3 * n_main * TILE_ROWS + 2 * std::min(plan_cap, w.cap_r) - 1) / (2 * std::min(plan_cap, w.cap_r));
     if (no_overflow <= 12) by_size = std::max(by_size, no_overflow);
     // ... and so many that the HOTTEST queries fit: on the benchmark's data a query passes ~20 k rows per 1 000 results through the bound
     // filter and ~4 k through the refine step, the hottest ten times that, whatever the corpus size -- on a 0.5 M-row corpus (BEIR quora,
@@ -1391,7 +1458,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     // were redone (60 ms per step instead of 28).  The first chunk is 3 / (2 M) of the pass.  (A shard chases its share of k.)
     {
       const double k_eff = (double)k / (double)std::max(1, stage >= 2 ? ix->sample_share : 1);
-      const int64_t by_hot = (int64_t)std::ceil(300.0 * k_eff / (double)w.cap);
+      const int64_t by_hot = (int64_t)std::ceil(300.0 * k_eff / (double)plan_cap);
       const int64_t by_hot_r = (int64_t)std::ceil(65.0 * k_eff / (double)w.cap_r);
       by_size = std::max(by_size, std::min<int64_t>(24, std::max(by_hot, by_hot_r)));
     }
@@ -1423,6 +1490,14 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       bound[M] = n_main;
     }
     const int c_lo = (stage == 2 && ix->pend.mid) ? 1 : 0, c_hi = stage == 3 ? 1 : M;      // the chunks THIS call runs
+    if (two_tier) {
+      // second tier of the bound lists, ONE plan for every chunk of the pass (both list sets share it): from the lists of the last sampled
+      // phase, scaled to the largest chunk -- the pass filters with thresholds at least as high as that phase did, and they only rise
+      int64_t big = 0;
+      for (int i = 0; i < M; ++i) big = std::max(big, bound[i + 1] - bound[i]);
+      HIP_TRY(launch_plan_overflow(w.plan_rows > 0 ? w.cnt_plan : nullptr, w.plan_rows > 0 ? (double)(big * TILE_ROWS) / (double)w.plan_rows : 0.0, (uint32_t)w.cap,
+                                   (uint32_t)(w.cap_deep - w.cap), (uint32_t)w.arena, Q, w.ovf_off, w.ovf_cap, s));
+    }
     std::vector<hipEvent_t> ev_gemm(M), ev_done(M);
     for (int i = 0; i < M; ++i) {
       HIP_TRY(hipEventCreateWithFlags(&ev_gemm[i], hipEventDisableTiming));
@@ -1439,6 +1514,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       g.seq_lo = lo; g.seq_hi = hi; g.map_mode = scatter ? 3 : 2; g.period = S; g.head = head; g.n_tiles = ix->n_tiles; g.perm_mul = perm_mul; g.perm_n = n_main;
       g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr_hat; g.cand = cand; g.cnt = cnt;
       g.cap = (uint32_t)w.cap; g.n_queries = Q;
+      if (two_tier) g.tier = w.tier_dev + (i & 1);
       HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)w.q_pad * 4, sg));
       if (!async_ctl) HIP_TRY(hipMemsetAsync(w.d_max2 + 4 * (i & 1), 0, 16, sg));
       tm.begin_on(T_GEMM, sg); HIP_TRY(launch_gemm_filter(g, sg)); tm.end_on(sg);
@@ -1462,7 +1538,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
         uint2* cand_a = (i & 1) ? w.cand2 : w.cand;
         uint32_t* cnt_a = (i & 1) ? w.cnt2 : w.cnt;
         if (sb != sg) HIP_TRY(hipStreamWaitEvent(sb, ev_gemm[i], 0));
-        if ((rc = rescore_select_async(ix, w, Q, gate, sel, cand_a, cnt_a, w.thr_hat, tm, sb)) != DHR_OK) return rc;
+        if ((rc = rescore_select_async(ix, w, Q, gate, sel, cand_a, cnt_a, w.thr_hat, tm, sb, nullptr, nullptr, two_tier ? ((i & 1) ? w.ovf2 : w.ovf) : nullptr)) != DHR_OK) return rc;
         if (ix->progressive_thr) HIP_TRY(launch_raise_thr(w.thr_hat, sel.thr, Q, sb));
         if (extrapolate && i + 1 < M) {
           const double f = (double)(head + n_sample + bound[i + 1]) / (double)ix->n_tiles;

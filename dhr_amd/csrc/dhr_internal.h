@@ -146,7 +146,29 @@ struct GemmArgs {
   const float* i8_mul;        // [Q_pad] or null.  Non-null: the td dense stages hold int8 columns (64 per stage); the kernel runs them
                               // FIRST on v_mfma_i32_32x32x32_i8 and turns the integer sums into fp32 with this per-query factor
                               // (corpus scale x query scale) before the gated stages accumulate on top
+  // Two-tier candidate lists (round 5): every query owns `cap` slots of the uniform array `cand`; a query the controller expects to need
+  // more (a few per cent of a batch pass 10-100 x the average through the filter) also owns ovf_cap[q] slots at ovf[ovf_off[q]] in a shared
+  // arena, planned on the device from the previous launch's list lengths (plan_overflow_kernel).  Slot s of query q lives at
+  // cand[q * cap + s] for s < cap and at ovf[ovf_off[q] + s - cap] behind it.  tier null: uniform lists only.
+  // (ONE pointer to a three-pointer record in device memory, read on the cold path only: three more pointer arguments cost the 4-wave kernel,
+  // which sits at the scalar-register limit, 1 KB of scratch per lane)
+  const struct ListTier* tier;
 };
+struct ListTier { uint2* ovf; const uint32_t* ovf_off; const uint32_t* ovf_cap; };
+#if defined(__HIPCC__)
+// TIER = false: the 4-wave kernel (gemm_filter_wx_kernel<NI = 4>, DHR_PARAM_GEMM_VARIANT 4) holds 509 registers per lane and 256 unrolled copies
+// of this store; the second tier in each of them costs it 1 KB of scratch per lane, so that kernel writes the uniform part only and
+// the controller does not plan a second tier for it (ensure_ws).
+template <bool TIER = true>
+__device__ __forceinline__ void cand_store(const GemmArgs& p, int q, uint32_t slot, uint2 v) {
+  if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = v;
+  else if (TIER && p.tier) {                  // cold: only the queries with an arena segment ever get here
+    const ListTier* t = p.tier;
+    const uint32_t o = slot - p.cap;
+    if (o < t->ovf_cap[q]) t->ovf[(size_t)t->ovf_off[q] + o] = v;
+  }
+}
+#endif
 
 // gated_i8: x >= 0 in units of a step, rounded UP to [0, 127].  inv_step carries a relative 1e-6 of head room, so that the fp32
 // rounding of the product can never make  step * q(x) < x ; the SAME expression in the tile builder, query_prep and the refine step
@@ -274,6 +296,7 @@ hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, 
                               const float* g8_inv_cs /* gated_i8 indexes: the key also carries the entry's int8 level */, int abs_mode, hipStream_t s);
 struct RefineArgs {
   const uint2* cand; const uint32_t* cnt; uint32_t cap;      // bound candidates (row, U bits)
+  const uint2* ovf; const uint32_t* ovf_off; const uint32_t* ovf_cap;   // ... their second tier (GemmArgs), or null
   const uint32_t* heavy_key; const __half* heavy_val;       // [n_rows][HEAVY]
   const uint32_t* q_pack; int d_dlr;                         // [Q_pad][d_dlr]: fp16 value | bucket | idx low bits
   const float* thr;                                          // [Q_pad]
@@ -315,10 +338,16 @@ hipError_t launch_pq_decode(const uint8_t* codes, int64_t ld_codes, int64_t n, i
                             int ksub, hipStream_t s);
 // exclusive scan of ceil(min(cnt[q], cap) / per) over the queries -> offs[0 .. n_queries] (one workgroup)
 hipError_t launch_block_offsets(const uint32_t* cnt, uint32_t cap, int n_queries, uint32_t per, uint32_t* offs, hipStream_t s);
+// second tier of the bound lists for the NEXT launch, from the list lengths of the previous one: a query whose list is expected to outgrow
+// its `cap` uniform slots -- 2 x cnt_prev x rows_next / rows_prev + 2048 entries -- gets the difference (rounded up to 256, at most
+// max_extra) as a segment of the arena; segments are handed out in query order until the arena is used up (ovf_off / ovf_cap [n_queries];
+// cnt_prev null: no segments)
+hipError_t launch_plan_overflow(const uint32_t* cnt_prev, double rows_ratio, uint32_t cap, uint32_t max_extra, uint32_t arena_entries, int n_queries,
+                                uint32_t* ovf_off, uint32_t* ovf_cap, hipStream_t s);
 hipError_t launch_max_u32(const uint32_t* v, int n, uint32_t* out_max, unsigned long long* out_sum, hipStream_t s);
 hipError_t launch_lists_ready(const uint32_t* cnt, uint32_t cap, int n_queries, uint32_t per, uint32_t* offs, uint32_t* out_max, uint32_t* out_max2,
                               unsigned long long* out_sum, unsigned long long* out_sum2, uint32_t* fail_flags, uint32_t* zero, int n_zero,
-                              hipStream_t s);
+                              hipStream_t s, const uint32_t* ovf_cap = nullptr);
 hipError_t launch_rows_to_local(const int64_t* rows, int64_t n, int64_t row_offset, int64_t n_rows, uint32_t* out,
                                 hipStream_t s);
 hipError_t launch_mark_overflow(const uint32_t* cnt, uint32_t cap, int n_queries, uint32_t* fail_flags, hipStream_t s);

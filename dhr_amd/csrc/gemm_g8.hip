@@ -99,7 +99,7 @@ __device__ __forceinline__ void g8_scan_half(const GemmArgs& p, floatx16 (&acc)[
             if constexpr (SURPLUS) {
               if (j >= EPI_STACK) {
                 const uint32_t slot = atomicAdd(p.cnt + q, 1u);
-                if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(row0 + rl), __float_as_uint(g8_score(v, mul)));
+                cand_store(p, q, slot, make_uint2((uint32_t)(row0 + rl), __float_as_uint(g8_score(v, mul))));
               }
             } else if (j < EPI_STACK) stack[j * G8_NT] = make_uint2((uint32_t)rl, (uint32_t)v);
             ++j;
@@ -150,12 +150,12 @@ __device__ __forceinline__ void g8_epilogue(const GemmArgs& p, floatx16 (&acc)[4
   for (uint32_t i = 0; i < s0; ++i) {
     const uint2 en = stack[i * G8_NT];
     const uint32_t slot = base0 + i;
-    if (slot < p.cap) p.cand[(int64_t)q0 * p.cap + slot] = make_uint2((uint32_t)row0 + en.x, __float_as_uint(g8_score((int)en.y, mul_r[0])));
+    cand_store(p, q0, slot, make_uint2((uint32_t)row0 + en.x, __float_as_uint(g8_score((int)en.y, mul_r[0]))));
   }
   for (uint32_t i = s0; i < s1; ++i) {
     const uint2 en = stack[i * G8_NT];
     const uint32_t slot = base1 + (i - s0);
-    if (slot < p.cap) p.cand[(int64_t)(q0 + 32) * p.cap + slot] = make_uint2((uint32_t)row0 + en.x, __float_as_uint(g8_score((int)en.y, mul_r[1])));
+    cand_store(p, q0 + 32, slot, make_uint2((uint32_t)row0 + en.x, __float_as_uint(g8_score((int)en.y, mul_r[1]))));
   }
 #endif
 }

@@ -104,7 +104,9 @@ __device__ __forceinline__ void g8p_scan_half(KArgs kp, floatx16 (&acc)[4][2], c
               if (j >= (uint32_t)G8P_DEPTH) {
                 const uint32_t cap = kp->cap;
                 const uint32_t slot = atomicAdd(kp->cnt + q, 1u);
-                if (slot < cap) kp->cand[(int64_t)q * cap + slot] = make_uint2(row0 + (uint32_t)rl, __float_as_uint(g8_score(v, mul)));
+                const uint2 ev = make_uint2(row0 + (uint32_t)rl, __float_as_uint(g8_score(v, mul)));
+                if (slot < cap) kp->cand[(int64_t)q * cap + slot] = ev;
+                else if (const ListTier* lt = kp->tier) { const uint32_t o = slot - cap; if (o < lt->ovf_cap[q]) lt->ovf[(size_t)lt->ovf_off[q] + o] = ev; }      // second tier (GemmArgs::tier)
               }
             } else if (j < (uint32_t)G8P_DEPTH) stack[j * G8_NT] = g8p_entry(v, rl);
             ++j;
@@ -287,8 +289,9 @@ __global__ void __launch_bounds__(G8_NT) __attribute__((amdgpu_waves_per_eu(2, 2
             const bool first = i < s0;
             const uint32_t slot = first ? fl_base0 + i : fl_base1 + (i - s0);
             const int q = first ? fl_q : fl_q + 32;
-            if (slot < cap)
-              cand[(int64_t)q * cap + slot] = make_uint2(fl_row0 + (en[u] & 255u), __float_as_uint(g8_score((int)(en[u] & 0xffffff00u), first ? fl_mul0 : fl_mul1)));
+            const uint2 ev = make_uint2(fl_row0 + (en[u] & 255u), __float_as_uint(g8_score((int)(en[u] & 0xffffff00u), first ? fl_mul0 : fl_mul1)));
+            if (slot < cap) cand[(int64_t)q * cap + slot] = ev;
+            else if (const ListTier* lt = k->tier) { const uint32_t o = slot - cap; if (o < lt->ovf_cap[q]) lt->ovf[(size_t)lt->ovf_off[q] + o] = ev; }      // second tier (GemmArgs::tier), cold
           }
         }
       }

@@ -85,7 +85,7 @@ __device__ __forceinline__ void gemm_epilogue_w(const GemmArgs& p, floatx16 (&ac
                   if (j < EPI_STACK) stack[j * NT] = make_uint2((uint32_t)rl, __float_as_uint(vs));
                   else {
                     const uint32_t slot = atomicAdd(p.cnt + q, 1u);
-                    if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(row0 + rl), __float_as_uint(vs));
+                    cand_store<NI != 4>(p, q, slot, make_uint2((uint32_t)(row0 + rl), __float_as_uint(vs)));
                   }
                   ++j;
                 }
@@ -114,7 +114,7 @@ __device__ __forceinline__ void gemm_epilogue_w(const GemmArgs& p, floatx16 (&ac
     for (uint32_t i = lo; i < hi; ++i) {
       const uint2 en = stack[i * NT];
       const uint32_t slot = base[ni] + (i - lo);
-      if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)row0 + en.x, en.y);
+      cand_store<NI != 4>(p, q, slot, make_uint2((uint32_t)row0 + en.x, en.y));
     }
   }
 }

@@ -807,7 +807,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, floatx16 (&acc)
               if (j < EPI_STACK) stack[j * 512] = make_uint2((uint32_t)rl, __float_as_uint(v));
               else {
                 const uint32_t slot = atomicAdd(p.cnt + q, 1u);
-                if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)(row0 + rl), __float_as_uint(v));
+                cand_store(p, q, slot, make_uint2((uint32_t)(row0 + rl), __float_as_uint(v)));
               }
               ++j;
             }
@@ -828,7 +828,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, floatx16 (&acc)
       for (uint32_t i = lo; i < hi; ++i) {
         const uint2 en = stack[i * 512];
         const uint32_t slot = base + (i - lo);
-        if (slot < p.cap) p.cand[(int64_t)q * p.cap + slot] = make_uint2((uint32_t)row0 + en.x, en.y);
+        cand_store(p, q, slot, make_uint2((uint32_t)row0 + en.x, en.y));
       }
     }
   }
@@ -1284,7 +1284,8 @@ hipError_t launch_block_offsets(const uint32_t* cnt, uint32_t cap, int n_queries
 __global__ void __launch_bounds__(1024) lists_ready_kernel(const uint32_t* __restrict__ cnt, uint32_t cap, int n_queries, uint32_t per,
                                                            uint32_t* __restrict__ offs, uint32_t* __restrict__ out_max, uint32_t* __restrict__ out_max2,
                                                            unsigned long long* __restrict__ out_sum, unsigned long long* __restrict__ out_sum2,
-                                                           uint32_t* __restrict__ fail_flags, uint32_t* __restrict__ zero, int n_zero) {
+                                                           uint32_t* __restrict__ fail_flags, uint32_t* __restrict__ zero, int n_zero,
+                                                           const uint32_t* __restrict__ ovf_cap) {
   __shared__ uint32_t part[1024];
   __shared__ uint32_t wmax[16];
   __shared__ unsigned long long wsum[16];
@@ -1297,7 +1298,8 @@ __global__ void __launch_bounds__(1024) lists_ready_kernel(const uint32_t* __res
     uint32_t c = cnt[q];
     m = c > m ? c : m;
     tot += c;
-    if (c > cap) { c = cap; if (fail_flags) fail_flags[q] = 1u; }
+    const uint32_t cq = ovf_cap ? cap + ovf_cap[q] : cap;          // two-tier lists: the query's own capacity
+    if (c > cq) { c = cq; if (fail_flags) fail_flags[q] = 1u; }
     s += (c + per - 1) / per;
   }
   part[tid] = s;
@@ -1316,7 +1318,7 @@ __global__ void __launch_bounds__(1024) lists_ready_kernel(const uint32_t* __res
     __syncthreads();
   }
   uint32_t run = tid ? part[tid - 1] : 0u;
-  for (int q = lo; q < hi; ++q) { offs[q] = run; uint32_t c = cnt[q]; if (c > cap) c = cap; run += (c + per - 1) / per; }
+  for (int q = lo; q < hi; ++q) { offs[q] = run; uint32_t c = cnt[q]; const uint32_t cq = ovf_cap ? cap + ovf_cap[q] : cap; if (c > cq) c = cq; run += (c + per - 1) / per; }
   if (tid == 1023) offs[n_queries] = part[1023];
   if (tid == 0) {
     for (int i = 1; i < 16; ++i) { m = wmax[i] > m ? wmax[i] : m; tot += wsum[i]; }
@@ -1329,9 +1331,51 @@ __global__ void __launch_bounds__(1024) lists_ready_kernel(const uint32_t* __res
 }
 hipError_t launch_lists_ready(const uint32_t* cnt, uint32_t cap, int n_queries, uint32_t per, uint32_t* offs, uint32_t* out_max, uint32_t* out_max2,
                               unsigned long long* out_sum, unsigned long long* out_sum2, uint32_t* fail_flags, uint32_t* zero, int n_zero,
-                              hipStream_t s) {
+                              hipStream_t s, const uint32_t* ovf_cap) {
   hipLaunchKernelGGL(lists_ready_kernel, dim3(1), dim3(1024), 0, s, cnt, cap, n_queries, per, offs, out_max, out_max2, out_sum, out_sum2, fail_flags,
-                     zero, n_zero);
+                     zero, n_zero, ovf_cap);
+  return hipGetLastError();
+}
+// Second tier of the bound lists (GemmArgs::ovf): one workgroup; thread t plans a contiguous range of queries, an exclusive scan of the
+// segment sizes gives the offsets, and what does not fit into the arena any more is cut (those lists overflow and flag their query).
+__global__ void __launch_bounds__(1024) plan_overflow_kernel(const uint32_t* __restrict__ cnt_prev, double rows_ratio, uint32_t cap, uint32_t max_extra,
+                                                             uint32_t arena_entries, int n_queries, uint32_t* __restrict__ ovf_off,
+                                                             uint32_t* __restrict__ ovf_cap) {
+  __shared__ unsigned long long part[1024];
+  const int tid = threadIdx.x;
+  const int chunk = (n_queries + 1023) / 1024;
+  const int lo = tid * chunk, hi = min(lo + chunk, n_queries);
+  auto want = [&](int q) -> uint32_t {
+    if (!cnt_prev) return 0u;
+    const double need = 2.0 * (double)cnt_prev[q] * rows_ratio + 2048.0;
+    if (!(need > (double)cap)) return 0u;
+    const double extra = need - (double)cap;
+    const uint32_t e = extra >= (double)max_extra ? max_extra : (uint32_t)extra;
+    return (e + 255u) & ~255u;
+  };
+  unsigned long long s = 0;
+  for (int q = lo; q < hi; ++q) s += want(q);
+  part[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const unsigned long long v = tid >= d ? part[tid - d] : 0ull;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  unsigned long long run = tid ? part[tid - 1] : 0ull;
+  for (int q = lo; q < hi; ++q) {
+    uint32_t w = want(q);
+    if (run >= arena_entries) w = 0u;
+    else if (run + w > arena_entries) w = (uint32_t)(arena_entries - run);
+    ovf_off[q] = (uint32_t)(run < arena_entries ? run : arena_entries);
+    ovf_cap[q] = w;
+    run += want(q);
+  }
+}
+hipError_t launch_plan_overflow(const uint32_t* cnt_prev, double rows_ratio, uint32_t cap, uint32_t max_extra, uint32_t arena_entries, int n_queries,
+                                uint32_t* ovf_off, uint32_t* ovf_cap, hipStream_t s) {
+  hipLaunchKernelGGL(plan_overflow_kernel, dim3(1), dim3(1024), 0, s, cnt_prev, rows_ratio, cap, max_extra, arena_entries, n_queries, ovf_off, ovf_cap);
   return hipGetLastError();
 }
 __device__ __forceinline__ bool flat_block(const uint32_t* __restrict__ offs, int n_queries, uint32_t b, int& q, uint32_t& blk) {
@@ -1441,7 +1485,8 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
   for (uint32_t fb = blockIdx.x;; fb += gridDim.x) {       // flat launches: grid stride over the block list (see rescore_kernel); else one pass
   if (p.blk_off && !flat_block(p.blk_off, p.n_queries, fb, q, blk)) return;
   uint32_t count = p.cnt[q];
-  if (count > p.cap) count = p.cap;
+  const uint32_t cap_q = p.ovf_cap ? p.cap + p.ovf_cap[q] : p.cap;      // two-tier lists (GemmArgs::ovf)
+  if (count > cap_q) count = cap_q;
   const uint32_t base = blk * REFINE_PER_WG;
   if (base >= count) { if (p.blk_off) continue; return; }
   __syncthreads();                                           // the previous block's readers are done with the staged query words
@@ -1461,7 +1506,7 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
     double back = 0.0;          // G8: real-valued products of those whose index values agree
     uint2 c = make_uint2(0u, 0u);
     if (i < count) {
-      c = p.cand[(int64_t)q * p.cap + i];
+      c = i < p.cap ? p.cand[(int64_t)q * p.cap + i] : p.ovf[(size_t)p.ovf_off[q] + (i - p.cap)];
       constexpr int EPL = HEAVY / 8;              // entries per lane: 8 (two 16-byte key loads + one 16-byte value load) or 4 (one + an 8-byte one)
       static_assert(EPL == 8 || EPL == 4, "8 lanes per candidate read 8 or 4 entries each");
       const uint32_t* hk = p.heavy_key + (int64_t)c.x * HEAVY_KEY_STRIDE + sub * EPL;
@@ -1583,7 +1628,8 @@ __global__ void __launch_bounds__(256) dense_refine_kernel(RefineArgs p) {
   for (uint32_t fb = blockIdx.x;; fb += gridDim.x) {       // flat launches: grid stride over the block list (see rescore_kernel); else one pass
   if (p.blk_off && !flat_block(p.blk_off, p.n_queries, fb, q, blk)) return;
   uint32_t count = p.cnt[q];
-  if (count > p.cap) count = p.cap;
+  const uint32_t cap_q = p.ovf_cap ? p.cap + p.ovf_cap[q] : p.cap;      // two-tier lists (GemmArgs::ovf)
+  if (count > cap_q) count = cap_q;
   const uint32_t base = blk * REFINE_PER_WG;
   if (base >= count) { if (p.blk_off) continue; return; }
   __syncthreads();                                           // the previous block's readers are done with the staged factors
@@ -1635,7 +1681,7 @@ __global__ void __launch_bounds__(256) dense_refine_kernel(RefineArgs p) {
 #pragma unroll
     for (int u = 0; u < U; ++u) v[u] = make_uint2(0x88888888u, 0x88888888u);
     if (i < count) {
-      c = p.cand[(int64_t)q * p.cap + i];
+      c = i < p.cap ? p.cand[(int64_t)q * p.cap + i] : p.ovf[(size_t)p.ovf_off[q] + (i - p.cap)];
       const uint8_t* r = p.resid8 + (int64_t)c.x * p.resid_ld + sub * 8;
 #pragma unroll
       for (int u = 0; u < U; ++u) v[u] = gather8(r + u * 128);

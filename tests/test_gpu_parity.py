@@ -724,6 +724,43 @@ def test_smaller_batch_reuses_the_workspace(G):
         ix.close()
 
 
+@pytest.mark.parametrize("stride", [256, 1024, 4096])
+def test_two_tier_candidate_lists(G, gated_image, stride):
+    """Two-tier bound lists (round 5: every query owns DHR_PARAM_LIST_STRIDE uniform slots, a hot query the rest of its depth from an arena
+    planned on the device).  With a stride far below what the lists of this batch hold, the second tier carries most entries of the hot
+    queries -- and a query whose plan came out too small overflows, is flagged and redone: either way the result must be the result of the
+    default stride, which is checked against the oracle.  The footprint shrinks with the stride."""
+    from dhr_amd import synth, _lib
+    cv, ci, qv, qi = synth.make_pair(91, 300_000, 640, 768, 64)
+    q = qv.astype(np.float32)
+    q[:40, :768] *= 3.0                               # a few HOT queries: their lists are several times the average
+    k = 200
+    ix = G.GipIndex(cv, ci)
+    try:
+        ix.set_param(_lib.PARAM_PROFILE, 1)
+        s0, r0 = ix.search(q, qi, k)
+        st0, b0 = ix.stats(), ix.device_bytes()
+        ix.set_param(_lib.PARAM_LIST_STRIDE, stride)
+        s1, r1 = ix.search(q, qi, k)
+        st1, b1 = ix.stats(), ix.device_bytes()
+        np.testing.assert_array_equal(r1, r0)
+        np.testing.assert_array_equal(s1, s0)
+        s2, r2 = ix.search(q[5:9], qi[5:9], k)         # a smaller batch in the same workspace
+        np.testing.assert_array_equal(r2, r0[5:9])
+        print("\n[stride %d, gated image %s] bound %.0f -> exact %.0f per query, redone %d (default stride: %.0f -> %.0f, redone %d); device bytes %.2f -> %.2f GB"
+              % (stride, gated_image, st1["candidates_bound"] / 640, st1["candidates_exact"] / 640, st1["sample_fallback_queries"],
+                 st0["candidates_bound"] / 640, st0["candidates_exact"] / 640, st0["sample_fallback_queries"], b0 / 1e9, b1 / 1e9))
+        if st1["sample_fallback_queries"] == 0:          # (a redone query brings the fallback workspace with its 16 x deeper lists)
+            assert b1 < b0
+        assert st1["sample_fallback_queries"] <= 64      # the plan (2 x the previous phase's rate + 2 048) covers all but a few queries
+        c32 = cv.astype(np.float32)
+        for i in (0, 3, 39, 40, 333, 639):
+            ex = O.gip_scores_f64(q[i], qi[i], c32, ci)
+            O.check_topk(r1[i], s1[i], ex, k)
+    finally:
+        ix.close()
+
+
 @pytest.mark.parametrize("mid", [False, True])
 @pytest.mark.parametrize("kind", ["hybrid", "dense"])
 def test_staged_sharded_search_common_threshold(G, kind, gated_image, mid):
