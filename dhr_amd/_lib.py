@@ -21,7 +21,7 @@ INFO_DENSE_I8, INFO_I8_SCALE, INFO_I8_ROW_ERR, INFO_I8_ROW_NORM, INFO_ROW_NORM_M
 EXPORTS = ["dhr_version", "dhr_abi_sizes", "dhr_set_option", "dhr_index_get_info", "dhr_last_error", "dhr_index_create", "dhr_index_destroy", "dhr_index_set_param",
            "dhr_index_device_bytes", "dhr_search", "dhr_score_rows", "dhr_merge_topk", "dhr_merge_topk_host", "dhr_merge_topk_lists", "dhr_merge_topk_lists_host",
            "dhr_get_stats", "dhr_debug_bound_scores", "dhr_debug_query_margins", "dhr_debug_gemm_time", "dhr_debug_seq_to_tile", "dhr_search_sample_rank", "dhr_search_union_rank", "dhr_search_begin",
-           "dhr_search_finish", "dhr_search_mid_ranks", "dhr_search_mid", "dhr_search_rerank", "dhr_comm_unique_id", "dhr_comm_create", "dhr_comm_wrap", "dhr_comm_create_callback", "dhr_comm_destroy", "dhr_comm_info", "dhr_comm_abort", "dhr_search_sharded", "dhr_search_sharded_local", "dhr_search_sharded_host", "dhr_pq_create", "dhr_pq_destroy", "dhr_pq_device_bytes", "dhr_pq_search", "dhr_pq_adc_scores", "dhr_pq_last_scan", "dhr_index_save", "dhr_index_file_info", "dhr_index_load", "dhr_densify", "dhr_pq_train", "dhr_pq_encode", "dhr_pq_decode", "dhr_pq_train_nbits", "dhr_pq_encode_nbits", "dhr_pq_decode_nbits", "dhr_write_trec", "dhr_format_float"]
+           "dhr_search_finish", "dhr_search_mid_ranks", "dhr_search_mid", "dhr_search_pre_ranks", "dhr_search_pre", "dhr_search_begin_rest", "dhr_search_rerank", "dhr_comm_unique_id", "dhr_comm_create", "dhr_comm_wrap", "dhr_comm_create_callback", "dhr_comm_destroy", "dhr_comm_info", "dhr_comm_abort", "dhr_search_sharded", "dhr_search_sharded_local", "dhr_search_sharded_host", "dhr_pq_create", "dhr_pq_destroy", "dhr_pq_device_bytes", "dhr_pq_search", "dhr_pq_adc_scores", "dhr_pq_last_scan", "dhr_index_save", "dhr_index_file_info", "dhr_index_load", "dhr_densify", "dhr_pq_train", "dhr_pq_encode", "dhr_pq_decode", "dhr_pq_train_nbits", "dhr_pq_encode_nbits", "dhr_pq_decode_nbits", "dhr_write_trec", "dhr_format_float"]
 
 
 class DhrError(RuntimeError):
@@ -68,11 +68,15 @@ HS_FINISH = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_
 HS_SEARCH = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(QueryBatch), C.c_int32, C.c_void_p, C.c_void_p)
 HS_MID_RANKS = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32))
 HS_MID = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+HS_PRE_RANKS = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32))
+HS_PRE = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(QueryBatch), C.c_int32, C.c_int32, C.c_int32, C.c_void_p)
+HS_BEGIN_REST = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
 
 
 class HostShard(C.Structure):
     _fields_ = [("user", C.c_void_p), ("sample_rank", HS_SAMPLE_RANK), ("union_rank", HS_UNION_RANK), ("begin", HS_BEGIN),
-                ("finish", HS_FINISH), ("search", HS_SEARCH), ("mid_ranks", HS_MID_RANKS), ("mid", HS_MID)]
+                ("finish", HS_FINISH), ("search", HS_SEARCH), ("mid_ranks", HS_MID_RANKS), ("mid", HS_MID),
+                ("pre_ranks", HS_PRE_RANKS), ("pre", HS_PRE), ("begin_rest", HS_BEGIN_REST)]
 
 _lib = None
 
@@ -182,6 +186,10 @@ def load():
     lib.dhr_search_mid_ranks.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.dhr_search_mid_ranks.restype = C.c_int32
     lib.dhr_search_mid.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.dhr_search_pre_ranks.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.dhr_search_pre_ranks.restype = C.c_int32
+    lib.dhr_search_pre.argtypes = [C.c_void_p, C.POINTER(QueryBatch), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.dhr_search_begin_rest.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 

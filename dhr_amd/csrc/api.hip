@@ -47,6 +47,7 @@ struct Workspace {
   int64_t arena = 0;     // two-tier lists: entries of each overflow arena (0: uniform lists only)
   uint2 *ovf = nullptr, *ovf2 = nullptr;          // the arenas of the two list sets
   uint32_t *ovf_off = nullptr, *ovf_cap = nullptr;   // [q_pad] a query's segment (plan_overflow_kernel); planned before every sampled phase and once for the main pass
+  uint32_t* boot_rows = nullptr;                  // [q_pad][BOOT_M] rows of the threshold bootstrap (search_core phase 0)
   bool keys_alias = false;                        // rs_keys IS cand_r (see ensure_ws)
   ListTier* tier_dev = nullptr;                   // device copy of {ovf, ovf_off, ovf_cap} and {ovf2, ovf_off, ovf_cap}: what GemmArgs::tier points at
   uint32_t* cnt_plan = nullptr;                   // [q_pad] bound-list lengths of the last sampled phase, kept for the plan of the main pass (a staged search resumes in another call)
@@ -150,14 +151,15 @@ struct dhr_index {
   hipStream_t s_gemm = nullptr;         // main-pass GEMM stream when CU masks are in use
   hipStream_t s_aux = nullptr;          // non-blocking stream for rescoring/select overlapped with the main-pass GEMM
   // staged search (dhr_search_begin / dhr_search_finish): state carried between the two calls
-  struct { bool valid = false, done = false, gate = false, mid = false; int Q = 0, k = 0; double rate = 0.0, rate_r = 0.0; int64_t dev_bound = 0, dev_exact = 0; } pend;   // mid: dhr_search_mid ran the first slice of the main pass
+  struct { bool valid = false, done = false, gate = false, mid = false, pre = false; int Q = 0, k = 0; double rate = 0.0, rate_r = 0.0; int64_t dev_bound = 0, dev_exact = 0;
+           int64_t pre_pos = 0, pre_seen = 0; } pend;   // mid: dhr_search_mid ran the first slice of the main pass; pre: dhr_search_pre ran the first part of the sampled run (sample positions [0, pre_pos), pre_seen rows)
   Workspace ws, ws_fb[2];              // ws_fb[d]: workspace of fallback depth d+1 (16x candidate capacity)
   dhr_search_stats stats{};
 };
 
 static void free_ws(Workspace& w) {
   hipFree(w.q_tiles); hipFree(w.q32); hipFree(w.q_idx); hipFree(w.q16); hipFree(w.q_idx8); hipFree(w.q_inexact); hipFree(w.margin); hipFree(w.i8_mul); hipFree(w.g8_q8); hipFree(w.g8_shift); hipFree(w.g8_unit); hipFree(w.tau); hipFree(w.thr);
-  hipFree(w.cnt); hipFree(w.cand); if (!w.keys_alias) hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2); hipFree(w.q_pack); hipFree(w.cand_r); hipFree(w.cnt_r); hipFree(w.thr_raise); hipFree(w.blk_off); hipFree(w.ovf); hipFree(w.ovf2); hipFree(w.ovf_off); hipFree(w.ovf_cap); hipFree(w.cnt_plan); hipFree(w.tier_dev);
+  hipFree(w.cnt); hipFree(w.cand); if (!w.keys_alias) hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2); hipFree(w.q_pack); hipFree(w.cand_r); hipFree(w.cnt_r); hipFree(w.thr_raise); hipFree(w.blk_off); hipFree(w.ovf); hipFree(w.ovf2); hipFree(w.ovf_off); hipFree(w.ovf_cap); hipFree(w.cnt_plan); hipFree(w.tier_dev); hipFree(w.boot_rows);
   if (w.h_pinned) hipHostFree(w.h_pinned);
   if (w.h_pinned2) hipHostFree(w.h_pinned2);
   hipFree(w.d_max2); hipFree(w.d_ref); hipFree(w.d_stats);
@@ -756,6 +758,7 @@ static hipError_t re_malloc(T*& p, size_t bytes, int64_t& total) {
 // queries_only: the caller needs the per-query buffers only (dhr_score_rows: no lists, no running top-k) -- ANY workspace of this index
 // with enough query rows serves, so that stage 2 of a composed --rerank / --PQIP step between two searches does not free and re-allocate
 // the multi-GB lists every time (hipFree synchronises the device).
+constexpr int BOOT_M = 64;       // most rows the threshold bootstrap rescores per query
 static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t keys_ld_min, int64_t cap_mult = 1, bool use_refine = true,
                      bool queries_only = false) {
   const int q_pad = (int)round_up(n_queries, TILE_ROWS);
@@ -844,6 +847,7 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.fail_flags, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.thr_hat, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.blk_off, (size_t)2 * (q_pad + 1) * 4, tot));
+  HIP_TRY(re_malloc(w.boot_rows, (size_t)q_pad * BOOT_M * 4, tot));
   if (ix->resid8) HIP_TRY(re_malloc(w.thr_raise, (size_t)q_pad * 4, tot));
   if (arena > 0) {
     HIP_TRY(re_malloc(w.ovf, (size_t)arena * 8, tot));
@@ -1144,8 +1148,8 @@ static int adaptive_rank(int r, double phi) {
 static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, int64_t n_seq, int map_mode,
                          int period, int64_t head, int64_t first_chunk, int64_t seen_rows, Timer& tm, dhr_search_stats& st,
                          hipStream_t s, double* last_rate = nullptr, double* last_rate_r = nullptr, bool async_ctl = false,
-                         int64_t* last_rows = nullptr, int rank_target = 0, int64_t rank_rows = 0) {
-  int64_t pos = 0;
+                         int64_t* last_rows = nullptr, int rank_target = 0, int64_t rank_rows = 0, int64_t pos0 = 0) {
+  int64_t pos = pos0;          // (pos0 > 0: the run resumes behind a part another call streamed -- dhr_search_begin_rest)
   int64_t prev_rows = 0;
   int64_t chunk = std::max<int64_t>(DOC_GROUP, first_chunk);
   while (pos < n_seq) {
@@ -1238,16 +1242,38 @@ static int local_sample_rank(const dhr_index* ix, int r) {
 
 // Share of the main pass that dhr_search_mid runs before the shards agree on thresholds a second time, in 1/16ths (default 2 = 1/8: with the
 // 1/32 sample the shards have then seen ~15 % of their rows)
+// Share of the SAMPLE that dhr_search_pre streams before the shards agree on a first common threshold, in 1/16ths (default 2 = 1/8), and the
+// sample positions that is (whole tile groups; 0: the sample is too small to split)
+static int pre_share16() {
+  static const int v = getenv("DHR_PRE_SHARE16") ? std::max(1, std::min(12, atoi(getenv("DHR_PRE_SHARE16")))) : 2;
+  return v;
+}
+static int64_t pre_positions(int64_t n_sample) {
+  if (n_sample < 64) return 0;
+  const int64_t a = round_up(std::max<int64_t>(DOC_GROUP, n_sample * pre_share16() / 16), DOC_GROUP);
+  return a < n_sample ? a : 0;
+}
 static int mid_share16() {
   static const int v = getenv("DHR_MID_SHARE16") ? std::max(1, std::min(12, atoi(getenv("DHR_MID_SHARE16")))) : 2;
   return v;
 }
+// Rows scored exhaustively in phase 0 (>= the rank that defines tau, so that tau exists afterwards), whole tiles -- 512 rows until round 3, 256
+// since; 0 = none: a sampled search (S >= 2) bootstraps its first thresholds from the bound GEMM instead (search_core), unless the caller
+// fixed the head (DHR_PARAM_FIRST_ROWS) or DHR_BOOTSTRAP=0.
+static int64_t head_rows(const dhr_index* ix, int S, int r_eff) {
+  static const int boot = getenv("DHR_BOOTSTRAP") ? atoi(getenv("DHR_BOOTSTRAP")) : 1;
+  if (boot && S >= 2 && ix->first_rows <= 0 && ix->n_tiles >= 8) return 0;
+  return ix->first_rows > 0 ? std::max<int64_t>(ix->first_rows, 2 * (int64_t)r_eff) : std::max<int64_t>(S >= 2 ? 256 : 512, 2 * (int64_t)r_eff);
+}
 static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, int k, int depth, Timer& tm,
                        dhr_search_stats& st, hipStream_t s, int stage = 0, const float* tau_ext = nullptr) {
   int rc;
-  const int Q = stage >= 2 ? ix->pend.Q : qb->n_queries;
-  const bool gate = stage >= 2 ? ix->pend.gate
-                               : (ix->d_dlr > 0 && qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE);   // else plain IP
+  // stage 4 (dhr_search_pre): query preparation, phase 0 and the FIRST part of the sampled run, then stop -- the shards exchange their best sample
+  // scores seen so far; stage 5 (dhr_search_begin_rest): the rest of the sampled run from the threshold they agreed on, then as stage 1.
+  const bool fresh = stage == 0 || stage == 1 || stage == 4;       // the call brings the query batch (else: resumed from ix->pend)
+  const int Q = !fresh ? ix->pend.Q : qb->n_queries;
+  const bool gate = !fresh ? ix->pend.gate
+                           : (ix->d_dlr > 0 && qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE);   // else plain IP
   const int64_t n = ix->n_rows;
   const int64_t group_rows = (int64_t)DOC_GROUP * TILE_ROWS;
   // depth 0: sampled thresholds; depth 1 (queries that failed at depth 0): the same with 16x list capacity;
@@ -1260,7 +1286,14 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   // rows scored exhaustively in phase 0 (>= the rank that defines tau, so that tau exists afterwards), whole tile groups
   // (512 rows until round 3; with sampled thresholds the head only has to hold 2 r rows, and it is a fixed cost of every rank of the
   // sharded search: 256 rows x 6 980 queries are 1.1 ms of exhaustive rescoring)
-  int64_t first = ix->first_rows > 0 ? std::max<int64_t>(ix->first_rows, 2 * (int64_t)r_eff) : std::max<int64_t>(S >= 2 ? 256 : 512, 2 * (int64_t)r_eff);
+  int64_t first = head_rows(ix, S, r_eff);
+  // Round 5: a SAMPLED search seeds its thresholds without an exhaustive head (use_bootstrap: first == 0).  The head cost every search
+  // 256 rows x all queries of exact rescoring, bound by instruction issue (0.9-1.1 ms; for a 1/8 shard a quarter of its sampled run), only
+  // to know the ~6th best score of 256 rows.  Instead: ONE corpus tile through the bound GEMM with an open filter, the BOOT_M-or-fewer best
+  // rows of every query BY BOUND rescored exactly, and the r0-th best of those exact scores is the first threshold -- a lower bound of the
+  // r0-th best of the tile whatever the bound's ranking is worth (adaptive_rank's argument with phi = 256 rows of the sample).  The running
+  // list is cleared again: tile 0 is the first tile of the sample and comes back through the ordinary filtered phases.
+  const bool bootstrap = first == 0;
   first = std::min(round_up(first, TILE_ROWS), round_up(n, TILE_ROWS));
   const int64_t first_valid = std::min(first, n);
   if ((rc = ensure_ws(ix, w, Q, k, first_valid, depth == 0 ? 1 : 16, gate || ix->gated_i8 || ix->resid8 != nullptr)) != DHR_OK) return rc;
@@ -1270,7 +1303,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   static const int env_async = getenv("DHR_ASYNC") ? atoi(getenv("DHR_ASYNC")) : -1;
   const bool async_ctl = depth == 0 && S >= 2 && (env_async < 0 ? ix->async_ctl != 0 : env_async != 0) && !getenv("DHR_DEBUG_PLAN");
   const bool plan_read = (env_async < 0 ? ix->async_ctl : env_async) >= 2;      // 2: the chunk plan of the main pass reads the sampled run's list lengths back
-  if (stage < 2) {
+  if (fresh) {
     tm.begin(T_PREP);
     if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
     HIP_TRY(hipMemsetAsync(w.topk_keys, 0, (size_t)w.q_pad * w.kp * 8, s));
@@ -1289,8 +1322,23 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   sel.kps = 64; while (sel.kps < k) sel.kps <<= 1; sel.margin = w.margin; sel.tau = w.tau; sel.thr = w.thr;
   sel.n_queries = Q;
 
-  // ---- phase 0: exhaustive exact scoring of rows [0, first_valid)
-  if (stage < 2) {
+  // ---- phase 0: threshold bootstrap (sampled searches), or exhaustive exact scoring of rows [0, first_valid)
+  if (fresh && bootstrap) {
+    const int64_t sample_rows = ((rest + S - 1) / S) * TILE_ROWS;
+    const int r0 = adaptive_rank(r_eff, (double)TILE_ROWS / (double)sample_rows);
+    const int m = std::min(BOOT_M, std::max(16, 2 * r0));
+    if ((rc = gemm_phase_async(ix, w, Q, 0, 1, 0, 1, 0, tm, st, s)) != DHR_OK) return rc;      // tile 0, thresholds still -inf: every row is listed
+    HIP_TRY(launch_bound_topm(w.cand, w.cnt, (uint32_t)w.cap, Q, m, w.boot_rows, s));
+    RescoreArgs r = base_rescore_args(ix, w, Q, gate);
+    r.rows32 = w.boot_rows; r.ld_rows = m; r.count_all = (uint32_t)m; r.max_count = (uint32_t)m;
+    r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
+    tm.begin(T_RESCORE); HIP_TRY(launch_rescore(r, s)); tm.end();
+    sel.cnt = nullptr; sel.count_all = (uint32_t)m;
+    sel.k = std::min(r0, m); sel.monotone = 1;
+    tm.begin(T_SELECT); HIP_TRY(launch_select(sel, s)); tm.end();
+    HIP_TRY(hipMemsetAsync(w.topk_keys, 0, (size_t)w.q_pad * w.kp * 8, s));       // thresholds stay (tau, thr); the rows come back with the sample
+    st.candidates_exact += (int64_t)m * Q;
+  } else if (fresh) {
     RescoreArgs r = base_rescore_args(ix, w, Q, gate);
     r.row0 = 0; r.count_all = (uint32_t)first_valid; r.max_count = (uint32_t)first_valid;
     r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
@@ -1304,21 +1352,38 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     tm.begin(T_SELECT); HIP_TRY(launch_select(sel, s)); tm.end();
     st.candidates_exact += (int64_t)first_valid * Q;
   }
-  if (stage >= 2 && ix->pend.done) return DHR_OK;              // the begin call already finished the search
+  if (!fresh && ix->pend.done) return DHR_OK;              // the begin call already finished the search
   if (rest <= 0 || S < 2) {
     // plain streaming over all remaining tiles
     if (rest > 0 && (rc = stream_phases(ix, w, Q, gate, sel, rest, 1, 1, head, head, first_valid, tm, st, s)) != DHR_OK) return rc;
-    if (stage == 1) { ix->pend.valid = true; ix->pend.done = true; ix->pend.gate = gate; ix->pend.Q = Q; ix->pend.k = k; }
+    if (stage == 1 || stage == 4) { ix->pend.valid = true; ix->pend.done = true; ix->pend.pre = false; ix->pend.gate = gate; ix->pend.Q = Q; ix->pend.k = k; }
     return DHR_OK;
   }
 
   // ---- sampled run: top-r_eff of {head rows} + {every S-th tile}  ->  tau_hat
   const int64_t n_sample = (rest + S - 1) / S;
   double rate = 0.0, rate_r = 0.0;
-  if (stage < 2) {
+  if (fresh || stage == 5) {
     int64_t last_rows = 0;
-    if ((rc = stream_phases(ix, w, Q, gate, sel, n_sample, 1, S, head, std::max<int64_t>(head, DOC_GROUP), first_valid, tm, st, s, &rate, &rate_r, async_ctl, &last_rows,
-                            r_eff, first_valid + n_sample * TILE_ROWS)) != DHR_OK) return rc;
+    int64_t pos0 = 0, seen0 = first_valid, n_hi = n_sample, chunk0 = std::max<int64_t>(head, DOC_GROUP);
+    if (stage == 4) {
+      n_hi = pre_positions(n_sample);
+      if (n_hi <= 0) return set_error(DHR_ERR_INVALID, "the sample of this index is too small for a pre step");
+    }
+    if (stage == 5) {
+      // the threshold the shards agreed on after the first part (never below this shard's own: thresholds only rise), and on with the growth rule
+      pos0 = ix->pend.pre_pos; seen0 = ix->pend.pre_seen;
+      HIP_TRY(launch_raise_thr(w.tau, tau_ext, Q, s));
+      HIP_TRY(launch_make_thr(w.tau, w.margin, Q, w.q_pad, w.thr, s));
+      chunk0 = std::max<int64_t>(DOC_GROUP, round_up(seen0 * ix->max_growth16 / 16 / TILE_ROWS, DOC_GROUP));
+    }
+    if ((rc = stream_phases(ix, w, Q, gate, sel, n_hi, 1, S, head, chunk0, seen0, tm, st, s, &rate, &rate_r, async_ctl, &last_rows,
+                            r_eff, first_valid + n_sample * TILE_ROWS, pos0)) != DHR_OK) return rc;
+    if (stage == 4) {
+      ix->pend.valid = true; ix->pend.done = false; ix->pend.mid = false; ix->pend.pre = true; ix->pend.gate = gate; ix->pend.Q = Q; ix->pend.k = k;
+      ix->pend.pre_pos = n_hi; ix->pend.pre_seen = first_valid + n_hi * TILE_ROWS;
+      return DHR_OK;
+    }
     HIP_TRY(hipMemcpyAsync(w.tau_hat, w.tau, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
     if (async_ctl && w.arena > 0) {          // the main pass plans its second list tier from these (possibly in a later call: staged search)
       HIP_TRY(hipMemcpyAsync(w.cnt_plan, w.cnt, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
@@ -1334,8 +1399,8 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       rate = (double)hp[0] / (double)last_rows;
       rate_r = uses_refine(ix, gate) ? (double)hp[4] / (double)last_rows : 0.0;
     }
-    if (stage == 1) {
-      ix->pend.valid = true; ix->pend.done = false; ix->pend.mid = false; ix->pend.gate = gate; ix->pend.Q = Q; ix->pend.k = k; ix->pend.rate = rate; ix->pend.rate_r = rate_r;
+    if (stage == 1 || stage == 5) {
+      ix->pend.valid = true; ix->pend.done = false; ix->pend.mid = false; ix->pend.pre = false; ix->pend.gate = gate; ix->pend.Q = Q; ix->pend.k = k; ix->pend.rate = rate; ix->pend.rate_r = rate_r;
       return DHR_OK;
     }
   } else {
@@ -1786,7 +1851,7 @@ extern "C" int32_t dhr_search_mid_ranks(const dhr_index* ix, int32_t k, int32_t*
   plan_sampling(ix, k, S, r);
   if (S < 2) return 0;
   const int r_eff = local_sample_rank(ix, r);
-  int64_t first = ix->first_rows > 0 ? std::max<int64_t>(ix->first_rows, 2 * (int64_t)r_eff) : std::max<int64_t>(256, 2 * (int64_t)r_eff);
+  int64_t first = head_rows(ix, S, r_eff);
   first = std::min(round_up(first, TILE_ROWS), round_up(ix->n_rows, TILE_ROWS));
   const int64_t head = first / TILE_ROWS, rest = ix->n_tiles - head;
   if (rest <= 0) return 0;
@@ -1835,6 +1900,105 @@ extern "C" int dhr_search_mid(dhr_index* ix, const float* tau_hat_dev, int32_t r
 }
 extern "C" int dhr_internal_search_mid_async(dhr_index* ix, const float* tau_hat_dev, int32_t r_local, float* out_scores_dev, void* stream) {
   return search_mid_impl(ix, tau_hat_dev, r_local, out_scores_dev, stream);
+}
+
+// ---- first agreement in TWO rounds (round 5).  The shards of a sharded search each ran their whole sampled run from nothing, chasing their
+// share of the union's rank on their own: eight runs together rescored 3.2 k rows per query where the unsharded search's one run rescores
+// 0.7 k.  dhr_search_pre streams the first part of the shard's sample (pre_share16 / 16 of it) and reports its best scores seen so far; the
+// union of the parts is a fraction phi of the union sample, so its (r phi + 6 sigma + 4)-th best score lies below the union sample's final
+// r-th best (adaptive_rank's argument), and dhr_search_begin_rest streams the rest of the sample filtering at that COMMON threshold.  Whatever
+// the threshold is worth, the lists a shard reports afterwards are complete above it, so the union threshold computed from them can only
+// come out lower than the true one -- still valid; the count check at the end of the step verifies everything as before.
+extern "C" int32_t dhr_search_pre_ranks(const dhr_index* ix, int32_t k, int32_t* out_local, int32_t* out_union) {
+  if (out_local) *out_local = 0;
+  if (out_union) *out_union = 0;
+  if (!ix || k <= 0) return 0;
+  static const bool on = !(getenv("DHR_SHARD_PRE") && atoi(getenv("DHR_SHARD_PRE")) == 0);
+  if (!on) return 0;
+  int S = 0, r = k;
+  plan_sampling(ix, k, S, r);
+  if (S < 2) return 0;
+  const int r_eff = local_sample_rank(ix, r);
+  int64_t first = head_rows(ix, S, r_eff);
+  first = std::min(round_up(first, TILE_ROWS), round_up(ix->n_rows, TILE_ROWS));
+  const int64_t first_valid = std::min(first, ix->n_rows);
+  const int64_t rest = ix->n_tiles - first / TILE_ROWS;
+  if (rest <= 0) return 0;
+  const int64_t n_sample = (rest + S - 1) / S;
+  const int64_t n_a = pre_positions(n_sample);
+  if (n_a <= 0) return 0;
+  const double phi = (double)(first_valid + n_a * TILE_ROWS) / (double)(first_valid + n_sample * TILE_ROWS);
+  const int ru = adaptive_rank(r, phi);
+  const double m = (double)ru / std::max(1, ix->sample_share);
+  const int rl = ix->sample_share <= 1 ? ru : std::min(ru, (int)std::ceil(m + 5.0 * std::sqrt(m) + 4.0));
+  if (out_local) *out_local = rl;
+  if (out_union) *out_union = ru;
+  return rl;
+}
+static int search_pre_impl(dhr_index* ix, const dhr_query_batch* qb, int32_t k, int32_t r_local, float* out_scores_dev, void* stream, bool sync) {
+  int rc = check_queries(ix, qb);
+  if (rc) return rc;
+  if (k <= 0 || k > (1 << 20)) return set_error(DHR_ERR_INVALID, "k must be in [1, 1048576]");
+  if (!out_scores_dev) return set_error(DHR_ERR_INVALID, "null pointer");
+  if (dhr_search_pre_ranks(ix, k, nullptr, nullptr) <= 0) return set_error(DHR_ERR_INVALID, "this index has no pre step (dhr_search_pre_ranks returned 0)");
+  if (r_local <= 0 || r_local > k) return set_error(DHR_ERR_INVALID, "r_local must be in [1, k]");
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = (hipStream_t)stream;
+  ix->pend.valid = false;
+  Timer tm{ix->profile != 0, s, {}, {}};
+  dhr_search_stats st{};
+  st.n_rows = ix->n_rows; st.n_queries = qb->n_queries; st.k = k;
+  if ((rc = search_core(ix, ix->ws, qb, k, 0, tm, st, s, 4)) != DHR_OK) return rc;
+  HIP_TRY(launch_emit_scores(ix->ws.topk_keys, ix->ws.kp, qb->n_queries, r_local, out_scores_dev, s));
+  ix->pend.dev_bound = ix->pend.dev_exact = 0;
+  if (sync || ix->profile) {
+    HIP_TRY(hipStreamSynchronize(s));
+    double ms[5] = {0, 0, 0, 0, 0};
+    tm.collect(ms);
+    st.gemm_ms = ms[T_GEMM]; st.refine_ms = ms[T_REFINE]; st.rescore_ms = ms[T_RESCORE]; st.select_ms = ms[T_SELECT]; st.prep_ms = ms[T_PREP];
+  }
+  ix->stats = st;
+  return DHR_OK;
+}
+extern "C" int dhr_search_pre(dhr_index* ix, const dhr_query_batch* qb, int32_t k, int32_t r_local, float* out_scores_dev, void* stream) {
+  return search_pre_impl(ix, qb, k, r_local, out_scores_dev, stream, true);
+}
+extern "C" int dhr_internal_search_pre_async(dhr_index* ix, const dhr_query_batch* qb, int32_t k, int32_t r_local, float* out_scores_dev, void* stream) {
+  return search_pre_impl(ix, qb, k, r_local, out_scores_dev, stream, false);
+}
+// the rest of the sampled run behind dhr_search_pre; leaves the handle where dhr_search_begin leaves it (out_sample_scores_dev: [Q, dhr_search_sample_rank])
+static int search_begin_rest_impl(dhr_index* ix, const float* tau_dev, float* out_sample_scores_dev, void* stream, bool sync) {
+  if (!ix || !ix->pend.valid || !ix->pend.pre) return set_error(DHR_ERR_INVALID, "dhr_search_begin_rest without a matching dhr_search_pre");
+  if (!tau_dev || !out_sample_scores_dev) return set_error(DHR_ERR_INVALID, "null pointer");
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int k = ix->pend.k, Q = ix->pend.Q;
+  Timer tm{ix->profile != 0, s, {}, {}};
+  dhr_search_stats st = ix->stats;                     // continue the counters of the pre call
+  int rc;
+  if ((rc = search_core(ix, ix->ws, nullptr, k, 0, tm, st, s, 5, tau_dev)) != DHR_OK) return rc;
+  const int r = dhr_search_sample_rank(ix, k);
+  if (r > 0 && !ix->pend.done) HIP_TRY(launch_emit_scores(ix->ws.topk_keys, ix->ws.kp, Q, r, out_sample_scores_dev, s));
+  ix->pend.dev_bound = ix->pend.dev_exact = 0;
+  if (sync || ix->profile) {
+    HIP_TRY(hipMemcpyAsync(ix->ws.h_stats, ix->ws.d_stats, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    ix->pend.dev_bound = (int64_t)((unsigned long long*)ix->ws.h_stats)[0];
+    ix->pend.dev_exact = (int64_t)((unsigned long long*)ix->ws.h_stats)[1];
+    st.candidates_bound += ix->pend.dev_bound;
+    st.candidates_exact += ix->pend.dev_exact;
+    double ms[5] = {0, 0, 0, 0, 0};
+    tm.collect(ms);
+    st.gemm_ms += ms[T_GEMM]; st.refine_ms += ms[T_REFINE]; st.rescore_ms += ms[T_RESCORE]; st.select_ms += ms[T_SELECT]; st.prep_ms += ms[T_PREP];
+  }
+  ix->stats = st;
+  return DHR_OK;
+}
+extern "C" int dhr_search_begin_rest(dhr_index* ix, const float* tau_dev, float* out_sample_scores_dev, void* stream) {
+  return search_begin_rest_impl(ix, tau_dev, out_sample_scores_dev, stream, true);
+}
+extern "C" int dhr_internal_search_begin_rest_async(dhr_index* ix, const float* tau_dev, float* out_sample_scores_dev, void* stream) {
+  return search_begin_rest_impl(ix, tau_dev, out_sample_scores_dev, stream, false);
 }
 
 // sync = false (dhr_search_sharded*): only enqueues when the controller runs without read-backs -- the shards of a one-process search then

@@ -2384,6 +2384,32 @@ __global__ void keys_to_rows_kernel(const uint64_t* __restrict__ topk_keys, int 
   const uint64_t key = topk_keys[(int64_t)q * kp + j];
   rows[g] = key ? 0xFFFFFFFFu - (uint32_t)key : 0xFFFFFFFFu;
 }
+// Threshold bootstrap (search_core): the m best rows of a query's FIRST bound list by bound score.  One workgroup per query, the list holds
+// at most 256 entries (one corpus tile through an open filter): every thread ranks its entry against the others (the keys are unique: the
+// row is part of the key) and the m best write their rows in rank order; slots beyond the list read 0xFFFFFFFF (not a row).
+__global__ void __launch_bounds__(256) bound_topm_kernel(const uint2* __restrict__ cand, const uint32_t* __restrict__ cnt, uint32_t cap, int n_queries, int m,
+                                                         uint32_t* __restrict__ rows) {
+  __shared__ uint64_t key[256];
+  const int q = blockIdx.x, t = threadIdx.x;
+  uint32_t count = cnt[q];
+  if (count > 256u) count = 256u;
+  if (count > cap) count = cap;
+  uint64_t mine = 0ull;
+  if ((uint32_t)t < count) { const uint2 c = cand[(int64_t)q * cap + t]; mine = make_key(__uint_as_float(c.y), c.x); }
+  key[t] = mine;
+  if (t < m) rows[(int64_t)q * m + t] = 0xFFFFFFFFu;
+  __syncthreads();
+  if (mine) {
+    int rank = 0;
+    for (int j = 0; j < 256; ++j) rank += key[j] > mine ? 1 : 0;
+    if (rank < m) rows[(int64_t)q * m + rank] = 0xFFFFFFFFu - (uint32_t)mine;
+  }
+}
+hipError_t launch_bound_topm(const uint2* cand, const uint32_t* cnt, uint32_t cap, int n_queries, int m, uint32_t* rows, hipStream_t s) {
+  if (n_queries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bound_topm_kernel, dim3((unsigned)n_queries), dim3(256), 0, s, cand, cnt, cap, n_queries, m, rows);
+  return hipGetLastError();
+}
 hipError_t launch_keys_to_rows(const uint64_t* topk_keys, int kp, int n_queries, int k, uint32_t* rows, hipStream_t s) {
   const int64_t total = (int64_t)n_queries * k;
   if (total <= 0) return hipSuccess;

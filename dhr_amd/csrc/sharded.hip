@@ -79,10 +79,14 @@ struct Backend {
   virtual int finish(int i, const float* tau, float* ls, int64_t* lr, int32_t* cnt) = 0;
   virtual int mid_ranks(int i, int k, int* r_local, int* r_union) = 0;   // second agreement (dhr_search_mid_ranks); r_local 0: the shard has no such step
   virtual int mid(int i, const float* tau, int r_local, float* scores) = 0;
+  // first agreement in two rounds (dhr_search_pre_ranks / dhr_search_pre / dhr_search_begin_rest); r_local 0: the shard has no such step
+  virtual int pre_ranks(int i, int k, int* r_local, int* r_union) = 0;
+  virtual int pre(int i, const dhr_query_batch* qb, int k, int r_local, float* scores) = 0;
+  virtual int begin_rest(int i, const float* tau, float* sample) = 0;
   virtual int search(int i, const dhr_query_batch* qb, int k, float* s, int64_t* r) = 0;
   // all-gather of `bytes` per shard: send[i] (local shard i's block) -> recv[i] = [world][bytes] in local shard i's memory
   virtual int gather(const std::vector<const void*>& send, const std::vector<void*>& recv, size_t bytes) = 0;
-  virtual int min_over_ranks(int32_t v[8]) = 0;                 // element-wise minimum over all processes; one host read
+  virtual int min_over_ranks(int32_t v[12]) = 0;                // element-wise minimum over all processes; one host read
   // [world, Q, r] sorted sample scores -> tau[q] = the ru-th best of the union
   virtual int union_threshold(int i, const float* gathered, int Q, int r, int ru, float* tau) = 0;
   virtual int union_threshold2(int i, const float* gathered, int Q, int r, int ru, float* tau) = 0;   // the same, tau[q] = max(tau[q], that)
@@ -162,10 +166,12 @@ int local_path(Backend& B, const std::vector<dhr_query_batch>& qb, int k, const 
 // index handles, and a rank that hit a cache the others missed would skip a collective they issue.
 // The ranks of the SECOND agreement (Backend::mid_ranks) ride along: shards whose sizes differ by a tile may compute ranks that differ by one;
 // every shard then uses the LARGEST (a lower threshold: still valid), and the step is skipped when some shard has none.
-int agree_rank(Backend& B, int k, int* r_out, int* ru_out, int* rl_mid_out, int* ru_mid_out) {
+// The ranks of the two-round FIRST agreement (Backend::pre_ranks) travel the same way: the largest over the shards, none if some shard has none.
+int agree_rank(Backend& B, int k, int* r_out, int* ru_out, int* rl_mid_out, int* ru_mid_out, int* rl_pre_out, int* ru_pre_out) {
   int r = B.sample_rank(0, k);
   int ru = B.union_rank(0, k);
   int ml_min = 1 << 30, ml_max = 0, mu_max = 0;
+  int pl_min = 1 << 30, pl_max = 0, pu_max = 0;
   static const bool mid_on = !(getenv("DHR_SHARD_MID") && atoi(getenv("DHR_SHARD_MID")) == 0);
   for (int i = 0; i < B.n_local; ++i) {
     if (B.sample_rank(i, k) != r || B.union_rank(i, k) != ru) r = 0;
@@ -173,13 +179,19 @@ int agree_rank(Backend& B, int k, int* r_out, int* ru_out, int* rl_mid_out, int*
     if (mid_on) SH_TRY(B.mid_ranks(i, k, &ml, &mu));
     if (ml <= 0 || mu <= 0) ml = mu = 0;
     ml_min = std::min(ml_min, ml); ml_max = std::max(ml_max, ml); mu_max = std::max(mu_max, mu);
+    int pl = 0, pu = 0;
+    SH_TRY(B.pre_ranks(i, k, &pl, &pu));
+    if (pl <= 0 || pu <= 0) pl = pu = 0;
+    pl_min = std::min(pl_min, pl); pl_max = std::max(pl_max, pl); pu_max = std::max(pu_max, pu);
   }
-  int32_t v[8] = {r, -r, ru, -ru, ml_min, -ml_max, -mu_max, 0};
+  int32_t v[12] = {r, -r, ru, -ru, ml_min, -ml_max, -mu_max, pl_min, -pl_max, -pu_max, 0, 0};
   SH_TRY(B.min_over_ranks(v));
   *r_out = (v[0] == r && -v[1] == r && v[2] == ru && -v[3] == ru) ? r : 0;
   *ru_out = ru;
   *rl_mid_out = v[4] > 0 ? -v[5] : 0;
   *ru_mid_out = v[4] > 0 ? -v[6] : 0;
+  *rl_pre_out = v[7] > 0 ? -v[8] : 0;
+  *ru_pre_out = v[7] > 0 ? -v[9] : 0;
   return DHR_OK;
 }
 // DHR_PARAM_SAMPLE_SHARE is handle state: the sharded entry points set it for their own staged calls and put 1 back on every way out, so
@@ -196,8 +208,8 @@ int sharded_core(Backend& B, const dhr_query_batch* qb_in, int k, const std::vec
   std::vector<dhr_query_batch> qb(nl, *qb_in);
   ShareGuard share_guard{B};
   for (int i = 0; i < nl; ++i) SH_TRY(B.set_share(i, world));      // a shard chases only its share of the union's rank
-  int r = 0, ru_all = 0, rl_mid = 0, ru_mid = 0;
-  SH_TRY(agree_rank(B, k, &r, &ru_all, &rl_mid, &ru_mid));
+  int r = 0, ru_all = 0, rl_mid = 0, ru_mid = 0, rl_pre = 0, ru_pre = 0;
+  SH_TRY(agree_rank(B, k, &r, &ru_all, &rl_mid, &ru_mid, &rl_pre, &ru_pre));
   if (r <= 0) return local_path(B, qb, k, out_s, out_r);
   const int ru = std::min<int>(ru_all, world * r);      // rank of the union that defines the threshold; the lists are r long
 
@@ -205,14 +217,40 @@ int sharded_core(Backend& B, const dhr_query_batch* qb_in, int k, const std::vec
   std::vector<const void*> send(nl);
   std::vector<void*> recv(nl);
   std::vector<float*> tau(nl);
+  // 1a (round 5): the first part of every shard's sample, a first common threshold from the union of the parts, the rest of the samples
+  // filtered at it -- eight sampled runs that each started from nothing rescored 3.2 k rows per query between them, the unsharded search's one
+  // run 0.7 k.  One more all-gather of [Q, ~17] scores.
+  std::vector<float*> sample_v(nl);
   for (int i = 0; i < nl; ++i) {
-    float* sample = (float*)B.alloc(i, (size_t)Q * r * 4);
+    sample_v[i] = (float*)B.alloc(i, (size_t)Q * r * 4);
     recv[i] = B.alloc(i, (size_t)world * Q * r * 4);
     tau[i] = (float*)B.alloc(i, (size_t)Q * 4);
-    if (!sample || !recv[i] || !tau[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
-    SH_TRY(B.begin(i, &qb[i], k, sample));
-    send[i] = sample;
+    if (!sample_v[i] || !recv[i] || !tau[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
   }
+  if (rl_pre > 0 && ru_pre > 0) {
+    const int ru0 = std::min<int>(ru_pre, world * rl_pre);
+    std::vector<const void*> send0(nl);
+    std::vector<void*> recv0(nl);
+    std::vector<float*> tau0(nl);
+    for (int i = 0; i < nl; ++i) {
+      float* seen = (float*)B.alloc(i, (size_t)Q * rl_pre * 4);
+      recv0[i] = B.alloc(i, (size_t)world * Q * rl_pre * 4);
+      tau0[i] = (float*)B.alloc(i, (size_t)Q * 4);
+      if (!seen || !recv0[i] || !tau0[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
+      SH_TRY(B.pre(i, &qb[i], k, rl_pre, seen));
+      send0[i] = seen;
+    }
+    SH_TRY(B.gather(send0, recv0, (size_t)Q * rl_pre * 4));
+    for (int i = 0; i < nl; ++i) {
+      SH_TRY(B.union_threshold(i, (const float*)recv0[i], Q, rl_pre, ru0, tau0[i]));
+      SH_TRY(B.begin_rest(i, tau0[i], sample_v[i]));
+      send[i] = sample_v[i];
+    }
+  } else
+    for (int i = 0; i < nl; ++i) {
+      SH_TRY(B.begin(i, &qb[i], k, sample_v[i]));
+      send[i] = sample_v[i];
+    }
   SH_TRY(B.gather(send, recv, (size_t)Q * r * 4));
   for (int i = 0; i < nl; ++i) SH_TRY(B.union_threshold(i, (const float*)recv[i], Q, r, ru, tau[i]));
   // 2b: second agreement.  Every shard runs the first slice of its main pass with tau and reports its best scores seen so far; the union of
@@ -402,6 +440,20 @@ struct HipBackend : Backend {
     SH_HIP(hipSetDevice(sh[i].device));
     return dhr_internal_search_mid_async(sh[i].ix, tau, r_local, scores, sh[i].stream);
   }
+  int pre_ranks(int i, int k, int* r_local, int* r_union) override {
+    int32_t a = 0, b = 0;
+    (void)dhr_search_pre_ranks(sh[i].ix, k, &a, &b);
+    *r_local = a; *r_union = b;
+    return DHR_OK;
+  }
+  int pre(int i, const dhr_query_batch* qb, int k, int r_local, float* scores) override {
+    SH_HIP(hipSetDevice(sh[i].device));
+    return dhr_internal_search_pre_async(sh[i].ix, qb, k, r_local, scores, sh[i].stream);
+  }
+  int begin_rest(int i, const float* tau, float* sample) override {
+    SH_HIP(hipSetDevice(sh[i].device));
+    return dhr_internal_search_begin_rest_async(sh[i].ix, tau, sample, sh[i].stream);
+  }
   int search(int i, const dhr_query_batch* qb, int k, float* s, int64_t* r) override {
     SH_HIP(hipSetDevice(sh[i].device));
     return dhr_search(sh[i].ix, qb, k, s, r, DHR_MEM_DEVICE, sh[i].stream);
@@ -437,18 +489,18 @@ struct HipBackend : Backend {
     for (int i = 0; i < n_local; ++i) SH_HIP(hipStreamSynchronize(sh[i].stream));
     return DHR_OK;
   }
-  int min_over_ranks(int32_t v[8]) override {
+  int min_over_ranks(int32_t v[12]) override {
     if (!comm || world <= 1) return DHR_OK;
     SH_HIP(hipSetDevice(sh[0].device));
-    int32_t* d = (int32_t*)sh[0].arena->get(32 + (size_t)world * 32);
+    int32_t* d = (int32_t*)sh[0].arena->get(64 + (size_t)world * 48);
     if (!d) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory");
-    SH_HIP(hipMemcpyAsync(d, v, 32, hipMemcpyHostToDevice, sh[0].stream));
-    SH_TRY(gather({d}, {d + 8}, 32));
-    std::vector<int32_t> all((size_t)world * 8);
-    SH_HIP(hipMemcpyAsync(all.data(), d + 8, (size_t)world * 32, hipMemcpyDeviceToHost, sh[0].stream));
+    SH_HIP(hipMemcpyAsync(d, v, 48, hipMemcpyHostToDevice, sh[0].stream));
+    SH_TRY(gather({d}, {d + 16}, 48));
+    std::vector<int32_t> all((size_t)world * 12);
+    SH_HIP(hipMemcpyAsync(all.data(), d + 16, (size_t)world * 48, hipMemcpyDeviceToHost, sh[0].stream));
     SH_HIP(hipStreamSynchronize(sh[0].stream));
     for (int w = 0; w < world; ++w)
-      for (int j = 0; j < 8; ++j) v[j] = std::min(v[j], all[(size_t)w * 8 + j]);
+      for (int j = 0; j < 12; ++j) v[j] = std::min(v[j], all[(size_t)w * 12 + j]);
     return DHR_OK;
   }
   int union_threshold(int i, const float* gathered, int Q, int r, int ru, float* tau) override {
@@ -571,17 +623,25 @@ struct HostBackend : Backend {
     return DHR_OK;
   }
   int mid(int, const float* tau, int r_local, float* scores) override { return shard->mid(shard->user, tau, r_local, scores) == 0 ? DHR_OK : dhr_set_error_message(DHR_ERR_INTERNAL, "host shard: mid failed"); }
+  int pre_ranks(int, int k, int* r_local, int* r_union) override {
+    int32_t a = 0, b = 0;
+    if (shard->pre_ranks && shard->pre && shard->begin_rest) (void)shard->pre_ranks(shard->user, k, share, &a, &b);
+    *r_local = a; *r_union = b;
+    return DHR_OK;
+  }
+  int pre(int, const dhr_query_batch* qb, int k, int r_local, float* scores) override { return shard->pre(shard->user, qb, k, share, r_local, scores) == 0 ? DHR_OK : dhr_set_error_message(DHR_ERR_INTERNAL, "host shard: pre failed"); }
+  int begin_rest(int, const float* tau, float* sample) override { return shard->begin_rest(shard->user, tau, sample) == 0 ? DHR_OK : dhr_set_error_message(DHR_ERR_INTERNAL, "host shard: begin_rest failed"); }
   int search(int, const dhr_query_batch* qb, int k, float* s, int64_t* r) override { return shard->search(shard->user, qb, k, s, r) == 0 ? DHR_OK : dhr_set_error_message(DHR_ERR_INTERNAL, "host shard: search failed"); }
   int gather(const std::vector<const void*>& send, const std::vector<void*>& recv, size_t bytes) override {
     if (world == 1) { memcpy(recv[0], send[0], bytes); return DHR_OK; }
     return cb(cb_user, send[0], recv[0], (int64_t)bytes) == 0 ? DHR_OK : dhr_set_error_message(DHR_ERR_INTERNAL, "the caller's all-gather callback failed");
   }
-  int min_over_ranks(int32_t v[8]) override {
+  int min_over_ranks(int32_t v[12]) override {
     if (world <= 1) return DHR_OK;
-    std::vector<int32_t> all((size_t)world * 8);
-    SH_TRY(gather({v}, {all.data()}, 32));
+    std::vector<int32_t> all((size_t)world * 12);
+    SH_TRY(gather({v}, {all.data()}, 48));
     for (int w = 0; w < world; ++w)
-      for (int j = 0; j < 8; ++j) v[j] = std::min(v[j], all[(size_t)w * 8 + j]);
+      for (int j = 0; j < 12; ++j) v[j] = std::min(v[j], all[(size_t)w * 12 + j]);
     return DHR_OK;
   }
   int union_threshold(int, const float* gathered, int Q, int r, int ru, float* tau) override {

@@ -365,7 +365,8 @@ def sharded_search_host(shard, q_value, q_index, k: int, group=None):
     """The library's sharded control flow (sharded.hip sharded_core) over a shard implemented in PYTHON on host memory -- no GPU is
     touched (dhr_search_sharded_host).  `shard` offers sample_rank(k, share), union_rank(k), search_begin(q, qi, k, share) ->
     [Q, r] float32, search_finish(tau [Q]) -> (scores [Q,k] f32, rows [Q,k] i64, count [Q] i32), search(q, qi, k) -> (scores, rows),
-    all numpy.  The all-gathers run over the torch.distributed group.  The CPU test-suite drives the shipped control flow this way."""
+    all numpy; optionally mid_ranks / search_mid (second agreement) and pre_ranks(k, share) -> (r_local, r_union) / search_pre(q, qi, k,
+    share, r_local) -> [Q, r_local] / search_begin_rest(tau [Q]) -> [Q, r] (first agreement in two rounds).  The all-gathers run over the torch.distributed group.  The CPU test-suite drives the shipped control flow this way."""
     import torch.distributed as dist
     lib = _lib.load()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -433,12 +434,34 @@ def sharded_search_host(shard, q_value, q_index, k: int, group=None):
         out(ps, (n, int(r_local)), np.float32)[...] = s
         return 0
 
+    def cb_pre_ranks(_u, kk, share, p_local, p_union):
+        rl, ru = shard.pre_ranks(int(kk), int(share))
+        p_local[0], p_union[0] = int(rl), int(ru)
+        return int(rl)
+
+    def cb_pre(_u, qb, kk, share, r_local, ps):
+        v, x = batch_arrays(qb)
+        state["n"] = v.shape[0]
+        s = np.asarray(shard.search_pre(v, x, int(kk), int(share), int(r_local)), np.float32)
+        out(ps, (v.shape[0], int(r_local)), np.float32)[...] = s
+        return 0
+
+    def cb_begin_rest(_u, tau, sample):
+        n = state["n"]
+        s = np.asarray(shard.search_begin_rest(out(tau, (n,), np.float32).copy()), np.float32)
+        out(sample, s.shape, np.float32)[...] = s
+        return 0
+
     has_mid = hasattr(shard, "search_mid")          # optional: the second threshold agreement (dhr_search_mid)
+    has_pre = hasattr(shard, "search_pre")          # optional: the first agreement in two rounds (dhr_search_pre / dhr_search_begin_rest)
     hs = _lib.HostShard(None, _lib.HS_SAMPLE_RANK(lambda _u, kk, share: int(shard.sample_rank(int(kk), int(share)))),
                         _lib.HS_UNION_RANK(lambda _u, kk: int(shard.union_rank(int(kk)))), _lib.HS_BEGIN(guard(cb_begin)),
                         _lib.HS_FINISH(guard(cb_finish)), _lib.HS_SEARCH(guard(cb_search)),
                         _lib.HS_MID_RANKS(guard(cb_mid_ranks)) if has_mid else _lib.HS_MID_RANKS(),
-                        _lib.HS_MID(guard(cb_mid)) if has_mid else _lib.HS_MID())
+                        _lib.HS_MID(guard(cb_mid)) if has_mid else _lib.HS_MID(),
+                        _lib.HS_PRE_RANKS(guard(cb_pre_ranks)) if has_pre else _lib.HS_PRE_RANKS(),
+                        _lib.HS_PRE(guard(cb_pre)) if has_pre else _lib.HS_PRE(),
+                        _lib.HS_BEGIN_REST(guard(cb_begin_rest)) if has_pre else _lib.HS_BEGIN_REST())
     gather = _host_allgather(group) if world > 1 else _lib.ALLGATHER_FN(lambda *_a: 1)
     qb, keep = _lib.make_query_batch(q_value, q_index)
     scores = np.empty((nq, k), np.float32)

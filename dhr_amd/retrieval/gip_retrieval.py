@@ -174,6 +174,34 @@ class GipIndex:
         del keep
         return out
 
+    def pre_ranks(self, k: int):
+        """(local, union) ranks of the first agreement's first round (dhr_search_pre_ranks); (0, 0): this index has no pre step."""
+        lo, un = C.c_int32(), C.c_int32()
+        self._lib.dhr_search_pre_ranks(self._h, int(k), C.byref(lo), C.byref(un))
+        return int(lo.value), int(un.value)
+
+    def search_pre(self, q_value, q_index, k: int, r_local: int = 0, stream: int = 0):
+        """Query preparation + the first part of the sampled run; -> torch cuda tensor [Q, r_local]: this shard's best sample scores seen so
+        far (dhr_search_pre).  search_begin_rest then takes the threshold the shards agree on from them."""
+        import torch
+        qb, keep = self._qb(q_value, q_index)
+        rl = int(r_local) or self.pre_ranks(k)[0]
+        out = torch.empty((qb.n_queries, rl), dtype=torch.float32, device=torch.device("cuda", self.device))
+        _lib.check(self._lib.dhr_search_pre(self._h, C.byref(qb), int(k), rl, out.data_ptr(), stream), "dhr_search_pre")
+        self._pending = (qb.n_queries, int(k))
+        del keep
+        return out
+
+    def search_begin_rest(self, tau, stream: int = 0):
+        """The rest of the sampled run, filtered at the agreed thresholds tau [Q]; -> what search_begin returns (dhr_search_begin_rest)."""
+        import torch
+        nq, k = self._pending
+        dev = torch.device("cuda", self.device)
+        out = torch.empty((nq, self.sample_rank(k)), dtype=torch.float32, device=dev)
+        tau = tau.to(device=dev, dtype=torch.float32).contiguous()
+        _lib.check(self._lib.dhr_search_begin_rest(self._h, tau.data_ptr(), out.data_ptr(), stream), "dhr_search_begin_rest")
+        return out
+
     def mid_ranks(self, k: int):
         """(local, union) ranks of the second threshold agreement (dhr_search_mid_ranks); (0, 0): this index has no mid step."""
         lo, un = C.c_int32(), C.c_int32()

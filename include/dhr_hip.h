@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DHR_VERSION 103 /* 0.1.3: dhr_comm_info / dhr_comm_abort (what the communicator really spans; a way out of a hung bring-up) */
+#define DHR_VERSION 104 /* 0.1.4: dhr_search_pre / dhr_search_pre_ranks / dhr_search_begin_rest (first agreement of the sharded search in two rounds), dhr_host_shard::pre_ranks / pre / begin_rest, DHR_PARAM_LIST_STRIDE; 0.1.3: dhr_comm_info / dhr_comm_abort */
 
 typedef enum dhr_status {
   DHR_OK = 0,
@@ -233,6 +233,16 @@ int dhr_search_finish(dhr_index* index, const float* tau_hat_dev, float* out_sco
  * out_local; 0: this index has no such step -- it is too small -- and dhr_search_finish follows dhr_search_begin directly). */
 int32_t dhr_search_mid_ranks(const dhr_index* index, int32_t k, int32_t* out_local, int32_t* out_union);
 int dhr_search_mid(dhr_index* index, const float* tau_hat_dev, int32_t r_local, float* out_scores_dev, void* stream);
+/* Optional: dhr_search_begin in TWO calls with an agreement in between (round 5).  dhr_search_pre prepares the batch and streams the first
+ * part of the shard's sample (1/8 of it), leaving the shard's r_local best scores seen so far in out_scores_dev [n_queries, r_local]
+ * (dhr_search_pre_ranks; 0: the sample is too small to split -- use dhr_search_begin).  The caller gathers the blocks, takes the r_union-th
+ * best of the union per query (it lies below the union sample's final rank-r score: the same argument as inside a sampled run) and hands it to
+ * dhr_search_begin_rest, which streams the rest of the sample filtering at it and leaves the handle exactly where dhr_search_begin does
+ * (out_sample_scores_dev [n_queries, dhr_search_sample_rank]).  Eight shards that each ran their sampled run from nothing rescored 3.2 k rows per
+ * query between them where the unsharded search's one run rescores 0.7 k. */
+int32_t dhr_search_pre_ranks(const dhr_index* index, int32_t k, int32_t* out_local, int32_t* out_union);
+int dhr_search_pre(dhr_index* index, const dhr_query_batch* queries, int32_t k, int32_t r_local, float* out_scores_dev, void* stream);
+int dhr_search_begin_rest(dhr_index* index, const float* tau_dev, float* out_sample_scores_dev, void* stream);
 
 /* Exact gated inner product of each query against m given rows (stage 2 of --rerank,
  * gip_retrieval.py:144-146 / :207-208).  rows [n_queries, m] int64 GLOBAL rows (row < 0 -> -inf).
@@ -408,6 +418,10 @@ typedef struct dhr_host_shard {
   /* optional (both NULL: no second agreement): dhr_search_mid_ranks / dhr_search_mid of the shard */
   int32_t (*mid_ranks)(void* user, int32_t k, int32_t share, int32_t* out_local, int32_t* out_union);
   int32_t (*mid)(void* user, const float* tau, int32_t r_local, float* out_scores);
+  /* optional (all NULL: begin in one call): dhr_search_pre_ranks / dhr_search_pre / dhr_search_begin_rest of the shard */
+  int32_t (*pre_ranks)(void* user, int32_t k, int32_t share, int32_t* out_local, int32_t* out_union);
+  int32_t (*pre)(void* user, const dhr_query_batch* queries, int32_t k, int32_t share, int32_t r_local, float* out_scores);
+  int32_t (*begin_rest)(void* user, const float* tau, float* out_sample);
 } dhr_host_shard;
 int dhr_search_sharded_host(const dhr_host_shard* shard, int32_t world, int32_t rank, dhr_allgather_fn allgather, void* user,
                             const dhr_query_batch* queries, int32_t k, float* out_scores, int64_t* out_rows);

@@ -139,6 +139,44 @@ class _FakeShardMid(_FakeShard):
         return super().search_finish(tau)
 
 
+class _FakeShardPre(_FakeShard):
+    """The same with the first agreement in two rounds (dhr_host_shard::pre_ranks / pre / begin_rest; dhr_search_pre / dhr_search_begin_rest of a
+    device shard): the first quarter of the sample positions, an agreed threshold, then the rest of the sample FILTERED at it -- what the
+    shard reports afterwards is its best sample scores among the first part and everything of the rest that reaches the threshold."""
+
+    def _first(self):
+        return max(1, len(range(0, self.cv.shape[0], self.period)) // 4)
+
+    def pre_ranks(self, k, share):
+        ns = len(range(0, self.cv.shape[0], self.period))
+        phi = self._first() / ns
+        m0 = self.r * phi
+        ru = int(max(1, min(self.r, np.ceil(m0 + 6.0 * np.sqrt(m0 * (1.0 - phi)) + 4.0))))
+        m = ru / max(share, 1)
+        rl = ru if share <= 1 else min(ru, int(np.ceil(m + 5.0 * np.sqrt(m) + 4.0)))
+        return rl, ru
+
+    def search_pre(self, q, qi, k, share, r_local):
+        self.q, self.k, self.share = np.array(q), k, share
+        s = self._scores(q)[:, ::self.period][:, : self._first()]
+        top = -np.sort(-s, axis=1)[:, :r_local]
+        if top.shape[1] < r_local:
+            top = np.concatenate([top, np.full((top.shape[0], r_local - top.shape[1]), -np.inf)], axis=1)
+        self.calls.append("pre")
+        return top.astype(np.float32)
+
+    def search_begin_rest(self, tau):
+        s = self._scores(self.q)[:, ::self.period].astype(np.float32)
+        f = self._first()
+        s[:, f:] = np.where(s[:, f:] >= np.asarray(tau, np.float32)[:, None], s[:, f:], -np.inf)      # the rest of the sample passes the agreed filter
+        top = -np.sort(-s, axis=1)[:, : self.sample_rank(self.k, self.share)]
+        self.calls.append("rest")
+        return top.astype(np.float32)
+
+    def search_begin(self, q, qi, k, share):
+        raise AssertionError("a shard that offers the pre step must not be asked for dhr_search_begin")
+
+
 def _staged_worker(rank, world, port, tmp, mode):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -156,7 +194,11 @@ def _staged_worker(rank, world, port, tmp, mode):
                 cv[lo_:lo_ + 400:4] += 3.0 * q[0] / np.linalg.norm(q[0])
         lo, hi = D.shard_bounds(n, world, rank)
         # "rank_mismatch": the last rank disagrees on the union rank -> every rank must take the local-threshold path
-        cls = _FakeShardMid if mode.startswith("mid") else _FakeShard
+        cls = _FakeShardMid if mode.startswith("mid") else _FakeShardPre if mode.startswith("pre") else _FakeShard
+        if mode == "pre_adversarial":      # the best rows of query 0 all sit on the FIRST sample positions of their shards -> the first common threshold is
+            for r_ in range(world):        # far too high; what the shards report afterwards is then incomplete, the union threshold comes out LOW -- still valid
+                lo_ = D.shard_bounds(n, world, r_)[0]
+                cv[lo_:lo_ + 200:4] += 3.0 * q[0] / np.linalg.norm(q[0])
         if mode == "mid_adversarial":      # the best rows of query 0 all sit on positions the shards have seen by the second agreement -> threshold too high
             for r_ in range(world):
                 lo_ = D.shard_bounds(n, world, r_)[0]
@@ -176,16 +218,17 @@ def _staged_worker(rank, world, port, tmp, mode):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("mode", ["plain", "adversarial", "rank_mismatch", "mid", "mid_adversarial"])
+@pytest.mark.parametrize("mode", ["plain", "adversarial", "rank_mismatch", "mid", "mid_adversarial", "pre", "pre_adversarial"])
 def test_sharded_core_over_gloo(tmp_path, mode, world):
     """The library's sharded control flow -- dhr_search_sharded_host: the same sharded_core that dhr_search_sharded runs over RCCL -- end
     to end with 2 and 3 ranks over gloo: sample exchange, agreement on the ranks, common threshold, count check, gathered prefixes,
     rank merge and, in the adversarial layout, the repair of the failed query with local thresholds; a rank that disagrees on the union
     rank sends every rank down the local-threshold path.  "mid": shards that offer the second threshold agreement (dhr_search_mid) -- one
     more exchange between begin and finish, thresholds that only rise; "mid_adversarial": the best rows of a query sit where the shards have
-    looked by then, the second threshold comes out too high, the counts catch it and the query is repaired."""
+    looked by then, the second threshold comes out too high, the counts catch it and the query is repaired.  "pre": shards that offer the first
+    agreement in two rounds (dhr_search_pre / dhr_search_begin_rest); "pre_adversarial": the first common threshold comes out far too high."""
     import torch.multiprocessing as mp
-    port = 29700 + (os.getpid() % 2000) + 7 * world + ["plain", "adversarial", "rank_mismatch", "mid", "mid_adversarial"].index(mode)
+    port = 29700 + (os.getpid() % 2000) + 9 * world + ["plain", "adversarial", "rank_mismatch", "mid", "mid_adversarial", "pre", "pre_adversarial"].index(mode)
     mp.spawn(_staged_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     calls = [list(np.load(tmp_path / f"calls{r}.npy")) for r in range(world)]
     rows = [np.load(tmp_path / f"rows{r}.npy") for r in range(world)]
@@ -194,6 +237,8 @@ def test_sharded_core_over_gloo(tmp_path, mode, world):
         np.testing.assert_array_equal(rows[r], rows[0])          # identical on every rank
     if mode == "rank_mismatch":
         assert calls[0] == ["search5"]
+    elif mode.startswith("pre"):
+        assert calls[0][:3] == ["pre", "rest", "finish"], calls[0]          # (a too-high first threshold only loosens the second: repaired or not, the result is checked in the worker)
     else:
         assert calls[0][:3] == ["begin", "mid", "finish"] if mode.startswith("mid") else calls[0][:2] == ["begin", "finish"]
         assert (len(calls[0]) == (4 if mode.startswith("mid") else 3)) == (mode in ("adversarial", "mid_adversarial"))

@@ -540,7 +540,7 @@ def test_larger_random_hybrid(G, gated_image):
     print(st)
 
 
-def _structured_corpus(n, boosted_mod, period=16, head_tiles=1):   # head = 256 exhaustive rows for k=1000 (max(256, 2 r) with sampled thresholds, api.hip search_core)
+def _structured_corpus(n, boosted_mod, period=16, head_tiles=0):   # head: no exhaustive rows in a sampled search since round 5 (threshold bootstrap, api.hip search_core); 1 tile until round 4
     """Dense-only corpus whose best rows all sit in tiles with (tile - head) % period == boosted_mod."""
     rng = np.random.default_rng(5)
     cv = (rng.standard_normal((n, 64)) * 0.05).astype(np.float16)
@@ -1270,15 +1270,23 @@ def test_config4_full_size_8_shards(G):
             ix.set_param(_lib.PARAM_SAMPLE_SHARE, ns)
         rnk = shards[0].union_rank(k)
         rl_mid, ru_mid = max(s.mid_ranks(k)[0] for s in shards), max(s.mid_ranks(k)[1] for s in shards)
-        assert rl_mid > 0
+        rl_pre, ru_pre = max(s.pre_ranks(k)[0] for s in shards), max(s.pre_ranks(k)[1] for s in shards)
+        assert rl_mid > 0 and rl_pre > 0
         best = None
         for it in range(3):
-            tb, tf, samples, outs = [], [], [], []
+            tb, tf, samples, outs, firsts, tb2 = [], [], [], [], [], []
+            # first agreement in two rounds (sharded.hip step 1a): the first part of every shard's sample, a common threshold, the rest filtered at it
             for ix in shards:
                 torch.cuda.synchronize(); t = time.perf_counter()
-                samples.append(ix.search_begin(qv, qi, k)); torch.cuda.synchronize(); tb.append(time.perf_counter() - t)
+                firsts.append(ix.search_pre(qv, qi, k, rl_pre)); torch.cuda.synchronize(); tb.append(time.perf_counter() - t)
             torch.cuda.synchronize(); t = time.perf_counter()
-            tau = D.common_threshold(torch.stack(samples), rnk); torch.cuda.synchronize(); tt = time.perf_counter() - t
+            tau0 = D.common_threshold(torch.stack(firsts), min(ru_pre, ns * rl_pre)); torch.cuda.synchronize(); tt = time.perf_counter() - t
+            for ix in shards:
+                torch.cuda.synchronize(); t = time.perf_counter()
+                samples.append(ix.search_begin_rest(tau0)); torch.cuda.synchronize(); tb2.append(time.perf_counter() - t)
+            tb = [a_ + b_ for a_, b_ in zip(tb, tb2)]                  # "begin" = both parts of the sampled run
+            torch.cuda.synchronize(); t = time.perf_counter()
+            tau = D.common_threshold(torch.stack(samples), rnk); torch.cuda.synchronize(); tt += time.perf_counter() - t
             # second agreement (sharded.hip step 2b): first slice of the main pass, the shards' best scores seen so far, tau raised
             seen, tmid = [], []
             for ix in shards:
@@ -1309,11 +1317,11 @@ def test_config4_full_size_8_shards(G):
         # blocks: sample scores [Q, r_local] fp32, counts [Q] int32, list prefixes [Q, kk] x (fp32 + int64), kk as sharded.hip prefix_len
         r_loc = shards[0].sample_rank(k)
         kk_fix = min(k, ((3 * k + ns - 1) // ns + 64 + 63) // 64 * 64)
-        coll = sum(50e-6 + b / 150e9 for b in (nq * r_loc * 4, nq * rl_mid * 4, nq * 4, nq * kk_fix * 4, nq * kk_fix * 8))
-        print("\n[config 4, emulated on one GPU] unsharded step %.1f ms; slowest shard per stage: begin %.2f + thresholds (two agreements) %.2f + main pass (first slice + rest) %.2f + merge %.2f "
-              "= %.2f ms -> %.2fx; + the 5 all-gathers modelled at 50 us + bytes / 150 GB/s each ([Q, %d] sample scores, [Q, %d] seen scores, [Q] counts, [Q, %d] x 12 B lists) "
+        coll = sum(50e-6 + b / 150e9 for b in (nq * rl_pre * 4, nq * r_loc * 4, nq * rl_mid * 4, nq * 4, nq * kk_fix * 4, nq * kk_fix * 8))
+        print("\n[config 4, emulated on one GPU] unsharded step %.1f ms; slowest shard per stage: begin (first part of the sample + rest) %.2f + thresholds (three agreements) %.2f + main pass (first slice + rest) %.2f + merge %.2f "
+              "= %.2f ms -> %.2fx; + the 6 all-gathers modelled at 50 us + bytes / 150 GB/s each ([Q, %d] first sample scores, [Q, %d] sample scores, [Q, %d] seen scores, [Q] counts, [Q, %d] x 12 B lists) "
               "= %.2f ms -> %.2f ms = %.2fx"
-              % (t_full * 1e3, best[1] * 1e3, best[2] * 1e3, best[3] * 1e3, best[4] * 1e3, best[0] * 1e3, t_full / best[0], r_loc, rl_mid, kk_fix, coll * 1e3,
+              % (t_full * 1e3, best[1] * 1e3, best[2] * 1e3, best[3] * 1e3, best[4] * 1e3, best[0] * 1e3, t_full / best[0], rl_pre, r_loc, rl_mid, kk_fix, coll * 1e3,
                  (best[0] + coll) * 1e3, t_full / (best[0] + coll)))
     finally:
         for s in shards:
@@ -1774,7 +1782,7 @@ def test_extrapolated_threshold_failure_is_redone(G, gated_image):
     rng = np.random.default_rng(11)
     cv = (rng.standard_normal((n, 64)) * 0.02).astype(np.float16)
     n_tiles = (n + 255) // 256
-    head = 1                                            # 256 exhaustive rows (max(256, 2 r), r = 40)
+    head = 0                                            # no exhaustive head in a sampled search (threshold bootstrap; 1 tile until round 4)
     rest = n_tiles - head
     n_sample = (rest + S - 1) // S
     n_main = rest - n_sample
@@ -2113,4 +2121,4 @@ def test_dense_only_residual_refine(G, kind):
     qv = qv.astype(np.float32)
     st0, st1, _, _ = _i8_pair(G, cv, None, qv, None, k)
     if kind == "gauss":
-        assert st1["candidates_exact"] - 256 * nq < 0.6 * st1["candidates_bound"], st1      # the residual level did prune (`exact` also counts the 256 head rows of every query)
+        assert st1["candidates_exact"] - 64 * nq < 0.6 * st1["candidates_bound"], st1      # the residual level did prune (`exact` also counts the <= 64 bootstrap rows of every query)

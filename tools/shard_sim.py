@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--overlap-aux", type=int, default=-1)
     ap.add_argument("--aux-cus", type=int, default=-1)
     ap.add_argument("--mid", type=int, default=0, help="1: second threshold agreement after the first slice of the main pass (dhr_search_mid)")
+    ap.add_argument("--pre", type=int, default=1, help="1 (default): the first agreement in two rounds (dhr_search_pre / dhr_search_begin_rest) where the shards offer it; 0: dhr_search_begin")
     a = ap.parse_args()
     import torch
     import bench
@@ -61,9 +62,23 @@ def main():
     for mid in ([0, 1] if a.mid else [0]):
         for it in range(2):
             tb, tf, samples, outs = [], [], [], []
-            for ix in shards:
-                torch.cuda.synchronize(); t = time.perf_counter()
-                samples.append(ix.search_begin(qv, qi, k)); torch.cuda.synchronize(); tb.append(time.perf_counter() - t)
+            rl_pre, ru_pre = max(s.pre_ranks(k)[0] for s in shards), max(s.pre_ranks(k)[1] for s in shards)
+            if a.pre and rl_pre > 0:
+                firsts, tb2 = [], []
+                for ix in shards:
+                    torch.cuda.synchronize(); t = time.perf_counter()
+                    firsts.append(ix.search_pre(qv, qi, k, rl_pre)); torch.cuda.synchronize(); tb.append(time.perf_counter() - t)
+                t = time.perf_counter(); tau0 = D.common_threshold(torch.stack(firsts), min(ru_pre, len(shards) * rl_pre)); torch.cuda.synchronize(); t_pre = time.perf_counter() - t
+                for ix in shards:
+                    torch.cuda.synchronize(); t = time.perf_counter()
+                    samples.append(ix.search_begin_rest(tau0)); torch.cuda.synchronize(); tb2.append(time.perf_counter() - t)
+                if it == 1:
+                    print("  begin in two rounds: first part max %.2f ms + threshold %.2f ms + rest max %.2f ms (ranks local %d / union %d)" % (max(tb) * 1e3, t_pre * 1e3, max(tb2) * 1e3, rl_pre, ru_pre))
+                tb = [x + y + t_pre for x, y in zip(tb, tb2)]
+            else:
+                for ix in shards:
+                    torch.cuda.synchronize(); t = time.perf_counter()
+                    samples.append(ix.search_begin(qv, qi, k)); torch.cuda.synchronize(); tb.append(time.perf_counter() - t)
             st_begin = shards[0].stats()
             t = time.perf_counter(); tau = D.common_threshold(torch.stack(samples), rnk); torch.cuda.synchronize(); tt = time.perf_counter() - t
             tmid, tt2 = [0.0], 0.0

@@ -60,7 +60,7 @@ def main():
                 boost = np.linspace(0.0, 2.0, n, dtype=np.float32)
             else:
                 p = max(period, 2)
-                head_tiles = 1        # 256 exhaustive rows with sampled thresholds
+                head_tiles = 0        # no exhaustive head in a sampled search since round 5 (threshold bootstrap)
                 res = 0 if order == "sample_tiles" else min(3, p - 1)
                 boost[(tile >= head_tiles) & (((tile - head_tiles) % p) == res)] = 2.0
             cv[:, col] = (cv[:, col].astype(np.float32) * 0.1 + boost).astype(np.float16)
