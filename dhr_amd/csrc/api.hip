@@ -48,6 +48,7 @@ struct Workspace {
   uint2 *ovf = nullptr, *ovf2 = nullptr;          // the arenas of the two list sets
   uint32_t *ovf_off = nullptr, *ovf_cap = nullptr;   // [q_pad] a query's segment (plan_overflow_kernel); planned before every sampled phase and once for the main pass
   uint32_t* boot_rows = nullptr;                  // [q_pad][BOOT_M] rows of the threshold bootstrap (search_core phase 0)
+  float* boot_bound = nullptr;                    // [q_pad][256] bound scores of corpus tile 0 (the GEMM's dump variant)
   bool keys_alias = false;                        // rs_keys IS cand_r (see ensure_ws)
   ListTier* tier_dev = nullptr;                   // device copy of {ovf, ovf_off, ovf_cap} and {ovf2, ovf_off, ovf_cap}: what GemmArgs::tier points at
   uint32_t* cnt_plan = nullptr;                   // [q_pad] bound-list lengths of the last sampled phase, kept for the plan of the main pass (a staged search resumes in another call)
@@ -159,7 +160,7 @@ struct dhr_index {
 
 static void free_ws(Workspace& w) {
   hipFree(w.q_tiles); hipFree(w.q32); hipFree(w.q_idx); hipFree(w.q16); hipFree(w.q_idx8); hipFree(w.q_inexact); hipFree(w.margin); hipFree(w.i8_mul); hipFree(w.g8_q8); hipFree(w.g8_shift); hipFree(w.g8_unit); hipFree(w.tau); hipFree(w.thr);
-  hipFree(w.cnt); hipFree(w.cand); if (!w.keys_alias) hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2); hipFree(w.q_pack); hipFree(w.cand_r); hipFree(w.cnt_r); hipFree(w.thr_raise); hipFree(w.blk_off); hipFree(w.ovf); hipFree(w.ovf2); hipFree(w.ovf_off); hipFree(w.ovf_cap); hipFree(w.cnt_plan); hipFree(w.tier_dev); hipFree(w.boot_rows);
+  hipFree(w.cnt); hipFree(w.cand); if (!w.keys_alias) hipFree(w.rs_keys); hipFree(w.topk_keys); hipFree(w.d_max); hipFree(w.tau_hat); hipFree(w.fail_flags); hipFree(w.thr_hat); hipFree(w.cand2); hipFree(w.cnt2); hipFree(w.q_pack); hipFree(w.cand_r); hipFree(w.cnt_r); hipFree(w.thr_raise); hipFree(w.blk_off); hipFree(w.ovf); hipFree(w.ovf2); hipFree(w.ovf_off); hipFree(w.ovf_cap); hipFree(w.cnt_plan); hipFree(w.tier_dev); hipFree(w.boot_rows); hipFree(w.boot_bound);
   if (w.h_pinned) hipHostFree(w.h_pinned);
   if (w.h_pinned2) hipHostFree(w.h_pinned2);
   hipFree(w.d_max2); hipFree(w.d_ref); hipFree(w.d_stats);
@@ -848,6 +849,7 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
   HIP_TRY(re_malloc(w.thr_hat, (size_t)q_pad * 4, tot));
   HIP_TRY(re_malloc(w.blk_off, (size_t)2 * (q_pad + 1) * 4, tot));
   HIP_TRY(re_malloc(w.boot_rows, (size_t)q_pad * BOOT_M * 4, tot));
+  HIP_TRY(re_malloc(w.boot_bound, (size_t)q_pad * TILE_ROWS * 4, tot));
   if (ix->resid8) HIP_TRY(re_malloc(w.thr_raise, (size_t)q_pad * 4, tot));
   if (arena > 0) {
     HIP_TRY(re_malloc(w.ovf, (size_t)arena * 8, tot));
@@ -1148,7 +1150,8 @@ static int adaptive_rank(int r, double phi) {
 static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, int64_t n_seq, int map_mode,
                          int period, int64_t head, int64_t first_chunk, int64_t seen_rows, Timer& tm, dhr_search_stats& st,
                          hipStream_t s, double* last_rate = nullptr, double* last_rate_r = nullptr, bool async_ctl = false,
-                         int64_t* last_rows = nullptr, int rank_target = 0, int64_t rank_rows = 0, int64_t pos0 = 0) {
+                         int64_t* last_rows = nullptr, int rank_target = 0, int64_t rank_rows = 0, int64_t pos0 = 0, int growth16 = 0) {
+  if (growth16 <= 0) growth16 = ix->max_growth16;
   int64_t pos = pos0;          // (pos0 > 0: the run resumes behind a part another call streamed -- dhr_search_begin_rest)
   int64_t prev_rows = 0;
   int64_t chunk = std::max<int64_t>(DOC_GROUP, first_chunk);
@@ -1172,7 +1175,7 @@ static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectAr
       if (last_rows) *last_rows = (hi - pos) * TILE_ROWS;
       seen_rows += (hi - pos) * TILE_ROWS;
       pos = hi;
-      chunk = std::max<int64_t>(DOC_GROUP, round_up(seen_rows * ix->max_growth16 / 16 / TILE_ROWS, DOC_GROUP));
+      chunk = std::max<int64_t>(DOC_GROUP, round_up(seen_rows * growth16 / 16 / TILE_ROWS, DOC_GROUP));
       continue;
     }
     uint32_t maxc; unsigned long long sumc;
@@ -1327,8 +1330,16 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     const int64_t sample_rows = ((rest + S - 1) / S) * TILE_ROWS;
     const int r0 = adaptive_rank(r_eff, (double)TILE_ROWS / (double)sample_rows);
     const int m = std::min(BOOT_M, std::max(16, 2 * r0));
-    if ((rc = gemm_phase_async(ix, w, Q, 0, 1, 0, 1, 0, tm, st, s)) != DHR_OK) return rc;      // tile 0, thresholds still -inf: every row is listed
-    HIP_TRY(launch_bound_topm(w.cand, w.cnt, (uint32_t)w.cap, Q, m, w.boot_rows, s));
+    {      // tile 0 through the bound GEMM's dump variant: [Q][256] bound scores, no lists
+      GemmArgs g{};
+      g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.k_split = ix->d_dlr / TILE_K; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr; g.g8_rsum = ix->g8_rsum;
+      g.seq_lo = 0; g.seq_hi = 1; g.map_mode = 0; g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles;
+      g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows; g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = Q;
+      g.dump = w.boot_bound; g.dump_ld = TILE_ROWS; g.dump_row0 = 0;
+      tm.begin(T_GEMM); HIP_TRY(launch_gemm_filter(g, s)); tm.end();
+      st.phases++;
+    }
+    HIP_TRY(launch_bound_topm(w.boot_bound, (int)std::min<int64_t>(TILE_ROWS, n), Q, m, w.boot_rows, s));
     RescoreArgs r = base_rescore_args(ix, w, Q, gate);
     r.rows32 = w.boot_rows; r.ld_rows = m; r.count_all = (uint32_t)m; r.max_count = (uint32_t)m;
     r.out_keys = w.rs_keys; r.ld_keys = w.keys_ld;
@@ -1375,10 +1386,16 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       pos0 = ix->pend.pre_pos; seen0 = ix->pend.pre_seen;
       HIP_TRY(launch_raise_thr(w.tau, tau_ext, Q, s));
       HIP_TRY(launch_make_thr(w.tau, w.margin, Q, w.q_pad, w.thr, s));
-      chunk0 = std::max<int64_t>(DOC_GROUP, round_up(seen0 * ix->max_growth16 / 16 / TILE_ROWS, DOC_GROUP));
+      // ONE phase for the rest (DHR_PRE_REST_ONE=0: the growth rule): the agreed threshold is the union's (r phi + 6 sigma + 4)-th best of 1/8 of
+      // the union sample -- 8 x the rows this shard has seen -- and a phase of a shard's sampled run is bound by its launches, not by its rows
+      static const int rest_one = getenv("DHR_PRE_REST_ONE") ? atoi(getenv("DHR_PRE_REST_ONE")) : 1;
+      chunk0 = rest_one ? round_up(n_sample - pos0, DOC_GROUP) : std::max<int64_t>(DOC_GROUP, round_up(seen0 * ix->max_growth16 / 16 / TILE_ROWS, DOC_GROUP));
     }
+    // (the first part of a shard's sample is 17 tiles of a 1/8 shard of the benchmark: phases of 4 + 13 tiles instead of 4 + 8 + 5 -- a phase there
+    // is bound by its ~8 dependent launches, 0.4-0.5 ms, not by its rows; DHR_PRE_GROWTH16 in 1/16ths)
+    static const int pre_growth = getenv("DHR_PRE_GROWTH16") ? std::max(16, atoi(getenv("DHR_PRE_GROWTH16"))) : 64;
     if ((rc = stream_phases(ix, w, Q, gate, sel, n_hi, 1, S, head, chunk0, seen0, tm, st, s, &rate, &rate_r, async_ctl, &last_rows,
-                            r_eff, first_valid + n_sample * TILE_ROWS, pos0)) != DHR_OK) return rc;
+                            r_eff, first_valid + n_sample * TILE_ROWS, pos0, stage == 4 ? std::max(ix->max_growth16, pre_growth) : 0)) != DHR_OK) return rc;
     if (stage == 4) {
       ix->pend.valid = true; ix->pend.done = false; ix->pend.mid = false; ix->pend.pre = true; ix->pend.gate = gate; ix->pend.Q = Q; ix->pend.k = k;
       ix->pend.pre_pos = n_hi; ix->pend.pre_seen = first_valid + n_hi * TILE_ROWS;

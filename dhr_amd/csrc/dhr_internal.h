@@ -330,7 +330,7 @@ hipError_t launch_merge_topk_global(int n_queries, int n_in, const float* in_sco
 hipError_t launch_emit(const uint64_t* topk_keys, int kp, int n_queries, int k, int64_t row_offset, float* out_scores,
                        int64_t* out_rows, hipStream_t s);
 hipError_t launch_keys_to_rows(const uint64_t* topk_keys, int kp, int n_queries, int k, uint32_t* rows, hipStream_t s);
-hipError_t launch_bound_topm(const uint2* cand, const uint32_t* cnt, uint32_t cap, int n_queries, int m, uint32_t* rows /*[n_queries][m]*/, hipStream_t s);
+hipError_t launch_bound_topm(const float* bound /*[n_queries][256]*/, int n_rows, int n_queries, int m, uint32_t* rows /*[n_queries][m]*/, hipStream_t s);
 hipError_t launch_densify(const void* lex, int in_is_f32, int64_t ld, int64_t batch, int remove, int dims, int n_groups, void* out_val,
                           int val_is_f32, int64_t ld_val, void* out_idx, int idx_is_i16, int64_t ld_idx, hipStream_t s);
 hipError_t launch_pq_init(const __half* vals, int64_t ld, int64_t n, int64_t stride, int dsub, int M, float* cb, int ksub, hipStream_t s);

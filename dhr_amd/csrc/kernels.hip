@@ -2384,18 +2384,15 @@ __global__ void keys_to_rows_kernel(const uint64_t* __restrict__ topk_keys, int 
   const uint64_t key = topk_keys[(int64_t)q * kp + j];
   rows[g] = key ? 0xFFFFFFFFu - (uint32_t)key : 0xFFFFFFFFu;
 }
-// Threshold bootstrap (search_core): the m best rows of a query's FIRST bound list by bound score.  One workgroup per query, the list holds
-// at most 256 entries (one corpus tile through an open filter): every thread ranks its entry against the others (the keys are unique: the
-// row is part of the key) and the m best write their rows in rank order; slots beyond the list read 0xFFFFFFFF (not a row).
-__global__ void __launch_bounds__(256) bound_topm_kernel(const uint2* __restrict__ cand, const uint32_t* __restrict__ cnt, uint32_t cap, int n_queries, int m,
-                                                         uint32_t* __restrict__ rows) {
+// Threshold bootstrap (search_core): the m best rows of corpus tile 0 by BOUND score, per query.  The bound scores come from the GEMM's dump
+// variant ([q][256] floats: an open filter would push all 65 536 pairs of a tile through the cold surplus path of the epilogue, one atomic
+// each -- 0.46 ms for the 28 workgroups of a shard's first launch).  One workgroup per query: every thread ranks its row against the others
+// (the keys are unique: the row is part of the key) and the m best write their rows in rank order; slots beyond the tile read 0xFFFFFFFF.
+__global__ void __launch_bounds__(256) bound_topm_kernel(const float* __restrict__ bound, int n_rows, int n_queries, int m, uint32_t* __restrict__ rows) {
   __shared__ uint64_t key[256];
   const int q = blockIdx.x, t = threadIdx.x;
-  uint32_t count = cnt[q];
-  if (count > 256u) count = 256u;
-  if (count > cap) count = cap;
   uint64_t mine = 0ull;
-  if ((uint32_t)t < count) { const uint2 c = cand[(int64_t)q * cap + t]; mine = make_key(__uint_as_float(c.y), c.x); }
+  if (t < n_rows) mine = make_key(bound[(int64_t)q * 256 + t], (uint32_t)t);      // bound scores of rows 0 .. 255 as the GEMM's dump variant leaves them
   key[t] = mine;
   if (t < m) rows[(int64_t)q * m + t] = 0xFFFFFFFFu;
   __syncthreads();
@@ -2405,9 +2402,9 @@ __global__ void __launch_bounds__(256) bound_topm_kernel(const uint2* __restrict
     if (rank < m) rows[(int64_t)q * m + rank] = 0xFFFFFFFFu - (uint32_t)mine;
   }
 }
-hipError_t launch_bound_topm(const uint2* cand, const uint32_t* cnt, uint32_t cap, int n_queries, int m, uint32_t* rows, hipStream_t s) {
+hipError_t launch_bound_topm(const float* bound, int n_rows, int n_queries, int m, uint32_t* rows, hipStream_t s) {
   if (n_queries <= 0) return hipSuccess;
-  hipLaunchKernelGGL(bound_topm_kernel, dim3((unsigned)n_queries), dim3(256), 0, s, cand, cnt, cap, n_queries, m, rows);
+  hipLaunchKernelGGL(bound_topm_kernel, dim3((unsigned)n_queries), dim3(256), 0, s, bound, n_rows, n_queries, m, rows);
   return hipGetLastError();
 }
 hipError_t launch_keys_to_rows(const uint64_t* topk_keys, int kp, int n_queries, int k, uint32_t* rows, hipStream_t s) {
