@@ -20,7 +20,7 @@ INFO_DENSE_I8, INFO_I8_SCALE, INFO_I8_ROW_ERR, INFO_I8_ROW_NORM, INFO_ROW_NORM_M
 
 EXPORTS = ["dhr_version", "dhr_abi_sizes", "dhr_set_option", "dhr_index_get_info", "dhr_last_error", "dhr_index_create", "dhr_index_destroy", "dhr_index_set_param",
            "dhr_index_device_bytes", "dhr_search", "dhr_score_rows", "dhr_merge_topk", "dhr_merge_topk_host", "dhr_merge_topk_lists", "dhr_merge_topk_lists_host",
-           "dhr_get_stats", "dhr_debug_bound_scores", "dhr_debug_query_margins", "dhr_debug_gemm_time", "dhr_debug_seq_to_tile", "dhr_search_sample_rank", "dhr_search_union_rank", "dhr_search_begin",
+           "dhr_get_stats", "dhr_debug_bound_scores", "dhr_debug_query_margins", "dhr_debug_gemm_time", "dhr_debug_seq_to_tile", "dhr_debug_sharded_repairs", "dhr_search_sample_rank", "dhr_search_union_rank", "dhr_search_begin",
            "dhr_search_finish", "dhr_search_mid_ranks", "dhr_search_mid", "dhr_search_pre_ranks", "dhr_search_pre", "dhr_search_begin_rest", "dhr_search_rerank", "dhr_comm_unique_id", "dhr_comm_create", "dhr_comm_wrap", "dhr_comm_create_callback", "dhr_comm_destroy", "dhr_comm_info", "dhr_comm_abort", "dhr_search_sharded", "dhr_search_sharded_local", "dhr_search_sharded_host", "dhr_pq_create", "dhr_pq_destroy", "dhr_pq_device_bytes", "dhr_pq_search", "dhr_pq_adc_scores", "dhr_pq_last_scan", "dhr_index_save", "dhr_index_file_info", "dhr_index_load", "dhr_densify", "dhr_pq_train", "dhr_pq_encode", "dhr_pq_decode", "dhr_pq_train_nbits", "dhr_pq_encode_nbits", "dhr_pq_decode_nbits", "dhr_write_trec", "dhr_format_float"]
 
 

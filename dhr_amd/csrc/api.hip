@@ -801,7 +801,7 @@ static int ensure_ws(dhr_index* ix, Workspace& w, int n_queries, int k, int64_t 
     const bool kernel_writes_tier = ix->gated_i8 || variant != 4;      // (the 4-wave kernel writes the uniform part only: dhr_internal.h cand_store)
     if (refine && cap_mult == 1 && ix->cand_cap <= 0 && cap > stride && kernel_writes_tier) {
       cap = stride;
-      arena = std::max<int64_t>((int64_t)4 << 20, std::min<int64_t>((int64_t)q_for_cap * 4096, (int64_t)64 << 20));
+      arena = std::max<int64_t>((int64_t)4 << 20, std::min<int64_t>((int64_t)q_for_cap * 8192, (int64_t)128 << 20));
       arena = std::max(arena, 2 * (cap_deep - cap));
     }
     // survivor lists: 32 768 entries, and at least 4 x the padded k (agip_topk 10 000: a chunk of the main pass must be able to bring
@@ -1550,6 +1550,9 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     // (config 3: 121.9 / 123.2 / 126.6 ms against 121.2-121.6 at 16 and 121.9 at 8 on one box).
     if (extrapolate) by_size = std::max(by_size, std::min<int64_t>(12, (n_main + 2799) / 2800));
     const int64_t want = async_ctl ? std::max<int64_t>(std::max<int64_t>(ix->main_chunks, by_size), (plan_read && stage == 0) ? need : 0) : std::max<int64_t>(ix->main_chunks, need);
+    // (k > 4096: every chunk boundary costs a merge of the 16 384-slot running list of every query, 1.0-2.3 ms whatever the chunk brought; capping
+    // the plan at 4 / 6 / 8 chunks there was measured in round 5 -- 242 -> 250-275 ms for --theta 0.3 --rerank with agip_topk 10 000: the
+    // lists of the hottest queries overflow and their queries are redone.  The plan stays.)
     const int M_plain = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, 64), n_main / (16 * DOC_GROUP)));
     // mid protocol: chunk 0 is the slice dhr_search_mid runs (mid_share16 / 16 of the pass), the plain plan covers the rest
     const int M = mid_proto ? M_plain + 1 : M_plain;

@@ -1342,19 +1342,44 @@ __global__ void __launch_bounds__(1024) plan_overflow_kernel(const uint32_t* __r
                                                              uint32_t arena_entries, int n_queries, uint32_t* __restrict__ ovf_off,
                                                              uint32_t* __restrict__ ovf_cap) {
   __shared__ unsigned long long part[1024];
+  __shared__ double scale_s;
   const int tid = threadIdx.x;
   const int chunk = (n_queries + 1023) / 1024;
   const int lo = tid * chunk, hi = min(lo + chunk, n_queries);
-  auto want = [&](int q) -> uint32_t {
+  auto want = [&](int q) -> uint32_t {          // what the query's list is expected to need beyond its uniform slots, with 2 x head room
     if (!cnt_prev) return 0u;
     const double need = 2.0 * (double)cnt_prev[q] * rows_ratio + 2048.0;
     if (!(need > (double)cap)) return 0u;
     const double extra = need - (double)cap;
-    const uint32_t e = extra >= (double)max_extra ? max_extra : (uint32_t)extra;
-    return (e + 255u) & ~255u;
+    return extra >= (double)max_extra ? max_extra : (uint32_t)extra;
   };
+  // pass 1: the batch's total.  If it exceeds the arena EVERY segment shrinks by the same factor (down to half, a segment still holds what its
+  // query is predicted to need; handing the arena out in query order instead left the later half of a batch without any -- found at 4
+  // shards, where the first chunk of a shard's main pass is 3/4 of the shard: 40 queries per step overflowed and took the repair path)
   unsigned long long s = 0;
   for (int q = lo; q < hi; ++q) s += want(q);
+  part[tid] = s;
+  __syncthreads();
+  for (int d = 512; d > 0; d >>= 1) {
+    if (tid < d) part[tid] += part[tid + d];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const unsigned long long total = part[0] + 256ull * (unsigned long long)n_queries;      // (+ the rounding of every segment up to 256)
+    scale_s = total > arena_entries ? (double)arena_entries / (double)total : 1.0;
+  }
+  __syncthreads();
+  const double scale = scale_s;
+  auto seg = [&](int q) -> uint32_t {
+    const uint32_t w = want(q);
+    if (w == 0u) return 0u;
+    const uint32_t v = scale < 1.0 ? (uint32_t)((double)w * scale) : w;
+    return (v + 255u) & ~255u;
+  };
+  __syncthreads();
+  // pass 2: exclusive scan of the segment sizes
+  s = 0;
+  for (int q = lo; q < hi; ++q) s += seg(q);
   part[tid] = s;
   __syncthreads();
   for (int d = 1; d < 1024; d <<= 1) {
@@ -1365,12 +1390,12 @@ __global__ void __launch_bounds__(1024) plan_overflow_kernel(const uint32_t* __r
   }
   unsigned long long run = tid ? part[tid - 1] : 0ull;
   for (int q = lo; q < hi; ++q) {
-    uint32_t w = want(q);
+    uint32_t w = seg(q);
     if (run >= arena_entries) w = 0u;
     else if (run + w > arena_entries) w = (uint32_t)(arena_entries - run);
     ovf_off[q] = (uint32_t)(run < arena_entries ? run : arena_entries);
     ovf_cap[q] = w;
-    run += want(q);
+    run += seg(q);
   }
 }
 hipError_t launch_plan_overflow(const uint32_t* cnt_prev, double rows_ratio, uint32_t cap, uint32_t max_extra, uint32_t arena_entries, int n_queries,

@@ -203,8 +203,11 @@ struct ShareGuard {
   ~ShareGuard() { for (int i = 0; i < B.n_local; ++i) { (void)B.set_share(i, 1); B.abort(i); } }
 };
 
+thread_local int g_last_repairs = 0;      // queries the calling thread's last sharded search redid with local thresholds (dhr_debug_sharded_repairs)
+
 int sharded_core(Backend& B, const dhr_query_batch* qb_in, int k, const std::vector<float*>& out_s, const std::vector<int64_t*>& out_r) {
   const int nl = B.n_local, world = B.world, Q = qb_in->n_queries;
+  g_last_repairs = 0;
   std::vector<dhr_query_batch> qb(nl, *qb_in);
   ShareGuard share_guard{B};
   for (int i = 0; i < nl; ++i) SH_TRY(B.set_share(i, world));      // a shard chases only its share of the union's rank
@@ -316,6 +319,7 @@ int sharded_core(Backend& B, const dhr_query_batch* qb_in, int k, const std::vec
   std::vector<int32_t> ids;
   SH_TRY(B.read_failed(n_failed, fail_ids, ids));
   const int F = (int)ids.size();
+  g_last_repairs = F;
   if (F == 0) return DHR_OK;
   std::sort(ids.begin(), ids.end());
   // failed queries (unrepresentative sample, skewed shards): sub-batch with local thresholds, gathered at full length, scattered into the result
@@ -745,6 +749,7 @@ extern "C" void dhr_comm_destroy(dhr_comm* c) {
   delete c;
 }
 
+extern "C" int32_t dhr_debug_sharded_repairs(void) { return g_last_repairs; }
 extern "C" int dhr_comm_info(const dhr_comm* c, int32_t what) {
   if (!c) return dhr_set_error_message(DHR_ERR_INVALID, "null communicator");
   int v = 0;

@@ -338,6 +338,9 @@ int dhr_debug_query_margins(dhr_index* index, const dhr_query_batch* queries, fl
 /* Test hook (host code only, no device needed): the corpus tile that position `seq` of a bound-GEMM launch maps to, computed with
  * the kernels' division-free arithmetic (out[0]) and with plain integer division (out[1]); the two must agree for every input. */
 void dhr_debug_seq_to_tile(int64_t seq, int32_t map_mode, int32_t period, int64_t head, int64_t perm_mul, int64_t perm_n, int64_t out[2]);
+/* Test hook: how many queries the calling thread's last dhr_search_sharded* call redid with local thresholds (its repair path: a
+ * correct result either way, but each repaired query costs the step an extra pass over its query tile). */
+int32_t dhr_debug_sharded_repairs(void);
 
 /* Kernel-tuning hook: the bound GEMM alone over the whole shard with the filter closed; average
  * milliseconds per launch over `iters` launches and the flops one launch issues (padded sizes). */
