@@ -21,7 +21,8 @@ in HBM before the timed region (the reference also times only its query loop,
 gip_retrieval.py:107,161-163).
 
 The default invocation (N=1, config 3) also times 5 steps each of config 2 (dense-only) and config 1
-(BM25, 100 k rows) and attaches them as `other_configs` to the same JSON line.
+(BM25, 100 k rows) and attaches them as `other_configs` to the same JSON line, and 3 steps each of the
+two-stage modes of the reference's docs on the resident config-3 index (`two_stage`).
 
 Prints ONE JSON line (rank 0).  See DESIGN.md section "Measurement" for the field definitions.
 """
@@ -167,6 +168,7 @@ def main():
     ap.add_argument("--parity-queries", type=int, default=24)
     ap.add_argument("--seed", type=int, default=1237)
     ap.add_argument("--rccl-timeout", type=float, default=300.0, help="N > 1: seconds the bring-up of the library's RCCL communicator (incl. one untimed sharded step) may take before every rank degrades to the host transport")
+    ap.add_argument("--two-stage", type=int, default=-1, help="1: after the timed steps also time 3 steps each of the two-stage modes of the reference's docs on the resident index (--theta 0.3 --rerank and --IP --rerank, agip_topk 10000) and attach them as two_stage (default: on for the plain N=1 hybrid invocation)")
     ap.add_argument("--other-configs", type=int, default=-1, help="1: after the headline workload also time 5 steps each of config 2 (dense) and config 1 (bm25) and attach them as other_configs (default: on for the plain N=1 hybrid invocation)")
     ap.add_argument("--data", default="iid", choices=["iid", "clustered"], help="dense columns: iid Gaussian (SURVEY 8d) or the structured variant (2 000 clusters, decaying spectrum, 1 %% near-duplicate rows, 5 %% hot queries)")
     ap.add_argument("--dist-backend", default="nccl", help="testing only: 'gloo' lets several ranks share ONE GPU (with DHR_BENCH_SINGLE_DEVICE=1)")
@@ -223,6 +225,7 @@ def main():
             for wl, tag in (("dense", "config2"), ("bm25", "config1")):
                 a2 = copy.copy(args)
                 a2.workload, a2.steps, a2.warmup, a2.no_cpu_baseline, a2.n_docs, a2.n_queries = wl, 5, 2, True, 0, 0
+                a2.two_stage = 0
                 o = run_workload(a2, specs[wl], ctx)
                 if rank == 0:
                     other[tag] = {key: o[key] for key in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "whole_job_frac_of_gemm_roofline",
@@ -445,6 +448,26 @@ def run_workload(args, spec, ctx):
                   "ms_per_step": (time.perf_counter() - t2) * 1e3 / 3}
         index.set_param(_lib.PARAM_OVERLAP_AUX, -1)
 
+    # side figure 3 (N = 1, hybrid): the two-stage modes every doc page of the reference recommends (gip_retrieval.py:128-156;
+    # docs/dhr/msmarco-passage-train-eval.md:114-125), both stages on the device (dhr_search_rerank), agip_topk 10 000 -> top-k, result lists on the host
+    index_device_bytes = index.device_bytes()          # (before the two-stage leg: agip_topk 10 000 grows the workspace)
+    two_stage = None
+    plain_hybrid = (spec["name"] == "hybrid" and world == 1 and pq is None and not args.n_docs and not args.n_queries and not args.uniform_idx and args.topk == 1000)
+    if spec["name"] == "hybrid" and world == 1 and pq is None and (args.two_stage == 1 or (args.two_stage < 0 and plain_hybrid and args.data == "iid")):
+        q32 = qv.float()
+        k1 = min(args.agip_topk, n)
+        two_stage = {"agip_topk": k1, "topk": min(k, k1), "steps": 3}
+        for name, qa, qia in (("theta0.3_rerank", torch.where(q32 > 0.3, q32, torch.zeros_like(q32)), qi), ("ip_rerank", q32, None)):
+            index.search_rerank(qa, qia, q32, qi, k1, min(k, k1))
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(3):
+                s2, r2 = index.search_rerank(qa, qia, q32, qi, k1, min(k, k1))
+            torch.cuda.synchronize()
+            two_stage[name] = {"ms_per_step": round((time.perf_counter() - t3) * 1e3 / 3, 2), "queries_per_s": round(nq * 3 / (time.perf_counter() - t3), 1),
+                               "result_checksum": {"rows": int(((r2.astype(np.int64) + 1) * (np.arange(r2.shape[1], dtype=np.int64) + 1)[None, :]).sum() & ((1 << 62) - 1))}}
+        del q32
+
     # ---- N > 1: size-independent checks of the sharded result, outside the timed region (the oracle cannot hold the
     # corpus): sorted lists of distinct rows; every returned score is the exact score of its row on the rank that holds
     # the row (dhr_score_rows, an independent code path); no sampled row of any shard outside a list beats its k-th score
@@ -553,8 +576,10 @@ def run_workload(args, spec, ctx):
             "sample_fallback_queries_per_step": stats_acc["sample_fallback_queries"] / args.steps,
             "overflow_retries_per_step": stats_acc["overflow_retries"] / args.steps,
             "setup_s": {"generate": round(t_gen, 2), "index_build": round(t_build, 2)},
-            "index_device_gb": round(index.device_bytes() / 1e9, 2),
+            "index_device_gb": round(index_device_bytes / 1e9, 2),
         }
+        if two_stage is not None:
+            out["two_stage"] = two_stage
         if pq is not None:
             # the dominant kernel of this mode is the ADC scan: HBM / LDS-gather bound integer-index work (roofline on HBM bytes)
             # Two rooflines, honestly labelled.  HBM: the UNIQUE code bytes of a step are rows x 64 B -- every query pair re-reads them, but from
