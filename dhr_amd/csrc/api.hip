@@ -153,7 +153,7 @@ struct dhr_index {
   hipStream_t s_aux = nullptr;          // non-blocking stream for rescoring/select overlapped with the main-pass GEMM
   // staged search (dhr_search_begin / dhr_search_finish): state carried between the two calls
   struct { bool valid = false, done = false, gate = false, mid = false, pre = false; int Q = 0, k = 0; double rate = 0.0, rate_r = 0.0; int64_t dev_bound = 0, dev_exact = 0;
-           int64_t pre_pos = 0, pre_seen = 0; } pend;   // mid: dhr_search_mid ran the first slice of the main pass; pre: dhr_search_pre ran the first part of the sampled run (sample positions [0, pre_pos), pre_seen rows)
+           int64_t pre_pos = 0, pre_seen = 0, pre_last_rows = 0; } pend;   // mid: dhr_search_mid ran the first slice of the main pass; pre: dhr_search_pre ran the first part of the sampled run (sample positions [0, pre_pos), pre_seen rows)
   Workspace ws, ws_fb[2];              // ws_fb[d]: workspace of fallback depth d+1 (16x candidate capacity)
   dhr_search_stats stats{};
 };
@@ -1150,10 +1150,10 @@ static int adaptive_rank(int r, double phi) {
 static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectArgs& sel, int64_t n_seq, int map_mode,
                          int period, int64_t head, int64_t first_chunk, int64_t seen_rows, Timer& tm, dhr_search_stats& st,
                          hipStream_t s, double* last_rate = nullptr, double* last_rate_r = nullptr, bool async_ctl = false,
-                         int64_t* last_rows = nullptr, int rank_target = 0, int64_t rank_rows = 0, int64_t pos0 = 0, int growth16 = 0) {
+                         int64_t* last_rows = nullptr, int rank_target = 0, int64_t rank_rows = 0, int64_t pos0 = 0, int growth16 = 0, int64_t prev_rows0 = 0) {
   if (growth16 <= 0) growth16 = ix->max_growth16;
   int64_t pos = pos0;          // (pos0 > 0: the run resumes behind a part another call streamed -- dhr_search_begin_rest)
-  int64_t prev_rows = 0;
+  int64_t prev_rows = prev_rows0;      // rows of the phase whose list lengths w.cnt still holds (the second list tier of the next phase is planned from them)
   int64_t chunk = std::max<int64_t>(DOC_GROUP, first_chunk);
   while (pos < n_seq) {
     chunk = std::min(chunk, round_up(n_seq - pos, DOC_GROUP));
@@ -1395,10 +1395,11 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     // is bound by its ~8 dependent launches, 0.4-0.5 ms, not by its rows; DHR_PRE_GROWTH16 in 1/16ths)
     static const int pre_growth = getenv("DHR_PRE_GROWTH16") ? std::max(16, atoi(getenv("DHR_PRE_GROWTH16"))) : 64;
     if ((rc = stream_phases(ix, w, Q, gate, sel, n_hi, 1, S, head, chunk0, seen0, tm, st, s, &rate, &rate_r, async_ctl, &last_rows,
-                            r_eff, first_valid + n_sample * TILE_ROWS, pos0, stage == 4 ? std::max(ix->max_growth16, pre_growth) : 0)) != DHR_OK) return rc;
+                            r_eff, first_valid + n_sample * TILE_ROWS, pos0, stage == 4 ? std::max(ix->max_growth16, pre_growth) : 0,
+                            stage == 5 ? ix->pend.pre_last_rows : 0)) != DHR_OK) return rc;      // (stage 5: w.cnt still holds the lists of the pre call's last phase)
     if (stage == 4) {
       ix->pend.valid = true; ix->pend.done = false; ix->pend.mid = false; ix->pend.pre = true; ix->pend.gate = gate; ix->pend.Q = Q; ix->pend.k = k;
-      ix->pend.pre_pos = n_hi; ix->pend.pre_seen = first_valid + n_hi * TILE_ROWS;
+      ix->pend.pre_pos = n_hi; ix->pend.pre_seen = first_valid + n_hi * TILE_ROWS; ix->pend.pre_last_rows = last_rows;
       return DHR_OK;
     }
     HIP_TRY(hipMemcpyAsync(w.tau_hat, w.tau, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
