@@ -2123,67 +2123,71 @@ __global__ void __launch_bounds__(SELECT_SM_THREADS) select_kernel(SelectArgs p)
   }
 }
 
-// Large k (4096 < k <= 16384, e.g. the documented --agip_topk 10000): the running top-k alone fills LDS
-// (kp keys), so new keys come in sorted batches of SELECT_BIG_BATCH and are merged IN PLACE: every old
-// and new key computes its final position (own index + number of keys of the other sequence that beat
-// it, by binary search), then all keys are written at once.
+// Large k (4096 < k <= 16384, e.g. the documented --agip_topk 10000): the running list stays in memory and is merged IN PLACE.
+// New keys that beat the current k-th come in sorted batches of SELECT_BIG_BATCH (LDS); every new key finds its final position by
+// a binary search over the list in memory (read-only pass), then the list is swept from its tail to its head in tiles: a tile's
+// entries are read, ranked against the batch (own index + number of new keys that beat them) and written at or behind their old
+// place -- positions an earlier (= later-in-the-list) tile has already vacated.  16 KB of LDS and 256 threads: 8 workgroups per CU
+// (rounds 2-4 held the whole list in LDS: 147 KB, one 1024-thread workgroup per CU, 1.0-2.3 ms per call; this form: see docs/experiments.md).
+// Only the first k_keep slots of the kp-slot list are ever touched (the controller clears the list before a search).
 constexpr int SELECT_BIG_BATCH = 2048;
-__global__ void __launch_bounds__(SELECT_THREADS) select_big_kernel(SelectArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint64_t* A = (uint64_t*)smem;
-  uint64_t* B = A + p.kp;
-  int& fill = *(int*)(smem + (size_t)(p.kp + SELECT_BIG_BATCH) * 8);
+constexpr int SELECT_BIG_THREADS = 256;
+constexpr int SELECT_BIG_EPT = 4;                                    // list entries per thread and tile
+__global__ void __launch_bounds__(SELECT_BIG_THREADS) select_big_kernel(SelectArgs p) {
+  __shared__ uint64_t B[SELECT_BIG_BATCH];
+  __shared__ int fill;
   const int q = blockIdx.x, tid = threadIdx.x;
   uint32_t count = p.cnt ? p.cnt[q] : p.count_all;
   if (p.cnt && count > p.cap) count = p.cap;
   uint64_t* topk = p.topk_keys + (int64_t)q * p.kp;
   const uint64_t* in = p.in_keys + (int64_t)q * p.ld_keys;
-  for (int j = tid; j < p.kp; j += SELECT_THREADS) A[j] = topk[j];
-  if (tid == 0) fill = 0;
-  __syncthreads();
-  const int per_thread = p.kp / SELECT_THREADS;                     // 8 or 16
   const int k_keep = p.k_keep ? p.k_keep : p.k;
+  constexpr int TILE = SELECT_BIG_THREADS * SELECT_BIG_EPT;
   for (uint32_t base = 0; base < count; base += SELECT_BIG_BATCH) {
-    const uint64_t kth = A[k_keep - 1];
-    __syncthreads();
+    if (tid == 0) fill = 0;
+    __syncthreads();                                                 // also orders the previous batch's writes before this read
+    const uint64_t kth = topk[k_keep - 1];
     const uint32_t end = (base + SELECT_BIG_BATCH < count) ? base + SELECT_BIG_BATCH : count;
-    for (uint32_t j = base + tid; j < end; j += SELECT_THREADS) {
+    for (uint32_t j = base + tid; j < end; j += SELECT_BIG_THREADS) {
       const uint64_t key = in[j];
       if (key > kth) B[atomicAdd(&fill, 1)] = key;
     }
     __syncthreads();
     const int m = fill;
-    if (m > 0) {
-      for (int j = m + tid; j < SELECT_BIG_BATCH; j += SELECT_THREADS) B[j] = 0ull;
-      __syncthreads();
-      bitonic_desc(B, SELECT_BIG_BATCH, tid, SELECT_THREADS);
-      uint64_t ka[16]; int da[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = tid + e * SELECT_THREADS;
-        if (e < per_thread) { ka[e] = A[i]; da[e] = i + count_greater(B, m, ka[e]); }
-      }
-      uint64_t kb[2]; int db[2];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int j = tid + e * SELECT_THREADS;
-        kb[e] = (j < m) ? B[j] : 0ull;
-        db[e] = (j < m) ? j + count_greater(A, p.kp, kb[e]) : p.kp;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if (e < per_thread && da[e] < p.kp) A[da[e]] = ka[e];
-#pragma unroll
-      for (int e = 0; e < 2; ++e)
-        if (db[e] < p.kp) A[db[e]] = kb[e];
-    }
-    if (tid == 0) fill = 0;
+    if (m == 0) continue;
+    int m2 = 2;
+    while (m2 < m) m2 <<= 1;
+    for (int j = m + tid; j < m2; j += SELECT_BIG_THREADS) B[j] = 0ull;
     __syncthreads();
+    bitonic_desc(B, m2, tid, SELECT_BIG_THREADS);
+    uint64_t kb[SELECT_BIG_BATCH / SELECT_BIG_THREADS]; int db[SELECT_BIG_BATCH / SELECT_BIG_THREADS];
+#pragma unroll
+    for (int e = 0; e < SELECT_BIG_BATCH / SELECT_BIG_THREADS; ++e) {
+      const int j = tid + e * SELECT_BIG_THREADS;
+      kb[e] = (j < m) ? B[j] : 0ull;
+      db[e] = (j < m) ? j + count_greater(topk, k_keep, kb[e]) : k_keep;
+    }
+    __syncthreads();                                                 // every rank against the old list is taken before the list moves
+    for (int t0 = (k_keep - 1) / TILE * TILE; t0 >= 0; t0 -= TILE) {
+      uint64_t ka[SELECT_BIG_EPT]; int da[SELECT_BIG_EPT];
+#pragma unroll
+      for (int e = 0; e < SELECT_BIG_EPT; ++e) {
+        const int i = t0 + tid + e * SELECT_BIG_THREADS;
+        da[e] = k_keep;
+        if (i < k_keep) { ka[e] = topk[i]; da[e] = i + count_greater(B, m, ka[e]); }     // empty slots (0) move behind every key
+      }
+      __syncthreads();                                               // the tile is in registers: its slots may be overwritten
+#pragma unroll
+      for (int e = 0; e < SELECT_BIG_EPT; ++e)
+        if (da[e] < k_keep) topk[da[e]] = ka[e];
+    }
+#pragma unroll
+    for (int e = 0; e < SELECT_BIG_BATCH / SELECT_BIG_THREADS; ++e)
+      if (db[e] < k_keep) topk[db[e]] = kb[e];
   }
-  for (int j = tid; j < p.kp; j += SELECT_THREADS) topk[j] = (j < k_keep) ? A[j] : 0ull;
+  __syncthreads();
   if (tid == 0) {
-    const uint64_t kth = A[p.k - 1];
+    const uint64_t kth = topk[p.k - 1];
     float t = kth ? ordered_f32((uint32_t)(kth >> 32)) : -INFINITY;
     if (p.monotone) t = fmaxf(t, p.tau[q]);      // the rank that defines the threshold changes between the phases of a sampled run
     p.tau[q] = t;
@@ -2194,10 +2198,7 @@ __global__ void __launch_bounds__(SELECT_THREADS) select_big_kernel(SelectArgs p
 hipError_t launch_select(const SelectArgs& a, hipStream_t s) {
   if (a.kp > 16384) return launch_select_global(a, s);       // beyond the LDS: concatenate + segmented sort (select_global.hip)
   if (a.kp > 4096) {
-    const int bytes = (a.kp + SELECT_BIG_BATCH) * 8 + 16;
-    static int big_bytes[64] = {};
-    if (hipError_t e = ensure_lds_attr((const void*)select_big_kernel, bytes, big_bytes); e != hipSuccess) return e;
-    hipLaunchKernelGGL(select_big_kernel, dim3((unsigned)a.n_queries), dim3(SELECT_THREADS), bytes, s, a);
+    hipLaunchKernelGGL(select_big_kernel, dim3((unsigned)a.n_queries), dim3(SELECT_BIG_THREADS), 0, s, a);
     return hipGetLastError();
   }
   static int attr_bytes[64] = {};
