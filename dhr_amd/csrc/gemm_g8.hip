@@ -298,7 +298,7 @@ __device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int
   // they were per-lane global loads, each pinned by an empty asm -- four serialised L2 round trips before the first DMA piece was
   // even issued, behind ~400 scalar instructions of 64-bit division: together most of the 2.5 us "per-tile constant" that neither a
   // persistent workgroup nor a skipped first-pair wait had removed in rounds 1-2.)
-  if (wave < 4) {
+  if (wave < 4 && (ts > 0 || wave == 1 || wave == 2)) {      // (a dense_i8 index runs here with ts = 0: no row sums, no shifts)
     const char* src = wave == 0 ? (const char*)(p.g8_rsum + dt * TILE_ROWS) : wave == 1 ? (const char*)(p.i8_mul + qt * TILE_ROWS)
                     : wave == 2 ? (const char*)(p.thr + qt * TILE_ROWS) : (const char*)(p.g8_shift + qt * TILE_ROWS);
     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + lane_off), LDS_PTR(smem + G8_META + wave * 1024), 16, 0, 0);
@@ -313,7 +313,7 @@ __device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int
   // The query's gated operand has 8 bits: level L in [0, 255] is stored as L - 128 (a column that carries nothing as -128), so
   //   sum_cols (stored + 128) * d8 = sum_cols stored * d8 + 128 * (sum of the row's gated int8 values),
   // and the second term is a constant of the ROW: the accumulators start there (g8_rsum, built with the index).
-  {
+  if (ts > 0) {
     const int32_t* rs = (const int32_t*)(smem + G8_META) + wm * 128 + 4 * (lane >> 5);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -323,6 +323,11 @@ __device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) acc[mi][0][4 * g4 + i4] = acc[mi][1][4 * g4 + i4] = __int_as_float(v[i4]);
       }
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][0][e] = acc[mi][1][e] = 0.f;
   }
   int sh_r[2];
   float mul_r[2], thr_f[2];
@@ -331,12 +336,14 @@ __device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int
     const int ql = wn * 64 + ni * 32 + (lane & 31);
     mul_r[ni] = ((const float*)(smem + G8_META + 1024))[ql];
     thr_f[ni] = ((const float*)(smem + G8_META + 2048))[ql];
-    sh_r[ni] = ((const int*)(smem + G8_META + 3072))[ql];
+    sh_r[ni] = ts > 0 ? ((const int*)(smem + G8_META + 3072))[ql] : 0;
     asm volatile("" : "+v"(mul_r[ni]), "+v"(thr_f[ni]), "+v"(sh_r[ni]));      // in registers from here on: the epilogue reuses the LDS
   }
   G8Frag f0, f1;
+  if (ts > 0) {
 #pragma unroll
-  for (int g = 0; g < 9; ++g) read_s8(f0, smem, g);
+    for (int g = 0; g < 9; ++g) read_s8(f0, smem, g);
+  }
   if (G8_ABL == 8) f1 = f0;
   constexpr std::integral_constant<int, 0> PH0{};
   constexpr std::integral_constant<int, 1> PH1{};
@@ -368,6 +375,7 @@ __device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");     // the last matrix results are in the accumulators
     __builtin_amdgcn_sched_barrier(0);
+    if (ts > 0)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll

@@ -1225,6 +1225,10 @@ static hipError_t launch_gemm_filter_grid(const GemmArgs& a, dim3 grid, hipStrea
   }
   const int variant = a.variant == 6 ? 5 : a.variant ? a.variant : g_gemm_variant;        // per handle (dhr_index_set_param), else the library default
   if (a.g8_shift) return (a.ts > 0 && !(a.ts & 1) && !(a.td & 1) && a.ts_q == a.ts) ? launch_gemm_g8(a, grid, s) : hipErrorInvalidValue;
+  // a dense-only int8 index (no gated stage on either side): the integer kernel of the gated_i8 indexes with ts = 0 -- the same operand
+  // images, integer filter epilogue; config 2: 2.78 -> 2.70 ms per launch alone, 76.4 -> 75.1 ms per step (DHR_DENSE_G8=0: gemm_filter_wx_kernel)
+  static const int dense_g8 = getenv("DHR_DENSE_G8") ? atoi(getenv("DHR_DENSE_G8")) : 1;
+  if (a.i8_mul && dense_g8 && a.ts == 0 && a.ts_q == 0 && a.td > 0 && !(a.td & 1)) return launch_gemm_g8(a, grid, s);
   if (a.i8_mul)      // int8 dense stages exist in the every-wave-computes kernels only (dhr_index_create enables them only where those run)
     return (a.ts + a.td > 0 && !(a.ts_q & 1) && !(a.td & 1)) ? launch_gemm_wx(a, grid, variant == 4 ? 4 : 5, s) : hipErrorInvalidValue;
   if (a.ts + a.td > 0 && (variant == 4 || variant == 5) && g_gemm_ablate == 0 && !(a.ts_q & 1) && !(a.td & 1)) return launch_gemm_wx(a, grid, variant, s);   // pairs of stages
