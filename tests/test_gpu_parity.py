@@ -598,6 +598,22 @@ def test_large_k(G, k):
     _search_check(G, cv, ci, qv.astype(np.float32), qi, k, queries=[0, 5])
 
 
+@pytest.mark.parametrize("order", ["ascending", "descending", "blocks"])
+def test_large_k_adversarial_row_order(G, order):
+    """The running list of 4 096 < k <= 16 384 is merged in place in memory (select_big_kernel).  Scores that RISE with the row id make
+    every batch of every phase beat the whole list (each merge moves all of it), scores that fall leave it untouched after the first
+    phases, alternating blocks interleave old and new keys; many rows tie (score desc, row asc decides)."""
+    from dhr_amd import synth
+    n, k = 60_000, 9000
+    cv, ci, qv, qi = synth.make_pair(61, n, 3, 768, 64)
+    r = np.arange(n, dtype=np.float32) / n
+    ramp = r if order == "ascending" else (1.0 - r) if order == "descending" else ((np.arange(n) // 997) % 2).astype(np.float32) * 0.5 + 0.25 * r
+    cv = cv.copy(); qv = qv.copy()
+    cv[:, -1] = (4.0 * ramp).astype(np.float16)               # one ungated column carries the order; fp16 steps: runs of tied rows
+    qv[:, -1] = np.float16(3.0)
+    _search_check(G, cv, ci, qv.astype(np.float32), qi, k)
+
+
 def test_two_stage_default_agip_topk(G):
     """--theta 0.3 --rerank with the reference's default --agip_topk 10000 against the oracle."""
     from dhr_amd import synth
@@ -1870,10 +1886,13 @@ def test_pq_search_k_beyond_16384(G):
         pix.close()
 
 
-def test_search_sharded_local_k_beyond_16384(G):
-    """The sharded search with k above the LDS select / LDS list merge: the shards' lists are reduced by the general device reduce."""
+@pytest.mark.parametrize("k", [20000, 10000, 4500])
+def test_search_sharded_local_k_beyond_16384(G, k):
+    """The sharded search with k above the LDS select / LDS list merge: the shards' lists are reduced by the general device reduce
+    (k = 20 000); 4 096 < k <= 16 384: every shard keeps its running list in memory and merges it in place (select_big_kernel)
+    under the sampled-rank / agreement protocol of the sharded step."""
     from dhr_amd import synth, _lib, dist as D
-    n, ns, k = 200_000, 4, 20000
+    n, ns = 200_000, 4
     cv, ci, qv, qi = synth.make_pair(52, n, 3, 768, 64)
     q32 = qv.astype(np.float32)
     full = G.GipIndex(cv, ci)
