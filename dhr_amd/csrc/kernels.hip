@@ -1529,13 +1529,19 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
   const double unit = G8 ? (double)p.g8_unit[q] : 0.0;
   // (A variant that issued the loads of all 8 candidates of a lane group up front ran 30 % SLOWER: 4x the gathers
   // in flight per CU only thrash the memory system; the dependent chain below at 8 waves per SIMD is the sweet spot.)
+  // the list entry of the NEXT round is loaded before the current one's record is gathered: one dependent round trip per round instead of two
+  auto entry = [&](uint32_t i) __attribute__((always_inline)) -> uint2 {
+    if (i >= count || i >= base + REFINE_PER_WG) return make_uint2(0u, 0u);
+    return i < p.cap ? p.cand[(int64_t)q * p.cap + i] : p.ovf[(size_t)p.ovf_off[q] + (i - p.cap)];
+  };
+  uint2 cn = entry(base + (threadIdx.x >> 3));
   for (uint32_t i = base + (threadIdx.x >> 3); i < base + REFINE_PER_WG; i += 32) {
     float corr = 0.f;
     int taken = 0;              // G8: operand products (integer units) of the listed same-bucket entries
     double back = 0.0;          // G8: real-valued products of those whose index values agree
-    uint2 c = make_uint2(0u, 0u);
+    const uint2 c = cn;
+    cn = entry(i + 32);
     if (i < count) {
-      c = i < p.cap ? p.cand[(int64_t)q * p.cap + i] : p.ovf[(size_t)p.ovf_off[q] + (i - p.cap)];
       constexpr int EPL = HEAVY / 8;              // entries per lane: 8 (two 16-byte key loads + one 16-byte value load) or 4 (one + an 8-byte one)
       static_assert(EPL == 8 || EPL == 4, "8 lanes per candidate read 8 or 4 entries each");
       const uint32_t* hk = p.heavy_key + (int64_t)c.x * HEAVY_KEY_STRIDE + sub * EPL;
