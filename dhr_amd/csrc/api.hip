@@ -1050,7 +1050,7 @@ static int rescore_select_async(dhr_index* ix, Workspace& w, int Q, bool gate, S
   if (!refine) ovf = nullptr;                    // (the second tier exists for lists a refine level reads, ensure_ws)
   const uint32_t* ovf_cap = ovf ? w.ovf_cap : nullptr;
   // the bound lists: statistics, overflow marks, block offsets of the kernel that walks them and (refine) the survivor counters cleared
-  HIP_TRY(launch_lists_ready(cnt, (uint32_t)w.cap, Q, refine ? 256u : (uint32_t)RESCORE_CANDS_PER_WG, refine ? w.blk_off : w.blk_off + w.q_pad + 1,
+  HIP_TRY(launch_lists_ready(cnt, (uint32_t)w.cap, Q, refine ? (uint32_t)REFINE_PER_WG : (uint32_t)RESCORE_CANDS_PER_WG, refine ? w.blk_off : w.blk_off + w.q_pad + 1,
                              d_fullest_bound, refine ? nullptr : d_fullest, w.d_stats + 0, refine ? nullptr : w.d_stats + 1, w.fail_flags,
                              refine ? w.cnt_r : nullptr, refine ? (int)w.q_pad : 0, s, ovf_cap));
   if (refine) {
@@ -1095,8 +1095,8 @@ static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectA
     if (ix->gated_i8) { f.g8_q8 = w.g8_q8; f.g8_inv_cs = ix->g8_inv_cs; f.g8_unit = w.g8_unit; f.abs_mode = ix->abs_mode ? 1 : 0; f.ungated = gate ? 0 : 1; }
     if (ix->resid8) { f.resid8 = ix->resid8; f.resid_ld = ix->resid_ld; f.q32 = w.q32; f.q32_ld = ix->k_rm; f.col_scale = ix->i8_col_scale; f.d_cls = ix->d_cls; f.thr_raise = w.thr_raise; }
     // flat launch: one workgroup per REAL block of 256 candidates (bound_sum / 256 + Q is an upper bound of their number)
-    HIP_TRY(launch_block_offsets(cnt, (uint32_t)w.cap, Q, 256, w.blk_off, s));
-    f.blk_off = w.blk_off; f.flat_blocks = (uint32_t)std::min<int64_t>(bound_sum / 256 + Q, (int64_t)0x7fffffff);
+    HIP_TRY(launch_block_offsets(cnt, (uint32_t)w.cap, Q, REFINE_PER_WG, w.blk_off, s));
+    f.blk_off = w.blk_off; f.flat_blocks = (uint32_t)std::min<int64_t>(bound_sum / REFINE_PER_WG + Q, (int64_t)0x7fffffff);
     HIP_TRY(hipMemsetAsync(w.cnt_r, 0, (size_t)w.q_pad * 4, s));
     HIP_TRY(hipMemsetAsync(w.d_ref, 0, 16, s));
     tm.begin_on(T_REFINE, s); HIP_TRY(launch_refine(f, s)); tm.end_on(s);

@@ -296,6 +296,10 @@ hipError_t launch_gemm_filter(const GemmArgs& a, hipStream_t s);
 hipError_t launch_heavy_build(const __half* vals_rm, int k_rm, const void* idx, int idx_dtype, int64_t n_rows, int d_dlr,
                               const uint8_t* map, int n_buckets, uint32_t* heavy_key, __half* heavy_val,
                               const float* g8_inv_cs /* gated_i8 indexes: the key also carries the entry's int8 level */, int abs_mode, hipStream_t s);
+#ifndef REFINE_PER_WG_N
+#define REFINE_PER_WG_N 512   // round 5: 256 -> 512 takes 1.0 ms off the refine level of a config-3 step (11.1 -> 10.05 ms alone; 1 024: 9.8)
+#endif
+constexpr int REFINE_PER_WG = REFINE_PER_WG_N;       // candidates of ONE query per refine workgroup (its operand words are staged in LDS once); a multiple of 32
 struct RefineArgs {
   const uint2* cand; const uint32_t* cnt; uint32_t cap;      // bound candidates (row, U bits)
   const uint2* ovf; const uint32_t* ovf_off; const uint32_t* ovf_cap;   // ... their second tier (GemmArgs), or null

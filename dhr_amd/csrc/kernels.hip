@@ -1504,7 +1504,9 @@ static __device__ __forceinline__ uint2 gather8(const void* p) { return *(const 
 // 1-3 -- prunes 60 % of the candidates after one line instead of three, and was SLOWER: refine 11.3 -> 15.9 ms per config-3 step.  The kernel
 // is bound by the round trips a wave waits for, not by bytes: nearly every wave holds a survivor among its 8 candidates and then pays two
 // dependent gathers per iteration.  It would take a compacting pass between the levels (a third list set); not built.)
-constexpr int REFINE_PER_WG = 256;       // candidates of ONE query per workgroup (its operand words are staged in LDS once)
+#ifndef REFINE_PREFETCH
+#define REFINE_PREFETCH 2   // rounds of a lane group in flight: 0 = entry -> record -> lookups in sequence, 1 = the next entries ahead, 2 = + the next record
+#endif
 template <bool G8>
 __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
   extern __shared__ uint32_t qw[];             // [d_dlr] query words (up to 4096 slices: the slice id has 12 bits in a heavy-list key);
@@ -1534,27 +1536,59 @@ __global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
     if (i >= count || i >= base + REFINE_PER_WG) return make_uint2(0u, 0u);
     return i < p.cap ? p.cand[(int64_t)q * p.cap + i] : p.ovf[(size_t)p.ovf_off[q] + (i - p.cap)];
   };
-  uint2 cn = entry(base + (threadIdx.x >> 3));
-  for (uint32_t i = base + (threadIdx.x >> 3); i < base + REFINE_PER_WG; i += 32) {
+  // ... and so is the next round's RECORD: two rounds of a lane group are in flight (entry of round r + 2, record of round r + 1) while
+  // round r is looked up.  (All 8 records of a lane group up front thrash the memory system, see above; one ahead does not.)
+  constexpr int EPL = HEAVY / 8;              // entries per lane: 8 (two 16-byte key loads + one 16-byte value load) or 4 (one + an 8-byte one)
+  static_assert(EPL == 8 || EPL == 4, "8 lanes per candidate read 8 or 4 entries each");
+  struct Rec { uint4 k0, k1, hv; };
+  auto record = [&](uint32_t i, const uint2 c, Rec& r) __attribute__((always_inline)) {
+    r.k0 = r.k1 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    r.hv = make_uint4(0u, 0u, 0u, 0u);
+    if (i < count && i < base + REFINE_PER_WG) {
+      const uint32_t* hk = p.heavy_key + (int64_t)c.x * HEAVY_KEY_STRIDE + sub * EPL;
+      r.k0 = gather16(hk);
+      if constexpr (EPL == 8) {
+        r.k1 = gather16(hk + 4);
+        r.hv = gather16(p.heavy_val + (int64_t)c.x * HEAVY_VAL_STRIDE + sub * 8);
+      } else {
+        const uint2 v2 = gather8(p.heavy_val + (int64_t)c.x * HEAVY_VAL_STRIDE + sub * 4);
+        r.hv = make_uint4(v2.x, v2.y, 0u, 0u);
+      }
+    }
+  };
+  const uint32_t i_first = base + (threadIdx.x >> 3);
+#if REFINE_PREFETCH >= 1
+  uint2 c_cur = entry(i_first), c_nx = entry(i_first + 32);
+#endif
+#if REFINE_PREFETCH >= 2
+  Rec r_cur;
+  record(i_first, c_cur, r_cur);
+#endif
+  for (uint32_t i = i_first; i < base + REFINE_PER_WG; i += 32) {
     float corr = 0.f;
     int taken = 0;              // G8: operand products (integer units) of the listed same-bucket entries
     double back = 0.0;          // G8: real-valued products of those whose index values agree
-    const uint2 c = cn;
-    cn = entry(i + 32);
+#if REFINE_PREFETCH >= 2
+    const uint2 c = c_cur;
+    const Rec rc = r_cur;
+    Rec r_nx;
+    record(i + 32, c_nx, r_nx);
+    const uint2 c_nx2 = entry(i + 64);
+    c_cur = c_nx; c_nx = c_nx2; r_cur = r_nx;
+#elif REFINE_PREFETCH == 1
+    const uint2 c = c_cur;
+    c_cur = c_nx; c_nx = entry(i + 64);
+    Rec rc;
+    record(i, c, rc);
+#else
+    const uint2 c = entry(i);
+    Rec rc;
+    record(i, c, rc);
+#endif
     if (i < count) {
-      constexpr int EPL = HEAVY / 8;              // entries per lane: 8 (two 16-byte key loads + one 16-byte value load) or 4 (one + an 8-byte one)
-      static_assert(EPL == 8 || EPL == 4, "8 lanes per candidate read 8 or 4 entries each");
-      const uint32_t* hk = p.heavy_key + (int64_t)c.x * HEAVY_KEY_STRIDE + sub * EPL;
-      const uint4 k0 = gather16(hk);
-      uint4 k1 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      const uint4 k0 = rc.k0, k1 = rc.k1;
       union { uint4 u; half8 h; } hvu;
-      if constexpr (EPL == 8) {
-        k1 = gather16(hk + 4);
-        hvu.u = gather16(p.heavy_val + (int64_t)c.x * HEAVY_VAL_STRIDE + sub * 8);
-      } else {
-        const uint2 v2 = gather8(p.heavy_val + (int64_t)c.x * HEAVY_VAL_STRIDE + sub * 4);
-        hvu.u = make_uint4(v2.x, v2.y, 0u, 0u);
-      }
+      hvu.u = rc.hv;
       const half8 hv = hvu.h;
       const uint32_t keys[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
 #pragma unroll
@@ -1928,6 +1962,8 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
     }
     return;
   }
+  // (Round 5: loading the row id of the wave's NEXT pair ahead of the current pair's gathers -- what gained 1.2 ms in refine_kernel -- made this
+  // kernel slower, 15.4 -> 16.2 ms per config-3 step: it sits at its register budget (72, 60 bytes of scratch), and it is bound by bytes, not by the chain.)
   for (uint32_t i = base + wave; i < base + RESCORE_CANDS_PER_WG && i < count; i += 4) {
     uint32_t row;
     if (p.cand) row = p.cand[(int64_t)q * p.cap + i].x;
