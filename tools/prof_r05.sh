@@ -34,8 +34,8 @@ if [ $PART = bench ] || [ $PART = all ]; then
 fi
 if [ $PART = trace ] || [ $PART = all ]; then
   cd /tmp && export TMPDIR=/tmp
-  timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --other-configs 0 > $O/trace_bench.log 2>&1
-  timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace_serial -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --other-configs 0 --overlap-aux 0 > $O/trace_serial_bench.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --other-configs 0 --two-stage 0 > $O/trace_bench.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats -d $O/trace_serial -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --other-configs 0 --two-stage 0 --overlap-aux 0 > $O/trace_serial_bench.log 2>&1
   cd $R
   DB=$(ls $O/trace/*/*_results.db 2>/dev/null | head -1)
   [ -n "$DB" ] && python tools/rocpd_summary.py $DB $O/${TAG}_kernel_stats.txt | head -14
