@@ -1507,8 +1507,16 @@ static __device__ __forceinline__ uint2 gather8(const void* p) { return *(const 
 #ifndef REFINE_PREFETCH
 #define REFINE_PREFETCH 2   // rounds of a lane group in flight: 0 = entry -> record -> lookups in sequence, 1 = the next entries ahead, 2 = + the next record
 #endif
+#ifndef REFINE_WPE
+#define REFINE_WPE 8      // waves per SIMD the register allocation aims at: 8 = 64 registers (8 bytes of scratch); the compiler's own choice (66: 7 waves) runs 9.95 instead of 8.85 ms per config-3 step
+#endif
+#if REFINE_WPE > 0
+#define REFINE_ATTR __attribute__((amdgpu_waves_per_eu(REFINE_WPE)))
+#else
+#define REFINE_ATTR
+#endif
 template <bool G8>
-__global__ void __launch_bounds__(256) refine_kernel(RefineArgs p) {
+__global__ void __launch_bounds__(256) REFINE_ATTR refine_kernel(RefineArgs p) {
   extern __shared__ uint32_t qw[];             // [d_dlr] query words (up to 4096 slices: the slice id has 12 bits in a heavy-list key);
                                                // G8: [d_dlr] pairs {query word, the query's int8 operand level}: one 8-byte LDS read per listed entry
   int q = blockIdx.y;
@@ -1685,8 +1693,16 @@ hipError_t launch_resid_build(const __half* vals_rm, int k_rm, int64_t n_rows, i
 // da_c; what that loses is at most 7 sum_c |da_c|, summed exactly here and taken off the level's threshold) so that eight columns cost
 // two v_dot4_i32_i8 and two mask operations instead of 32 vector instructions -- the first cut (fp32 factors, one shift + mask + convert +
 // multiply-add per nibble) spent more time on its arithmetic than on its gathers.  Integer sums: nothing is rounded before the final conversion.
+#ifndef DENSE_REFINE_WPE
+#define DENSE_REFINE_WPE 8   // 64 registers, 8 waves per SIMD (the compiler picks 68: 7 waves): 10.4 -> 9.85 ms per config-2 step alone
+#endif
+#if DENSE_REFINE_WPE > 0
+#define DENSE_REFINE_ATTR __attribute__((amdgpu_waves_per_eu(DENSE_REFINE_WPE)))
+#else
+#define DENSE_REFINE_ATTR
+#endif
 template <int CH>
-__global__ void __launch_bounds__(256) dense_refine_kernel(RefineArgs p) {
+__global__ void __launch_bounds__(256) DENSE_REFINE_ATTR dense_refine_kernel(RefineArgs p) {
   __shared__ float a_s[1024];
   __shared__ uint32_t f_s[2 * 128];        // packed int8 factors: [0, 128) even columns of every group of eight, [128, 256) odd columns
   __shared__ float red[3 * 4];             // per wave: max |a|, then sum a8 and sum |da| (as floats: both are below 2^24 in magnitude / harmlessly rounded UP below)
