@@ -983,6 +983,10 @@ enum { T_GEMM = 0, T_REFINE = 1, T_RESCORE = 2, T_SELECT = 3, T_PREP = 4 };
 
 // The refine step serves gated batches, and -- on gated_i8 indexes -- ungated ones too (--IP stage 1): there it takes the int8
 // products of a row's listed entries off the bound and puts their real products back, whatever the index values (RefineArgs::ungated).
+#ifndef SELECT_SORT_Q
+#define SELECT_SORT_Q 8       // LDS keys of select_kernel in quarters of kp: the list + one round of up to kp new keys (16 until round 5: 32 KB for top-1000 held a CU at 5 workgroups)
+#endif
+static inline int select_sort_n(int kp) { return kp * SELECT_SORT_Q / 4; }
 static inline bool uses_refine(const dhr_index* ix, bool gate) { return (ix->heavy_key != nullptr && (gate || ix->gated_i8)) || ix->resid8 != nullptr; }
 static RescoreArgs base_rescore_args(const dhr_index* ix, const Workspace& w, int n_queries, bool gate) {
   RescoreArgs r{};
@@ -1320,7 +1324,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
 
   SelectArgs sel{};
   sel.topk_keys = w.topk_keys; sel.in_keys = w.rs_keys; sel.ld_keys = w.keys_ld; sel.cap = (uint32_t)w.cap;
-  sel.k = r_eff; sel.kp = w.kp; sel.sort_n = 4 * w.kp;
+  sel.k = r_eff; sel.kp = w.kp; sel.sort_n = select_sort_n(w.kp);
   sel.k_keep = k;                          // the threshold is the r-th best seen, the list keeps the k best (ties with the final k-th score survive the sampled run)
   sel.kps = 64; while (sel.kps < k) sel.kps <<= 1; sel.margin = w.margin; sel.tau = w.tau; sel.thr = w.thr;
   sel.n_queries = Q;
@@ -1811,7 +1815,7 @@ extern "C" int dhr_search_rerank(dhr_index* ix, const dhr_query_batch* qb1, cons
   SelectArgs sel{};
   sel.topk_keys = w.topk_keys; sel.in_keys = w.rs_keys; sel.ld_keys = w.keys_ld; sel.cap = (uint32_t)w.cap;
   sel.cnt = nullptr; sel.count_all = (uint32_t)k1;
-  sel.k = k; sel.kp = w.kp; sel.sort_n = 4 * w.kp;
+  sel.k = k; sel.kp = w.kp; sel.sort_n = select_sort_n(w.kp);
   sel.kps = 64; while (sel.kps < k) sel.kps <<= 1;
   sel.margin = w.margin; sel.tau = w.tau; sel.thr = w.thr; sel.n_queries = Q;
   tm.begin(T_SELECT);

@@ -2111,6 +2111,9 @@ __device__ __forceinline__ int count_greater(const uint64_t* arr, int n, uint64_
 // position is its own index plus the number of keys of the other list that beat it (keys are unique: the row
 // id is part of the key).  A full re-sort of kps + |B| keys per call cost 2.5x the barriers.
 constexpr int SELECT_SM_THREADS = 256;
+// EA = list entries per thread: 16 covers kp <= 4096; the top-1000 searches (kp = 1024) run the EA = 4 instantiation, whose 48 fewer registers
+// double the workgroups a CU holds (round 5)
+template <int EA>
 __global__ void __launch_bounds__(SELECT_SM_THREADS) select_kernel(SelectArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint64_t* A = (uint64_t*)smem;
@@ -2145,10 +2148,10 @@ __global__ void __launch_bounds__(SELECT_SM_THREADS) select_kernel(SelectArgs p)
       for (int j = m + tid; j < m2; j += SELECT_SM_THREADS) B[j] = 0ull;
       __syncthreads();
       bitonic_desc(B, m2, tid, SELECT_SM_THREADS);
-      uint64_t ka[16], kb[8];
-      int da[16], db[8];
+      uint64_t ka[EA], kb[8];
+      int da[EA], db[8];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
+      for (int e = 0; e < EA; ++e) {
         const int i = tid + e * SELECT_SM_THREADS;
         da[e] = kps;
         if (i < kps) { ka[e] = A[i]; da[e] = ka[e] ? i + count_greater(B, m, ka[e]) : kps; }
@@ -2165,7 +2168,7 @@ __global__ void __launch_bounds__(SELECT_SM_THREADS) select_kernel(SelectArgs p)
       __syncthreads();
       for (int j = total + tid; j < kps; j += SELECT_SM_THREADS) A[j] = 0ull;
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
+      for (int e = 0; e < EA; ++e)
         if (da[e] < kps) A[da[e]] = ka[e];
 #pragma unroll
       for (int e = 0; e < 8; ++e)
@@ -2263,10 +2266,15 @@ hipError_t launch_select(const SelectArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(select_big_kernel, dim3((unsigned)a.n_queries), dim3(SELECT_BIG_THREADS), 0, s, a);
     return hipGetLastError();
   }
-  static int attr_bytes[64] = {};
+  static int attr_bytes[64] = {}, attr_bytes4[64] = {};
   const int bytes = a.sort_n * 8 + 16;
-  if (hipError_t e = ensure_lds_attr((const void*)select_kernel, bytes, attr_bytes); e != hipSuccess) return e;
-  hipLaunchKernelGGL(select_kernel, dim3((unsigned)a.n_queries), dim3(SELECT_SM_THREADS), bytes, s, a);
+  if (a.kp <= 4 * SELECT_SM_THREADS) {
+    if (hipError_t e = ensure_lds_attr((const void*)select_kernel<4>, bytes, attr_bytes4); e != hipSuccess) return e;
+    hipLaunchKernelGGL(select_kernel<4>, dim3((unsigned)a.n_queries), dim3(SELECT_SM_THREADS), bytes, s, a);
+    return hipGetLastError();
+  }
+  if (hipError_t e = ensure_lds_attr((const void*)select_kernel<16>, bytes, attr_bytes); e != hipSuccess) return e;
+  hipLaunchKernelGGL(select_kernel<16>, dim3((unsigned)a.n_queries), dim3(SELECT_SM_THREADS), bytes, s, a);
   return hipGetLastError();
 }
 
