@@ -219,6 +219,7 @@ struct RescoreArgs {
   uint32_t max_count;         // grid.x * CANDS_PER_WG covers this many
   // flat launch (candidate-list mode): workgroup b serves the query q with blk_off[q] <= b < blk_off[q+1]; grid = flat_blocks
   const uint32_t* blk_off; uint32_t flat_blocks;
+  int split;                  // set by launch_rescore: 1 = rescore_fast_kernel was launched beside this kernel and takes the batches it can
 };
 
 struct SelectArgs {
