@@ -1846,9 +1846,10 @@ __device__ __forceinline__ uint32_t pair_mask(uint32_t x, uint32_t sel) {
   t.v = t.v - one.v;
   return t.u;
 }
-// FAST_ONLY: the instantiation of rescore_fast_kernel -- wide rows, every query fp16-representable with no all-zero chunk (the hybrid brute-force
-// batch): the general loop's fast branch alone is 51 registers, the whole function 72 with 60 bytes of scratch.
-template <bool FAST_ONLY>
+// PATH 0: every path (72 registers with 60 bytes of scratch: the allocation is the maximum over the paths).  PATH 1 / 2: the instantiations of
+// rescore_fast_kernel / rescore_narrow_kernel -- every query fp16-representable with no all-zero chunk, rows of more than / at most 128 chunks:
+// the general loop's fast branch alone (52 registers) / the 16-lanes-per-pair path alone.
+template <int PATH>
 __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q, const uint32_t blk) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -1878,7 +1879,7 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
   // pair would run 1-8 of its 64 lanes and still pay a full memory round trip per pair.  Instead 8 lanes per pair, 8 pairs per wave:
   // lane (pair slot ci, s) owns the s-th non-zero chunk.  Same products, fp64 sums over at most 64 terms (the zero chunks the dense
   // path adds are exact zeros).
-  if constexpr (!FAST_ONLY)
+  if constexpr (PATH == 0)
   if (fast && some_zero) {
     int nzc[8];
     int m = 0;
@@ -1937,7 +1938,7 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
   // 3.8 KB hybrid rows.  Instead 16 lanes per pair, four pairs per wave: lane s of a pair owns chunks s, s + 16, ... (ascending: six
   // independent 16-byte gathers in flight per lane), then the xor butterfly over the 16 lanes.  The summation order is fixed by the row
   // width alone, so scores stay reproducible between searches, shards and entry points.  (32 lanes per pair: 2.9-3.1 TB/s.)
-  if constexpr (!FAST_ONLY)
+  if constexpr (PATH == 0 || PATH == 2)
   if (fast && !some_zero && nchunks <= 128) {
     constexpr int L = 16, P = 64 / L;
     const int g = lane / L, sl = lane % L;
@@ -1985,6 +1986,7 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
   }
   // (Round 5: loading the row id of the wave's NEXT pair ahead of the current pair's gathers -- what gained 1.2 ms in refine_kernel -- made this
   // kernel slower, 15.4 -> 16.2 ms per config-3 step: it sits at its register budget (72, 60 bytes of scratch), and it is bound by bytes, not by the chain.)
+  if constexpr (PATH != 2)
   for (uint32_t i = base + wave; i < base + RESCORE_CANDS_PER_WG && i < count; i += 4) {
     uint32_t row;
     if (p.cand) row = p.cand[(int64_t)q * p.cap + i].x;
@@ -2016,7 +2018,7 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
         }
       }
       acc = wave_sum_f64(acc);
-    } else if (!FAST_ONLY && valid) {
+    } else if (PATH == 0 && valid) {
       for (int c = lane; c < nchunks; c += 64) {
         if (!((nz_mask >> (c >> 6)) & 1u)) continue;
         const half8 dv = *(const half8*)(p.vals_rm + (int64_t)row * p.k_rm + c * 8);
@@ -2063,48 +2065,51 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
 #ifndef RESCORE_WPE
 #define RESCORE_WPE 7          // waves per SIMD the register allocation aims at (7 = 72 registers, 8 = 64)
 #endif
-// Which kernel takes a batch is decided ON THE DEVICE (the flags of query_prep_kernel are never read by the host): both are launched, one returns at once.
+// Which kernel takes a batch is decided ON THE DEVICE (the flags of query_prep_kernel are never read by the host): the general kernel and the
+// specialised one for the index's row width are both launched, one of them returns at once.
 __device__ __forceinline__ bool rescore_fast_batch(const RescoreArgs& p) {
-  return p.q16 && p.q_inexact[0] == 0u && p.q_inexact[1] == 0u && (p.k_rm >> 3) > 128 &&
+  return p.q16 && p.q_inexact[0] == 0u && p.q_inexact[1] == 0u &&
          (!p.gate || p.d_dlr == 0 || p.c_idx_dtype == DHR_IDX_U8 || p.c_idx_dtype == DHR_IDX_I8);
+}
+template <int PATH>
+__device__ __forceinline__ void rescore_run(const RescoreArgs& p) {
+  if (!p.blk_off) { rescore_block<PATH>(p, (int)blockIdx.y, blockIdx.x); return; }
+  for (uint32_t b = blockIdx.x;; b += gridDim.x) {
+    int q; uint32_t blk;
+    if (!flat_block(p.blk_off, p.n_queries, b, q, blk)) return;
+    rescore_block<PATH>(p, q, blk);
+  }
 }
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RESCORE_WPE))) rescore_kernel(RescoreArgs p) {
   if (p.split && rescore_fast_batch(p)) return;
-  if (!p.blk_off) { rescore_block<false>(p, (int)blockIdx.y, blockIdx.x); return; }
-  for (uint32_t b = blockIdx.x;; b += gridDim.x) {
-    int q; uint32_t blk;
-    if (!flat_block(p.blk_off, p.n_queries, b, q, blk)) return;
-    rescore_block<false>(p, q, blk);
-  }
+  rescore_run<0>(p);
 }
-// The hybrid brute-force batch (round 5): the same sums in the same order from the fast branch alone, 51 registers, 8 waves per SIMD --
+// The hybrid brute-force batch (round 5): the same sums in the same order from the fast branch alone, 52 registers, 8 waves per SIMD --
 // 15.4 -> 13.9 ms of row gathers per config-3 step.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) rescore_fast_kernel(RescoreArgs p) {
-  if (!rescore_fast_batch(p)) return;
-  if (!p.blk_off) { rescore_block<true>(p, (int)blockIdx.y, blockIdx.x); return; }
-  for (uint32_t b = blockIdx.x;; b += gridDim.x) {
-    int q; uint32_t blk;
-    if (!flat_block(p.blk_off, p.n_queries, b, q, blk)) return;
-    rescore_block<true>(p, q, blk);
-  }
+  if (!rescore_fast_batch(p) || (p.k_rm >> 3) <= 128) return;
+  rescore_run<1>(p);
 }
-
+// ... and the narrow-row batch (dense-only 768, BM25, the 768 + 128 BEIR layout).
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) rescore_narrow_kernel(RescoreArgs p) {
+  if (!rescore_fast_batch(p) || (p.k_rm >> 3) > 128) return;
+  rescore_run<2>(p);
+}
 hipError_t launch_rescore(const RescoreArgs& a_in, hipStream_t s) {
   if (a_in.max_count == 0 || a_in.n_queries <= 0) return hipSuccess;
   RescoreArgs a = a_in;
-  // wide rows with an fp16 copy of the queries: rescore_fast_kernel beside the general kernel (rescore_fast_batch decides on the device)
+  // with an fp16 copy of the queries: the specialised kernel of the row width beside the general kernel (rescore_fast_batch decides on the device)
   static const int split_on = getenv("DHR_RESCORE_SPLIT") ? atoi(getenv("DHR_RESCORE_SPLIT")) : 1;
-  a.split = (split_on && a.q16 && a.q_inexact && (a.k_rm >> 3) > 128) ? 1 : 0;
+  a.split = (split_on && a.q16 && a.q_inexact) ? 1 : 0;
+  const bool wide = (a.k_rm >> 3) > 128;
+  dim3 grid;
   if (a.blk_off) {
     if (!a.flat_blocks) return hipSuccess;
-    const dim3 grid(std::min<uint32_t>(a.flat_blocks, FLAT_GRID_MAX));
-    if (a.split) hipLaunchKernelGGL(rescore_fast_kernel, grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(rescore_kernel, grid, dim3(256), 0, s, a);
-    return hipGetLastError();
-  }
-  const unsigned gx = (a.max_count + RESCORE_CANDS_PER_WG - 1) / RESCORE_CANDS_PER_WG;
-  if (a.split) hipLaunchKernelGGL(rescore_fast_kernel, dim3(gx, (unsigned)a.n_queries), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(rescore_kernel, dim3(gx, (unsigned)a.n_queries), dim3(256), 0, s, a);
+    grid = dim3(std::min<uint32_t>(a.flat_blocks, FLAT_GRID_MAX));
+  } else grid = dim3((a.max_count + RESCORE_CANDS_PER_WG - 1) / RESCORE_CANDS_PER_WG, (unsigned)a.n_queries);
+  if (a.split && wide) hipLaunchKernelGGL(rescore_fast_kernel, grid, dim3(256), 0, s, a);
+  if (a.split && !wide) hipLaunchKernelGGL(rescore_narrow_kernel, grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(rescore_kernel, grid, dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
