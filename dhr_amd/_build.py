@@ -14,8 +14,8 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdhr_hip.so")
 OBJDIR = os.path.join(CSRC, "build")
-SOURCES = ["kernels.hip", "gemm_w4.hip", "gemm_g8.hip", "gemm_g8p.hip", "api.hip", "sharded.hip", "pq_adc.hip", "select_global.hip", "host_io.hip"]
-HEADERS = ["dhr_internal.h", "gemm_common.h", "gemm_g8.h", os.path.join("..", "..", "include", "dhr_hip.h")]
+SOURCES = ["abi.cpp", "kernels.hip", "gemm_w4.hip", "gemm_g8.hip", "gemm_g8p.hip", "api.hip", "sharded.hip", "pq_adc.hip", "select_global.hip", "host_io.hip"]
+HEADERS = ["dhr_internal.h", "abi_guard.h", "libdhr.map", "gemm_common.h", "gemm_g8.h", os.path.join("..", "..", "include", "dhr_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -29,7 +29,7 @@ def _stale() -> bool:
 
 
 def _compile(hipcc: str, src: str, newest_header: float, force: bool, verbose: bool) -> str:
-    obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
     if not force and _mtime(obj) > max(_mtime(os.path.join(CSRC, src)), newest_header):
         return obj
     tmp = obj + ".tmp.%d" % os.getpid()
@@ -55,7 +55,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
                 objs = list(ex.map(lambda s: _compile(hipcc, s, newest_header, force, verbose), SOURCES))
             tmp = LIB + ".tmp.%d" % os.getpid()
-            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-L/opt/rocm/lib", "-lrccl"]
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "libdhr.map"), "-o", tmp] + objs + ["-L/opt/rocm/lib", "-lrccl"]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, cwd=CSRC, check=True)

@@ -10,6 +10,8 @@ import numpy as np
 from . import _build
 
 DHR_OK = 0
+ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_INTERNAL, ERR_NOMEM, ERR_PEER = -1, -2, -3, -4, -5, -6
+ABI_INDEX_DESC, ABI_QUERY_BATCH, ABI_SEARCH_STATS, ABI_FILE_INFO, ABI_HOST_SHARD = 0, 1, 2, 3, 4
 IDX_NONE, IDX_U8, IDX_I8, IDX_I16 = 0, 1, 2, 3
 VAL_F16, VAL_F32 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -18,14 +20,18 @@ OPT_DENSE_I8, OPT_GATED_I8 = 1, 2
 COMM_TRANSPORT, COMM_WORLD, COMM_RANK, COMM_DEVICE = 0, 1, 2, 3
 INFO_DENSE_I8, INFO_I8_SCALE, INFO_I8_ROW_ERR, INFO_I8_ROW_NORM, INFO_ROW_NORM_MAX, INFO_TILE_BYTES, INFO_GATED_I8 = 1, 2, 3, 4, 5, 6, 7
 
-EXPORTS = ["dhr_version", "dhr_abi_sizes", "dhr_set_option", "dhr_index_get_info", "dhr_last_error", "dhr_index_create", "dhr_index_destroy", "dhr_index_set_param",
+EXPORTS = ["dhr_version", "dhr_abi_sizes", "dhr_abi_size", "dhr_debug_fail_alloc", "dhr_set_option", "dhr_index_get_info", "dhr_last_error", "dhr_index_create", "dhr_index_destroy", "dhr_index_set_param",
            "dhr_index_device_bytes", "dhr_search", "dhr_score_rows", "dhr_merge_topk", "dhr_merge_topk_host", "dhr_merge_topk_lists", "dhr_merge_topk_lists_host",
            "dhr_get_stats", "dhr_debug_bound_scores", "dhr_debug_query_margins", "dhr_debug_gemm_time", "dhr_debug_seq_to_tile", "dhr_debug_sharded_repairs", "dhr_search_sample_rank", "dhr_search_union_rank", "dhr_search_begin",
            "dhr_search_finish", "dhr_search_mid_ranks", "dhr_search_mid", "dhr_search_pre_ranks", "dhr_search_pre", "dhr_search_begin_rest", "dhr_search_rerank", "dhr_comm_unique_id", "dhr_comm_create", "dhr_comm_wrap", "dhr_comm_create_callback", "dhr_comm_destroy", "dhr_comm_info", "dhr_comm_abort", "dhr_search_sharded", "dhr_search_sharded_local", "dhr_search_sharded_host", "dhr_pq_create", "dhr_pq_destroy", "dhr_pq_device_bytes", "dhr_pq_search", "dhr_pq_adc_scores", "dhr_pq_last_scan", "dhr_index_save", "dhr_index_file_info", "dhr_index_load", "dhr_densify", "dhr_pq_train", "dhr_pq_encode", "dhr_pq_decode", "dhr_pq_train_nbits", "dhr_pq_encode_nbits", "dhr_pq_decode_nbits", "dhr_write_trec", "dhr_format_float"]
 
 
 class DhrError(RuntimeError):
-    pass
+    """A failed C-ABI call.  `status` is the negative dhr_status (None when the failure is the binding's own)."""
+
+    def __init__(self, msg, status=None):
+        super().__init__(msg)
+        self.status = status
 
 
 class IndexDesc(C.Structure):
@@ -74,7 +80,7 @@ HS_BEGIN_REST = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
 
 
 class HostShard(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("sample_rank", HS_SAMPLE_RANK), ("union_rank", HS_UNION_RANK), ("begin", HS_BEGIN),
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("user", C.c_void_p), ("sample_rank", HS_SAMPLE_RANK), ("union_rank", HS_UNION_RANK), ("begin", HS_BEGIN),
                 ("finish", HS_FINISH), ("search", HS_SEARCH), ("mid_ranks", HS_MID_RANKS), ("mid", HS_MID),
                 ("pre_ranks", HS_PRE_RANKS), ("pre", HS_PRE), ("begin_rest", HS_BEGIN_REST)]
 
@@ -112,6 +118,12 @@ def load():
     want = [C.sizeof(IndexDesc), C.sizeof(QueryBatch), C.sizeof(SearchStats), C.sizeof(FileInfo)]
     if list(sizes) != want:
         raise DhrError(f"libdhr_hip.so struct sizes {list(sizes)} differ from the binding's {want}: stale library, rebuild it")
+    lib.dhr_abi_size.argtypes = [C.c_int32]
+    lib.dhr_abi_size.restype = C.c_int32
+    if lib.dhr_abi_size(ABI_HOST_SHARD) != C.sizeof(HostShard):
+        raise DhrError(f"libdhr_hip.so: sizeof(dhr_host_shard) = {lib.dhr_abi_size(ABI_HOST_SHARD)}, the binding's {C.sizeof(HostShard)}: stale library, rebuild it")
+    lib.dhr_debug_fail_alloc.argtypes = [C.c_int64]
+    lib.dhr_debug_fail_alloc.restype = C.c_int64
     lib.dhr_last_error.restype = C.c_char_p
     lib.dhr_index_create.argtypes = [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]
     lib.dhr_index_destroy.argtypes = [C.c_void_p]
@@ -196,7 +208,7 @@ def load():
 
 def check(rc: int, what: str):
     if rc != DHR_OK:
-        raise DhrError(f"{what} failed ({rc}): {load().dhr_last_error().decode()}")
+        raise DhrError(f"{what} failed ({rc}): {load().dhr_last_error().decode()}", status=rc)
 
 
 _NP_IDX = {np.dtype(np.uint8): IDX_U8, np.dtype(np.int8): IDX_I8, np.dtype(np.int16): IDX_I16}

@@ -23,11 +23,8 @@
 
 using namespace dhr;
 
-static thread_local std::string g_last_error;
-static int set_error(int code, const std::string& msg) {
-  g_last_error = msg;
-  return code;
-}
+// the calling thread's error record lives in abi.cpp (a fixed buffer: recording a failure does not allocate)
+static int set_error(int code, const std::string& msg) { return dhr_set_error_message(code, msg.c_str()); }
 #define HIP_TRY(expr)                                                                                          \
   do {                                                                                                         \
     hipError_t _e = (expr);                                                                                    \
@@ -37,6 +34,30 @@ static int set_error(int code, const std::string& msg) {
   } while (0)
 
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+// Scratch that must not outlive a call whichever way it ends -- an early `return set_error(...)`, or an exception on its way to the barrier
+// of the entry point (abi_guard.h)
+struct DevMem {
+  void* p = nullptr;
+  DevMem() = default;
+  DevMem(const DevMem&) = delete;
+  DevMem& operator=(const DevMem&) = delete;
+  ~DevMem() { if (p) (void)hipFree(p); }
+};
+struct Events {
+  std::vector<hipEvent_t> v;
+  Events() = default;
+  Events(const Events&) = delete;
+  Events& operator=(const Events&) = delete;
+  ~Events() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); }
+  hipError_t add(hipEvent_t* out, unsigned flags = hipEventDefault) {
+    v.reserve(v.size() + 1);                 // (grow first: an event that exists is always in the list)
+    hipEvent_t e = nullptr;
+    const hipError_t rc = hipEventCreateWithFlags(&e, flags);
+    if (rc == hipSuccess) v.push_back(e);
+    *out = e;
+    return rc;
+  }
+};
 static inline int idx_esize(int dt) { return dt == DHR_IDX_I16 ? 2 : 1; }
 
 struct Workspace {
@@ -170,15 +191,7 @@ static void free_ws(Workspace& w) {
   w = Workspace();
 }
 
-extern "C" int dhr_version(void) { return DHR_VERSION; }
-extern "C" void dhr_abi_sizes(int32_t out[4]) {
-  out[0] = (int32_t)sizeof(dhr_index_desc); out[1] = (int32_t)sizeof(dhr_query_batch);
-  out[2] = (int32_t)sizeof(dhr_search_stats); out[3] = (int32_t)sizeof(dhr_file_info);
-}
-extern "C" const char* dhr_last_error(void) { return g_last_error.c_str(); }
-extern "C" int dhr_set_error_message(int code, const char* msg) { return set_error(code, msg ? msg : ""); }
-
-extern "C" void dhr_index_destroy(dhr_index* ix) {
+extern "C" void dhr_index_destroy(dhr_index* ix) try {
   if (!ix) return;
   hipSetDevice(ix->device);
   free_ws(ix->ws);
@@ -188,7 +201,7 @@ extern "C" void dhr_index_destroy(dhr_index* ix) {
   if (ix->s_gemm) hipStreamDestroy(ix->s_gemm);
   hipFree(ix->resid8); hipFree(ix->i8_col_scale); hipFree(ix->g8_inv_cs); hipFree(ix->g8_w); hipFree(ix->g8_rsum); hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map); hipFree(ix->heavy_key);      // (heavy_val points into the heavy_key records)
   delete ix;
-}
+} DHR_CATCH_VOID
 
 static int g_opt_dense_i8 = -1;      // -1: gated indexes with ungated columns only; 0: never; 1: dense-only indexes too
 static int g_opt_gated_i8 = -1;      // int8 image of the gated half: -1 by corpus size (>= GATED_I8_MIN_ROWS rows; _NARROW where the ungated half is narrower than half the gated one), 0 never, 1 wherever the layout allows it
@@ -201,12 +214,12 @@ static int g_opt_gated_i8 = -1;      // int8 image of the gated half: -1 by corp
 // of the candidates, so it breaks even 8x earlier -- hence 1 M / 4 M.
 constexpr int64_t GATED_I8_MIN_ROWS = 1000000, GATED_I8_MIN_ROWS_NARROW = 4000000;
 constexpr int64_t DENSE_ONLY_I8_MIN_ROWS = 1000000;      // dense-only indexes: the int8 image by default from this many rows (if its margin is small enough, dhr_index_create)
-extern "C" int dhr_set_option(int32_t option, int64_t value) {
+extern "C" int dhr_set_option(int32_t option, int64_t value) try {
   if (option == DHR_OPT_DENSE_I8) { g_opt_dense_i8 = value < 0 ? -1 : (value != 0); return DHR_OK; }
   if (option == DHR_OPT_GATED_I8) { g_opt_gated_i8 = value < 0 ? -1 : (value != 0); return DHR_OK; }
   return set_error(DHR_ERR_INVALID, "unknown option");
-}
-extern "C" int dhr_index_get_info(const dhr_index* ix, int32_t what, double* out) {
+} DHR_CATCH_STATUS
+extern "C" int dhr_index_get_info(const dhr_index* ix, int32_t what, double* out) try {
   if (!ix || !out) return set_error(DHR_ERR_INVALID, "null argument");
   switch (what) {
     case DHR_INFO_DENSE_I8: *out = ix->dense_i8 ? 1.0 : 0.0; return DHR_OK;
@@ -219,9 +232,9 @@ extern "C" int dhr_index_get_info(const dhr_index* ix, int32_t what, double* out
                                                                       : (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2); return DHR_OK;
   }
   return set_error(DHR_ERR_INVALID, "unknown info id");
-}
+} DHR_CATCH_STATUS
 
-extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) {
+extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) try {
   if (!ix) return set_error(DHR_ERR_INVALID, "null index");
   switch (param) {
     case DHR_PARAM_CAND_CAP:
@@ -258,15 +271,15 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
       ix->max_growth16 = (int)value; return DHR_OK;
   }
   return set_error(DHR_ERR_INVALID, "unknown parameter");
-}
+} DHR_CATCH_STATUS
 
-extern "C" int dhr_index_device(const dhr_index* ix) { return ix ? ix->device : -1; }
-extern "C" int64_t dhr_index_device_bytes(const dhr_index* ix) { return ix ? ix->index_bytes + ix->ws.bytes + ix->ws_fb[0].bytes + ix->ws_fb[1].bytes : 0; }
-extern "C" int dhr_get_stats(const dhr_index* ix, dhr_search_stats* out) {
+extern "C" int dhr_index_device(const dhr_index* ix) try { return ix ? ix->device : -1; } DHR_CATCH_VALUE(-1)
+extern "C" int64_t dhr_index_device_bytes(const dhr_index* ix) try { return ix ? ix->index_bytes + ix->ws.bytes + ix->ws_fb[0].bytes + ix->ws_fb[1].bytes : 0; } DHR_CATCH_VALUE(0)
+extern "C" int dhr_get_stats(const dhr_index* ix, dhr_search_stats* out) try {
   if (!ix || !out) return set_error(DHR_ERR_INVALID, "null argument");
   *out = ix->stats;
   return DHR_OK;
-}
+} DHR_CATCH_STATUS
 
 // ------------------------------------------------------------------------------------------ index build
 // Pass 1 of the index build: the caller's rows (host rows staged block by block) -> row-major device copy vals_rm, norms and
@@ -340,7 +353,7 @@ static void build_bucket_map(const std::vector<float>& hist, int d_dlr, int nb, 
   }
 }
 
-extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
+extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) try {
   if (!d_user || !out) return set_error(DHR_ERR_INVALID, "null argument");
   // --emb_dim that is not a multiple of 8: the library appends zero slices (dhr_index::dlr_pad); below, `d` is the descriptor with
   // the padded width -- only the two places that READ the caller's arrays (the index copy, ingest) use the caller's widths
@@ -363,9 +376,15 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
   if (d->d_dlr + d->d_cls > 8192) return set_error(DHR_ERR_UNSUPPORTED, "more than 8192 columns");
   if (d->idx_buckets < 0 || d->idx_buckets > 16) return set_error(DHR_ERR_INVALID, "idx_buckets must be in [0,16] (0 = default)");
   if (d->mem_kind != DHR_MEM_HOST && d->mem_kind != DHR_MEM_DEVICE) return set_error(DHR_ERR_INVALID, "bad mem_kind");
+  dhr::alloc_checkpoint();
   HIP_TRY(hipSetDevice(d->device));
 
-  dhr_index* ix = new dhr_index();
+  // everything below is released by this guard unless the build reaches its end (early returns and exceptions alike)
+  struct Build {
+    dhr_index* ix = nullptr; void* stage = nullptr; uint32_t* d_flags = nullptr; uint32_t* d_hist = nullptr;
+    ~Build() { (void)hipFree(stage); (void)hipFree(d_flags); (void)hipFree(d_hist); if (ix) dhr_index_destroy(ix); }
+  } build;
+  dhr_index* ix = build.ix = new dhr_index();
   ix->device = d->device;
   ix->idx_buckets_req = d->idx_buckets;
   { hipDeviceProp_t pr; HIP_TRY(hipGetDeviceProperties(&pr, d->device)); ix->n_cu = pr.multiProcessorCount; }
@@ -415,11 +434,11 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
   ix->idx_dtype = has_idx ? d->index_dtype : DHR_IDX_NONE;
   ix->n_tiles = (d->n_rows + TILE_ROWS - 1) / TILE_ROWS;
   hipStream_t s = nullptr;
-  void* stage = nullptr;
-  uint32_t* d_flags = nullptr;
-  uint32_t* d_hist = nullptr;
+  void*& stage = build.stage;
+  uint32_t*& d_flags = build.d_flags;
+  uint32_t*& d_hist = build.d_hist;
   int rc = DHR_OK;
-  auto fail = [&](int code) { hipFree(stage); hipFree(d_flags); hipFree(d_hist); dhr_index_destroy(ix); return code; };
+  auto fail = [&](int code) { return code; };        // (the guard above releases the handle and the scratch)
 
   const size_t rm_bytes = (size_t)ix->n_rows * ix->k_rm * 2;
   if (hipMalloc((void**)&ix->vals_rm, rm_bytes) != hipSuccess)
@@ -463,18 +482,16 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
     // (query_prep_kernel) -- a few large columns (outlier dimensions of encoder outputs) then do not push
     // every other column into a handful of int8 levels
     std::vector<uint32_t> cm((size_t)ix->d_cls, 0u);
-    uint32_t* d_cm = nullptr;
-    if (hipMalloc((void**)&d_cm, cm.size() * 4) != hipSuccess || hipMalloc((void**)&ix->i8_col_scale, cm.size() * 4) != hipSuccess) {
-      hipFree(d_cm);
-      return fail(set_error(DHR_ERR_HIP, "hipMalloc failed"));
+    {
+      DevMem cmd;
+      uint32_t*& d_cm = (uint32_t*&)cmd.p;
+      if (hipMalloc((void**)&d_cm, cm.size() * 4) != hipSuccess || hipMalloc((void**)&ix->i8_col_scale, cm.size() * 4) != hipSuccess)
+        return fail(set_error(DHR_ERR_HIP, "hipMalloc failed"));
+      if (hipMemsetAsync(d_cm, 0, cm.size() * 4, s) != hipSuccess ||
+          launch_col_absmax(ix->vals_rm, ix->k_rm, ix->n_rows, ix->d_dlr, ix->d_cls, d_cm, s) != hipSuccess ||
+          hipMemcpy(cm.data(), d_cm, cm.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(set_error(DHR_ERR_HIP, "column scan failed"));
     }
-    if (hipMemsetAsync(d_cm, 0, cm.size() * 4, s) != hipSuccess ||
-        launch_col_absmax(ix->vals_rm, ix->k_rm, ix->n_rows, ix->d_dlr, ix->d_cls, d_cm, s) != hipSuccess ||
-        hipMemcpy(cm.data(), d_cm, cm.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
-      hipFree(d_cm);
-      return fail(set_error(DHR_ERR_HIP, "column scan failed"));
-    }
-    hipFree(d_cm);
     std::vector<float> cs(cm.size());
     for (size_t j = 0; j < cm.size(); ++j) {
       float m;
@@ -541,19 +558,17 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
     float gmax;
     memcpy(&gmax, &flags[3], 4);
     std::vector<uint32_t> cm((size_t)ix->d_dlr, 0u);
-    uint32_t* d_cm = nullptr;
-    if (hipMalloc((void**)&d_cm, cm.size() * 4) != hipSuccess || hipMalloc((void**)&ix->g8_inv_cs, cm.size() * 4) != hipSuccess ||
-        hipMalloc((void**)&ix->g8_w, cm.size() * 4) != hipSuccess) {
-      hipFree(d_cm);
-      return fail(set_error(DHR_ERR_HIP, "hipMalloc failed"));
+    {
+      DevMem cmd;
+      uint32_t*& d_cm = (uint32_t*&)cmd.p;
+      if (hipMalloc((void**)&d_cm, cm.size() * 4) != hipSuccess || hipMalloc((void**)&ix->g8_inv_cs, cm.size() * 4) != hipSuccess ||
+          hipMalloc((void**)&ix->g8_w, cm.size() * 4) != hipSuccess)
+        return fail(set_error(DHR_ERR_HIP, "hipMalloc failed"));
+      if (hipMemsetAsync(d_cm, 0, cm.size() * 4, s) != hipSuccess ||
+          launch_col_absmax(ix->vals_rm, ix->k_rm, ix->n_rows, 0, ix->d_dlr, d_cm, s) != hipSuccess ||
+          hipMemcpy(cm.data(), d_cm, cm.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(set_error(DHR_ERR_HIP, "column scan failed"));
     }
-    if (hipMemsetAsync(d_cm, 0, cm.size() * 4, s) != hipSuccess ||
-        launch_col_absmax(ix->vals_rm, ix->k_rm, ix->n_rows, 0, ix->d_dlr, d_cm, s) != hipSuccess ||
-        hipMemcpy(cm.data(), d_cm, cm.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
-      hipFree(d_cm);
-      return fail(set_error(DHR_ERR_HIP, "column scan failed"));
-    }
-    hipFree(d_cm);
     ix->g8_sref = (gmax > 0.f ? gmax : 1.f) * (1.00001f / 127.f);
     std::vector<float> inv(cm.size()), wj(cm.size());
     for (size_t j = 0; j < cm.size(); ++j) {
@@ -603,12 +618,10 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) {
       return fail(set_error(DHR_ERR_HIP, "heavy_build launch failed"));
   }
   if (hipStreamSynchronize(s) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "index build failed on the device"));
-  hipFree(stage);
-  hipFree(d_flags);
-  hipFree(d_hist);
+  build.ix = nullptr;          // the caller's from here on
   *out = ix;
   return DHR_OK;
-}
+} DHR_CATCH_STATUS
 
 // ------------------------------------------------------------------------------------------ index file
 // [4096-byte header][values: n_rows x k_rm fp16][slice indices: n_rows x d_dlr][caller blob], sections page-aligned.
@@ -657,7 +670,7 @@ int read_header(const char* path, FileHeader& h, int* fd_out) {
 }
 }  // namespace
 
-extern "C" int dhr_index_save(const dhr_index* ix, const char* path, const void* blob, int64_t blob_bytes) {
+extern "C" int dhr_index_save(const dhr_index* ix, const char* path, const void* blob, int64_t blob_bytes) try {
   if (!ix || !path || blob_bytes < 0 || (blob_bytes > 0 && !blob)) return set_error(DHR_ERR_INVALID, "null index / path or bad blob");
   HIP_TRY(hipSetDevice(ix->device));
   FileHeader h{};
@@ -696,9 +709,9 @@ extern "C" int dhr_index_save(const dhr_index* ix, const char* path, const void*
   hipHostFree(pin);
   if (close(fd) != 0) { unlink(path); return set_error(DHR_ERR_INVALID, "close failed"); }
   return DHR_OK;
-}
+} DHR_CATCH_STATUS
 
-extern "C" int dhr_index_file_info(const char* path, dhr_file_info* out) {
+extern "C" int dhr_index_file_info(const char* path, dhr_file_info* out) try {
   if (!out) return set_error(DHR_ERR_INVALID, "null output");
   FileHeader h;
   int rc = read_header(path, h, nullptr);
@@ -708,9 +721,9 @@ extern "C" int dhr_index_file_info(const char* path, dhr_file_info* out) {
   out->payload_bytes = (int64_t)(h.val_bytes + h.idx_bytes);
   out->blob_offset = (int64_t)h.blob_offset; out->blob_bytes = (int64_t)h.blob_bytes;
   return DHR_OK;
-}
+} DHR_CATCH_STATUS
 
-extern "C" int dhr_index_load(const char* path, int32_t device, int64_t row_offset, dhr_index** out) {
+extern "C" int dhr_index_load(const char* path, int32_t device, int64_t row_offset, dhr_index** out) try {
   if (!out) return set_error(DHR_ERR_INVALID, "null output");
   *out = nullptr;
   FileHeader h;
@@ -740,7 +753,7 @@ extern "C" int dhr_index_load(const char* path, int32_t device, int64_t row_offs
   munmap(map, (size_t)sb.st_size);
   if (rc == DHR_OK && h.pad0 > 0 && h.pad0 < 8) (*out)->dlr_pad = h.pad0;
   return rc;
-}
+} DHR_CATCH_STATUS
 
 // ------------------------------------------------------------------------------------------ workspace
 template <typename T>
@@ -966,9 +979,10 @@ static int prep_queries(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, 
 
 struct Timer {
   bool on; hipStream_t s; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; std::vector<int> kind;
+  ~Timer() { for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } }      // a call that failed before collect()
   void begin(int k) { begin_on(k, s); }
   void end() { end_on(s); }
-  void begin_on(int k, hipStream_t st) { if (!on) return; hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); ev.push_back({a, b}); kind.push_back(k); }
+  void begin_on(int k, hipStream_t st) { if (!on) return; ev.reserve(ev.size() + 1); kind.reserve(kind.size() + 1); hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); ev.push_back({a, b}); kind.push_back(k); }
   void end_on(hipStream_t st) { if (!on) return; hipEventRecord(ev.back().second, st); }
   void collect(double* ms /*[5]*/) {
     for (size_t i = 0; i < ev.size(); ++i) {
@@ -1515,13 +1529,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     // is profiled with DHR_PARAM_OVERLAP_AUX = 0 (bench.py reports both).
     const bool overlap = ix->overlap_aux < 0 ? true : ix->overlap_aux != 0;
     hipStream_t sb = overlap ? ix->s_aux : sg;
-    hipEvent_t ev_enter = nullptr;
-    if (sg != s) {
-      HIP_TRY(hipEventCreateWithFlags(&ev_enter, hipEventDisableTiming));
-      HIP_TRY(hipEventRecord(ev_enter, s));
-      HIP_TRY(hipStreamWaitEvent(sg, ev_enter, 0));
-      HIP_TRY(hipStreamWaitEvent(sb, ev_enter, 0));
-    }
+    Events evs;                 // every event of the pass (destroyed on every way out)
     // chunk count: at least main_chunks, more when the sampled run predicts that the fullest list would not fit
     // (rate = bound candidates per corpus row of the fullest query at the final sample thresholds, 1.5x headroom)
     // ... and the same for the survivor lists of the refine step, which are shallower (cap_r): a query whose bound the heavy lists
@@ -1588,10 +1596,20 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       HIP_TRY(launch_plan_overflow(w.plan_rows > 0 ? w.cnt_plan : nullptr, w.plan_rows > 0 ? (double)(big * TILE_ROWS) / (double)w.plan_rows : 0.0, (uint32_t)w.cap,
                                    (uint32_t)(w.cap_deep - w.cap), (uint32_t)w.arena, Q, w.ovf_off, w.ovf_cap, s));
     }
+    // The GEMM / aux streams enter the pass behind everything the caller's stream holds so far -- INCLUDING the plan above: with CU masks
+    // (DHR_PARAM_AUX_CUS / GEMM_EXCLUSIVE) the bound GEMM runs on s_gemm and refine on s_aux, and until round 5 they waited on an event
+    // recorded BEFORE the plan kernel, so a GEMM that spilled past `cap` could pair a new ovf_cap with an old ovf_off.
+    if (sg != s || sb != s) {
+      hipEvent_t ev_enter = nullptr;
+      HIP_TRY(evs.add(&ev_enter, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(ev_enter, s));
+      if (sg != s) HIP_TRY(hipStreamWaitEvent(sg, ev_enter, 0));
+      if (sb != s) HIP_TRY(hipStreamWaitEvent(sb, ev_enter, 0));
+    }
     std::vector<hipEvent_t> ev_gemm(M), ev_done(M);
     for (int i = 0; i < M; ++i) {
-      HIP_TRY(hipEventCreateWithFlags(&ev_gemm[i], hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming));
+      HIP_TRY(evs.add(&ev_gemm[i], hipEventDisableTiming));
+      HIP_TRY(evs.add(&ev_done[i], hipEventDisableTiming));
     }
     uint32_t* h = (uint32_t*)w.h_pinned;          // 16 bytes per set: {max, pad, sum64}; two sets live in 32 bytes
     auto enqueue_gemm = [&](int i) -> int {
@@ -1657,8 +1675,6 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       HIP_TRY(hipEventRecord(ev_done[i], sb));
     }
     HIP_TRY(hipStreamWaitEvent(s, ev_done[c_hi - 1], 0));
-    for (int i = 0; i < M; ++i) { hipEventDestroy(ev_gemm[i]); hipEventDestroy(ev_done[i]); }
-    if (ev_enter) hipEventDestroy(ev_enter);
   }
   if (stage == 3) ix->pend.mid = true;
   if (stage >= 2) return DHR_OK;                                // the caller verifies across shards
@@ -1700,13 +1716,14 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   int next_depth = depth + 1;
   if (depth == 0 && (int)n_overflow == 0) next_depth = 2;
   const int nf = (int)ids.size();
-  void* tmp = nullptr;
+  DevMem tmp_mem;
+  void*& tmp = tmp_mem.p;
   const size_t b32 = (size_t)nf * ix->k_rm * 4, bidx = (size_t)nf * std::max(ix->d_dlr, 8) * 2, bids = (size_t)nf * 4;
   HIP_TRY(hipMalloc(&tmp, b32 + bidx + bids + 64));
   float* f32 = (float*)tmp;
   int16_t* fidx = (int16_t*)((char*)tmp + b32);
   int32_t* d_ids = (int32_t*)((char*)tmp + b32 + bidx);
-  auto done = [&](int code) { hipFree(tmp); return code; };
+  auto done = [&](int code) { return code; };       // (tmp_mem releases the scratch)
   if (hipMemcpyAsync(d_ids, ids.data(), bids, hipMemcpyHostToDevice, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "H2D failed"));
   if (launch_gather_queries(w.q32, w.q_idx, ix->k_rm, ix->d_dlr, d_ids, nf, f32, fidx, s) != hipSuccess)
     return done(set_error(DHR_ERR_HIP, "gather_queries launch failed"));
@@ -1723,7 +1740,8 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
 }
 
 extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_scores, int64_t* out_rows,
-                          int32_t out_mem_kind, void* stream) {
+                          int32_t out_mem_kind, void* stream) try {
+  dhr::alloc_checkpoint();
   int rc = check_queries(ix, qb);
   if (rc) return rc;
   if (k <= 0) return set_error(DHR_ERR_INVALID, "k must be > 0");
@@ -1733,8 +1751,9 @@ extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, f
   hipStream_t s = (hipStream_t)stream;
   const int Q = qb->n_queries;
   ix->pend.valid = false;          // a plain search overwrites the workspace of any staged search left open on this handle
+  Events evs;
   hipEvent_t ev0, ev1;
-  HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
+  HIP_TRY(evs.add(&ev0)); HIP_TRY(evs.add(&ev1));
   HIP_TRY(hipEventRecord(ev0, s));
   Timer tm{ix->profile != 0, s, {}, {}};
   dhr_search_stats st{};
@@ -1760,7 +1779,6 @@ extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, f
   HIP_TRY(hipStreamSynchronize(s));
   float total = 0.f;
   hipEventElapsedTime(&total, ev0, ev1);
-  hipEventDestroy(ev0); hipEventDestroy(ev1);
   st.total_ms = total;
   double ms[5] = {0, 0, 0, 0, 0};
   tm.collect(ms);
@@ -1768,13 +1786,14 @@ extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, f
   st.prep_ms = ms[T_PREP];
   ix->stats = st;
   return DHR_OK;
-}
+} DHR_CATCH_STATUS
 
 // Two-stage approximate GIP on the device (gip_retrieval.py:128-156): stage 1 is an ordinary search of the
 // restricted batch for k1 rows, stage 2 the exact gated inner product of the full batch on exactly those rows
 // and the top-k of that; the k1 rows never leave the device.
 extern "C" int dhr_search_rerank(dhr_index* ix, const dhr_query_batch* qb1, const dhr_query_batch* qb2, int32_t k1, int32_t k,
-                                 float* out_scores, int64_t* out_rows, int32_t out_mem_kind, void* stream) {
+                                 float* out_scores, int64_t* out_rows, int32_t out_mem_kind, void* stream) try {
+  dhr::alloc_checkpoint();
   int rc = check_queries(ix, qb1);
   if (rc) return rc;
   if ((rc = check_queries(ix, qb2)) != DHR_OK) return rc;
@@ -1785,8 +1804,9 @@ extern "C" int dhr_search_rerank(dhr_index* ix, const dhr_query_batch* qb1, cons
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = (hipStream_t)stream;
   const int Q = qb1->n_queries;
+  Events evs;
   hipEvent_t ev0, ev1;
-  HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
+  HIP_TRY(evs.add(&ev0)); HIP_TRY(evs.add(&ev1));
   HIP_TRY(hipEventRecord(ev0, s));
   Timer tm{ix->profile != 0, s, {}, {}};
   dhr_search_stats st{};
@@ -1795,9 +1815,10 @@ extern "C" int dhr_search_rerank(dhr_index* ix, const dhr_query_batch* qb1, cons
   // ---- stage 1
   if ((rc = search_core(ix, w, qb1, k1, 0, tm, st, s)) != DHR_OK) return rc;
   // ---- stage 2: exact scores of the stage-1 rows under the full batch, top-k of those
-  uint32_t* d_rows32 = nullptr;
+  DevMem rows_mem;
+  uint32_t*& d_rows32 = (uint32_t*&)rows_mem.p;
   HIP_TRY(hipMalloc((void**)&d_rows32, (size_t)Q * k1 * 4));
-  auto done = [&](int code) { hipFree(d_rows32); return code; };
+  auto done = [&](int code) { return code; };       // (rows_mem releases the scratch)
   if (launch_keys_to_rows(w.topk_keys, w.kp, Q, k1, d_rows32, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "keys_to_rows launch failed"));
   if (w.keys_ld < k1) return done(set_error(DHR_ERR_INTERNAL, "key buffer smaller than k1"));
   const bool gate2 = ix->d_dlr > 0 && qb2->index != nullptr && qb2->index_dtype != DHR_IDX_NONE;
@@ -1839,7 +1860,6 @@ extern "C" int dhr_search_rerank(dhr_index* ix, const dhr_query_batch* qb1, cons
   if (hipEventRecord(ev1, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "two-stage search failed on the device"));
   float total = 0.f;
   hipEventElapsedTime(&total, ev0, ev1);
-  hipEventDestroy(ev0); hipEventDestroy(ev1);
   st.total_ms = total;
   double ms[5] = {0, 0, 0, 0, 0};
   tm.collect(ms);
@@ -1847,28 +1867,28 @@ extern "C" int dhr_search_rerank(dhr_index* ix, const dhr_query_batch* qb1, cons
   st.prep_ms = ms[T_PREP];
   ix->stats = st;
   return done(DHR_OK);
-}
+} DHR_CATCH_STATUS
 
 // ---- staged search for the row-sharded path (dhr_amd/dist.py): the shards agree on ONE threshold per
 // query after their sampled runs, so each shard collects only its share of the global top-k.
-extern "C" int32_t dhr_search_sample_rank(const dhr_index* ix, int32_t k) {
+extern "C" int32_t dhr_search_sample_rank(const dhr_index* ix, int32_t k) try {
   if (!ix || k <= 0) return 0;
   int S = 0, r = k;
   plan_sampling(ix, k, S, r);
   return S >= 2 ? local_sample_rank(ix, r) : 0;
-}
-extern "C" int32_t dhr_search_union_rank(const dhr_index* ix, int32_t k) {
+} DHR_CATCH_VALUE(0)
+extern "C" int32_t dhr_search_union_rank(const dhr_index* ix, int32_t k) try {
   if (!ix || k <= 0) return 0;
   int S = 0, r = k;
   plan_sampling(ix, k, S, r);
   return S >= 2 ? r : 0;
-}
+} DHR_CATCH_VALUE(0)
 
 // Ranks of the second agreement (dhr_search_mid): after the head, the sample and the first slice of the main pass a shard has seen the
 // fraction f of its rows, scattered; the union of what the shards have seen holds k f +- sqrt(k f (1 - f)) of the final top-k, so its
 // (k f + 6 sigma + 4)-th best score lies below the final k-th best (the counts verify it; a failure is repaired like any other).  A shard
 // reports its share of that rank (local_sample_rank's rule).
-extern "C" int32_t dhr_search_mid_ranks(const dhr_index* ix, int32_t k, int32_t* out_local, int32_t* out_union) {
+extern "C" int32_t dhr_search_mid_ranks(const dhr_index* ix, int32_t k, int32_t* out_local, int32_t* out_union) try {
   if (out_local) *out_local = 0;
   if (out_union) *out_union = 0;
   if (!ix || k <= 0) return 0;
@@ -1890,7 +1910,7 @@ extern "C" int32_t dhr_search_mid_ranks(const dhr_index* ix, int32_t k, int32_t*
   if (out_local) *out_local = rl;
   if (out_union) *out_union = ru;
   return rl;
-}
+} DHR_CATCH_VALUE(0)
 // The first slice of the main pass with the thresholds of the first agreement; leaves the shard's r_local best scores seen so far in
 // out_scores_dev [Q, r_local] (r_local: dhr_search_mid_ranks, or what the shards agreed on).  dhr_search_finish then takes the thresholds of the
 // second agreement.
@@ -1918,14 +1938,14 @@ static int search_mid_impl(dhr_index* ix, const float* tau_hat_dev, int32_t r_lo
   ix->stats = st;
   return DHR_OK;
 }
-extern "C" int dhr_search_mid(dhr_index* ix, const float* tau_hat_dev, int32_t r_local, float* out_scores_dev, void* stream) {
+extern "C" int dhr_search_mid(dhr_index* ix, const float* tau_hat_dev, int32_t r_local, float* out_scores_dev, void* stream) try {
   int rc = search_mid_impl(ix, tau_hat_dev, r_local, out_scores_dev, stream);
   if (rc == DHR_OK && ix) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return rc;
-}
-extern "C" int dhr_internal_search_mid_async(dhr_index* ix, const float* tau_hat_dev, int32_t r_local, float* out_scores_dev, void* stream) {
+} DHR_CATCH_STATUS
+extern "C" int dhr_internal_search_mid_async(dhr_index* ix, const float* tau_hat_dev, int32_t r_local, float* out_scores_dev, void* stream) try {
   return search_mid_impl(ix, tau_hat_dev, r_local, out_scores_dev, stream);
-}
+} DHR_CATCH_STATUS
 
 // ---- first agreement in TWO rounds (round 5).  The shards of a sharded search each ran their whole sampled run from nothing, chasing their
 // share of the union's rank on their own: eight runs together rescored 3.2 k rows per query where the unsharded search's one run rescores
@@ -1934,7 +1954,7 @@ extern "C" int dhr_internal_search_mid_async(dhr_index* ix, const float* tau_hat
 // r-th best (adaptive_rank's argument), and dhr_search_begin_rest streams the rest of the sample filtering at that COMMON threshold.  Whatever
 // the threshold is worth, the lists a shard reports afterwards are complete above it, so the union threshold computed from them can only
 // come out lower than the true one -- still valid; the count check at the end of the step verifies everything as before.
-extern "C" int32_t dhr_search_pre_ranks(const dhr_index* ix, int32_t k, int32_t* out_local, int32_t* out_union) {
+extern "C" int32_t dhr_search_pre_ranks(const dhr_index* ix, int32_t k, int32_t* out_local, int32_t* out_union) try {
   if (out_local) *out_local = 0;
   if (out_union) *out_union = 0;
   if (!ix || k <= 0) return 0;
@@ -1959,8 +1979,9 @@ extern "C" int32_t dhr_search_pre_ranks(const dhr_index* ix, int32_t k, int32_t*
   if (out_local) *out_local = rl;
   if (out_union) *out_union = ru;
   return rl;
-}
+} DHR_CATCH_VALUE(0)
 static int search_pre_impl(dhr_index* ix, const dhr_query_batch* qb, int32_t k, int32_t r_local, float* out_scores_dev, void* stream, bool sync) {
+  dhr::alloc_checkpoint();
   int rc = check_queries(ix, qb);
   if (rc) return rc;
   if (k <= 0 || k > (1 << 20)) return set_error(DHR_ERR_INVALID, "k must be in [1, 1048576]");
@@ -1985,12 +2006,12 @@ static int search_pre_impl(dhr_index* ix, const dhr_query_batch* qb, int32_t k, 
   ix->stats = st;
   return DHR_OK;
 }
-extern "C" int dhr_search_pre(dhr_index* ix, const dhr_query_batch* qb, int32_t k, int32_t r_local, float* out_scores_dev, void* stream) {
+extern "C" int dhr_search_pre(dhr_index* ix, const dhr_query_batch* qb, int32_t k, int32_t r_local, float* out_scores_dev, void* stream) try {
   return search_pre_impl(ix, qb, k, r_local, out_scores_dev, stream, true);
-}
-extern "C" int dhr_internal_search_pre_async(dhr_index* ix, const dhr_query_batch* qb, int32_t k, int32_t r_local, float* out_scores_dev, void* stream) {
+} DHR_CATCH_STATUS
+extern "C" int dhr_internal_search_pre_async(dhr_index* ix, const dhr_query_batch* qb, int32_t k, int32_t r_local, float* out_scores_dev, void* stream) try {
   return search_pre_impl(ix, qb, k, r_local, out_scores_dev, stream, false);
-}
+} DHR_CATCH_STATUS
 // the rest of the sampled run behind dhr_search_pre; leaves the handle where dhr_search_begin leaves it (out_sample_scores_dev: [Q, dhr_search_sample_rank])
 static int search_begin_rest_impl(dhr_index* ix, const float* tau_dev, float* out_sample_scores_dev, void* stream, bool sync) {
   if (!ix || !ix->pend.valid || !ix->pend.pre) return set_error(DHR_ERR_INVALID, "dhr_search_begin_rest without a matching dhr_search_pre");
@@ -2019,16 +2040,17 @@ static int search_begin_rest_impl(dhr_index* ix, const float* tau_dev, float* ou
   ix->stats = st;
   return DHR_OK;
 }
-extern "C" int dhr_search_begin_rest(dhr_index* ix, const float* tau_dev, float* out_sample_scores_dev, void* stream) {
+extern "C" int dhr_search_begin_rest(dhr_index* ix, const float* tau_dev, float* out_sample_scores_dev, void* stream) try {
   return search_begin_rest_impl(ix, tau_dev, out_sample_scores_dev, stream, true);
-}
-extern "C" int dhr_internal_search_begin_rest_async(dhr_index* ix, const float* tau_dev, float* out_sample_scores_dev, void* stream) {
+} DHR_CATCH_STATUS
+extern "C" int dhr_internal_search_begin_rest_async(dhr_index* ix, const float* tau_dev, float* out_sample_scores_dev, void* stream) try {
   return search_begin_rest_impl(ix, tau_dev, out_sample_scores_dev, stream, false);
-}
+} DHR_CATCH_STATUS
 
 // sync = false (dhr_search_sharded*): only enqueues when the controller runs without read-backs -- the shards of a one-process search then
 // work concurrently until the collective layer's own synchronisation; statistics and timers are then not collected
 static int search_begin_impl(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_sample_scores_dev, void* stream, bool sync) {
+  dhr::alloc_checkpoint();
   int rc = check_queries(ix, qb);
   if (rc) return rc;
   if (k <= 0 || k > (1 << 20)) return set_error(DHR_ERR_INVALID, "k must be in [1, 1048576]");
@@ -2060,15 +2082,15 @@ static int search_begin_impl(dhr_index* ix, const dhr_query_batch* qb, int32_t k
   ix->stats = st;
   return DHR_OK;
 }
-extern "C" void dhr_internal_search_abort(dhr_index* ix) {
+extern "C" void dhr_internal_search_abort(dhr_index* ix) try {
   if (ix) ix->pend.valid = false;
-}
-extern "C" int dhr_search_begin(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_sample_scores_dev, void* stream) {
+} DHR_CATCH_VOID
+extern "C" int dhr_search_begin(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_sample_scores_dev, void* stream) try {
   return search_begin_impl(ix, qb, k, out_sample_scores_dev, stream, true);
-}
-extern "C" int dhr_internal_search_begin_async(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_sample_scores_dev, void* stream) {
+} DHR_CATCH_STATUS
+extern "C" int dhr_internal_search_begin_async(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_sample_scores_dev, void* stream) try {
   return search_begin_impl(ix, qb, k, out_sample_scores_dev, stream, false);
-}
+} DHR_CATCH_STATUS
 
 static int search_finish_impl(dhr_index* ix, const float* tau_hat_dev, float* out_scores, int64_t* out_rows,
                               int32_t* out_count_dev, int32_t out_mem_kind, void* stream, bool sync) {
@@ -2113,16 +2135,17 @@ static int search_finish_impl(dhr_index* ix, const float* tau_hat_dev, float* ou
   return DHR_OK;
 }
 extern "C" int dhr_search_finish(dhr_index* ix, const float* tau_hat_dev, float* out_scores, int64_t* out_rows,
-                                 int32_t* out_count_dev, int32_t out_mem_kind, void* stream) {
+                                 int32_t* out_count_dev, int32_t out_mem_kind, void* stream) try {
   return search_finish_impl(ix, tau_hat_dev, out_scores, out_rows, out_count_dev, out_mem_kind, stream, true);
-}
+} DHR_CATCH_STATUS
 extern "C" int dhr_internal_search_finish_async(dhr_index* ix, const float* tau_hat_dev, float* out_scores, int64_t* out_rows,
-                                                int32_t* out_count_dev, int32_t out_mem_kind, void* stream) {
+                                                int32_t* out_count_dev, int32_t out_mem_kind, void* stream) try {
   return search_finish_impl(ix, tau_hat_dev, out_scores, out_rows, out_count_dev, out_mem_kind, stream, false);
-}
+} DHR_CATCH_STATUS
 
 extern "C" int dhr_score_rows(dhr_index* ix, const dhr_query_batch* qb, int32_t m, const int64_t* rows, float* out_scores,
-                              int32_t mem_kind, void* stream) {
+                              int32_t mem_kind, void* stream) try {
+  dhr::alloc_checkpoint();
   int rc = check_queries(ix, qb);
   if (rc) return rc;
   if (m <= 0 || !rows || !out_scores) return set_error(DHR_ERR_INVALID, "bad m / null pointer");
@@ -2136,13 +2159,14 @@ extern "C" int dhr_score_rows(dhr_index* ix, const dhr_query_batch* qb, int32_t 
   if ((rc = ensure_ws(ix, w, Q, 1, 0, 1, true, true)) != DHR_OK) return rc;
   if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
   const size_t n = (size_t)Q * m;
-  void* tmp = nullptr;                     // [rows64 (host input only)] [rows32] [scores]
+  DevMem tmp_mem;
+  void*& tmp = tmp_mem.p;                  // [rows64 (host input only)] [rows32] [scores]
   HIP_TRY(hipMalloc(&tmp, n * 16));
   int64_t* d_rows64 = (int64_t*)tmp;
   uint32_t* d_rows32 = (uint32_t*)((char*)tmp + n * 8);
   float* d_sc = (float*)((char*)tmp + n * 12);
   const int64_t* src_rows = rows;
-  auto done = [&](int code) { hipFree(tmp); return code; };
+  auto done = [&](int code) { return code; };       // (tmp_mem releases the scratch)
   if (mem_kind == DHR_MEM_HOST) {
     if (hipMemcpyAsync(d_rows64, rows, n * 8, hipMemcpyHostToDevice, s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "H2D failed"));
     src_rows = d_rows64;
@@ -2157,11 +2181,11 @@ extern "C" int dhr_score_rows(dhr_index* ix, const dhr_query_batch* qb, int32_t 
     return done(set_error(DHR_ERR_HIP, "D2H failed"));
   if (hipStreamSynchronize(s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "score_rows failed on the device"));
   return done(DHR_OK);
-}
+} DHR_CATCH_STATUS
 
 extern "C" int dhr_densify(int32_t device, int32_t mem_kind, const void* lexical, int32_t value_dtype, int64_t ld, int64_t batch, int32_t vocab,
                            int32_t remove_dims, int32_t dims, void* out_value, int32_t out_value_dtype, int64_t ld_value, void* out_index,
-                           int32_t index_dtype, int64_t ld_index, void* stream) {
+                           int32_t index_dtype, int64_t ld_index, void* stream) try {
   if (!lexical || !out_value || !out_index) return set_error(DHR_ERR_INVALID, "null pointer");
   if (batch < 0 || vocab <= 0 || dims <= 0 || remove_dims < 0 || remove_dims >= vocab || ld < vocab || ld_value < dims || ld_index < dims)
     return set_error(DHR_ERR_INVALID, "bad sizes / strides");
@@ -2185,8 +2209,9 @@ extern "C" int dhr_densify(int32_t device, int32_t mem_kind, const void* lexical
   }
   // host arrays: stage blocks of rows through the device
   const int64_t block = std::max<int64_t>(1, std::min<int64_t>(batch, ((int64_t)256 << 20) / ((int64_t)vocab * ies)));
-  void *d_in = nullptr, *d_val = nullptr, *d_idx = nullptr;
-  auto done = [&](int code) { hipFree(d_in); hipFree(d_val); hipFree(d_idx); return code; };
+  DevMem m_in, m_val, m_idx;
+  void *&d_in = m_in.p, *&d_val = m_val.p, *&d_idx = m_idx.p;
+  auto done = [&](int code) { return code; };       // (the three DevMem release the staging buffers)
   if (hipMalloc(&d_in, (size_t)block * vocab * ies) != hipSuccess || hipMalloc(&d_val, (size_t)block * dims * oes) != hipSuccess ||
       hipMalloc(&d_idx, (size_t)block * dims * xes) != hipSuccess)
     return done(set_error(DHR_ERR_HIP, "hipMalloc failed"));
@@ -2206,7 +2231,7 @@ extern "C" int dhr_densify(int32_t device, int32_t mem_kind, const void* lexical
     if (hipStreamSynchronize(s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "densify failed on the device"));
   }
   return done(DHR_OK);
-}
+} DHR_CATCH_STATUS
 
 // ------------------------------------------------------------------------------------------ product quantiser
 namespace {
@@ -2236,11 +2261,11 @@ struct Staged {
 }  // namespace
 
 extern "C" int dhr_pq_train(int32_t device, int32_t mem_kind, const void* values, int64_t ld, int64_t n, int32_t d, int32_t M, int32_t iters,
-                            int64_t max_points, float* codebooks, double* out_error, void* stream) {
+                            int64_t max_points, float* codebooks, double* out_error, void* stream) try {
   return dhr_pq_train_nbits(device, mem_kind, values, ld, n, d, M, 8, iters, max_points, codebooks, out_error, stream);
-}
+} DHR_CATCH_STATUS
 extern "C" int dhr_pq_train_nbits(int32_t device, int32_t mem_kind, const void* values, int64_t ld, int64_t n, int32_t d, int32_t M, int32_t nbits,
-                                  int32_t iters, int64_t max_points, float* codebooks, double* out_error, void* stream) {
+                                  int32_t iters, int64_t max_points, float* codebooks, double* out_error, void* stream) try {
   int rc = pq_check(values, codebooks, n, d, M, ld);
   if (rc) return rc;
   if (nbits < 1 || nbits > 8) return set_error(DHR_ERR_UNSUPPORTED, "nbits must be in [1, 8] (one code byte per sub-quantiser on the device; faiss' bit-packed rows are a file format matter)");
@@ -2266,8 +2291,9 @@ extern "C" int dhr_pq_train_nbits(int32_t device, int32_t mem_kind, const void* 
   if ((rc = cb.in(nullptr, cb_bytes, mem_kind == DHR_MEM_HOST ? DHR_MEM_HOST : DHR_MEM_DEVICE, s)) != DHR_OK) return rc;
   if (mem_kind == DHR_MEM_DEVICE) cb.dev = codebooks;
   float* d_cb = (float*)cb.dev;
-  float* sums = nullptr; uint32_t* counts = nullptr; float* err = nullptr;
-  auto done = [&](int code) { hipFree(sums); hipFree(counts); hipFree(err); return code; };
+  DevMem m_sums, m_counts, m_err;
+  float*& sums = (float*&)m_sums.p; uint32_t*& counts = (uint32_t*&)m_counts.p; float*& err = (float*&)m_err.p;
+  auto done = [&](int code) { return code; };       // (the three DevMem release the scratch)
   if (hipMalloc((void**)&sums, cb_bytes) != hipSuccess || hipMalloc((void**)&counts, (size_t)M * ksub * 4) != hipSuccess ||
       hipMalloc((void**)&err, (size_t)M * 4) != hipSuccess)
     return done(set_error(DHR_ERR_HIP, "hipMalloc failed"));
@@ -2292,14 +2318,14 @@ extern "C" int dhr_pq_train_nbits(int32_t device, int32_t mem_kind, const void* 
   if ((rc = cb.out(codebooks, cb_bytes, s)) != DHR_OK) return done(rc);
   if (hipStreamSynchronize(s) != hipSuccess) return done(set_error(DHR_ERR_HIP, "PQ training failed on the device"));
   return done(DHR_OK);
-}
+} DHR_CATCH_STATUS
 
 extern "C" int dhr_pq_encode(int32_t device, int32_t mem_kind, const void* values, int64_t ld, int64_t n, int32_t d, int32_t M,
-                             const float* codebooks, uint8_t* codes, void* stream) {
+                             const float* codebooks, uint8_t* codes, void* stream) try {
   return dhr_pq_encode_nbits(device, mem_kind, values, ld, n, d, M, 8, codebooks, codes, stream);
-}
+} DHR_CATCH_STATUS
 extern "C" int dhr_pq_encode_nbits(int32_t device, int32_t mem_kind, const void* values, int64_t ld, int64_t n, int32_t d, int32_t M, int32_t nbits,
-                                   const float* codebooks, uint8_t* codes, void* stream) {
+                                   const float* codebooks, uint8_t* codes, void* stream) try {
   int rc = pq_check(values, codebooks, n, d, M, ld);
   if (rc) return rc;
   if (nbits < 1 || nbits > 8) return set_error(DHR_ERR_UNSUPPORTED, "nbits must be in [1, 8]");
@@ -2317,30 +2343,28 @@ extern "C" int dhr_pq_encode_nbits(int32_t device, int32_t mem_kind, const void*
     HIP_TRY(launch_pq_assign((const __half*)values, ld, n, 1, dsub, M, (const float*)cb.dev, (uint8_t*)cd.dev, M, nullptr, nullptr, nullptr, ksub, s));
   } else {
     const int64_t block = 1 << 18;                          // rows per staged block
-    void* stage = nullptr;
+    DevMem stage_mem;
+    void*& stage = stage_mem.p;
     if (hipMalloc(&stage, (size_t)std::min<int64_t>(block, n) * d * 2) != hipSuccess) return set_error(DHR_ERR_HIP, "hipMalloc failed");
     for (int64_t lo = 0; lo < n; lo += block) {
       const int64_t rows = std::min(block, n - lo);
       if (hipMemcpy2DAsync(stage, (size_t)d * 2, (const char*)values + lo * ld * 2, (size_t)ld * 2, (size_t)d * 2, (size_t)rows, hipMemcpyHostToDevice, s) != hipSuccess ||
           launch_pq_assign((const __half*)stage, d, rows, 1, dsub, M, (const float*)cb.dev, (uint8_t*)cd.dev + lo * M, M, nullptr, nullptr, nullptr, ksub, s) != hipSuccess ||
-          hipStreamSynchronize(s) != hipSuccess) {
-        hipFree(stage);
+          hipStreamSynchronize(s) != hipSuccess)
         return set_error(DHR_ERR_HIP, "PQ encoding failed on the device");
-      }
     }
-    hipFree(stage);
   }
   if ((rc = cd.out(codes, (size_t)n * M, s)) != DHR_OK) return rc;
   HIP_TRY(hipStreamSynchronize(s));
   return DHR_OK;
-}
+} DHR_CATCH_STATUS
 
 extern "C" int dhr_pq_decode(int32_t device, int32_t mem_kind, const uint8_t* codes, int64_t n, int32_t d, int32_t M, const float* codebooks,
-                             void* out_values, int64_t ld_out, void* stream) {
+                             void* out_values, int64_t ld_out, void* stream) try {
   return dhr_pq_decode_nbits(device, mem_kind, codes, n, d, M, 8, codebooks, out_values, ld_out, stream);
-}
+} DHR_CATCH_STATUS
 extern "C" int dhr_pq_decode_nbits(int32_t device, int32_t mem_kind, const uint8_t* codes, int64_t n, int32_t d, int32_t M, int32_t nbits,
-                                   const float* codebooks, void* out_values, int64_t ld_out, void* stream) {
+                                   const float* codebooks, void* out_values, int64_t ld_out, void* stream) try {
   int rc = pq_check(codes, codebooks, n, d, M, ld_out);
   if (rc) return rc;
   if (nbits < 1 || nbits > 8) return set_error(DHR_ERR_UNSUPPORTED, "nbits must be in [1, 8]");
@@ -2365,10 +2389,10 @@ extern "C" int dhr_pq_decode_nbits(int32_t device, int32_t mem_kind, const uint8
     HIP_TRY(hipMemcpy2DAsync(out_values, (size_t)ld_out * 2, ov.dev, (size_t)d * 2, (size_t)d * 2, (size_t)n, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return DHR_OK;
-}
+} DHR_CATCH_STATUS
 
 extern "C" int dhr_debug_bound_scores(dhr_index* ix, const dhr_query_batch* qb, int64_t row_lo, int64_t row_hi,
-                                      float* out_dev, void* stream) {
+                                      float* out_dev, void* stream) try {
   int rc = check_queries(ix, qb);
   if (rc) return rc;
   if (row_lo < 0 || row_hi > ix->n_rows || row_lo >= row_hi || !out_dev) return set_error(DHR_ERR_INVALID, "bad row range");
@@ -2385,9 +2409,9 @@ extern "C" int dhr_debug_bound_scores(dhr_index* ix, const dhr_query_batch* qb, 
   HIP_TRY(launch_gemm_filter(g, s));
   HIP_TRY(hipStreamSynchronize(s));
   return DHR_OK;
-}
+} DHR_CATCH_STATUS
 
-extern "C" int dhr_debug_query_margins(dhr_index* ix, const dhr_query_batch* qb, float* out_host, void* stream) {
+extern "C" int dhr_debug_query_margins(dhr_index* ix, const dhr_query_batch* qb, float* out_host, void* stream) try {
   int rc = check_queries(ix, qb);
   if (rc) return rc;
   if (!out_host) return set_error(DHR_ERR_INVALID, "null output pointer");
@@ -2399,16 +2423,16 @@ extern "C" int dhr_debug_query_margins(dhr_index* ix, const dhr_query_batch* qb,
   HIP_TRY(hipMemcpyAsync(out_host, w.margin, (size_t)qb->n_queries * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return DHR_OK;
-}
+} DHR_CATCH_STATUS
 
 // Kernel-tuning hook: the bound GEMM alone over the whole shard with the filter closed (thr = +inf),
 // `iters` launches, average milliseconds per launch (hipEvents on the stream).
-extern "C" void dhr_debug_seq_to_tile(int64_t seq, int32_t map_mode, int32_t period, int64_t head, int64_t perm_mul, int64_t perm_n, int64_t out[2]) {
+extern "C" void dhr_debug_seq_to_tile(int64_t seq, int32_t map_mode, int32_t period, int64_t head, int64_t perm_mul, int64_t perm_n, int64_t out[2]) try {
   out[0] = seq_to_tile_fast(seq, map_mode, period, head, perm_mul, perm_n, 1.0 / (double)(perm_n > 0 ? perm_n : 1), 1.0 / (double)(period > 1 ? period - 1 : 1));
   out[1] = seq_to_tile(seq, map_mode, period, head, perm_mul, perm_n);
-}
+} DHR_CATCH_VOID
 extern "C" int dhr_debug_gemm_time(dhr_index* ix, const dhr_query_batch* qb, int32_t iters, double* ms_out, double* flops_out,
-                                   void* stream) {
+                                   void* stream) try {
   int rc = check_queries(ix, qb);
   if (rc) return rc;
   if (iters <= 0 || !ms_out) return set_error(DHR_ERR_INVALID, "bad iters / null pointer");
@@ -2452,8 +2476,9 @@ extern "C" int dhr_debug_gemm_time(dhr_index* ix, const dhr_query_batch* qb, int
   g.period = 1; g.head = 0; g.n_tiles = ix->n_tiles; g.n_qtiles = w.q_pad / TILE_ROWS; g.n_rows = ix->n_rows;
   g.thr = w.thr; g.cand = w.cand; g.cnt = w.cnt; g.cap = (uint32_t)w.cap; g.n_queries = qb->n_queries;
   HIP_TRY(launch_gemm_filter(g, s));                      // warm-up
+  Events evs;
   hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(evs.add(&e0)); HIP_TRY(evs.add(&e1));
   HIP_TRY(hipEventRecord(e0, s));
   for (int i = 0; i < iters; ++i) {
     if (opened) HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));       // the lists fill as in a search (a full list takes the cold surplus path)
@@ -2463,15 +2488,14 @@ extern "C" int dhr_debug_gemm_time(dhr_index* ix, const dhr_query_batch* qb, int
   HIP_TRY(hipStreamSynchronize(s));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  hipEventDestroy(e0); hipEventDestroy(e1);
   *ms_out = ms / iters;
   if (flops_out) *flops_out = 2.0 * (double)w.q_pad * (double)ix->n_tiles * TILE_ROWS * (double)ix->kt;
   return DHR_OK;
-}
+} DHR_CATCH_STATUS
 
 // ------------------------------------------------------------------------------------------ shard reduce
 extern "C" int dhr_merge_topk(int32_t device, int32_t n_queries, int32_t n_in, const float* in_scores,
-                              const int64_t* in_rows, int32_t k_out, float* out_scores, int64_t* out_rows, void* stream) {
+                              const int64_t* in_rows, int32_t k_out, float* out_scores, int64_t* out_rows, void* stream) try {
   if (n_queries <= 0 || n_in <= 0 || k_out <= 0 || !in_scores || !in_rows || !out_scores || !out_rows)
     return set_error(DHR_ERR_INVALID, "bad argument");
   HIP_TRY(hipSetDevice(device));
@@ -2482,10 +2506,10 @@ extern "C" int dhr_merge_topk(int32_t device, int32_t n_queries, int32_t n_in, c
   }
   HIP_TRY(launch_merge_topk(n_queries, n_in, in_scores, in_rows, k_out, out_scores, out_rows, (hipStream_t)stream));
   return DHR_OK;
-}
+} DHR_CATCH_STATUS
 
 extern "C" int dhr_merge_topk_lists(int32_t device, int32_t n_queries, int32_t n_lists, int32_t list_len, const float* in_scores,
-                                    const int64_t* in_rows, int32_t k_out, float* out_scores, int64_t* out_rows, void* stream) {
+                                    const int64_t* in_rows, int32_t k_out, float* out_scores, int64_t* out_rows, void* stream) try {
   if (n_queries <= 0 || n_lists <= 0 || list_len <= 0 || k_out <= 0 || !in_scores || !out_scores || (in_rows && !out_rows))
     return set_error(DHR_ERR_INVALID, "bad argument");
   if (((int64_t)n_lists * list_len + k_out) * (in_rows ? 12 : 4) > 160 * 1024 || n_lists > 64)
@@ -2494,10 +2518,10 @@ extern "C" int dhr_merge_topk_lists(int32_t device, int32_t n_queries, int32_t n
   HIP_TRY(launch_merge_lists(n_queries, n_lists, list_len, in_scores, in_rows, k_out, out_scores, in_rows ? out_rows : nullptr,
                              (hipStream_t)stream));
   return DHR_OK;
-}
+} DHR_CATCH_STATUS
 
 extern "C" int dhr_merge_topk_lists_host(int32_t n_queries, int32_t n_lists, int32_t list_len, const float* in_scores,
-                                         const int64_t* in_rows, int32_t k_out, float* out_scores, int64_t* out_rows) {
+                                         const int64_t* in_rows, int32_t k_out, float* out_scores, int64_t* out_rows) try {
   if (n_queries <= 0 || n_lists <= 0 || list_len <= 0 || k_out <= 0 || !in_scores || !out_scores || (in_rows && !out_rows))
     return set_error(DHR_ERR_INVALID, "bad argument");
   std::vector<int64_t> order;
@@ -2521,10 +2545,10 @@ extern "C" int dhr_merge_topk_lists_host(int32_t n_queries, int32_t n_lists, int
     }
   }
   return DHR_OK;
-}
+} DHR_CATCH_STATUS
 
 extern "C" int dhr_merge_topk_host(int32_t n_queries, int32_t n_in, const float* in_scores, const int64_t* in_rows,
-                                   int32_t k_out, float* out_scores, int64_t* out_rows) {
+                                   int32_t k_out, float* out_scores, int64_t* out_rows) try {
   if (n_queries <= 0 || n_in <= 0 || k_out <= 0 || !in_scores || !in_rows || !out_scores || !out_rows)
     return set_error(DHR_ERR_INVALID, "bad argument");
   std::vector<int> order;
@@ -2546,4 +2570,4 @@ extern "C" int dhr_merge_topk_host(int32_t n_queries, int32_t n_in, const float*
     }
   }
   return DHR_OK;
-}
+} DHR_CATCH_STATUS

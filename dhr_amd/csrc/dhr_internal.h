@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "../../include/dhr_hip.h"
+#include "abi_guard.h"
 
 // library-internal helpers with C linkage (api.hip), used by the other translation units
 extern "C" int dhr_set_error_message(int code, const char* msg);   // records the calling thread's last error, returns code
@@ -373,8 +374,10 @@ hipError_t launch_count_ge(const uint64_t* topk_keys, int kp, int k, const float
                            int32_t* out, hipStream_t s);
 hipError_t launch_merge_topk(int n_queries, int n_in, const float* in_scores, const int64_t* in_rows, int k_out,
                              float* out_scores, int64_t* out_rows, hipStream_t s);
+// stride_s / stride_r: elements between the [Q, list_len] sections of consecutive lists in in_scores / in_rows (0: dense [n_lists, Q, list_len]);
+// the sharded search gathers [counts | scores | rows | status] blocks, so a rank's sections lie a whole block apart
 hipError_t launch_merge_lists(int n_queries, int n_lists, int list_len, const float* in_scores, const int64_t* in_rows, int k_out,
-                              float* out_scores, int64_t* out_rows, hipStream_t s);
+                              float* out_scores, int64_t* out_rows, hipStream_t s, int64_t stride_s = 0, int64_t stride_r = 0);
 
 extern int g_gemm_variant;
 constexpr int RESCORE_CANDS_PER_WG = 32;

@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(G8_NT) G8_KERNEL_ATTR gemm_filter_g8_kernel(Ge
 #if G8_TRACE
 }  // namespace dhr
 // tuning hook of the trace build: copies the first `max_slots` trace records (8 x u64 each) to the host and resets the record counter
-extern "C" int dhr_debug_g8_trace(unsigned long long* out, int max_slots, unsigned* n_out) {
+extern "C" int dhr_debug_g8_trace(unsigned long long* out, int max_slots, unsigned* n_out) try {
   unsigned n = 0;
   if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(dhr::g8_trace_n), 4) != hipSuccess) return -1;
   if (n_out) *n_out = n;
@@ -481,7 +481,7 @@ extern "C" int dhr_debug_g8_trace(unsigned long long* out, int max_slots, unsign
   const unsigned zero = 0;
   if (hipMemcpyToSymbol(HIP_SYMBOL(dhr::g8_trace_n), &zero, 4) != hipSuccess) return -1;
   return 0;
-}
+} DHR_CATCH_STATUS
 namespace dhr {
 #endif
 

@@ -624,17 +624,17 @@ bool gemm_g8p_ok(const GemmArgs& a) {
 
 #if G8_TRACE
 // tuning hook of the trace build: copies the trace records (8 x u64 per tile, slot = 1024 x workgroup + the workgroup's tile count) to the host
-extern "C" int dhr_debug_g8p_stat(unsigned long long* out16) {
+extern "C" int dhr_debug_g8p_stat(unsigned long long* out16) try {
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(dhr::g8p_stat), 128) != hipSuccess) return -1;
   unsigned long long z[16] = {};
   return hipMemcpyToSymbol(HIP_SYMBOL(dhr::g8p_stat), z, 128) == hipSuccess ? 0 : -1;
-}
-extern "C" int dhr_debug_g8p_trace(unsigned long long* out, int max_slots) {
+} DHR_CATCH_STATUS
+extern "C" int dhr_debug_g8p_trace(unsigned long long* out, int max_slots) try {
   const int m = max_slots < dhr::G8P_TRACE_SLOTS ? max_slots : dhr::G8P_TRACE_SLOTS;
   if (out && m > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(dhr::g8p_trace_buf), (size_t)m * 64) != hipSuccess) return -1;
   void* ptr = nullptr;
   if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(dhr::g8p_trace_buf)) != hipSuccess) return -1;
   if (hipMemset(ptr, 0, (size_t)dhr::G8P_TRACE_SLOTS * 64) != hipSuccess) return -1;
   return 0;
-}
+} DHR_CATCH_STATUS
 #endif

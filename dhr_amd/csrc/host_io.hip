@@ -2,6 +2,7 @@
 // '{} Q0 {} {} {} {}\n'.format(...) per result line on one thread: 14 s for 6 980 x 1 000 lines, ninety times the search itself).
 // No device code in this translation unit; it lives in the library so that a binding gets the writer with the search.
 #include "../../include/dhr_hip.h"
+#include "abi_guard.h"
 #include <charconv>
 #include <cstdio>
 #include <cstring>
@@ -70,17 +71,17 @@ inline char* put_uint(char* p, uint64_t v) {
 
 }  // namespace
 
-extern "C" int dhr_format_float(double x, char* out, int32_t cap) {
+extern "C" int dhr_format_float(double x, char* out, int32_t cap) try {
   char buf[64];
   const int n = (int)(put_py_float(buf, x) - buf);
   if (!out || cap <= n) return dhr_set_error_message(DHR_ERR_INVALID, "buffer too small");
   memcpy(out, buf, n); out[n] = 0;
   return n;
-}
+} DHR_CATCH_STATUS
 
 extern "C" int dhr_write_trec(const char* path, int32_t append, int64_t n_queries, int64_t k, const char* qid_blob, const int64_t* qid_off,
                               const char* docid_blob, const int64_t* docid_off, int64_t n_docs, const int64_t* rows, int64_t row_base,
-                              const float* scores, const char* run_name, int32_t id_sep_bytes, int32_t n_threads, int64_t* lines_out) {
+                              const float* scores, const char* run_name, int32_t id_sep_bytes, int32_t n_threads, int64_t* lines_out) try {
   if (!path || !qid_blob || !qid_off || !docid_blob || !docid_off || !rows || !scores || !run_name || n_queries < 0 || k < 0 || n_docs < 0 || id_sep_bytes < 0)
     return dhr_set_error_message(DHR_ERR_INVALID, "null argument / negative size");
   const size_t run_len = strlen(run_name);
@@ -89,7 +90,7 @@ extern "C" int dhr_write_trec(const char* path, int32_t append, int64_t n_querie
   std::vector<std::string> part((size_t)T);
   std::vector<int64_t> lines((size_t)T, 0);
   std::vector<int> bad((size_t)T, 0);
-  auto work = [&](int t) {
+  auto work_body = [&](int t) {
     const int64_t lo = n_queries * t / T, hi = n_queries * (t + 1) / T;
     std::string& out = part[t];
     out.reserve((size_t)((hi - lo) * k) * 48 + 64);
@@ -123,14 +124,27 @@ extern "C" int dhr_write_trec(const char* path, int32_t append, int64_t n_querie
       }
     }
   };
+  // (an exception must not leave a thread function -- std::terminate --: a worker that runs out of memory marks its part and returns)
+  auto work = [&](int t) noexcept {
+    try { work_body(t); } catch (const std::bad_alloc&) { bad[t] = 2; } catch (...) { bad[t] = 3; }
+  };
   {
     std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    th.reserve((size_t)T);
+    try {
+      for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    } catch (...) {              // thread creation failed (std::system_error) or the vector could not grow: join what runs, then report
+      for (auto& x : th) x.join();
+      throw;
+    }
     work(0);
     for (auto& x : th) x.join();
   }
-  for (int t = 0; t < T; ++t)
-    if (bad[t]) return dhr_set_error_message(DHR_ERR_INVALID, "a result row lies outside the docid list");
+  for (int t = 0; t < T; ++t) {
+    if (bad[t] == 1) return dhr_set_error_message(DHR_ERR_INVALID, "a result row lies outside the docid list");
+    if (bad[t] == 2) return dhr_set_error_message(DHR_ERR_NOMEM, "out of host memory while formatting the run file");
+    if (bad[t]) return dhr_set_error_message(DHR_ERR_INTERNAL, "a formatting thread failed");
+  }
   FILE* f = fopen(path, append ? "ab" : "wb");
   if (!f) return dhr_set_error_message(DHR_ERR_INVALID, "cannot open the output file");
   int64_t total = 0;
@@ -141,4 +155,4 @@ extern "C" int dhr_write_trec(const char* path, int32_t append, int64_t n_querie
   if (fclose(f) != 0) return dhr_set_error_message(DHR_ERR_INVALID, "close failed");
   if (lines_out) *lines_out = total;
   return DHR_OK;
-}
+} DHR_CATCH_STATUS

@@ -2798,7 +2798,8 @@ hipError_t launch_merge_topk(int n_queries, int n_in, const float* in_scores, co
 template <int NL>
 __global__ void __launch_bounds__(1024) merge_lists_kernel(int n_lists, int L, int n_queries, const float* __restrict__ in_scores,
                                                           const int64_t* __restrict__ in_rows, int k_out,
-                                                          float* __restrict__ out_scores, int64_t* __restrict__ out_rows) {
+                                                          float* __restrict__ out_scores, int64_t* __restrict__ out_rows,
+                                                          int64_t stride_s, int64_t stride_r) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n_tot = n_lists * L;
   int64_t* rw = (int64_t*)smem;                           // [n_tot] rows (only with in_rows)
@@ -2816,13 +2817,13 @@ __global__ void __launch_bounds__(1024) merge_lists_kernel(int n_lists, int L, i
     for (int j = tid; j < L; j += nthr) {
       float sc[8];
       int64_t rr[8];
-      const int64_t src0 = ((int64_t)l0 * n_queries + q) * L + j;
+      const int64_t in_list = (int64_t)q * L + j;          // (list l's section starts at l * stride)
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         sc[u] = 0.f; rr[u] = 0;
         if (l0 + u < n_lists) {
-          sc[u] = in_scores[src0 + (int64_t)u * n_queries * L];
-          if (in_rows) rr[u] = in_rows[src0 + (int64_t)u * n_queries * L];
+          sc[u] = in_scores[(int64_t)(l0 + u) * stride_s + in_list];
+          if (in_rows) rr[u] = in_rows[(int64_t)(l0 + u) * stride_r + in_list];
         }
       }
 #pragma unroll
@@ -2920,8 +2921,10 @@ __global__ void __launch_bounds__(1024) merge_lists_kernel(int n_lists, int L, i
   }
 }
 hipError_t launch_merge_lists(int n_queries, int n_lists, int list_len, const float* in_scores, const int64_t* in_rows, int k_out,
-                              float* out_scores, int64_t* out_rows, hipStream_t s) {
+                              float* out_scores, int64_t* out_rows, hipStream_t s, int64_t stride_s, int64_t stride_r) {
   if (n_queries <= 0) return hipSuccess;
+  if (stride_s <= 0) stride_s = (int64_t)n_queries * list_len;
+  if (stride_r <= 0) stride_r = (int64_t)n_queries * list_len;
   const size_t bytes = ((size_t)n_lists * list_len + (size_t)k_out) * (in_rows ? 12 : 4);
   if (bytes > 160 * 1024 || n_lists > 64) return hipErrorInvalidValue;
   static const int env_threads = getenv("DHR_MERGE_THREADS") ? atoi(getenv("DHR_MERGE_THREADS")) : 0;
@@ -2933,7 +2936,7 @@ hipError_t launch_merge_lists(int n_queries, int n_lists, int list_len, const fl
       attr_bytes = bytes;
     }
     hipLaunchKernelGGL(kernel, dim3((unsigned)n_queries), dim3(threads), bytes, s, n_lists, list_len, n_queries, in_scores, in_rows,
-                       k_out, out_scores, out_rows);
+                       k_out, out_scores, out_rows, stride_s, stride_r);
     return hipGetLastError();
   };
   static size_t a2 = 0, a4 = 0, a8 = 0, a16 = 0, a64 = 0;

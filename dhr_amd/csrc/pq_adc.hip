@@ -207,7 +207,7 @@ int scan(dhr_pq* pq, int nq, int64_t lo, int64_t hi, bool filter, float* dump, i
 }  // namespace
 
 extern "C" int dhr_pq_create(int32_t device, int32_t mem_kind, int64_t n, int32_t d, int32_t M, int32_t nbits, const float* codebooks,
-                             const uint8_t* codes, int64_t row_offset, dhr_pq** out) {
+                             const uint8_t* codes, int64_t row_offset, dhr_pq** out) try {
   if (!out || !codebooks || !codes || n <= 0 || d <= 0 || M <= 0 || d % M || nbits < 1 || nbits > 8)
     return dhr_set_error_message(DHR_ERR_INVALID, "bad argument (1 <= nbits <= 8, d a multiple of M)");
   if ((M << nbits) * 8 > 160 * 1024 - 1024) return dhr_set_error_message(DHR_ERR_UNSUPPORTED, "the lookup tables of a query pair (M * 2^nbits * 8 B) do not fit the LDS");
@@ -225,24 +225,24 @@ extern "C" int dhr_pq_create(int32_t device, int32_t mem_kind, int64_t n, int32_
   pq->bytes = (int64_t)(cb_bytes + code_bytes);
   *out = pq;
   return DHR_OK;
-}
-extern "C" void dhr_pq_destroy(dhr_pq* pq) {
+} DHR_CATCH_STATUS
+extern "C" void dhr_pq_destroy(dhr_pq* pq) try {
   if (!pq) return;
   (void)hipSetDevice(pq->device);
   void* ps[] = {pq->cb, pq->codes, pq->lut, pq->q32, pq->cand, pq->cnt, pq->keys, pq->topk, pq->thr, pq->tau, pq->margin, pq->d_max};
   for (void* p : ps) (void)hipFree(p);
   delete pq;
-}
-extern "C" int64_t dhr_pq_device_bytes(const dhr_pq* pq) { return pq ? pq->bytes : 0; }
-extern "C" int dhr_pq_last_scan(const dhr_pq* pq, double* ms, double* code_bytes) {
+} DHR_CATCH_VOID
+extern "C" int64_t dhr_pq_device_bytes(const dhr_pq* pq) try { return pq ? pq->bytes : 0; } DHR_CATCH_VALUE(0)
+extern "C" int dhr_pq_last_scan(const dhr_pq* pq, double* ms, double* code_bytes) try {
   if (!pq) return dhr_set_error_message(DHR_ERR_INVALID, "null handle");
   if (ms) *ms = pq->last_scan_ms;
   if (code_bytes) *code_bytes = pq->last_code_bytes;
   return DHR_OK;
-}
+} DHR_CATCH_STATUS
 
 // Raw ADC scores of rows [row_lo, row_hi) for every query: out [n_queries][row_hi - row_lo] fp32, device memory (tests).
-extern "C" int dhr_pq_adc_scores(dhr_pq* pq, const dhr_query_batch* qb, int64_t row_lo, int64_t row_hi, float* out_dev, void* stream) {
+extern "C" int dhr_pq_adc_scores(dhr_pq* pq, const dhr_query_batch* qb, int64_t row_lo, int64_t row_hi, float* out_dev, void* stream) try {
   if (!pq || !qb || !qb->value || !out_dev || row_lo < 0 || row_hi > pq->n || row_lo >= row_hi) return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
   PQ_HIP(hipSetDevice(pq->device));
   hipStream_t s = (hipStream_t)stream;
@@ -255,12 +255,12 @@ extern "C" int dhr_pq_adc_scores(dhr_pq* pq, const dhr_query_batch* qb, int64_t 
   }
   PQ_HIP(hipStreamSynchronize(s));
   return DHR_OK;
-}
+} DHR_CATCH_STATUS
 
 // IndexPQ.search(queries, k): per query the k rows with the largest ADC score, best first (score desc, row asc on exact ties);
 // out_scores [n_queries][k] fp32, out_rows [n_queries][k] int64 global rows; (-inf, -1) beyond the corpus size.
 extern "C" int dhr_pq_search(dhr_pq* pq, const dhr_query_batch* qb, int32_t k, float* out_scores, int64_t* out_rows, int32_t out_mem_kind,
-                             void* stream) {
+                             void* stream) try {
   if (!pq || !qb || !qb->value || !out_scores || !out_rows || qb->n_queries <= 0) return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
   if (k <= 0 || k > (1 << 20)) return dhr_set_error_message(DHR_ERR_INVALID, "k must be in [1, 1048576]");      // k > 16384: the global-memory merge (select_global.hip)
   PQ_HIP(hipSetDevice(pq->device));
@@ -327,4 +327,4 @@ extern "C" int dhr_pq_search(dhr_pq* pq, const dhr_query_batch* qb, int32_t k, f
   if (hipStreamSynchronize(s) != hipSuccess) return done(dhr_set_error_message(DHR_ERR_HIP, "stream synchronize failed"));
   pq->last_scan_ms = scan_ms; pq->last_code_bytes = code_bytes;
   return done(DHR_OK);
-}
+} DHR_CATCH_STATUS

@@ -29,6 +29,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,6 +46,7 @@ struct dhr_comm {
   size_t arena_bytes = 0;
   void* h_stage = nullptr;        // pinned staging of the callback transport: [send | recv]
   size_t h_stage_bytes = 0;
+  bool dead = false;              // dhr_comm_abort ran: the handle only waits for dhr_comm_destroy
 };
 
 
@@ -67,10 +69,39 @@ using namespace dhr;
 //                THIS control flow with world size 2 / 3 over gloo (tests/test_dist_gloo.py) -- until round 4 those tests ran
 //                a torch restatement of it (dhr_amd/dist.py sharded_search_torch, now deleted).
 // ------------------------------------------------------------------------------------------------------------------------------------
+// One rank's share of an all-gather: [payload | status record (16 B)], `stride` bytes apart in the receive buffer.  The status record is what
+// makes a failed step COLLECTIVE (round 6): a rank whose local work failed (a HIP error, out of memory, a failing shard callback) does not leave
+// the sequence of collectives -- it skips its remaining local work, keeps issuing the step's all-gathers with the agreed sizes, and its status
+// travels in the record of every block it sends.  A transport whose blocks pass through host memory (the caller's host transport, host shards)
+// reads the records right behind each gather and every rank returns from the SAME gather; over RCCL (and in the one-process form) the records are
+// folded on the device into the word that the step's one host read fetches anyway, and every rank returns at the end of the step.  The failing
+// rank returns its own status and message, the others DHR_ERR_PEER naming it.  (Until round 5 the failing rank returned at once and the others
+// waited in their next collective for the transport's timeout.)
+struct Block { size_t payload, stride; };
+inline Block block_of(size_t payload) {
+  payload = (payload + 15) & ~(size_t)15;
+  return {payload, (payload + 16 + 255) & ~(size_t)255};
+}
+// first failing rank of a gathered buffer in HOST memory (0: none)
+inline int host_block_status(const void* blocks, int world, const Block& b, int* who) {
+  for (int w = 0; w < world; ++w) {
+    int32_t st;
+    memcpy(&st, (const char*)blocks + (size_t)w * b.stride + b.payload, 4);
+    if (st != 0) { *who = w; return st; }
+  }
+  return 0;
+}
+inline int peer_error(int who, int status) {
+  char buf[160];
+  snprintf(buf, sizeof(buf), "rank %d failed in this sharded step (its status: %d); the step was abandoned on every rank", who, status);
+  return dhr_set_error_message(DHR_ERR_PEER, buf);
+}
+
 struct Backend {
   int world = 1, n_local = 1;
   virtual ~Backend() {}
   virtual void* alloc(int i, size_t bytes) = 0;                 // scratch in local shard i's memory, released when the call ends
+  virtual int zero(int i, void* p, size_t bytes) = 0;
   virtual int set_share(int i, int share) = 0;                  // DHR_PARAM_SAMPLE_SHARE
   virtual void abort(int) {}                                    // forget a staged search that did not reach its finish call
   virtual int sample_rank(int i, int k) = 0;
@@ -84,18 +115,25 @@ struct Backend {
   virtual int pre(int i, const dhr_query_batch* qb, int k, int r_local, float* scores) = 0;
   virtual int begin_rest(int i, const float* tau, float* sample) = 0;
   virtual int search(int i, const dhr_query_batch* qb, int k, float* s, int64_t* r) = 0;
-  // all-gather of `bytes` per shard: send[i] (local shard i's block) -> recv[i] = [world][bytes] in local shard i's memory
-  virtual int gather(const std::vector<const void*>& send, const std::vector<void*>& recv, size_t bytes) = 0;
+  // the status record of local shard i's outgoing block
+  virtual int put_status(int i, void* block, const Block& b, int status) = 0;
+  // all-gather of one block per shard: send[i] (local shard i's block, b.stride bytes) -> recv[i] = [world][b.stride] in local shard i's memory.
+  // A transport whose blocks pass through host memory returns DHR_ERR_PEER here when some rank's record carries a failure.
+  virtual int gather(const std::vector<const void*>& send, const std::vector<void*>& recv, const Block& b) = 0;
+  // ... the others fold the records of a gathered buffer into rec[1] (status of the first failing rank) / rec[2] (that rank), on the device
+  virtual int fold_status(int i, const void* gathered, const Block& b, int32_t* rec) = 0;
   virtual int min_over_ranks(int32_t v[12]) = 0;                // element-wise minimum over all processes; one host read
-  // [world, Q, r] sorted sample scores -> tau[q] = the ru-th best of the union
-  virtual int union_threshold(int i, const float* gathered, int Q, int r, int ru, float* tau) = 0;
-  virtual int union_threshold2(int i, const float* gathered, int Q, int r, int ru, float* tau) = 0;   // the same, tau[q] = max(tau[q], that)
-  // counts [world][Q] -> compact list of failed query ids + their number (a query is complete iff the union holds >= k rows, no
-  // shard overflowed (-1) and no shard's share exceeds the gathered prefix kk)
-  virtual int flag_failures(int i, const int32_t* counts, int Q, int k, int kk, int32_t* fail_ids, int32_t* n_failed) = 0;
+  // gathered [world] blocks of [Q, r] sorted sample scores -> tau[q] = the ru-th best of the union
+  virtual int union_threshold(int i, const float* gathered, const Block& b, int Q, int r, int ru, float* tau) = 0;
+  virtual int union_threshold2(int i, const float* gathered, const Block& b, int Q, int r, int ru, float* tau) = 0;   // the same, tau[q] = max(tau[q], that)
+  // counts [world] blocks of [Q] -> compact list of failed query ids + their number in rec[0] (a query is complete iff the union holds >= k rows,
+  // no shard overflowed (-1) and no shard's share exceeds the gathered prefix kk)
+  virtual int flag_failures(int i, const int32_t* counts, const Block& b, int Q, int k, int kk, int32_t* fail_ids, int32_t* rec) = 0;
   virtual int prefix(int i, const float* s, const int64_t* r, int k, int kk, int Q, float* os, int64_t* orow) = 0;
-  virtual int merge(int i, int Q, int L, const float* gs, const int64_t* gr, int k, float* os, int64_t* orow) = 0;   // [world, Q, L] sorted lists -> [Q, k]
-  virtual int read_failed(const std::vector<int32_t*>& n_failed, const std::vector<int32_t*>& fail_ids, std::vector<int32_t>& ids) = 0;   // THE host read
+  // [world] blocks holding a query-major [Q, L] score section (gs) and row section (gr) each, sorted lists -> [Q, k]
+  virtual int merge(int i, int Q, int L, const float* gs, const int64_t* gr, const Block& b, int k, float* os, int64_t* orow) = 0;
+  // THE host read: rec[0] failed queries (+ their ids), rec[1] / rec[2] the first failing rank's status / rank (0: none)
+  virtual int read_failed(const std::vector<int32_t*>& rec, const std::vector<int32_t*>& fail_ids, std::vector<int32_t>& ids, int* peer_status, int* peer_rank) = 0;
   virtual int sub_batch(int i, const dhr_query_batch* in, const std::vector<int32_t>& ids, dhr_query_batch* out, int32_t** ids_mem) = 0;
   virtual int scatter(int i, const float* s, const int64_t* r, const int32_t* ids_mem, int F, int k, float* os, int64_t* orow) = 0;
   virtual int sync(int i) = 0;
@@ -108,13 +146,13 @@ int prefix_len(int k, int world) {
 }
 
 // host-side pieces shared by both backends ------------------------------------------------------------------------------------------
-void host_flag_failures(const int32_t* counts, int world, int Q, int k, int kk, int32_t* fail_ids, int32_t* n_failed) {
+void host_flag_failures(const int32_t* counts, const Block& b, int world, int Q, int k, int kk, int32_t* fail_ids, int32_t* n_failed) {
   int nf = 0;
   for (int q = 0; q < Q; ++q) {
     int64_t tot = 0;
     bool bad = false;
     for (int w = 0; w < world; ++w) {
-      const int32_t c = counts[(int64_t)w * Q + q];
+      const int32_t c = ((const int32_t*)((const char*)counts + (size_t)w * b.stride))[q];
       if (c < 0 || c > kk) bad = true;
       tot += c > 0 ? c : 0;
     }
@@ -140,23 +178,73 @@ void host_sub_batch(const dhr_query_batch* in, const std::vector<int32_t>& ids, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-// local thresholds for a (sub-)batch: every shard searches with k, full lists gathered and merged.  out_* [n_q, k] per local shard.
-int local_path(Backend& B, const std::vector<dhr_query_batch>& qb, int k, const std::vector<float*>& out_s, const std::vector<int64_t*>& out_r) {
-  const int nl = B.n_local, world = B.world, Q = qb[0].n_queries;
-  std::vector<const void*> send_s(nl), send_r(nl);
-  std::vector<void*> recv_s(nl), recv_r(nl);
-  for (int i = 0; i < nl; ++i) {
-    float* ls = (float*)B.alloc(i, (size_t)Q * k * 4);
-    int64_t* lr = (int64_t*)B.alloc(i, (size_t)Q * k * 8);
-    recv_s[i] = B.alloc(i, (size_t)world * Q * k * 4);
-    recv_r[i] = B.alloc(i, (size_t)world * Q * k * 8);
-    if (!ls || !lr || !recv_s[i] || !recv_r[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
-    SH_TRY(B.search(i, &qb[i], k, ls, lr));
-    send_s[i] = ls; send_r[i] = lr;
+// The state of ONE sharded step: which local shard has failed (and with what message), and the device record the status words of the
+// gathered blocks are folded into.
+struct Step {
+  Backend& B;
+  const bool spmd;                 // other processes take part in the collectives: a local failure must not leave their sequence
+  std::vector<int> st;             // first failure of local shard i (DHR_OK: none); its later local work is skipped
+  std::vector<int32_t*> rec;       // per local shard: {failed queries, first failing rank's status, that rank, -} in the shard's memory
+  char msg[1024];                  // dhr_last_error() of the first local failure (later calls overwrite the thread's record)
+  explicit Step(Backend& b) : B(b), spmd(b.world > b.n_local), st(b.n_local, DHR_OK), rec(b.n_local, nullptr) { msg[0] = 0; }
+  int own() const { for (int v : st) if (v != DHR_OK) return v; return DHR_OK; }
+  int own_error() const { return dhr_set_error_message(own(), msg); }
+  // local work of shard i.  A failure is recorded; in a one-process search (nobody else is waiting) it ends the step at once.
+  template <class F> int local(int i, F&& op) {
+    if (st[i] != DHR_OK) return DHR_OK;
+    int rc;
+    try { rc = op(); } catch (...) { rc = dhr::on_exception(); }
+    if (rc == DHR_OK) return DHR_OK;
+    if (!spmd) return rc;
+    if (own() == DHR_OK) snprintf(msg, sizeof(msg), "%s", dhr_last_error());
+    st[i] = rc;
+    return DHR_OK;
   }
-  SH_TRY(B.gather(send_s, recv_s, (size_t)Q * k * 4));
-  SH_TRY(B.gather(send_r, recv_r, (size_t)Q * k * 8));
-  for (int i = 0; i < nl; ++i) SH_TRY(B.merge(i, Q, k, (const float*)recv_s[i], (const int64_t*)recv_r[i], k, out_s[i], out_r[i]));
+  int init() {
+    for (int i = 0; i < B.n_local; ++i) {
+      rec[i] = (int32_t*)B.alloc(i, 256);
+      if (!rec[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
+      SH_TRY(B.zero(i, rec[i], 16));
+    }
+    return DHR_OK;
+  }
+  // the all-gather of one block per shard, status records included
+  int gather(const std::vector<const void*>& send, const std::vector<void*>& recv, const Block& b) {
+    for (int i = 0; i < B.n_local; ++i) SH_TRY(B.put_status(i, const_cast<void*>(send[i]), b, st[i]));
+    const int rc = B.gather(send, recv, b);
+    if (rc == DHR_ERR_PEER && own() != DHR_OK) return own_error();      // this rank is the one that failed
+    SH_TRY(rc);
+    for (int i = 0; i < B.n_local; ++i) SH_TRY(B.fold_status(i, recv[i], b, rec[i]));
+    return DHR_OK;
+  }
+  // the verdict of a step whose status words travelled on the device (peer_status / peer_rank from the host read)
+  int verdict(int peer_status, int peer_rank) const {
+    if (own() != DHR_OK) return own_error();
+    if (peer_status != 0) return peer_error(peer_rank, peer_status);
+    return DHR_OK;
+  }
+};
+#define SH_LOCAL(i, expr) SH_TRY(S.local(i, [&]() -> int { return (expr); }))
+
+// local thresholds for a (sub-)batch: every shard searches with k, full lists gathered (ONE all-gather: scores and rows in one block) and
+// merged.  out_* [n_q, k] per local shard.
+int local_path(Step& S, const std::vector<dhr_query_batch>& qb, int k, const std::vector<float*>& out_s, const std::vector<int64_t*>& out_r) {
+  Backend& B = S.B;
+  const int nl = B.n_local, world = B.world, Q = qb[0].n_queries;
+  const size_t off_r = ((size_t)Q * k * 4 + 15) & ~(size_t)15;
+  const Block b = block_of(off_r + (size_t)Q * k * 8);
+  std::vector<const void*> send(nl);
+  std::vector<void*> recv(nl);
+  for (int i = 0; i < nl; ++i) {
+    char* blk = (char*)B.alloc(i, b.stride);
+    recv[i] = B.alloc(i, (size_t)world * b.stride);
+    if (!blk || !recv[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
+    SH_LOCAL(i, B.search(i, &qb[i], k, (float*)blk, (int64_t*)(blk + off_r)));
+    send[i] = blk;
+  }
+  SH_TRY(S.gather(send, recv, b));
+  for (int i = 0; i < nl; ++i)
+    SH_LOCAL(i, B.merge(i, Q, k, (const float*)recv[i], (const int64_t*)((const char*)recv[i] + off_r), b, k, out_s[i], out_r[i]));
   return DHR_OK;
 }
 
@@ -167,7 +255,9 @@ int local_path(Backend& B, const std::vector<dhr_query_batch>& qb, int k, const 
 // The ranks of the SECOND agreement (Backend::mid_ranks) ride along: shards whose sizes differ by a tile may compute ranks that differ by one;
 // every shard then uses the LARGEST (a lower threshold: still valid), and the step is skipped when some shard has none.
 // The ranks of the two-round FIRST agreement (Backend::pre_ranks) travel the same way: the largest over the shards, none if some shard has none.
-int agree_rank(Backend& B, int k, int* r_out, int* ru_out, int* rl_mid_out, int* ru_mid_out, int* rl_pre_out, int* ru_pre_out) {
+// v[10] carries the ranks' status so far (a rank whose set-up failed says so here instead of staying away from the exchange).
+int agree_rank(Step& S, int k, int* r_out, int* ru_out, int* rl_mid_out, int* ru_mid_out, int* rl_pre_out, int* ru_pre_out) {
+  Backend& B = S.B;
   int r = B.sample_rank(0, k);
   int ru = B.union_rank(0, k);
   int ml_min = 1 << 30, ml_max = 0, mu_max = 0;
@@ -176,16 +266,17 @@ int agree_rank(Backend& B, int k, int* r_out, int* ru_out, int* rl_mid_out, int*
   for (int i = 0; i < B.n_local; ++i) {
     if (B.sample_rank(i, k) != r || B.union_rank(i, k) != ru) r = 0;
     int ml = 0, mu = 0;
-    if (mid_on) SH_TRY(B.mid_ranks(i, k, &ml, &mu));
+    if (mid_on) SH_LOCAL(i, B.mid_ranks(i, k, &ml, &mu));
     if (ml <= 0 || mu <= 0) ml = mu = 0;
     ml_min = std::min(ml_min, ml); ml_max = std::max(ml_max, ml); mu_max = std::max(mu_max, mu);
     int pl = 0, pu = 0;
-    SH_TRY(B.pre_ranks(i, k, &pl, &pu));
+    SH_LOCAL(i, B.pre_ranks(i, k, &pl, &pu));
     if (pl <= 0 || pu <= 0) pl = pu = 0;
     pl_min = std::min(pl_min, pl); pl_max = std::max(pl_max, pl); pu_max = std::max(pu_max, pu);
   }
-  int32_t v[12] = {r, -r, ru, -ru, ml_min, -ml_max, -mu_max, pl_min, -pl_max, -pu_max, 0, 0};
+  int32_t v[12] = {r, -r, ru, -ru, ml_min, -ml_max, -mu_max, pl_min, -pl_max, -pu_max, S.own(), 0};
   SH_TRY(B.min_over_ranks(v));
+  if (v[10] != DHR_OK) return S.own() != DHR_OK ? S.own_error() : dhr_set_error_message(DHR_ERR_PEER, "another rank failed while setting up this sharded step; the step was abandoned on every rank");
   *r_out = (v[0] == r && -v[1] == r && v[2] == ru && -v[3] == ru) ? r : 0;
   *ru_out = ru;
   *rl_mid_out = v[4] > 0 ? -v[5] : 0;
@@ -210,13 +301,24 @@ int sharded_core(Backend& B, const dhr_query_batch* qb_in, int k, const std::vec
   g_last_repairs = 0;
   std::vector<dhr_query_batch> qb(nl, *qb_in);
   ShareGuard share_guard{B};
-  for (int i = 0; i < nl; ++i) SH_TRY(B.set_share(i, world));      // a shard chases only its share of the union's rank
+  Step S(B);
+  for (int i = 0; i < nl; ++i) SH_LOCAL(i, B.set_share(i, world));      // a shard chases only its share of the union's rank
   int r = 0, ru_all = 0, rl_mid = 0, ru_mid = 0, rl_pre = 0, ru_pre = 0;
-  SH_TRY(agree_rank(B, k, &r, &ru_all, &rl_mid, &ru_mid, &rl_pre, &ru_pre));
-  if (r <= 0) return local_path(B, qb, k, out_s, out_r);
+  SH_TRY(agree_rank(S, k, &r, &ru_all, &rl_mid, &ru_mid, &rl_pre, &ru_pre));
+  SH_TRY(S.init());
+  std::vector<int32_t*> fail_ids(nl, nullptr);
+  std::vector<int32_t> ids;
+  int peer_status = 0, peer_rank = 0;
+  if (r <= 0) {
+    // shards that cannot be sampled alike: local thresholds for the whole batch
+    SH_TRY(local_path(S, qb, k, out_s, out_r));
+    SH_TRY(B.read_failed(S.rec, fail_ids, ids, &peer_status, &peer_rank));
+    return S.verdict(peer_status, peer_rank);
+  }
   const int ru = std::min<int>(ru_all, world * r);      // rank of the union that defines the threshold; the lists are r long
 
   // 1-2: sampled passes, common thresholds
+  const Block b_sample = block_of((size_t)Q * r * 4);
   std::vector<const void*> send(nl);
   std::vector<void*> recv(nl);
   std::vector<float*> tau(nl);
@@ -225,102 +327,96 @@ int sharded_core(Backend& B, const dhr_query_batch* qb_in, int k, const std::vec
   // run 0.7 k.  One more all-gather of [Q, ~17] scores.
   std::vector<float*> sample_v(nl);
   for (int i = 0; i < nl; ++i) {
-    sample_v[i] = (float*)B.alloc(i, (size_t)Q * r * 4);
-    recv[i] = B.alloc(i, (size_t)world * Q * r * 4);
+    sample_v[i] = (float*)B.alloc(i, b_sample.stride);
+    recv[i] = B.alloc(i, (size_t)world * b_sample.stride);
     tau[i] = (float*)B.alloc(i, (size_t)Q * 4);
     if (!sample_v[i] || !recv[i] || !tau[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
   }
   if (rl_pre > 0 && ru_pre > 0) {
     const int ru0 = std::min<int>(ru_pre, world * rl_pre);
+    const Block b0 = block_of((size_t)Q * rl_pre * 4);
     std::vector<const void*> send0(nl);
     std::vector<void*> recv0(nl);
     std::vector<float*> tau0(nl);
     for (int i = 0; i < nl; ++i) {
-      float* seen = (float*)B.alloc(i, (size_t)Q * rl_pre * 4);
-      recv0[i] = B.alloc(i, (size_t)world * Q * rl_pre * 4);
+      float* seen = (float*)B.alloc(i, b0.stride);
+      recv0[i] = B.alloc(i, (size_t)world * b0.stride);
       tau0[i] = (float*)B.alloc(i, (size_t)Q * 4);
       if (!seen || !recv0[i] || !tau0[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
-      SH_TRY(B.pre(i, &qb[i], k, rl_pre, seen));
+      SH_LOCAL(i, B.pre(i, &qb[i], k, rl_pre, seen));
       send0[i] = seen;
     }
-    SH_TRY(B.gather(send0, recv0, (size_t)Q * rl_pre * 4));
+    SH_TRY(S.gather(send0, recv0, b0));
     for (int i = 0; i < nl; ++i) {
-      SH_TRY(B.union_threshold(i, (const float*)recv0[i], Q, rl_pre, ru0, tau0[i]));
-      SH_TRY(B.begin_rest(i, tau0[i], sample_v[i]));
+      SH_LOCAL(i, B.union_threshold(i, (const float*)recv0[i], b0, Q, rl_pre, ru0, tau0[i]));
+      SH_LOCAL(i, B.begin_rest(i, tau0[i], sample_v[i]));
       send[i] = sample_v[i];
     }
   } else
     for (int i = 0; i < nl; ++i) {
-      SH_TRY(B.begin(i, &qb[i], k, sample_v[i]));
+      SH_LOCAL(i, B.begin(i, &qb[i], k, sample_v[i]));
       send[i] = sample_v[i];
     }
-  SH_TRY(B.gather(send, recv, (size_t)Q * r * 4));
-  for (int i = 0; i < nl; ++i) SH_TRY(B.union_threshold(i, (const float*)recv[i], Q, r, ru, tau[i]));
+  SH_TRY(S.gather(send, recv, b_sample));
+  for (int i = 0; i < nl; ++i) SH_LOCAL(i, B.union_threshold(i, (const float*)recv[i], b_sample, Q, r, ru, tau[i]));
   // 2b: second agreement.  Every shard runs the first slice of its main pass with tau and reports its best scores seen so far; the union of
   // what the shards have seen is a scattered fraction f of the corpus, and its (k f + 6 sigma + 4)-th best score is the threshold of the rest
   // of the pass (the shard keeps the larger of the two; the counts below are taken against it).  A 1/8 shard of the 8.8 M-row benchmark
   // rescores ~360 instead of ~490 rows per query in its main pass for one more all-gather of [Q, ~60] scores.
   if (rl_mid > 0 && ru_mid > 0) {
     const int ru2 = std::min<int>(ru_mid, world * rl_mid);
+    const Block b2 = block_of((size_t)Q * rl_mid * 4);
     std::vector<const void*> send2(nl);
     std::vector<void*> recv2(nl);
     for (int i = 0; i < nl; ++i) {
-      float* seen = (float*)B.alloc(i, (size_t)Q * rl_mid * 4);
-      recv2[i] = B.alloc(i, (size_t)world * Q * rl_mid * 4);
+      float* seen = (float*)B.alloc(i, b2.stride);
+      recv2[i] = B.alloc(i, (size_t)world * b2.stride);
       if (!seen || !recv2[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
-      SH_TRY(B.mid(i, tau[i], rl_mid, seen));
+      SH_LOCAL(i, B.mid(i, tau[i], rl_mid, seen));
       send2[i] = seen;
     }
-    SH_TRY(B.gather(send2, recv2, (size_t)Q * rl_mid * 4));
-    for (int i = 0; i < nl; ++i) SH_TRY(B.union_threshold2(i, (const float*)recv2[i], Q, rl_mid, ru2, tau[i]));
+    SH_TRY(S.gather(send2, recv2, b2));
+    for (int i = 0; i < nl; ++i) SH_LOCAL(i, B.union_threshold2(i, (const float*)recv2[i], b2, Q, rl_mid, ru2, tau[i]));
   }
-  // 3-4: main passes, counts, failure flags
+  // 3-5: main passes; ONE all-gather of [counts | list prefixes: scores | rows] per shard (round 6; until then the counts travelled in a
+  // collective of their own, and scores and rows in one each), failure flags, reduce
   const int kk = prefix_len(k, world);
-  std::vector<float*> ls(nl);
-  std::vector<int64_t*> lr(nl);
-  std::vector<int32_t*> fail_ids(nl), n_failed(nl);
-  std::vector<const void*> send_c(nl);
-  std::vector<void*> recv_c(nl);
+  const size_t off_s = ((size_t)Q * 4 + 15) & ~(size_t)15, off_r = (off_s + (size_t)Q * kk * 4 + 15) & ~(size_t)15;
+  const Block bl = block_of(off_r + (size_t)Q * kk * 8);
+  std::vector<const void*> send_l(nl);
+  std::vector<void*> recv_l(nl);
   for (int i = 0; i < nl; ++i) {
-    ls[i] = (float*)B.alloc(i, (size_t)Q * k * 4);
-    lr[i] = (int64_t*)B.alloc(i, (size_t)Q * k * 8);
-    int32_t* cnt = (int32_t*)B.alloc(i, (size_t)Q * 4);
-    recv_c[i] = B.alloc(i, (size_t)world * Q * 4);
+    char* blk = (char*)B.alloc(i, bl.stride);
+    recv_l[i] = B.alloc(i, (size_t)world * bl.stride);
     fail_ids[i] = (int32_t*)B.alloc(i, (size_t)Q * 4);
-    n_failed[i] = (int32_t*)B.alloc(i, 256);
-    if (!ls[i] || !lr[i] || !cnt || !recv_c[i] || !fail_ids[i] || !n_failed[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
-    SH_TRY(B.finish(i, tau[i], ls[i], lr[i], cnt));
-    send_c[i] = cnt;
-  }
-  SH_TRY(B.gather(send_c, recv_c, (size_t)Q * 4));
-  // 5: list prefixes, reduce
-  std::vector<const void*> send_s(nl), send_r(nl);
-  std::vector<void*> recv_s(nl), recv_r(nl);
-  for (int i = 0; i < nl; ++i) {
-    SH_TRY(B.flag_failures(i, (const int32_t*)recv_c[i], Q, k, kk, fail_ids[i], n_failed[i]));
-    float* ps = ls[i];
-    int64_t* pr = lr[i];
-    if (kk < k) {
-      ps = (float*)B.alloc(i, (size_t)Q * kk * 4);
-      pr = (int64_t*)B.alloc(i, (size_t)Q * kk * 8);
-      if (!ps || !pr) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
-      SH_TRY(B.prefix(i, ls[i], lr[i], k, kk, Q, ps, pr));
+    if (!blk || !recv_l[i] || !fail_ids[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
+    float* ps = (float*)(blk + off_s);
+    int64_t* pr = (int64_t*)(blk + off_r);
+    if (kk == k) {
+      SH_LOCAL(i, B.finish(i, tau[i], ps, pr, (int32_t*)blk));          // the full lists ARE the prefixes: straight into the block
+    } else {
+      float* ls = (float*)B.alloc(i, (size_t)Q * k * 4);
+      int64_t* lr = (int64_t*)B.alloc(i, (size_t)Q * k * 8);
+      if (!ls || !lr) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
+      SH_LOCAL(i, B.finish(i, tau[i], ls, lr, (int32_t*)blk));
+      SH_LOCAL(i, B.prefix(i, ls, lr, k, kk, Q, ps, pr));
     }
-    recv_s[i] = B.alloc(i, (size_t)world * Q * kk * 4);
-    recv_r[i] = B.alloc(i, (size_t)world * Q * kk * 8);
-    if (!recv_s[i] || !recv_r[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
-    send_s[i] = ps; send_r[i] = pr;
+    send_l[i] = blk;
   }
-  SH_TRY(B.gather(send_s, recv_s, (size_t)Q * kk * 4));
-  SH_TRY(B.gather(send_r, recv_r, (size_t)Q * kk * 8));
-  for (int i = 0; i < nl; ++i) SH_TRY(B.merge(i, Q, kk, (const float*)recv_s[i], (const int64_t*)recv_r[i], k, out_s[i], out_r[i]));
-  // 6: the one host read; identical on every rank (it is a function of the gathered counts).  The ids come out of an atomic append on
-  // the device: sorted, so that every rank (and every local shard) holds the same order.
-  std::vector<int32_t> ids;
-  SH_TRY(B.read_failed(n_failed, fail_ids, ids));
+  SH_TRY(S.gather(send_l, recv_l, bl));
+  for (int i = 0; i < nl; ++i) {
+    SH_LOCAL(i, B.flag_failures(i, (const int32_t*)recv_l[i], bl, Q, k, kk, fail_ids[i], S.rec[i]));
+    SH_LOCAL(i, B.merge(i, Q, kk, (const float*)((const char*)recv_l[i] + off_s), (const int64_t*)((const char*)recv_l[i] + off_r), bl, k, out_s[i], out_r[i]));
+  }
+  // 6: the one host read; identical on every rank (it is a function of the gathered counts and status records).  The ids come out of an
+  // atomic append on the device: sorted, so that every rank (and every local shard) holds the same order.
+  SH_TRY(B.read_failed(S.rec, fail_ids, ids, &peer_status, &peer_rank));
+  if (peer_status != 0) return S.verdict(peer_status, peer_rank);      // a failure from before the last gather: every rank reads the same record
   const int F = (int)ids.size();
   g_last_repairs = F;
-  if (F == 0) return DHR_OK;
+  // (a failure of THIS rank behind the last gather -- its reduce -- is unknown to the others: without a repair step there is no collective left
+  // and it just reports it; with one it keeps to the sequence below and its status travels in that gather)
+  if (F == 0) return S.verdict(0, 0);
   std::sort(ids.begin(), ids.end());
   // failed queries (unrepresentative sample, skewed shards): sub-batch with local thresholds, gathered at full length, scattered into the result
   std::vector<dhr_query_batch> sub(nl, *qb_in);
@@ -328,17 +424,19 @@ int sharded_core(Backend& B, const dhr_query_batch* qb_in, int k, const std::vec
   std::vector<int64_t*> fr(nl);
   std::vector<int32_t*> ids_mem(nl);
   for (int i = 0; i < nl; ++i) {
-    SH_TRY(B.sub_batch(i, qb_in, ids, &sub[i], &ids_mem[i]));
+    SH_LOCAL(i, B.sub_batch(i, qb_in, ids, &sub[i], &ids_mem[i]));
     fs[i] = (float*)B.alloc(i, (size_t)F * k * 4);
     fr[i] = (int64_t*)B.alloc(i, (size_t)F * k * 8);
     if (!fs[i] || !fr[i]) return dhr_set_error_message(DHR_ERR_HIP, "out of memory in the sharded search");
+    if (S.st[i] != DHR_OK) sub[i].n_queries = F;            // (a shard that failed before it built its sub-batch still sizes its blocks by F)
   }
-  SH_TRY(local_path(B, sub, k, fs, fr));
-  for (int i = 0; i < nl; ++i) {
-    SH_TRY(B.scatter(i, fs[i], fr[i], ids_mem[i], F, k, out_s[i], out_r[i]));
-    SH_TRY(B.sync(i));
-  }
-  return DHR_OK;
+  for (int i = 0; i < nl; ++i) SH_TRY(B.zero(i, S.rec[i], 16));
+  SH_TRY(local_path(S, sub, k, fs, fr));
+  for (int i = 0; i < nl; ++i) SH_LOCAL(i, B.scatter(i, fs[i], fr[i], ids_mem[i], F, k, out_s[i], out_r[i]));
+  std::vector<int32_t*> no_ids(nl, nullptr);
+  std::vector<int32_t> none;
+  SH_TRY(B.read_failed(S.rec, no_ids, none, &peer_status, &peer_rank));      // (synchronises every local shard)
+  return S.verdict(peer_status, peer_rank);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -352,14 +450,22 @@ __global__ void column_max_kernel(const float* __restrict__ in, int ld, int col,
   if (i < n) out[i] = fmaxf(out[i], in[(int64_t)i * ld + col]);
 }
 // counts [world][Q] -> compact list of failed query ids, their number
-__global__ void fail_kernel(const int32_t* __restrict__ counts, int world, int n_queries, int k, int kk, int32_t* __restrict__ fail_ids,
+// the status records of a gathered buffer -> rec[1] / rec[2] = status / rank of the first failing rank (kept once set)
+__global__ void fold_status_kernel(const char* __restrict__ gathered, int world, size_t stride, size_t payload, int32_t* __restrict__ rec) {
+  if (threadIdx.x != 0 || rec[1] != 0) return;
+  for (int w = 0; w < world; ++w) {
+    const int32_t st = *(const int32_t*)(gathered + (size_t)w * stride + payload);
+    if (st != 0) { rec[1] = st; rec[2] = w; return; }
+  }
+}
+__global__ void fail_kernel(const int32_t* __restrict__ counts, size_t stride, int world, int n_queries, int k, int kk, int32_t* __restrict__ fail_ids,
                             int32_t* __restrict__ n_failed) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n_queries) return;
   int64_t tot = 0;
   bool bad = false;
   for (int w = 0; w < world; ++w) {
-    const int32_t c = counts[(int64_t)w * n_queries + q];
+    const int32_t c = ((const int32_t*)((const char*)counts + (size_t)w * stride))[q];
     if (c < 0 || c > kk) bad = true;
     tot += c > 0 ? c : 0;
   }
@@ -422,6 +528,22 @@ struct HipBackend : Backend {
   std::vector<std::vector<char>> host_v, host_i;      // host sub-batches of the repair step (shared by the local shards)
 
   void* alloc(int i, size_t bytes) override { (void)hipSetDevice(sh[i].device); return sh[i].arena->get(bytes); }
+  int zero(int i, void* p, size_t bytes) override {
+    SH_HIP(hipSetDevice(sh[i].device));
+    SH_HIP(hipMemsetAsync(p, 0, bytes, sh[i].stream));
+    return DHR_OK;
+  }
+  int put_status(int i, void* block, const Block& b, int status) override {
+    SH_HIP(hipSetDevice(sh[i].device));
+    SH_HIP(hipMemsetD32Async((hipDeviceptr_t)((char*)block + b.payload), status, 4, sh[i].stream));
+    return DHR_OK;
+  }
+  int fold_status(int i, const void* gathered, const Block& b, int32_t* rec) override {
+    if (comm && comm->cb) return DHR_OK;             // the host transport read the records behind the gather already
+    SH_HIP(hipSetDevice(sh[i].device));
+    hipLaunchKernelGGL(fold_status_kernel, dim3(1), dim3(64), 0, sh[i].stream, (const char*)gathered, world, b.stride, b.payload, rec);
+    return DHR_OK;
+  }
   int set_share(int i, int share) override { return dhr_index_set_param(sh[i].ix, DHR_PARAM_SAMPLE_SHARE, share); }
   void abort(int i) override { dhr_internal_search_abort(sh[i].ix); }
   int sample_rank(int i, int k) override { return dhr_search_sample_rank(sh[i].ix, k); }
@@ -462,7 +584,9 @@ struct HipBackend : Backend {
     SH_HIP(hipSetDevice(sh[i].device));
     return dhr_search(sh[i].ix, qb, k, s, r, DHR_MEM_DEVICE, sh[i].stream);
   }
-  int gather(const std::vector<const void*>& send, const std::vector<void*>& recv, size_t bytes) override {
+  int gather(const std::vector<const void*>& send, const std::vector<void*>& recv, const Block& b) override {
+    const size_t bytes = b.stride;
+    if (comm && comm->dead) return dhr_set_error_message(DHR_ERR_INVALID, "the communicator was aborted (dhr_comm_abort)");
     if (comm && comm->comm) {
       SH_NCCL(ncclAllGather(send[0], recv[0], bytes, ncclInt8, comm->comm, sh[0].stream));
       return DHR_OK;
@@ -480,6 +604,8 @@ struct HipBackend : Backend {
       SH_HIP(hipMemcpyAsync(hs, send[0], bytes, hipMemcpyDeviceToHost, sh[0].stream));
       SH_HIP(hipStreamSynchronize(sh[0].stream));
       if (comm->cb(comm->cb_user, hs, hr, (int64_t)bytes) != 0) return dhr_set_error_message(DHR_ERR_INTERNAL, "the caller's all-gather callback failed");
+      int who = 0;
+      if (const int st = host_block_status(hr, world, b, &who)) return peer_error(who, st);      // the blocks are in host memory: every rank leaves HERE
       SH_HIP(hipMemcpyAsync(recv[0], hr, bytes * (size_t)world, hipMemcpyHostToDevice, sh[0].stream));
       return DHR_OK;
     }
@@ -495,38 +621,49 @@ struct HipBackend : Backend {
   }
   int min_over_ranks(int32_t v[12]) override {
     if (!comm || world <= 1) return DHR_OK;
-    SH_HIP(hipSetDevice(sh[0].device));
-    int32_t* d = (int32_t*)sh[0].arena->get(64 + (size_t)world * 48);
-    if (!d) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory");
-    SH_HIP(hipMemcpyAsync(d, v, 48, hipMemcpyHostToDevice, sh[0].stream));
-    SH_TRY(gather({d}, {d + 16}, 48));
+    if (comm->dead) return dhr_set_error_message(DHR_ERR_INVALID, "the communicator was aborted (dhr_comm_abort)");
     std::vector<int32_t> all((size_t)world * 12);
-    SH_HIP(hipMemcpyAsync(all.data(), d + 16, (size_t)world * 48, hipMemcpyDeviceToHost, sh[0].stream));
-    SH_HIP(hipStreamSynchronize(sh[0].stream));
+    if (comm->cb) {                                  // host transport: the values are host memory already
+      if (comm->cb(comm->cb_user, v, all.data(), 48) != 0) return dhr_set_error_message(DHR_ERR_INTERNAL, "the caller's all-gather callback failed");
+    } else {                                         // (no status record on this exchange: v[10] is the status)
+      SH_HIP(hipSetDevice(sh[0].device));
+      int32_t* d = (int32_t*)sh[0].arena->get(64 + (size_t)world * 48);
+      if (!d) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory");
+      SH_HIP(hipMemcpyAsync(d, v, 48, hipMemcpyHostToDevice, sh[0].stream));
+      SH_NCCL(ncclAllGather(d, d + 16, 48, ncclInt8, comm->comm, sh[0].stream));
+      SH_HIP(hipMemcpyAsync(all.data(), d + 16, (size_t)world * 48, hipMemcpyDeviceToHost, sh[0].stream));
+      SH_HIP(hipStreamSynchronize(sh[0].stream));
+    }
     for (int w = 0; w < world; ++w)
       for (int j = 0; j < 12; ++j) v[j] = std::min(v[j], all[(size_t)w * 12 + j]);
     return DHR_OK;
   }
-  int union_threshold(int i, const float* gathered, int Q, int r, int ru, float* tau) override {
+  // the r best of [world] sorted score lists per query, lists b.stride bytes apart
+  int merge_scores(int i, const float* gathered, const Block& b, int Q, int r, int ru, float** merged_out) {
     SH_HIP(hipSetDevice(sh[i].device));
     float* merged = (float*)sh[i].arena->get((size_t)Q * ru * 4);
     if (!merged) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the sharded search");
-    SH_TRY(dhr_merge_topk_lists(sh[i].device, Q, world, r, gathered, nullptr, ru, merged, nullptr, sh[i].stream));
+    if (((int64_t)world * r + ru) * 4 > 160 * 1024 || world > 64)
+      return dhr_set_error_message(DHR_ERR_UNSUPPORTED, "the sample lists of one query do not fit the LDS");
+    SH_HIP(launch_merge_lists(Q, world, r, gathered, nullptr, ru, merged, nullptr, sh[i].stream, (int64_t)(b.stride / 4), 0));
+    *merged_out = merged;
+    return DHR_OK;
+  }
+  int union_threshold(int i, const float* gathered, const Block& b, int Q, int r, int ru, float* tau) override {
+    float* merged = nullptr;
+    SH_TRY(merge_scores(i, gathered, b, Q, r, ru, &merged));
     hipLaunchKernelGGL(column_kernel, dim3((Q + 255) / 256), dim3(256), 0, sh[i].stream, merged, ru, ru - 1, Q, tau);
     return DHR_OK;
   }
-  int union_threshold2(int i, const float* gathered, int Q, int r, int ru, float* tau) override {
-    SH_HIP(hipSetDevice(sh[i].device));
-    float* merged = (float*)sh[i].arena->get((size_t)Q * ru * 4);
-    if (!merged) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the sharded search");
-    SH_TRY(dhr_merge_topk_lists(sh[i].device, Q, world, r, gathered, nullptr, ru, merged, nullptr, sh[i].stream));
+  int union_threshold2(int i, const float* gathered, const Block& b, int Q, int r, int ru, float* tau) override {
+    float* merged = nullptr;
+    SH_TRY(merge_scores(i, gathered, b, Q, r, ru, &merged));
     hipLaunchKernelGGL(column_max_kernel, dim3((Q + 255) / 256), dim3(256), 0, sh[i].stream, merged, ru, ru - 1, Q, tau);
     return DHR_OK;
   }
-  int flag_failures(int i, const int32_t* counts, int Q, int k, int kk, int32_t* fail_ids, int32_t* n_failed) override {
+  int flag_failures(int i, const int32_t* counts, const Block& b, int Q, int k, int kk, int32_t* fail_ids, int32_t* rec) override {
     SH_HIP(hipSetDevice(sh[i].device));
-    SH_HIP(hipMemsetAsync(n_failed, 0, 4, sh[i].stream));
-    hipLaunchKernelGGL(fail_kernel, dim3((Q + 255) / 256), dim3(256), 0, sh[i].stream, counts, world, Q, k, kk, fail_ids, n_failed);
+    hipLaunchKernelGGL(fail_kernel, dim3((Q + 255) / 256), dim3(256), 0, sh[i].stream, counts, b.stride, world, Q, k, kk, fail_ids, rec);
     return DHR_OK;
   }
   int prefix(int i, const float* s, const int64_t* r, int k, int kk, int Q, float* os, int64_t* orow) override {
@@ -535,27 +672,31 @@ struct HipBackend : Backend {
     hipLaunchKernelGGL(prefix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sh[i].stream, s, r, k, kk, Q, os, orow);
     return DHR_OK;
   }
-  int merge(int i, int Q, int L, const float* gs, const int64_t* gr, int k, float* os, int64_t* orow) override {
+  int merge(int i, int Q, int L, const float* gs, const int64_t* gr, const Block& b, int k, float* os, int64_t* orow) override {
     const ShardCtx& c = sh[i];
     SH_HIP(hipSetDevice(c.device));
-    // sorted per-shard lists in [world, Q, L] layout: rank merge in the LDS when the lists of a query fit, else the general reduce
-    if (world <= 64 && ((int64_t)world * L + k) * 12 <= 160 * 1024)
-      return dhr_merge_topk_lists(c.device, Q, world, L, gs, gr, k, os, orow, c.stream);
+    // sorted per-shard lists, one [Q, L] section per rank: rank merge in the LDS when the lists of a query fit, else the general reduce
+    if (world <= 64 && ((int64_t)world * L + k) * 12 <= 160 * 1024) {
+      SH_HIP(launch_merge_lists(Q, world, L, gs, gr, k, os, orow, c.stream, (int64_t)(b.stride / 4), (int64_t)(b.stride / 8)));
+      return DHR_OK;
+    }
     // [world, Q, L] -> [Q, world * L]
     float* ts = (float*)c.arena->get((size_t)Q * world * L * 4);
     int64_t* tr = (int64_t*)c.arena->get((size_t)Q * world * L * 8);
     if (!ts || !tr) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory in the shard reduce");
     for (int w = 0; w < world; ++w) {
-      SH_HIP(hipMemcpy2DAsync(ts + (size_t)w * L, (size_t)world * L * 4, gs + (size_t)w * Q * L, (size_t)L * 4, (size_t)L * 4, Q, hipMemcpyDeviceToDevice, c.stream));
-      SH_HIP(hipMemcpy2DAsync(tr + (size_t)w * L, (size_t)world * L * 8, gr + (size_t)w * Q * L, (size_t)L * 8, (size_t)L * 8, Q, hipMemcpyDeviceToDevice, c.stream));
+      SH_HIP(hipMemcpy2DAsync(ts + (size_t)w * L, (size_t)world * L * 4, (const char*)gs + (size_t)w * b.stride, (size_t)L * 4, (size_t)L * 4, Q, hipMemcpyDeviceToDevice, c.stream));
+      SH_HIP(hipMemcpy2DAsync(tr + (size_t)w * L, (size_t)world * L * 8, (const char*)gr + (size_t)w * b.stride, (size_t)L * 8, (size_t)L * 8, Q, hipMemcpyDeviceToDevice, c.stream));
     }
     return dhr_merge_topk(c.device, Q, world * L, ts, tr, k, os, orow, c.stream);
   }
-  int read_failed(const std::vector<int32_t*>& n_failed, const std::vector<int32_t*>& fail_ids, std::vector<int32_t>& ids) override {
-    int32_t nf = 0;
+  int read_failed(const std::vector<int32_t*>& rec, const std::vector<int32_t*>& fail_ids, std::vector<int32_t>& ids, int* peer_status, int* peer_rank) override {
+    int32_t h[4] = {0, 0, 0, 0};
     SH_HIP(hipSetDevice(sh[0].device));
-    SH_HIP(hipMemcpyAsync(&nf, n_failed[0], 4, hipMemcpyDeviceToHost, sh[0].stream));
+    SH_HIP(hipMemcpyAsync(h, rec[0], 16, hipMemcpyDeviceToHost, sh[0].stream));
     for (int i = 0; i < n_local; ++i) SH_HIP(hipStreamSynchronize(sh[i].stream));
+    *peer_status = h[1]; *peer_rank = h[2];
+    const int32_t nf = fail_ids[0] ? h[0] : 0;
     ids.resize((size_t)nf);
     if (nf > 0) SH_HIP(hipMemcpy(ids.data(), fail_ids[0], (size_t)nf * 4, hipMemcpyDeviceToHost));
     return DHR_OK;
@@ -615,6 +756,9 @@ struct HostBackend : Backend {
   std::vector<int32_t> sub_ids;
 
   void* alloc(int, size_t bytes) override { mem.emplace_back(bytes ? bytes : 16); return mem.back().data(); }
+  int zero(int, void* p, size_t bytes) override { memset(p, 0, bytes); return DHR_OK; }
+  int put_status(int, void* block, const Block& b, int status) override { const int32_t st = status; memcpy((char*)block + b.payload, &st, 4); return DHR_OK; }
+  int fold_status(int, const void*, const Block&, int32_t*) override { return DHR_OK; }      // (gather read the records)
   int set_share(int, int s) override { share = s; return DHR_OK; }
   int sample_rank(int, int k) override { return shard->sample_rank(shard->user, k, share); }
   int union_rank(int, int k) override { return shard->union_rank(shard->user, k); }
@@ -636,32 +780,44 @@ struct HostBackend : Backend {
   int pre(int, const dhr_query_batch* qb, int k, int r_local, float* scores) override { return shard->pre(shard->user, qb, k, share, r_local, scores) == 0 ? DHR_OK : dhr_set_error_message(DHR_ERR_INTERNAL, "host shard: pre failed"); }
   int begin_rest(int, const float* tau, float* sample) override { return shard->begin_rest(shard->user, tau, sample) == 0 ? DHR_OK : dhr_set_error_message(DHR_ERR_INTERNAL, "host shard: begin_rest failed"); }
   int search(int, const dhr_query_batch* qb, int k, float* s, int64_t* r) override { return shard->search(shard->user, qb, k, s, r) == 0 ? DHR_OK : dhr_set_error_message(DHR_ERR_INTERNAL, "host shard: search failed"); }
-  int gather(const std::vector<const void*>& send, const std::vector<void*>& recv, size_t bytes) override {
-    if (world == 1) { memcpy(recv[0], send[0], bytes); return DHR_OK; }
-    return cb(cb_user, send[0], recv[0], (int64_t)bytes) == 0 ? DHR_OK : dhr_set_error_message(DHR_ERR_INTERNAL, "the caller's all-gather callback failed");
+  int gather(const std::vector<const void*>& send, const std::vector<void*>& recv, const Block& b) override {
+    if (world == 1) memcpy(recv[0], send[0], b.stride);
+    else if (cb(cb_user, send[0], recv[0], (int64_t)b.stride) != 0) return dhr_set_error_message(DHR_ERR_INTERNAL, "the caller's all-gather callback failed");
+    int who = 0;
+    if (const int st = host_block_status(recv[0], world, b, &who)) return peer_error(who, st);
+    return DHR_OK;
   }
   int min_over_ranks(int32_t v[12]) override {
     if (world <= 1) return DHR_OK;
     std::vector<int32_t> all((size_t)world * 12);
-    SH_TRY(gather({v}, {all.data()}, 48));
+    if (cb(cb_user, v, all.data(), 48) != 0) return dhr_set_error_message(DHR_ERR_INTERNAL, "the caller's all-gather callback failed");
     for (int w = 0; w < world; ++w)
       for (int j = 0; j < 12; ++j) v[j] = std::min(v[j], all[(size_t)w * 12 + j]);
     return DHR_OK;
   }
-  int union_threshold(int, const float* gathered, int Q, int r, int ru, float* tau) override {
+  // [world] sections of [Q, L] floats / int64, b.stride bytes apart -> the dense [world, Q, L] arrays dhr_merge_topk_lists_host takes
+  void densify(const void* g, const Block& b, size_t section_bytes, std::vector<char>& out) const {
+    out.resize((size_t)world * section_bytes);
+    for (int w = 0; w < world; ++w) memcpy(out.data() + (size_t)w * section_bytes, (const char*)g + (size_t)w * b.stride, section_bytes);
+  }
+  int union_threshold(int, const float* gathered, const Block& b, int Q, int r, int ru, float* tau) override {
     std::vector<float> merged((size_t)Q * ru);
-    SH_TRY(dhr_merge_topk_lists_host(Q, world, r, gathered, nullptr, ru, merged.data(), nullptr));
+    std::vector<char> dense;
+    densify(gathered, b, (size_t)Q * r * 4, dense);
+    SH_TRY(dhr_merge_topk_lists_host(Q, world, r, (const float*)dense.data(), nullptr, ru, merged.data(), nullptr));
     for (int q = 0; q < Q; ++q) tau[q] = merged[(size_t)q * ru + (ru - 1)];
     return DHR_OK;
   }
-  int union_threshold2(int, const float* gathered, int Q, int r, int ru, float* tau) override {
+  int union_threshold2(int, const float* gathered, const Block& b, int Q, int r, int ru, float* tau) override {
     std::vector<float> merged((size_t)Q * ru);
-    SH_TRY(dhr_merge_topk_lists_host(Q, world, r, gathered, nullptr, ru, merged.data(), nullptr));
+    std::vector<char> dense;
+    densify(gathered, b, (size_t)Q * r * 4, dense);
+    SH_TRY(dhr_merge_topk_lists_host(Q, world, r, (const float*)dense.data(), nullptr, ru, merged.data(), nullptr));
     for (int q = 0; q < Q; ++q) tau[q] = std::max(tau[q], merged[(size_t)q * ru + (ru - 1)]);
     return DHR_OK;
   }
-  int flag_failures(int, const int32_t* counts, int Q, int k, int kk, int32_t* fail_ids, int32_t* n_failed) override {
-    host_flag_failures(counts, world, Q, k, kk, fail_ids, n_failed);
+  int flag_failures(int, const int32_t* counts, const Block& b, int Q, int k, int kk, int32_t* fail_ids, int32_t* rec) override {
+    host_flag_failures(counts, b, world, Q, k, kk, fail_ids, rec);
     return DHR_OK;
   }
   int prefix(int, const float* s, const int64_t* r, int k, int kk, int Q, float* os, int64_t* orow) override {
@@ -671,11 +827,15 @@ struct HostBackend : Backend {
     }
     return DHR_OK;
   }
-  int merge(int, int Q, int L, const float* gs, const int64_t* gr, int k, float* os, int64_t* orow) override {
-    return dhr_merge_topk_lists_host(Q, world, L, gs, gr, k, os, orow);
+  int merge(int, int Q, int L, const float* gs, const int64_t* gr, const Block& b, int k, float* os, int64_t* orow) override {
+    std::vector<char> ds, dr;
+    densify(gs, b, (size_t)Q * L * 4, ds);
+    densify(gr, b, (size_t)Q * L * 8, dr);
+    return dhr_merge_topk_lists_host(Q, world, L, (const float*)ds.data(), (const int64_t*)dr.data(), k, os, orow);
   }
-  int read_failed(const std::vector<int32_t*>& n_failed, const std::vector<int32_t*>& fail_ids, std::vector<int32_t>& ids) override {
-    ids.assign(fail_ids[0], fail_ids[0] + *n_failed[0]);
+  int read_failed(const std::vector<int32_t*>& rec, const std::vector<int32_t*>& fail_ids, std::vector<int32_t>& ids, int* peer_status, int* peer_rank) override {
+    *peer_status = 0; *peer_rank = 0;                 // (host-visible blocks: a failure ended the step at its gather)
+    if (fail_ids[0]) ids.assign(fail_ids[0], fail_ids[0] + rec[0][0]); else ids.clear();
     return DHR_OK;
   }
   int sub_batch(int, const dhr_query_batch* in, const std::vector<int32_t>& ids, dhr_query_batch* out, int32_t** ids_mem) override {
@@ -707,14 +867,14 @@ int deliver(const ShardCtx& c, int Q, int k, const float* ds, const int64_t* dr,
 }  // namespace
 
 
-extern "C" int dhr_comm_unique_id(void* out, int32_t out_bytes) {
+extern "C" int dhr_comm_unique_id(void* out, int32_t out_bytes) try {
   if (!out || out_bytes < (int32_t)NCCL_UNIQUE_ID_BYTES) return dhr_set_error_message(DHR_ERR_INVALID, "the unique id needs a 128-byte buffer");
   ncclUniqueId id;
   SH_NCCL(ncclGetUniqueId(&id));
   memcpy(out, id.internal, NCCL_UNIQUE_ID_BYTES);
   return DHR_OK;
-}
-extern "C" int dhr_comm_create(const void* unique_id, int32_t world, int32_t rank, int32_t device, dhr_comm** out) {
+} DHR_CATCH_STATUS
+extern "C" int dhr_comm_create(const void* unique_id, int32_t world, int32_t rank, int32_t device, dhr_comm** out) try {
   if (!unique_id || !out || world < 1 || rank < 0 || rank >= world) return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
   SH_HIP(hipSetDevice(device));
   ncclUniqueId id;
@@ -725,33 +885,34 @@ extern "C" int dhr_comm_create(const void* unique_id, int32_t world, int32_t ran
   if (r != ncclSuccess) { delete c; return dhr_set_error_message(DHR_ERR_HIP, (std::string("ncclCommInitRank: ") + ncclGetErrorString(r)).c_str()); }
   *out = c;
   return DHR_OK;
-}
-extern "C" int dhr_comm_wrap(void* nccl_comm, int32_t world, int32_t rank, int32_t device, dhr_comm** out) {
+} DHR_CATCH_STATUS
+extern "C" int dhr_comm_wrap(void* nccl_comm, int32_t world, int32_t rank, int32_t device, dhr_comm** out) try {
   if (!nccl_comm || !out || world < 1 || rank < 0 || rank >= world) return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
   dhr_comm* c = new dhr_comm();
   c->comm = (ncclComm_t)nccl_comm; c->world = world; c->rank = rank; c->device = device; c->owned = false;
   *out = c;
   return DHR_OK;
-}
-extern "C" int dhr_comm_create_callback(int32_t world, int32_t rank, int32_t device, dhr_allgather_fn allgather, void* user, dhr_comm** out) {
+} DHR_CATCH_STATUS
+extern "C" int dhr_comm_create_callback(int32_t world, int32_t rank, int32_t device, dhr_allgather_fn allgather, void* user, dhr_comm** out) try {
   if (!allgather || !out || world < 1 || rank < 0 || rank >= world) return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
   dhr_comm* c = new dhr_comm();
   c->cb = allgather; c->cb_user = user; c->world = world; c->rank = rank; c->device = device; c->owned = false;
   *out = c;
   return DHR_OK;
-}
-extern "C" void dhr_comm_destroy(dhr_comm* c) {
+} DHR_CATCH_STATUS
+extern "C" void dhr_comm_destroy(dhr_comm* c) try {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->owned && c->comm) (void)ncclCommDestroy(c->comm);
+  if (c->owned && c->comm && !c->dead) (void)ncclCommDestroy(c->comm);      // (an aborted communicator is gone already)
   (void)hipFree(c->arena);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   delete c;
-}
+} DHR_CATCH_VOID
 
-extern "C" int32_t dhr_debug_sharded_repairs(void) { return g_last_repairs; }
-extern "C" int dhr_comm_info(const dhr_comm* c, int32_t what) {
+extern "C" int32_t dhr_debug_sharded_repairs(void) try { return g_last_repairs; } DHR_CATCH_VALUE(0)
+extern "C" int dhr_comm_info(const dhr_comm* c, int32_t what) try {
   if (!c) return dhr_set_error_message(DHR_ERR_INVALID, "null communicator");
+  if (c->dead) return dhr_set_error_message(DHR_ERR_INVALID, "the communicator was aborted (dhr_comm_abort)");
   int v = 0;
   switch (what) {
     case DHR_COMM_TRANSPORT: return c->comm ? 0 : 1;
@@ -760,29 +921,37 @@ extern "C" int dhr_comm_info(const dhr_comm* c, int32_t what) {
     case DHR_COMM_DEVICE: if (!c->comm) return c->device; SH_NCCL(ncclCommCuDevice(c->comm, &v)); return v;
     default: return dhr_set_error_message(DHR_ERR_INVALID, "unknown dhr_comm_info field");
   }
-}
-extern "C" void dhr_comm_abort(dhr_comm* c) {
-  if (!c) return;
+} DHR_CATCH_STATUS
+// Only aborts and marks the handle: the thread that was blocked in one of the communicator's collectives returns through sharded_core /
+// HipBackend, which still use the struct and its arena (until round 5 this freed both under that thread: use after free).  The caller
+// frees the handle with dhr_comm_destroy once that thread is back.
+extern "C" void dhr_comm_abort(dhr_comm* c) try {
+  if (!c || c->dead) return;
+  c->dead = true;
   if (c->owned && c->comm) (void)ncclCommAbort(c->comm);
-  c->comm = nullptr;
-  dhr_comm_destroy(c);
-}
+} DHR_CATCH_VOID
 
 extern "C" int dhr_search_sharded_host(const dhr_host_shard* shard, int32_t world, int32_t rank, dhr_allgather_fn allgather, void* user,
-                                       const dhr_query_batch* qb, int32_t k, float* out_scores, int64_t* out_rows) {
-  if (!shard || !shard->sample_rank || !shard->union_rank || !shard->begin || !shard->finish || !shard->search || !qb || !out_scores || !out_rows ||
+                                       const dhr_query_batch* qb, int32_t k, float* out_scores, int64_t* out_rows) try {
+  if (!shard) return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
+  if (shard->struct_size != (uint32_t)sizeof(dhr_host_shard))
+    return dhr_set_error_message(DHR_ERR_INVALID, "dhr_host_shard::struct_size does not match this library (the caller was built against another version of dhr_hip.h)");
+  if (!shard->sample_rank || !shard->union_rank || !shard->begin || !shard->finish || !shard->search || !qb || !out_scores || !out_rows ||
       k <= 0 || world < 1 || rank < 0 || rank >= world || (world > 1 && !allgather))
     return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
   if (qb->mem_kind != DHR_MEM_HOST) return dhr_set_error_message(DHR_ERR_INVALID, "host shards take host query batches");
+  dhr::alloc_checkpoint();
   HostBackend B;
   B.world = world; B.n_local = 1;
   B.shard = shard; B.cb = allgather; B.cb_user = user;
   return sharded_core(B, qb, k, {out_scores}, {out_rows});
-}
+} DHR_CATCH_STATUS
 
 extern "C" int dhr_search_sharded(dhr_index* shard, dhr_comm* comm, const dhr_query_batch* qb, int32_t k, float* out_scores, int64_t* out_rows,
-                                  int32_t out_mem_kind, void* stream) {
+                                  int32_t out_mem_kind, void* stream) try {
   if (!shard || !comm || !qb || !out_scores || !out_rows || k <= 0) return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
+  if (comm->dead) return dhr_set_error_message(DHR_ERR_INVALID, "the communicator was aborted (dhr_comm_abort)");
+  dhr::alloc_checkpoint();
   const int device = dhr_index_device(shard);
   if (device != comm->device) return dhr_set_error_message(DHR_ERR_INVALID, "the shard and the communicator live on different devices");
   SH_HIP(hipSetDevice(device));
@@ -805,12 +974,12 @@ extern "C" int dhr_search_sharded(dhr_index* shard, dhr_comm* comm, const dhr_qu
   else (void)hipStreamSynchronize((hipStream_t)stream);
   arena.finish();
   return rc;
-}
+} DHR_CATCH_STATUS
 
 namespace { struct LocalScratch { void* base = nullptr; size_t cap = 0; }; }
 
 extern "C" int dhr_search_sharded_local(dhr_index** shards, int32_t n_shards, const dhr_query_batch* qb, int32_t k, float* out_scores,
-                                        int64_t* out_rows, int32_t out_mem_kind, void* stream) {
+                                        int64_t* out_rows, int32_t out_mem_kind, void* stream) try {
   if (!shards || n_shards < 1 || n_shards > 64 || !qb || !out_scores || !out_rows || k <= 0) return dhr_set_error_message(DHR_ERR_INVALID, "bad argument (1 <= n_shards <= 64)");
   std::vector<LocalScratch> scratch(n_shards);
   std::vector<Arena> arenas;
@@ -849,4 +1018,4 @@ extern "C" int dhr_search_sharded_local(dhr_index** shards, int32_t n_shards, co
     if (own[i]) (void)hipStreamDestroy(own[i]);
   }
   return rc;
-}
+} DHR_CATCH_STATUS

@@ -190,14 +190,17 @@ class ShardComm:
             self._h = None
 
     def abort(self):
-        """ncclCommAbort: callable while another thread of this process is blocked in one of the communicator's collectives."""
+        """ncclCommAbort: callable while another thread of this process is blocked in one of the communicator's collectives.  The handle
+        is only marked dead (the blocked thread unwinds through code that still uses it); close() frees it -- call that once the thread
+        is back.  A handle that is never closed after an abort is a small leak, never a use-after-free."""
         if getattr(self, "_h", None):
             self._lib.dhr_comm_abort(self._h)
-            self._h = None
+            self._aborted = True
 
     def __del__(self):
         try:
-            self.close()
+            if not getattr(self, "_aborted", False):      # (an aborted handle may still be in use by the thread it unblocked: bring_up closes it)
+                self.close()
         except Exception:  # noqa: BLE001
             pass
 
@@ -299,6 +302,9 @@ def bring_up(device: int, group=None, trial=None, timeout_s: float = 120.0, want
     if c is not None:
         try:
             c.abort()              # also unblocks a worker thread parked in one of this communicator's collectives
+            th.join(5.0)           # ... which unwinds through the library with the handle still in its hands: free it only once it is back
+            if not th.is_alive():
+                c.close()
         except Exception:  # noqa: BLE001
             pass
     comm = ShardComm(device, ctl, "host")
@@ -454,7 +460,7 @@ def sharded_search_host(shard, q_value, q_index, k: int, group=None):
 
     has_mid = hasattr(shard, "search_mid")          # optional: the second threshold agreement (dhr_search_mid)
     has_pre = hasattr(shard, "search_pre")          # optional: the first agreement in two rounds (dhr_search_pre / dhr_search_begin_rest)
-    hs = _lib.HostShard(None, _lib.HS_SAMPLE_RANK(lambda _u, kk, share: int(shard.sample_rank(int(kk), int(share)))),
+    hs = _lib.HostShard(C.sizeof(_lib.HostShard), 0, None, _lib.HS_SAMPLE_RANK(lambda _u, kk, share: int(shard.sample_rank(int(kk), int(share)))),
                         _lib.HS_UNION_RANK(lambda _u, kk: int(shard.union_rank(int(kk)))), _lib.HS_BEGIN(guard(cb_begin)),
                         _lib.HS_FINISH(guard(cb_finish)), _lib.HS_SEARCH(guard(cb_search)),
                         _lib.HS_MID_RANKS(guard(cb_mid_ranks)) if has_mid else _lib.HS_MID_RANKS(),

@@ -27,14 +27,17 @@
 extern "C" {
 #endif
 
-#define DHR_VERSION 104 /* 0.1.4: dhr_search_pre / dhr_search_pre_ranks / dhr_search_begin_rest (first agreement of the sharded search in two rounds), dhr_host_shard::pre_ranks / pre / begin_rest, DHR_PARAM_LIST_STRIDE; 0.1.3: dhr_comm_info / dhr_comm_abort */
+#define DHR_VERSION 105 /* 0.1.5: exception barrier on every entry point (DHR_ERR_NOMEM), a failed sharded step is collective (DHR_ERR_PEER), dhr_abi_size, dhr_host_shard::struct_size, dhr_comm_abort no longer frees the handle, counts + list prefixes in ONE all-gather; 0.1.4: dhr_search_pre / dhr_search_pre_ranks / dhr_search_begin_rest (first agreement of the sharded search in two rounds), dhr_host_shard::pre_ranks / pre / begin_rest, DHR_PARAM_LIST_STRIDE; 0.1.3: dhr_comm_info / dhr_comm_abort */
 
 typedef enum dhr_status {
   DHR_OK = 0,
   DHR_ERR_INVALID = -1,     /* bad argument (NULL, negative size, unsupported dtype ...) */
   DHR_ERR_UNSUPPORTED = -2, /* legal input the kernels do not cover (see dhr_last_error) */
   DHR_ERR_HIP = -3,         /* a HIP runtime call failed (no device, OOM, launch failure) */
-  DHR_ERR_INTERNAL = -4
+  DHR_ERR_INTERNAL = -4,
+  DHR_ERR_NOMEM = -5,       /* a host allocation failed (std::bad_alloc caught at the boundary); the handle stays usable */
+  DHR_ERR_PEER = -6         /* sharded search: ANOTHER rank failed in this step (its status travelled with the step's all-gathers); every rank
+                               returns from the same step with an error -- the failing rank with its own status, the others with this one */
 } dhr_status;
 
 typedef enum dhr_idx_dtype { DHR_IDX_NONE = 0, DHR_IDX_U8 = 1, DHR_IDX_I8 = 2, DHR_IDX_I16 = 3 } dhr_idx_dtype;
@@ -156,6 +159,9 @@ int dhr_version(void);
  * dhr_file_info }.  A binding compares them with its own declarations at load time (a stale library whose struct layout
  * differs would otherwise corrupt memory silently). */
 void dhr_abi_sizes(int32_t out[4]);
+/* The same, one struct at a time (new structs get an id here instead of a longer array): returns sizeof as compiled, or a negative status. */
+enum { DHR_ABI_INDEX_DESC = 0, DHR_ABI_QUERY_BATCH = 1, DHR_ABI_SEARCH_STATS = 2, DHR_ABI_FILE_INFO = 3, DHR_ABI_HOST_SHARD = 4 };
+int32_t dhr_abi_size(int32_t which);
 /* Message of the last failure on the calling thread ("" if none). */
 const char* dhr_last_error(void);
 
@@ -338,6 +344,10 @@ int dhr_debug_query_margins(dhr_index* index, const dhr_query_batch* queries, fl
 /* Test hook (host code only, no device needed): the corpus tile that position `seq` of a bound-GEMM launch maps to, computed with
  * the kernels' division-free arithmetic (out[0]) and with plain integer division (out[1]); the two must agree for every input. */
 void dhr_debug_seq_to_tile(int64_t seq, int32_t map_mode, int32_t period, int64_t head, int64_t perm_mul, int64_t perm_n, int64_t out[2]);
+/* Test hook of the exception barrier: arms a failure of the library's n-th HOST allocation from now (operator new inside the library only --
+ * the process' allocator is not interposed; 0 disarms; the environment variable DHR_TEST_FAIL_ALLOC=n arms it at load time).  The entry
+ * point in which it fires returns DHR_ERR_NOMEM.  Returns the number of host allocations the library has made so far. */
+int64_t dhr_debug_fail_alloc(int64_t n);
 /* Test hook: how many queries the calling thread's last dhr_search_sharded* call redid with local thresholds (its repair path: a
  * correct result either way, but each repaired query costs the step an extra pass over its query tile). */
 int32_t dhr_debug_sharded_repairs(void);
@@ -404,7 +414,9 @@ void dhr_comm_destroy(dhr_comm* comm);
 enum { DHR_COMM_TRANSPORT = 0, DHR_COMM_WORLD = 1, DHR_COMM_RANK = 2, DHR_COMM_DEVICE = 3 };
 int dhr_comm_info(const dhr_comm* comm, int32_t what);
 /* Way out of a bring-up that hangs (a peer never reached ncclCommInitRank / a collective): ncclCommAbort instead of ncclCommDestroy --
- * may be called from another host thread than the one blocked in the collective; the handle is gone afterwards. */
+ * may be called from another host thread than the one blocked in the collective.  The handle is only marked dead (every later call on it
+ * fails with DHR_ERR_INVALID): the thread that was blocked unwinds through code that still uses it, so the caller frees it with
+ * dhr_comm_destroy once that thread has returned. */
 void dhr_comm_abort(dhr_comm* comm);
 /* The sharded control flow over a shard the CALLER implements in host memory (no device is touched): test / bring-up hook.  The
  * callbacks mirror the staged C ABI: sample_rank / union_rank (dhr_search_sample_rank with DHR_PARAM_SAMPLE_SHARE = share /
@@ -412,6 +424,9 @@ void dhr_comm_abort(dhr_comm* comm);
  * [n_queries, k] sorted lists with (-inf, -1) tails + per-query counts of rows >= tau, -1 = incomplete), search (plain top-k).
  * All return 0 on success; all arrays are host memory; rows are global.  The query batch must be a host batch. */
 typedef struct dhr_host_shard {
+  uint32_t struct_size; /* sizeof(dhr_host_shard) as the CALLER compiled it: dhr_search_sharded_host rejects any other value (the struct has grown
+                           between versions; a shorter caller struct would otherwise be read past its end) */
+  uint32_t reserved;
   void* user;
   int32_t (*sample_rank)(void* user, int32_t k, int32_t share);
   int32_t (*union_rank)(void* user, int32_t k);

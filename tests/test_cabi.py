@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/dhr_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names
-    assert lib.dhr_version() == 104
+    assert lib.dhr_version() == 105
 
 
 def test_struct_layouts_match_header():

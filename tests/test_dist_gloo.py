@@ -284,3 +284,67 @@ def test_bring_up_degrades_collectively(tmp_path, env):
         assert "still blocked" in notes[0]
     if "DHR_TEST_COMM_FAIL_RANK" in env:
         assert "injected failure" in notes[1]
+
+
+# ---- a failure on ONE rank in the middle of a sharded step is COLLECTIVE (round 6): the failing rank keeps to the sequence of all-gathers,
+# its status travels in the status record of every block it sends, and every rank leaves the step at the same gather -- the failing rank with
+# its own status, the others with DHR_ERR_PEER -- instead of waiting in their next collective for the group's timeout.
+def _failing_worker(rank, world, port, tmp, where):
+    sys.path.insert(0, ROOT)
+    import time
+    import datetime
+    import torch.distributed as dist
+    from dhr_amd import dist as D, _lib
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        rng = np.random.default_rng(7)
+        n, k, nq = 4000, 60, 5
+        cv = rng.standard_normal((n, 16)).astype(np.float32)
+        q = rng.standard_normal((nq, 16)).astype(np.float32)
+        if where == "search":              # the failure happens in the REPAIR step: query 0 must fail its count check first
+            for r_ in range(world):
+                lo_ = D.shard_bounds(n, world, r_)[0]
+                cv[lo_:lo_ + 400:4] += 3.0 * q[0] / np.linalg.norm(q[0])
+        lo, hi = D.shard_bounds(n, world, rank)
+        base = {"begin": _FakeShard, "finish": _FakeShard, "search": _FakeShard, "mid": _FakeShardMid, "pre": _FakeShardPre, "rest": _FakeShardPre}[where]
+        bad = world - 1                    # the rank whose callback fails
+
+        class Failing(base):
+            pass
+        name = {"begin": "search_begin", "finish": "search_finish", "search": "search", "mid": "search_mid", "pre": "search_pre", "rest": "search_begin_rest"}[where]
+        if rank == bad:
+            def boom(self, *a):
+                raise RuntimeError("injected shard failure in %s" % name)
+            setattr(Failing, name, boom)
+        shard = Failing(cv[lo:hi], lo)
+        dist.barrier()
+        t0 = time.time()
+        with pytest.raises(_lib.DhrError) as ei:
+            D.sharded_search_host(shard, q, None, k)
+        dt = time.time() - t0
+        open(os.path.join(tmp, f"fail{rank}"), "w").write("%d %.3f %s" % (ei.value.status, dt, ei.value))
+        # the group is still usable: every rank left the step at the same collective
+        ok_shard = base(cv[lo:hi], lo)
+        ms, mr = D.sharded_search_host(ok_shard, q, None, k)
+        full = q.astype(np.float64) @ cv.astype(np.float64).T
+        for i in range(nq):
+            assert set(mr[i].tolist()) == set(np.argsort(-full[i], kind="stable")[:k].tolist())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("where", ["begin", "finish", "mid", "pre", "rest", "search"])
+def test_failed_shard_step_is_collective(tmp_path, where, world):
+    import torch.multiprocessing as mp
+    port = 30900 + (os.getpid() % 2000) + 7 * world + ["begin", "finish", "mid", "pre", "rest", "search"].index(where)
+    mp.spawn(_failing_worker, args=(world, port, str(tmp_path), where), nprocs=world, join=True)
+    from dhr_amd import _lib
+    for r in range(world):
+        status, dt, msg = open(tmp_path / f"fail{r}").read().split(" ", 2)
+        assert float(dt) < 1.0, (r, dt)                       # nobody waited for a timeout
+        if r == world - 1:
+            assert int(status) == _lib.ERR_INTERNAL and "host shard" in msg, msg
+        else:
+            assert int(status) == _lib.ERR_PEER and ("rank %d failed" % (world - 1)) in msg, msg

@@ -777,6 +777,85 @@ def test_two_tier_candidate_lists(G, gated_image, stride):
         ix.close()
 
 
+@pytest.mark.parametrize("aux_cus,exclusive", [(64, 0), (128, 1)])
+def test_two_tier_lists_with_cu_masked_streams(G, aux_cus, exclusive):
+    """DHR_PARAM_AUX_CUS / DHR_PARAM_GEMM_EXCLUSIVE put the main pass' bound GEMM and its refine / rescoring on CU-masked streams of their own;
+    both must enter the pass BEHIND the kernel that plans the second tier of the bound lists (until round 5 they waited on an event recorded
+    before it: a GEMM that spilled past the uniform stride could pair a new ovf_cap with an old ovf_off -- the round-5 advisor's finding).  A
+    small stride, hot queries, CU masks on: the result is the default configuration's, bit for bit, and no query is lost silently."""
+    from dhr_amd import synth, _lib
+    cv, ci, qv, qi = synth.make_pair(92, 300_000, 640, 768, 64)
+    q = qv.astype(np.float32)
+    q[:40, :768] *= 3.0
+    k = 200
+    ix = G.GipIndex(cv, ci)
+    try:
+        s0, r0 = ix.search(q, qi, k)
+        ix.set_param(_lib.PARAM_LIST_STRIDE, 256)
+        ix.set_param(_lib.PARAM_AUX_CUS, aux_cus)
+        ix.set_param(_lib.PARAM_GEMM_EXCLUSIVE, exclusive)
+        for _ in range(3):                                 # (the plan of a step reads what the previous one left in the workspace)
+            s1, r1 = ix.search(q, qi, k)
+            np.testing.assert_array_equal(r1, r0)
+            np.testing.assert_array_equal(s1, s0)
+        c32 = cv.astype(np.float32)
+        for i in (0, 39, 333):
+            O.check_topk(r1[i], s1[i], O.gip_scores_f64(q[i], qi[i], c32, ci), k)
+    finally:
+        ix.close()
+
+
+def test_allocation_failures_with_a_device(G):
+    """The exception barrier with a device behind it (tests/test_abi_guard.py is the CPU part): every host allocation of dhr_index_create and of
+    dhr_search fails once -- `new dhr_index()`, the std::vectors of the index build and of the controller, the event lists -- and each call
+    comes back with DHR_ERR_NOMEM and a message; nothing unwinds through ctypes, the handle stays usable, the result is unchanged."""
+    import ctypes as C
+    from dhr_amd import synth, _lib
+    lib = _lib.load()
+    cv, ci, qv, qi = synth.make_pair(93, 70_000, 24, 768, 64)
+    q = qv.astype(np.float32)
+    k = 50
+    d = _lib.IndexDesc(0, _lib.MEM_HOST, cv.shape[0], 768, 64, cv.ctypes.data, cv.shape[1], ci.ctypes.data, _lib.idx_code(ci.dtype), 0, ci.shape[1], 0)
+
+    def create():
+        h = C.c_void_p()
+        rc = lib.dhr_index_create(C.byref(d), C.byref(h))
+        return rc, h
+    a0 = lib.dhr_debug_fail_alloc(0)
+    rc, h = create()
+    assert rc == 0
+    n_create = lib.dhr_debug_fail_alloc(0) - a0
+    assert n_create >= 3
+    for i in range(1, n_create + 1):
+        lib.dhr_debug_fail_alloc(i)
+        rc, hh = create()
+        lib.dhr_debug_fail_alloc(0)
+        assert rc == _lib.ERR_NOMEM and not hh.value, (i, rc, lib.dhr_last_error())
+    qb, keep = _lib.make_query_batch(q, qi)
+    s0, r0 = np.zeros((24, k), np.float32), np.zeros((24, k), np.int64)
+    s1, r1 = np.zeros((24, k), np.float32), np.zeros((24, k), np.int64)
+    lib.dhr_index_set_param(h, _lib.PARAM_PROFILE, 1)       # (the timers allocate too)
+    assert lib.dhr_search(h, C.byref(qb), k, s0.ctypes.data, r0.ctypes.data, _lib.MEM_HOST, None) == 0      # warm: the workspace exists
+    a0 = lib.dhr_debug_fail_alloc(0)
+    assert lib.dhr_search(h, C.byref(qb), k, s0.ctypes.data, r0.ctypes.data, _lib.MEM_HOST, None) == 0
+    n_search = lib.dhr_debug_fail_alloc(0) - a0
+    assert n_search >= 3
+    for i in range(1, n_search + 1):
+        lib.dhr_debug_fail_alloc(i)
+        rc = lib.dhr_search(h, C.byref(qb), k, s1.ctypes.data, r1.ctypes.data, _lib.MEM_HOST, None)
+        lib.dhr_debug_fail_alloc(0)
+        assert rc == _lib.ERR_NOMEM and b"memory" in lib.dhr_last_error(), (i, rc, lib.dhr_last_error())
+        assert lib.dhr_search(h, C.byref(qb), k, s1.ctypes.data, r1.ctypes.data, _lib.MEM_HOST, None) == 0      # the handle is usable right away
+        np.testing.assert_array_equal(r1, r0)
+        np.testing.assert_array_equal(s1, s0)
+    print("\n[host allocations: dhr_index_create %d, dhr_search %d -- each failed once]" % (n_create, n_search))
+    c32 = cv.astype(np.float32)
+    for i in (0, 23):
+        O.check_topk(r0[i], s0[i], O.gip_scores_f64(q[i], qi[i], c32, ci), k)
+    lib.dhr_index_destroy(h)
+    del keep
+
+
 @pytest.mark.parametrize("mid", [False, True])
 @pytest.mark.parametrize("kind", ["hybrid", "dense"])
 def test_staged_sharded_search_common_threshold(G, kind, gated_image, mid):
