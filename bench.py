@@ -124,7 +124,7 @@ def cpu_baseline_legs(sample, k, n_full, q_one, q_all):
                           "sample": "%d queries x %d rows, same loop with torch.set_num_threads(%d); %.3f s/query measured, x%.2f"
                                     % (q_all, c32.shape[0], cores, sa, scale)},
             "host_cpus": os.cpu_count() or 1, "affinity_cpus": usable, "torch_num_threads_in_all_cores_leg": threads_seen,
-            "time_budget": "the default run spends ~15 s (1 thread) + ~25 s (all cores) here; SURVEY.md section 8(d)'s 32 queries: --cpu-queries 32 --cpu-queries-1t 32 (~3.5 min)",
+            "time_budget": "SURVEY.md section 8(d): 32 queries on a 1 M-row slice per leg (~3.5 min for both); --quick runs 4 (1 thread) + 8 (all cores) queries in ~40 s",
             "note": "the reference's op sequence is three elementwise passes over the fp32 corpus per query (mask, product, einsum): one query moves ~15 GB through "
                     "one socket's memory system, and torch parallelises each pass over the rows but the passes stay bandwidth-bound and serial -- the all-cores leg is "
                     "barely faster than one thread, as measured"}
@@ -162,8 +162,15 @@ def main():
     ap.add_argument("--list-stride", type=int, default=0, help="tuning: DHR_PARAM_LIST_STRIDE (uniform slots per query of the bound lists; 262144 = the uniform lists of rounds 3-4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline slice (SURVEY.md section 8d: 1 M)")
-    ap.add_argument("--cpu-queries", type=int, default=8, help="queries of the all-cores CPU leg (~3.3 s per query and M rows on the 256-thread host; section 8d's 32 with --cpu-queries 32)")
-    ap.add_argument("--cpu-queries-1t", type=int, default=4, help="queries of the one-thread CPU leg (~3.5 s per query and M rows)")
+    ap.add_argument("--cpu-queries", type=int, default=32, help="queries of the all-cores CPU leg (SURVEY.md section 8d: 32 queries on a 1 M-row slice; ~3 s per query and M rows on the 256-thread host)")
+    ap.add_argument("--cpu-queries-1t", type=int, default=32, help="queries of the one-thread CPU leg (section 8d: 32; ~3.3 s per query and M rows)")
+    ap.add_argument("--quick", action="store_true", help="the CPU legs on 8 (all cores) / 4 (one thread) queries instead of section 8d's 32 + 32 (~40 s instead of ~3.5 min)")
+    ap.add_argument("--index-path", default="", help="REAL data: the reference's index pickle ([value, index, ids], retrieval/index.py output) or a device-ready index file (GipIndex.save); "
+                                                     "with --query-path the timed steps run on it instead of the synthetic corpus (N = 1)")
+    ap.add_argument("--query-path", default="", help="REAL data: the reference's query pickle ([value, index, qids])")
+    ap.add_argument("--qrels", default="", help="REAL data: qrels (qid 0 docid rel, or the tab-separated layout of retrieval/rcap_eval.py) -> nDCG@10 / MRR@10 / R@1000 of the timed search's lists, attached as `effectiveness`")
+    ap.add_argument("--emb-dim", type=int, default=768, help="REAL data: gated columns of the records (the reference's --emb_dim)")
+    ap.add_argument("--lamda", type=float, default=1.0, help="REAL data: the reference's --lamda (CLS tail of the queries scaled in fp32)")
     ap.add_argument("--parity-rows", type=int, default=200_000)
     ap.add_argument("--parity-queries", type=int, default=24)
     ap.add_argument("--seed", type=int, default=1237)
@@ -173,6 +180,10 @@ def main():
     ap.add_argument("--data", default="iid", choices=["iid", "clustered"], help="dense columns: iid Gaussian (SURVEY 8d) or the structured variant (2 000 clusters, decaying spectrum, 1 %% near-duplicate rows, 5 %% hot queries)")
     ap.add_argument("--dist-backend", default="nccl", help="testing only: 'gloo' lets several ranks share ONE GPU (with DHR_BENCH_SINGLE_DEVICE=1)")
     args = ap.parse_args()
+    if args.quick:
+        args.cpu_queries, args.cpu_queries_1t = min(args.cpu_queries, 8), min(args.cpu_queries_1t, 4)
+    if bool(args.index_path) != bool(args.query_path):
+        raise SystemExit("--index-path and --query-path go together")
 
     import torch
     from dhr_amd import _lib, dist as D, synth
@@ -214,10 +225,14 @@ def main():
         spec = specs[args.workload]
         spec["n"] = args.n_docs or spec["n"]
         spec["nq"] = args.n_queries or spec["nq"]
+        if args.index_path:
+            if world != 1:
+                raise SystemExit("the real-data leg runs on one GPU (--gpus 1)")
+            spec = load_real(args, torch)
         out = run_workload(args, spec, ctx)
         # configs 1 and 2 on the same clock: the plain default invocation (N = 1, config 3 at full size) also times 5 steps each of the
         # dense-only and the BM25 workload -- same code path, same seed rule, their own roofline and checksum -- and attaches them to the line
-        plain = (args.workload == "hybrid" and world == 1 and not args.n_docs and not args.n_queries and not args.uniform_idx and args.data == "iid"
+        plain = (args.workload == "hybrid" and not args.index_path and world == 1 and not args.n_docs and not args.n_queries and not args.uniform_idx and args.data == "iid"
                  and not args.pq and args.topk == 1000)
         if (args.other_configs == 1 or (args.other_configs < 0 and plain)) and world == 1 and args.workload == "hybrid":
             import copy
@@ -239,6 +254,29 @@ def main():
         dist.destroy_process_group()
 
 
+def load_real(args, torch):
+    """The optional real-data leg: an encoded index + query set in the reference's own record layout (tevatron/driver/encode.py:203-204,
+    merged by retrieval/index.py) -> the spec run_workload times instead of the synthetic corpus.  The search is the same call; what it adds
+    is the second half of BASELINE.json's metric (nDCG@10), computed from the timed search's lists when --qrels is given."""
+    from dhr_amd.retrieval import gip_retrieval as G
+    q32, qidx, qids = G.load_queries(args.query_path, args.emb_dim, args.lamda)
+    if G.GipIndex.is_device_file(args.index_path):
+        real = {"device_file": args.index_path}
+        probe, docids = G.GipIndex.load(args.index_path)
+        n, d_dlr, k_all = probe.n_rows, probe.d_dlr, probe.k
+        probe.close()
+    else:
+        cv, ci, docids, _ = G.load_corpus_shard(args.index_path)
+        real = {"cv": cv, "ci": ci}
+        n, k_all = cv.shape
+        d_dlr = 0 if ci is None else ci.shape[1]
+    if qidx is None and d_dlr:
+        raise SystemExit("the index has a slice-index array, the queries have none")
+    real.update(q32=q32, qi=qidx, qids=[str(x) for x in qids], docids=[str(x) for x in docids])
+    return dict(name="real", n=int(n), nq=int(q32.shape[0]), d_dlr=int(d_dlr), d_cls=int(k_all - d_dlr), kind="real", seed=args.seed, real=real,
+                baseline_config="real data: index %s, queries %s" % (os.path.basename(args.index_path), os.path.basename(args.query_path)))
+
+
 def run_workload(args, spec, ctx):
     torch, _lib, D, synth = ctx["torch"], ctx["_lib"], ctx["D"], ctx["synth"]
     world, rank, local_rank, device = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["device"]
@@ -250,7 +288,15 @@ def run_workload(args, spec, ctx):
 
     # ---------------- data (outside the timed region)
     t_gen = time.perf_counter()
-    if spec["kind"] == "bm25":
+    real = spec.get("real")
+    if real is not None:
+        qv = torch.from_numpy(real["q32"]).to(device)
+        qi = None if real["qi"] is None else torch.from_numpy(real["qi"]).to(device)
+        cv = ci = None
+        if "cv" in real:
+            cv = torch.from_numpy(np.ascontiguousarray(real["cv"])).to(device)
+            ci = None if real["ci"] is None else torch.from_numpy(np.ascontiguousarray(real["ci"])).to(device)
+    elif spec["kind"] == "bm25":
         # config 1: whole-word vocabulary (2.6 M terms -> int16 slice index < 3400), no background, integer query weights;
         # generated on the host (the numpy generator covers int16 indices), rows [lo, hi) of the SAME matrix on every rank
         cvh, cih, qvh, qih = synth.make_pair(seed, n, nq, d_dlr, 0, kind="bm25")
@@ -266,7 +312,10 @@ def run_workload(args, spec, ctx):
     t_gen = time.perf_counter() - t_gen
     t_build = time.perf_counter()
     _lib.check(_lib.load().dhr_set_option(_lib.OPT_DENSE_I8, args.dense_i8), "dhr_set_option")
-    index = GipIndex(cv, ci, device=local_rank, row_offset=lo, idx_buckets=args.idx_buckets)
+    if real is not None and cv is None:
+        index, _ = GipIndex.load(real["device_file"], device=local_rank)
+    else:
+        index = GipIndex(cv, ci, device=local_rank, row_offset=lo, idx_buckets=args.idx_buckets)
     dense_i8 = bool(index.info(_lib.INFO_DENSE_I8))
     gated_i8 = bool(index.info(_lib.INFO_GATED_I8))
     torch.cuda.synchronize()
@@ -287,7 +336,7 @@ def run_workload(args, spec, ctx):
 
     # host samples for the CPU baseline and the in-bench parity check (rank 0, N=1 only; BEFORE the corpus tensors are dropped)
     cpu_sample = par_sample = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and cv is not None:
         def host_slice(m, mq):
             m, mq = min(m, hi - lo), min(mq, nq)
             return (cv[:m].cpu().numpy(), None if ci is None else ci[:m].cpu().numpy(), qv[:mq].cpu().numpy(), None if qi is None else qi[:mq].cpu().numpy())
@@ -504,17 +553,21 @@ def run_workload(args, spec, ctx):
         sparse_layout = d_dlr > 0 and args.idx_buckets in (0, 2)
         stage_layout = sparse_layout or (d_dlr == 0 and args.idx_buckets == 0)      # dense-only indexes run on the stage images too (ts = 0)
         variant = args.gemm_variant if args.gemm_variant >= 0 else 5
-        kernel = ("gemm_filter_g8_kernel (integer bound GEMM: gated half on v_smfmac_i32_32x32x64_i8, ungated half on v_mfma_i32_32x32x32_i8, fused threshold filter, 8 waves)"
-                  if gated_i8 else
-                  "gemm_filter_wx_kernel<NI=%d> (bound GEMM on the %s + fused threshold filter, %d waves)"
-                  % ((4 if variant == 4 else 2), "2:4 sparse matrix cores" if sparse_layout else "matrix cores, 32-column stage images", (4 if variant == 4 else 8))
-                  if stage_layout and variant in (4, 5) else
-                  "gemm_filter_sparse_kernel (bound GEMM on the 2:4 sparse matrix cores + fused threshold filter)" if sparse_layout else
-                  "gemm_filter_v3_kernel (bound GEMM + fused threshold filter)")
+        # the kernel the timed launches really ran, asked of the library (DHR_INFO_GEMM_KERNEL) -- until round 5 this label was re-derived here
+        # from the index flags and named gemm_filter_wx_kernel for dense-only int8 indexes, which run gemm_filter_g8_kernel (DHR_DENSE_G8)
+        kid = int(index.info(_lib.INFO_GEMM_KERNEL))
+        g8_ops = ("gated half on v_smfmac_i32_32x32x64_i8, ungated half on v_mfma_i32_32x32x32_i8" if d_dlr and d_cls else
+                  "v_smfmac_i32_32x32x64_i8 (2:4 int8)" if d_dlr else "v_mfma_i32_32x32x32_i8 on the int8 stage images, no gated stage")
+        kernel = {1: "gemm_filter_v3_kernel (bound GEMM on the K-step tile layout + fused threshold filter)",
+                  2: "gemm_filter_sparse_kernel (bound GEMM on the 2:4 sparse matrix cores + fused threshold filter, 12 waves)",
+                  3: "gemm_filter_wx_kernel<NI=2> (bound GEMM on the %s + fused threshold filter, 8 waves)" % ("2:4 sparse matrix cores" if sparse_layout else "matrix cores, 32-column stage images"),
+                  4: "gemm_filter_wx_kernel<NI=4> (bound GEMM on the %s + fused threshold filter, 4 waves)" % ("2:4 sparse matrix cores" if sparse_layout else "matrix cores, 32-column stage images"),
+                  5: "gemm_filter_g8_kernel (integer bound GEMM: %s, fused threshold filter, 8 waves)" % g8_ops,
+                  6: "gemm_filter_g8p_kernel (integer bound GEMM with persistent workgroups: %s)" % g8_ops}.get(kid, "unknown (DHR_INFO_GEMM_KERNEL = %d)" % kid)
         # fabric-side (Infinity Cache + HBM) read bytes: PMC passes cannot run inside this process (a torch process hangs under
         # --pmc), so `traffic` is the per-corpus-row figure of the committed rocprofv3 FETCH_SIZE pass over the SAME kernel
         # (tools/prof.sh -> profiles/r02_gemm_pmc.txt; torch-free driver, 6 980 queries) x the average rows per launch
-        traffic_per_row = TRAFFIC_BYTES_PER_ROW.get((d_dlr, d_cls, nq, variant, int(dense_i8), int(gated_i8))) if stage_layout and world == 1 else None
+        traffic_per_row = TRAFFIC_BYTES_PER_ROW.get((d_dlr, d_cls, nq, kid, int(dense_i8), int(gated_i8))) if stage_layout and world == 1 else None
         # `peak`: the contract's figure for this metric -- the dense fp16 / bf16 matrix peak the north-star prices the Q x D^T against
         # (BASELINE.json).  Beside it the peak of the instruction mix the kernel really issues: gated columns on the fp16 2:4
         # instruction (two bucket columns per slice at twice the rate = the fp16 peak per algorithmic column) or, gated_i8, on the
@@ -535,7 +588,8 @@ def run_workload(args, spec, ctx):
                       "filter margin) + f64-accumulated f16 x f32 exact rescoring of the survivors -- the returned scores are the exact scores rounded once, identical to the fp16 bound's" if gated_i8 else
                       "f16 + i8 (bound: gated columns fp16 x fp16 -> fp32, ungated columns int8 x int8 -> int32 on the matrix cores, the quantisation error paid by the filter margin; "
                       "fp64-accumulated exact rescoring of the survivors in fp16 x fp32 -- results identical to the fp16 bound)" if dense_i8 else
-                      "f16 (fp16 x fp16 -> fp32 on the matrix cores for the bound; fp64-accumulated exact rescoring)"), "data": "synthetic",
+                      "f16 (fp16 x fp16 -> fp32 on the matrix cores for the bound; fp64-accumulated exact rescoring)"),
+            "data": "synthetic" if real is None else "real (index %s, queries %s)" % (args.index_path, args.query_path),
             "config": {"workload": ("%s: %d rows x (%d DLR + %d dense) fp16%s, %d queries, top-%d, %s"
                                     % (spec["name"], n, d_dlr, d_cls,
                                        (" + int16 slice index" if spec["kind"] == "bm25" else " + uint8 slice index") if d_dlr else "", nq, k,
@@ -580,6 +634,16 @@ def run_workload(args, spec, ctx):
         }
         if two_stage is not None:
             out["two_stage"] = two_stage
+        if real is not None and args.qrels:
+            # the second half of BASELINE.json's metric on real data: nDCG@10 (+ MRR@10, R@1000) of the lists the timed steps produced
+            from dhr_amd.retrieval import trec
+            rows_h, sc_h = host_r.numpy(), host_s.numpy()
+            run = {}
+            for qx, qid in enumerate(real["qids"]):
+                keep = [(real["docids"][int(r)], float(sc_h[qx, j])) for j, r in enumerate(rows_h[qx]) if r >= 0 and real["docids"][int(r)] != qid]   # gip_retrieval.py:340
+                run[qid] = ([d for d, _ in keep], [x for _, x in keep])
+            out["effectiveness"] = dict(trec.effectiveness(trec.read_qrels_any(args.qrels), run), qrels=args.qrels,
+                                        note="trec_eval's definitions (dhr_amd/retrieval/trec.py effectiveness); the docid == query_id filter of gip_retrieval.py:340 applied")
         if pq is not None:
             # the dominant kernel of this mode is the ADC scan: HBM / LDS-gather bound integer-index work (roofline on HBM bytes)
             # Two rooflines, honestly labelled.  HBM: the UNIQUE code bytes of a step are rows x 64 B -- every query pair re-reads them, but from
@@ -633,11 +697,13 @@ def run_workload(args, spec, ctx):
 
 # fabric-side read bytes per corpus row of the bound GEMM, from the committed PMC pass (d_dlr, d_cls, queries, kernel variant)
 # (d_dlr, d_cls, queries, kernel variant, dense_i8) -> fabric-side read bytes per corpus row, profiles/r02_gemm_pmc.txt
-TRAFFIC_BYTES_PER_ROW = {(768, 768, 6980, 5, 0, 0): 34.6e3,     # fp16 image of the ungated columns: 17.31 GB per 500 000-row launch (r02)
-                         (768, 768, 6980, 5, 1, 0): 26.2e3,     # int8 image of the ungated columns, fp16 gated: 13.10 GB (r02)
-                         (768, 768, 6980, 5, 1, 1): 22.5e3,     # gated_i8 (default since round 3): 11.23 GB (profiles/r05_gemm_pmc.txt; r04: 11.23, r03: 11.27)
-                         (0, 768, 6980, 5, 0, 0): 14.6e3,       # dense-only index, fp16 stage images: 7.30 GB (r04)
-                         (0, 768, 6980, 5, 1, 0): 6.06e3}       # dense-only index, int8 stage images: 3.03 GB (r04)
+# (key: d_dlr, d_cls, queries, DHR_INFO_GEMM_KERNEL id, dense_i8, gated_i8)
+TRAFFIC_BYTES_PER_ROW = {(768, 768, 6980, 3, 0, 0): 34.6e3,     # gemm_filter_wx_kernel, fp16 image of the ungated columns: 17.31 GB per 500 000-row launch (r02)
+                         (768, 768, 6980, 3, 1, 0): 26.2e3,     # ... int8 image of the ungated columns, fp16 gated: 13.10 GB (r02)
+                         (768, 768, 6980, 5, 1, 1): 22.5e3,     # gemm_filter_g8_kernel, gated_i8 (default since round 3): 11.23 GB (profiles/r05_gemm_pmc.txt; r04: 11.23, r03: 11.27)
+                         (0, 768, 6980, 3, 0, 0): 14.6e3,       # dense-only index, fp16 stage images: 7.30 GB (r04)
+                         (0, 768, 6980, 3, 1, 0): 6.06e3,       # dense-only index, int8 stage images on gemm_filter_wx_kernel (DHR_DENSE_G8=0): 3.03 GB (r04)
+                         (0, 768, 6980, 5, 1, 0): 6.06e3}       # ... on gemm_filter_g8_kernel with no gated stage (default since round 5): the same operand images and tile order
 
 
 if __name__ == "__main__":

@@ -18,7 +18,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 PARAM_CAND_CAP, PARAM_FIRST_ROWS, PARAM_PROFILE, PARAM_MAX_GROWTH, PARAM_SAMPLE_PERIOD, PARAM_GEMM_VARIANT, PARAM_MAIN_CHUNKS, PARAM_PROGRESSIVE_THR, PARAM_AUX_CUS, PARAM_GEMM_EXCLUSIVE, PARAM_OVERLAP_AUX, PARAM_SAMPLE_SHARE, PARAM_ASYNC_CONTROLLER, PARAM_LIST_STRIDE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14
 OPT_DENSE_I8, OPT_GATED_I8 = 1, 2
 COMM_TRANSPORT, COMM_WORLD, COMM_RANK, COMM_DEVICE = 0, 1, 2, 3
-INFO_DENSE_I8, INFO_I8_SCALE, INFO_I8_ROW_ERR, INFO_I8_ROW_NORM, INFO_ROW_NORM_MAX, INFO_TILE_BYTES, INFO_GATED_I8 = 1, 2, 3, 4, 5, 6, 7
+INFO_DENSE_I8, INFO_I8_SCALE, INFO_I8_ROW_ERR, INFO_I8_ROW_NORM, INFO_ROW_NORM_MAX, INFO_TILE_BYTES, INFO_GATED_I8, INFO_GEMM_KERNEL = 1, 2, 3, 4, 5, 6, 7, 8
 
 EXPORTS = ["dhr_version", "dhr_abi_sizes", "dhr_abi_size", "dhr_debug_fail_alloc", "dhr_set_option", "dhr_index_get_info", "dhr_last_error", "dhr_index_create", "dhr_index_destroy", "dhr_index_set_param",
            "dhr_index_device_bytes", "dhr_search", "dhr_score_rows", "dhr_merge_topk", "dhr_merge_topk_host", "dhr_merge_topk_lists", "dhr_merge_topk_lists_host",

@@ -167,6 +167,7 @@ struct dhr_index {
   int progressive_thr = 2;
   int n_cu = 256;
   int gemm_variant = 0;                    // 2:4 layout kernel of THIS handle (0 = library default)
+  int last_gemm_kernel = 0;                // DHR_INFO_GEMM_KERNEL: what the latest search's bound-GEMM launches ran (kernels.hip g_last_gemm_kernel)
   int overlap_aux = -1;                    // 0: refine / rescoring / select run on the GEMM's stream (every kernel gets the whole chip); 1: beside the next chunk's GEMM on the aux stream; -1 (default) = 1 (round 4; until then gated unsharded searches ran serially)
   int aux_cus = -1, gemm_exclusive = 0;    // CU-masked streams of the main pass (0 = no mask; -1 = default: 128 CUs for dense-only indexes, no mask for gated ones)
   int aux_cus_made = -1, gemm_excl_made = -1;
@@ -228,6 +229,7 @@ extern "C" int dhr_index_get_info(const dhr_index* ix, int32_t what, double* out
     case DHR_INFO_I8_ROW_NORM: *out = ix->i8_nc; return DHR_OK;
     case DHR_INFO_ROW_NORM_MAX: *out = ix->dmax; return DHR_OK;
     case DHR_INFO_GATED_I8: *out = ix->gated_i8 ? 1.0 : 0.0; return DHR_OK;
+    case DHR_INFO_GEMM_KERNEL: *out = (double)ix->last_gemm_kernel; return DHR_OK;
     case DHR_INFO_TILE_BYTES: *out = (double)(ix->ts + ix->td > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * (ix->gated_i8 ? S8_STAGE_A : SP_STAGE_A) + (size_t)ix->td * SP_DENSE)
                                                                       : (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2); return DHR_OK;
   }
@@ -977,6 +979,19 @@ static int prep_queries(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, 
   return DHR_OK;
 }
 
+// A search that fails half-way (a HIP error, an exception on its way to the barrier) has kernels in flight on the caller's stream and on the
+// handle's aux / GEMM streams, all working on the handle's workspace: the streams are drained before the call returns, so that the next call on
+// the handle starts from idle streams.  Disarmed on the successful way out (which synchronises, or hands the stream back, by its own rules).
+struct Drain {
+  dhr_index* ix; hipStream_t s; bool armed = true;
+  ~Drain() {
+    if (!armed) return;
+    (void)hipStreamSynchronize(s);
+    if (ix->s_aux) (void)hipStreamSynchronize(ix->s_aux);
+    if (ix->s_gemm) (void)hipStreamSynchronize(ix->s_gemm);
+    (void)hipGetLastError();
+  }
+};
 struct Timer {
   bool on; hipStream_t s; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; std::vector<int> kind;
   ~Timer() { for (auto& e : ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } }      // a call that failed before collect()
@@ -1022,6 +1037,7 @@ static int gemm_phase(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi
   HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));
   HIP_TRY(hipMemsetAsync(w.d_max, 0, 16, s));
   tm.begin(T_GEMM); HIP_TRY(launch_gemm_filter(g, s)); tm.end();
+  ix->last_gemm_kernel = g_last_gemm_kernel;
   HIP_TRY(launch_max_u32(w.cnt, Q, w.d_max, (unsigned long long*)(w.d_max + 2), s));
   HIP_TRY(hipMemcpyAsync(w.h_pinned, w.d_max, 16, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -1052,6 +1068,7 @@ static int gemm_phase_async(dhr_index* ix, Workspace& w, int Q, int64_t lo, int6
   g.cap = (uint32_t)w.cap; g.n_queries = Q;
   HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));
   tm.begin(T_GEMM); HIP_TRY(launch_gemm_filter(g, s)); tm.end();      // (list statistics + overflow marks: rescore_select_async, one launch)
+  ix->last_gemm_kernel = g_last_gemm_kernel;
   const double rows = (double)(hi - lo) * TILE_ROWS;
   st.phases++;
   st.gemm_rows += (int64_t)rows;
@@ -1626,6 +1643,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
       HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)w.q_pad * 4, sg));
       if (!async_ctl) HIP_TRY(hipMemsetAsync(w.d_max2 + 4 * (i & 1), 0, 16, sg));
       tm.begin_on(T_GEMM, sg); HIP_TRY(launch_gemm_filter(g, sg)); tm.end_on(sg);
+      ix->last_gemm_kernel = g_last_gemm_kernel;
       if (!async_ctl) {       // the host-driven controller sizes the per-candidate launches from the list lengths; the enqueue-only one leaves them on the device
         HIP_TRY(launch_max_u32(cnt, Q, w.d_max2 + 4 * (i & 1), (unsigned long long*)(w.d_max2 + 4 * (i & 1) + 2), sg));
         HIP_TRY(hipMemcpyAsync(w.h_pinned2 + 16 * (i & 1), w.d_max2 + 4 * (i & 1), 16, hipMemcpyDeviceToHost, sg));
@@ -1759,6 +1777,7 @@ extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, f
   dhr_search_stats st{};
   st.n_rows = ix->n_rows; st.n_queries = Q; st.k = k;
   Workspace& w = ix->ws;
+  Drain drain{ix, s};
   if ((rc = search_core(ix, w, qb, k, 0, tm, st, s)) != DHR_OK) return rc;
 
   // ---- results
@@ -1785,6 +1804,7 @@ extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, f
   st.gemm_ms = ms[T_GEMM]; st.refine_ms = ms[T_REFINE]; st.rescore_ms = ms[T_RESCORE]; st.select_ms = ms[T_SELECT];
   st.prep_ms = ms[T_PREP];
   ix->stats = st;
+  drain.armed = false;
   return DHR_OK;
 } DHR_CATCH_STATUS
 
@@ -1812,6 +1832,7 @@ extern "C" int dhr_search_rerank(dhr_index* ix, const dhr_query_batch* qb1, cons
   dhr_search_stats st{};
   st.n_rows = ix->n_rows; st.n_queries = Q; st.k = k;
   Workspace& w = ix->ws;
+  Drain drain{ix, s};
   // ---- stage 1
   if ((rc = search_core(ix, w, qb1, k1, 0, tm, st, s)) != DHR_OK) return rc;
   // ---- stage 2: exact scores of the stage-1 rows under the full batch, top-k of those
@@ -1866,6 +1887,7 @@ extern "C" int dhr_search_rerank(dhr_index* ix, const dhr_query_batch* qb1, cons
   st.gemm_ms = ms[T_GEMM]; st.refine_ms = ms[T_REFINE]; st.rescore_ms = ms[T_RESCORE]; st.select_ms = ms[T_SELECT];
   st.prep_ms = ms[T_PREP];
   ix->stats = st;
+  drain.armed = false;
   return done(DHR_OK);
 } DHR_CATCH_STATUS
 
@@ -1927,6 +1949,7 @@ static int search_mid_impl(dhr_index* ix, const float* tau_hat_dev, int32_t r_lo
   Timer tm{ix->profile != 0, s, {}, {}};
   dhr_search_stats st = ix->stats;
   int rc;
+  Drain drain{ix, s};
   if ((rc = search_core(ix, ix->ws, nullptr, ix->pend.k, 0, tm, st, s, 3, tau_hat_dev)) != DHR_OK) return rc;
   HIP_TRY(launch_emit_scores(ix->ws.topk_keys, ix->ws.kp, ix->pend.Q, rl, out_scores_dev, s));
   if (ix->profile) {
@@ -1936,6 +1959,7 @@ static int search_mid_impl(dhr_index* ix, const float* tau_hat_dev, int32_t r_lo
     st.gemm_ms += ms[T_GEMM]; st.refine_ms += ms[T_REFINE]; st.rescore_ms += ms[T_RESCORE]; st.select_ms += ms[T_SELECT];
   }
   ix->stats = st;
+  drain.armed = false;
   return DHR_OK;
 }
 extern "C" int dhr_search_mid(dhr_index* ix, const float* tau_hat_dev, int32_t r_local, float* out_scores_dev, void* stream) try {
@@ -1994,6 +2018,7 @@ static int search_pre_impl(dhr_index* ix, const dhr_query_batch* qb, int32_t k, 
   Timer tm{ix->profile != 0, s, {}, {}};
   dhr_search_stats st{};
   st.n_rows = ix->n_rows; st.n_queries = qb->n_queries; st.k = k;
+  Drain drain{ix, s};
   if ((rc = search_core(ix, ix->ws, qb, k, 0, tm, st, s, 4)) != DHR_OK) return rc;
   HIP_TRY(launch_emit_scores(ix->ws.topk_keys, ix->ws.kp, qb->n_queries, r_local, out_scores_dev, s));
   ix->pend.dev_bound = ix->pend.dev_exact = 0;
@@ -2004,6 +2029,7 @@ static int search_pre_impl(dhr_index* ix, const dhr_query_batch* qb, int32_t k, 
     st.gemm_ms = ms[T_GEMM]; st.refine_ms = ms[T_REFINE]; st.rescore_ms = ms[T_RESCORE]; st.select_ms = ms[T_SELECT]; st.prep_ms = ms[T_PREP];
   }
   ix->stats = st;
+  drain.armed = false;
   return DHR_OK;
 }
 extern "C" int dhr_search_pre(dhr_index* ix, const dhr_query_batch* qb, int32_t k, int32_t r_local, float* out_scores_dev, void* stream) try {
@@ -2022,6 +2048,7 @@ static int search_begin_rest_impl(dhr_index* ix, const float* tau_dev, float* ou
   Timer tm{ix->profile != 0, s, {}, {}};
   dhr_search_stats st = ix->stats;                     // continue the counters of the pre call
   int rc;
+  Drain drain{ix, s};
   if ((rc = search_core(ix, ix->ws, nullptr, k, 0, tm, st, s, 5, tau_dev)) != DHR_OK) return rc;
   const int r = dhr_search_sample_rank(ix, k);
   if (r > 0 && !ix->pend.done) HIP_TRY(launch_emit_scores(ix->ws.topk_keys, ix->ws.kp, Q, r, out_sample_scores_dev, s));
@@ -2038,6 +2065,7 @@ static int search_begin_rest_impl(dhr_index* ix, const float* tau_dev, float* ou
     st.gemm_ms += ms[T_GEMM]; st.refine_ms += ms[T_REFINE]; st.rescore_ms += ms[T_RESCORE]; st.select_ms += ms[T_SELECT]; st.prep_ms += ms[T_PREP];
   }
   ix->stats = st;
+  drain.armed = false;
   return DHR_OK;
 }
 extern "C" int dhr_search_begin_rest(dhr_index* ix, const float* tau_dev, float* out_sample_scores_dev, void* stream) try {
@@ -2060,6 +2088,7 @@ static int search_begin_impl(dhr_index* ix, const dhr_query_batch* qb, int32_t k
   Timer tm{ix->profile != 0, s, {}, {}};
   dhr_search_stats st{};
   st.n_rows = ix->n_rows; st.n_queries = qb->n_queries; st.k = k;
+  Drain drain{ix, s};
   if ((rc = search_core(ix, ix->ws, qb, k, 0, tm, st, s, 1)) != DHR_OK) return rc;
   const int r = dhr_search_sample_rank(ix, k);
   if (r > 0 && !ix->pend.done) {
@@ -2080,6 +2109,7 @@ static int search_begin_impl(dhr_index* ix, const dhr_query_batch* qb, int32_t k
     st.gemm_ms = ms[T_GEMM]; st.refine_ms = ms[T_REFINE]; st.rescore_ms = ms[T_RESCORE]; st.select_ms = ms[T_SELECT]; st.prep_ms = ms[T_PREP];
   }
   ix->stats = st;
+  drain.armed = false;
   return DHR_OK;
 }
 extern "C" void dhr_internal_search_abort(dhr_index* ix) try {
@@ -2104,6 +2134,7 @@ static int search_finish_impl(dhr_index* ix, const float* tau_hat_dev, float* ou
   Timer tm{ix->profile != 0, s, {}, {}};
   dhr_search_stats st = ix->stats;                     // continue the counters of the begin call
   int rc;
+  Drain drain{ix, s};
   if ((rc = search_core(ix, w, nullptr, k, 0, tm, st, s, 2, tau_hat_dev)) != DHR_OK) return rc;
   HIP_TRY(launch_count_ge(w.topk_keys, w.kp, k, ix->pend.done ? nullptr : w.tau_hat, ix->pend.done ? nullptr : w.fail_flags, Q,
                           out_count_dev, s));
@@ -2132,6 +2163,7 @@ static int search_finish_impl(dhr_index* ix, const float* tau_hat_dev, float* ou
   }
   ix->stats = st;
   ix->pend.valid = false;
+  drain.armed = false;
   return DHR_OK;
 }
 extern "C" int dhr_search_finish(dhr_index* ix, const float* tau_hat_dev, float* out_scores, int64_t* out_rows,

@@ -380,6 +380,7 @@ hipError_t launch_merge_lists(int n_queries, int n_lists, int list_len, const fl
                               float* out_scores, int64_t* out_rows, hipStream_t s, int64_t stride_s = 0, int64_t stride_r = 0);
 
 extern int g_gemm_variant;
+extern thread_local int g_last_gemm_kernel;      // kernels.hip: the bound-GEMM kernel of the calling thread's latest launch_gemm_filter
 constexpr int RESCORE_CANDS_PER_WG = 32;
 constexpr uint32_t FLAT_GRID_MAX = 1u << 20;      // flat launches: at most this many workgroups, the rest of the block list by grid stride
 constexpr uint32_t FLAT_GRID_ASYNC = 16384;       // ... and this many when the host does not know the block count (controller without read-backs)

@@ -1169,6 +1169,10 @@ int g_gemm_variant = 5;   // DHR_PARAM_GEMM_VARIANT: 2:4 layout kernels 3 (12 wa
 
 // The bound GEMM + filter over the tiles [seq_lo, seq_hi) of the sequence: gemm_filter_sparse_kernel for the 2:4 layout
 // (a.ts > 0), gemm_filter_v3_kernel for the K-step tile layout (dense-only indexes, other bucket counts).
+// which bound-GEMM kernel the calling thread's latest launch_gemm_filter ran (dhr_index_get_info(DHR_INFO_GEMM_KERNEL): a report names the
+// kernel that really ran instead of re-deriving the dispatch below): 1 gemm_filter_v3_kernel, 2 gemm_filter_sparse_kernel, 3 / 4
+// gemm_filter_wx_kernel<2> / <4>, 5 gemm_filter_g8_kernel, 6 gemm_filter_g8p_kernel
+thread_local int g_last_gemm_kernel = 0;
 static hipError_t launch_gemm_filter_grid(const GemmArgs& a, dim3 grid, hipStream_t s);
 hipError_t launch_gemm_filter(const GemmArgs& a_in, hipStream_t s) {
   static bool env_read = false;
@@ -1189,7 +1193,7 @@ hipError_t launch_gemm_filter(const GemmArgs& a_in, hipStream_t s) {
   // Not the default: the kernel runs at the package power cap, where the ~10 % of cycles the persistent form saves come back as a lower
   // clock, not as time, and a workgroup that never leaves its CU keeps refine / rescoring of the previous chunk from interleaving
   static const int g8_persist = getenv("DHR_G8_PERSIST") ? atoi(getenv("DHR_G8_PERSIST")) : 0;
-  if (a_in.g8_shift && (g8_persist || a_in.variant == 6) && gemm_g8p_ok(a_in)) return launch_gemm_g8p(a_in, s);
+  if (a_in.g8_shift && (g8_persist || a_in.variant == 6) && gemm_g8p_ok(a_in)) { g_last_gemm_kernel = 6; return launch_gemm_g8p(a_in, s); }
   GemmArgs a = a_in;
   a.inv_perm_n = 1.0 / (double)(a.perm_n > 0 ? a.perm_n : 1);
   a.inv_pm1 = 1.0 / (double)(a.period > 1 ? a.period - 1 : 1);
@@ -1224,14 +1228,17 @@ static hipError_t launch_gemm_filter_grid(const GemmArgs& a, dim3 grid, hipStrea
     attr_set = true;
   }
   const int variant = a.variant == 6 ? 5 : a.variant ? a.variant : g_gemm_variant;        // per handle (dhr_index_set_param), else the library default
-  if (a.g8_shift) return (a.ts > 0 && !(a.ts & 1) && !(a.td & 1) && a.ts_q == a.ts) ? launch_gemm_g8(a, grid, s) : hipErrorInvalidValue;
+  if (a.g8_shift) { g_last_gemm_kernel = 5; return (a.ts > 0 && !(a.ts & 1) && !(a.td & 1) && a.ts_q == a.ts) ? launch_gemm_g8(a, grid, s) : hipErrorInvalidValue; }
   // a dense-only int8 index (no gated stage on either side): the integer kernel of the gated_i8 indexes with ts = 0 -- the same operand
   // images, integer filter epilogue; config 2: 2.78 -> 2.70 ms per launch alone, 76.4 -> 75.1 ms per step (DHR_DENSE_G8=0: gemm_filter_wx_kernel)
   static const int dense_g8 = getenv("DHR_DENSE_G8") ? atoi(getenv("DHR_DENSE_G8")) : 1;
-  if (a.i8_mul && dense_g8 && a.ts == 0 && a.ts_q == 0 && a.td > 0 && !(a.td & 1)) return launch_gemm_g8(a, grid, s);
-  if (a.i8_mul)      // int8 dense stages exist in the every-wave-computes kernels only (dhr_index_create enables them only where those run)
+  if (a.i8_mul && dense_g8 && a.ts == 0 && a.ts_q == 0 && a.td > 0 && !(a.td & 1)) { g_last_gemm_kernel = 5; return launch_gemm_g8(a, grid, s); }
+  if (a.i8_mul) {    // int8 dense stages exist in the every-wave-computes kernels only (dhr_index_create enables them only where those run)
+    g_last_gemm_kernel = variant == 4 ? 4 : 3;
     return (a.ts + a.td > 0 && !(a.ts_q & 1) && !(a.td & 1)) ? launch_gemm_wx(a, grid, variant == 4 ? 4 : 5, s) : hipErrorInvalidValue;
-  if (a.ts + a.td > 0 && (variant == 4 || variant == 5) && g_gemm_ablate == 0 && !(a.ts_q & 1) && !(a.td & 1)) return launch_gemm_wx(a, grid, variant, s);   // pairs of stages
+  }
+  if (a.ts + a.td > 0 && (variant == 4 || variant == 5) && g_gemm_ablate == 0 && !(a.ts_q & 1) && !(a.td & 1)) { g_last_gemm_kernel = variant == 4 ? 4 : 3; return launch_gemm_wx(a, grid, variant, s); }   // pairs of stages
+  g_last_gemm_kernel = a.ts + a.td > 0 ? 2 : 1;
   if (a.ts + a.td > 0) {
     if (a.dump)
       hipLaunchKernelGGL(gemm_filter_sparse_kernel<true>, grid, dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a);

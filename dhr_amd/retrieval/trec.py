@@ -100,6 +100,51 @@ def recall_cap(qrels, results, k_values):
     return {'R_cap@{}'.format(k): round(totals[k] / len(qrels), 5) for k in k_values}
 
 
+def read_qrels_any(path):
+    """Qrels in either of the two layouts the reference's pipelines use: the tab-separated 4 columns of rcap_eval.py:11-18, or the
+    space-separated TREC layout `qid 0 docid rel` that trec_eval reads (docs/dhr/msmarco-passage-train-eval.md:153-154)."""
+    qrels = {}
+    with open(path, 'r') as f:
+        for line in f:
+            fields = line.split()
+            if not fields:
+                continue
+            if len(fields) != 4:
+                raise ValueError('{}: expected 4 fields per line, got {!r}'.format(path, line))
+            qrels.setdefault(fields[0], {})[fields[2]] = int(fields[3])
+    return qrels
+
+
+def effectiveness(qrels, run, ndcg_k=10, mrr_k=10, recall_k=1000):
+    """The second half of BASELINE.json's metric: nDCG@10 (plus MRR@10 and R@1000, what the reference's doc pages report with trec_eval:
+    docs/dhr/msmarco-passage-train-eval.md:153-154) of a run {qid: ([docid...], [score...])} in rank order.  trec_eval's definitions:
+    DCG = sum over the ranks i = 1..k of rel_i / log2(i + 1) with the judged gain as it stands, the ideal DCG from the query's judged
+    gains sorted descending; MRR = 1 / rank of the first doc with rel > 0 among the first k; recall = relevant found among the first k /
+    all relevant.  Averages run over the queries of the run that have at least one relevant judgment (trec_eval skips the others);
+    docs that are not judged count as rel = 0."""
+    disc = 1.0 / np.log2(np.arange(2, max(ndcg_k, 2) + 2))
+    n = 0
+    ndcg = mrr = rec = 0.0
+    for qid, (docs, _scores) in run.items():
+        judged = qrels.get(qid)
+        if not judged:
+            continue
+        rels = sorted((r for r in judged.values() if r > 0), reverse=True)
+        if not rels:
+            continue
+        n += 1
+        gains = np.array([max(judged.get(d, 0), 0) for d in docs[:ndcg_k]], dtype=np.float64)
+        ideal = np.array(rels[:ndcg_k], dtype=np.float64)
+        ndcg += float((gains * disc[:len(gains)]).sum() / (ideal * disc[:len(ideal)]).sum())
+        first = next((i for i, d in enumerate(docs[:mrr_k]) if judged.get(d, 0) > 0), None)
+        mrr += 0.0 if first is None else 1.0 / (first + 1)
+        rec += sum(1 for d in docs[:recall_k] if judged.get(d, 0) > 0) / len(rels)
+    if n == 0:
+        return {'queries_evaluated': 0}
+    return {'nDCG@{}'.format(ndcg_k): round(ndcg / n, 5), 'MRR@{}'.format(mrr_k): round(mrr / n, 5),
+            'R@{}'.format(recall_k): round(rec / n, 5), 'queries_evaluated': n}
+
+
 def rcap_main(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument("--qrel_file_path", type=str, required=True)

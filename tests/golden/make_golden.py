@@ -44,13 +44,13 @@ def import_reference():
 
 def make_inputs():
     inp = {}
-    cv, ci, qv, qi = synth.make_pair(101, 2048, 8, 768, 768, kind="encoder")
+    cv, ci, qv, qi = synth.make_pair(101, 4096, 16, 768, 768, kind="encoder")          # N = 4096, Q = 16 for F2-F4 too (2 048 x 8 / 1 024 x 8 until round 5)
     inp["hyb"] = dict(cv=cv, ci=ci, qv=qv, qi=qi)
-    cv, ci, qv, qi = synth.make_pair(102, 1024, 8, 768, 128, kind="encoder")
+    cv, ci, qv, qi = synth.make_pair(102, 4096, 16, 768, 128, kind="encoder")
     inp["hyb128"] = dict(cv=cv, ci=ci, qv=qv, qi=qi)
     cv, ci, qv, qi = synth.make_pair(103, 4096, 16, 768, 0, kind="bm25")
     inp["bm25"] = dict(cv=cv, ci=ci, qv=qv, qi=qi)
-    cv, _, qv, _ = synth.make_pair(104, 2048, 8, 0, 768, kind="dense")
+    cv, _, qv, _ = synth.make_pair(104, 4096, 16, 0, 768, kind="dense")
     inp["dense"] = dict(cv=cv, qv=qv)
     # int8 corpus index vs int16 query index (densify_corpus.py:70-72 vs densify_query.py:73)
     cv, ci, qv, qi = synth.make_pair(105, 1024, 8, 768, 0, kind="encoder")
@@ -221,7 +221,7 @@ def main():
         # dense: split files -> index.main() merge (records glob order) -> gip main()
         dd = inp["dense"]
         sp = os.path.join(tmp, "splits"); os.makedirs(sp)
-        bounds = [0, 700, 1400, 2048]
+        bounds = [0, 1400, 2800, 4096]
         for i in range(3):
             dump_pickle(os.path.join(sp, f"msmarco-passage.split{i:02d}.pt"), dd["cv"][bounds[i]:bounds[i + 1]],
                         None, list(dd["docids"][bounds[i]:bounds[i + 1]]))

@@ -1206,13 +1206,59 @@ def _exhaustive_topk(ix, qv, qi, n, k, slab=1 << 20):
     return scores, rows
 
 
+def _independent_truth_check(slab_fn, n, d_dlr, qv, qi, rows, scores, k, slab=1 << 18):
+    """Ground truth that shares NO code with the library (the round-5 review: the exhaustive truth above scores its rows with dhr_score_rows,
+    i.e. through the same rescoring kernels as the search -- a 64-bit addressing bug for rows beyond 2^32 / 3072 would be self-consistent).
+    torch float64 straight from the corpus values / slice indices: for every query of the (small) batch the gated inner product of EVERY
+    row, slab by slab (slab_fn(lo, hi) -> (fp16 values, index bytes or None) of rows [lo, hi) on the device) -- fp16 x fp32 products are
+    exact in float64, their sum is good to ~1e-13 --; then, per query:
+      * every returned score is its row's float64 score rounded to fp32 (within one fp32 ulp: the library rounds its own float64 sum once);
+      * the returned set is the exact top-k: every row strictly above the k-th best float64 score (by more than an fp32 ulp) is in the list,
+        no returned row lies below it by more than that -- whatever its position in the row range;
+      * rows are distinct and inside the corpus."""
+    import torch
+    dev = qv.device
+    m = qv.shape[0]
+    q64 = qv.double()
+    exact = torch.empty((m, n), dtype=torch.float64, device=dev)
+    zero = torch.zeros((), dtype=torch.float16, device=dev)
+    for lo in range(0, n, slab):
+        hi = min(n, lo + slab)
+        v, x = slab_fn(lo, hi)
+        exact[:, lo:hi] = (v[:, d_dlr:].double() @ q64[:, d_dlr:].T).T
+        if d_dlr:
+            vg = v[:, :d_dlr]
+            for i in range(m):
+                gate = x == qi[i][None, :].to(x.dtype)                # [rows, d_dlr]: c_idx[n][j] == q_idx[j] (gip_retrieval.py:115)
+                exact[i, lo:hi] += torch.where(gate, vg, zero).double() @ q64[i, :d_dlr]
+        del v, x
+    ulp = 2.0 ** -23
+    for i in range(m):
+        ex = exact[i]
+        r, sc = rows[i], scores[i].double()
+        assert bool((r >= 0).all()) and bool((r < n).all()) and int(torch.unique(r).numel()) == k
+        got = ex[r]
+        assert bool(((sc - got).abs() <= ulp * got.abs().clamp_min(1e-30) + 1e-12).all()), "query %d: a returned score is not its row's exact score" % i
+        sk = torch.topk(ex, k).values[-1]
+        eps = ulp * float(sk.abs()) + 1e-12
+        must = torch.nonzero(ex > sk + eps).flatten()
+        inlist = torch.zeros(n, dtype=torch.bool, device=dev)
+        inlist[r] = True
+        assert bool(inlist[must].all()), "query %d: %d rows strictly above the k-th best score are missing (first: row %d)" % (
+            i, int((~inlist[must]).sum()), int(must[~inlist[must]][0]))
+        assert bool((got >= sk - eps).all()), "query %d: a returned row lies below the k-th best score" % i
+    return exact
+
+
 @pytest.mark.parametrize("kind", ["hybrid", "dense"])
 def test_full_size_properties(G, kind):
     """BASELINE config 3 (hybrid) / config 2 (dense-only) at FULL size (8 841 823 x (768+768), 6 980 queries, top-1000), where the oracle cannot run: properties
     that do not depend on the size.  (1) lists are sorted (score desc, row asc) with distinct valid rows; (2) the search is
     idempotent; (3) every returned score is the exact score of its row (dhr_score_rows, an independent code path);
     (4) completeness spot check: for sampled queries, none of 200 000 random rows outside the list beats the k-th score;
-    (5) a 200 000-row slice of the same corpus searched alone agrees with the oracle (ties the generator to the CPU path)."""
+    (5) the first and the last 200 000 rows of the same corpus searched alone agree with the oracle (ties the generator to the CPU path);
+    (6) 36 queries equal the exhaustive top-k bit for bit (scored through dhr_score_rows); (7) the same 36 queries against torch float64
+    scores of EVERY row computed from cv / ci directly -- no library code (_independent_truth_check)."""
     import sys, os
     import torch
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -1252,13 +1298,24 @@ def test_full_size_properties(G, kind):
         assert torch.equal(er, r1[ex_q]), "rows differ from the exhaustive top-k for queries %s" % ex_q[(er != r1[ex_q]).any(dim=1)].tolist()
         assert torch.equal(es.view(torch.int32), s1[ex_q].view(torch.int32))
         print("\n[%s, full size] %d queries: dhr_search == exhaustive top-%d over all %d rows" % (kind, len(ex_q), k, n))
-    finally:
+        # (7) the same 36 queries against a ground truth that shares no code with the library: torch float64 from cv / ci directly, every row
+        # of the corpus (the rows beyond 2^32 / 3072 bytes included), returned scores == exact scores, no outsider above the k-th score
         ix.close()
+        ix = None
+        torch.cuda.empty_cache()
+        _independent_truth_check(lambda lo, hi: (cv[lo:hi], None if ci is None else ci[lo:hi]), n, d_dlr, qv[ex_q].float(),
+                                 None if qi is None else qi[ex_q], r1[ex_q], s1[ex_q], k)
+        print("[%s, full size] %d queries: dhr_search == torch float64 ground truth over all %d rows (no library code)" % (kind, len(ex_q), n))
+    finally:
+        if ix is not None:
+            ix.close()
     m = 200_000
     cvs, cis = cv[:m].cpu().numpy(), (None if ci is None else ci[:m].cpu().numpy())
+    cvl, cil = cv[n - m:].cpu().numpy(), (None if ci is None else ci[n - m:].cpu().numpy())
     del cv, ci
     torch.cuda.empty_cache()
-    _search_check(G, cvs, cis, qs[:6], None if qis is None else qis[:6], 100)                     # (5)
+    _search_check(G, cvs, cis, qs[:6], None if qis is None else qis[:6], 100)                     # (5) the first 200 000 rows ...
+    _search_check(G, cvl, cil, qs[:6], None if qis is None else qis[:6], 100, row_offset=n - m)   #     ... and the LAST (row offsets beyond 2^32 / 3072)
 
 
 @pytest.mark.parametrize("kind", ["hybrid", "dense"])
@@ -1300,7 +1357,9 @@ def test_clustered_data_exhaustive(G, kind):
         assert torch.equal(er, r1[ex_q]), "rows differ from the exhaustive top-k for queries %s" % ex_q[(er != r1[ex_q]).any(dim=1)].tolist()
         assert torch.equal(es.view(torch.int32), s1[ex_q].view(torch.int32))
         assert st["sample_fallback_queries"] == 0, st
-        print("\n[clustered %s, %d rows] %d queries (%d hot) == exhaustive top-%d; bound %.0f -> exact %.0f rows per query, %d launches"
+        _independent_truth_check(lambda lo, hi: (cv[lo:hi], None if ci is None else ci[lo:hi]), n, d_dlr, qv[ex_q].float(),
+                                 None if qi is None else qi[ex_q], r1[ex_q], s1[ex_q], k)          # ... and the torch float64 truth (no library code)
+        print("\n[clustered %s, %d rows] %d queries (%d hot) == exhaustive top-%d == torch float64 truth; bound %.0f -> exact %.0f rows per query, %d launches"
               % (kind, n, len(ex_q), min(24, len(hot)), k, st["candidates_bound"] / nq, st["candidates_exact"] / nq, st["phases"]))
     finally:
         ix.close()
@@ -1364,6 +1423,9 @@ def test_config4_full_size_8_shards(G, ns):
         assert got == want, (got, want)
         assert torch.equal(sr, fr) and torch.equal(ss, fs)
         assert torch.equal(sr[ex_q], er) and torch.equal(ss[ex_q].view(torch.int32), es.view(torch.int32))       # 8 shards == exhaustive ground truth
+        if ns == 8:      # ... == the torch float64 truth from the generator's own rows (no library code; the corpus is regenerated slab by slab)
+            _independent_truth_check(lambda lo, hi: bench.gen_rows(torch, synth, dev, 1237, lo, hi, 768, 768, 30, 90, False), n, 768, qv[ex_q].float(),
+                                     qi[ex_q], sr[ex_q], ss[ex_q], k)
         # stage times, slowest shard per stage: begin (phase 0 + sampled run) | common threshold | finish (main pass) | merge
         for ix in shards:
             ix.set_param(_lib.PARAM_SAMPLE_SHARE, ns)
@@ -1513,6 +1575,38 @@ def test_bench_two_ranks_share_one_gpu():
     assert j["config"]["parallelism"] == "rowshard2+allgather"
     pc = j["parity_check"]                               # the sharded result's property check ran on both ranks
     assert pc["sorted"] and pc["distinct_rows"] and pc["scores_equal_exact_rescoring"] and pc["rows_beating_kth_outside_list"] == 0
+
+
+def test_bench_real_data_leg(tmp_path):
+    """bench.py --index-path / --query-path / --qrels: the timed search on an index + query set in the reference's own record layout, and the
+    second half of BASELINE.json's metric (nDCG@10; MRR@10, R@1000) computed from the timed search's lists.  The qrels are built from the
+    float64 oracle (the true best row of a query has rel 2, the next two rel 1), so the expected values are known: an exact search must
+    score nDCG@10 = MRR@10 = R@1000 = 1."""
+    import json, os, subprocess, sys
+    from dhr_amd import synth
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    cv, ci, qv, qi = synth.make_pair(77, 40_000, 12, 768, 64)
+    docids = ["D%d" % (3 * i + 1) for i in range(cv.shape[0])]
+    qids = ["Q%d" % i for i in range(qv.shape[0])]
+    dump_pickle(str(tmp_path / "corpus.index.pt"), cv, ci, docids)
+    dump_pickle(str(tmp_path / "queries.pt"), qv, qi, qids)
+    c32 = cv.astype(np.float32)
+    with open(tmp_path / "qrels.tsv", "w") as f:
+        for i, qid in enumerate(qids):
+            ex = O.gip_scores_f64(qv[i].astype(np.float32), qi[i], c32, ci)
+            top = O.topk_desc(ex, 3)
+            for j, r in enumerate(top):
+                f.write("%s\t0\t%s\t%d\n" % (qid, docids[int(r)], 2 if j == 0 else 1))
+            f.write("%s\t0\t%s\t0\n" % (qid, docids[int(np.argmin(ex))]))
+    cmd = [sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--quick", "--cpu-rows", "20000", "--topk", "100", "--index-path", str(tmp_path / "corpus.index.pt"),
+           "--query-path", str(tmp_path / "queries.pt"), "--qrels", str(tmp_path / "qrels.tsv"), "--emb-dim", "768"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["data"].startswith("real") and j["value"] > 0 and "other_configs" not in j
+    e = j["effectiveness"]
+    assert e["queries_evaluated"] == 12 and e["nDCG@10"] == 1.0 and e["MRR@10"] == 1.0 and e["R@1000"] == 1.0, e
+    assert j["parity_check"]["failed"] == 0 and "gemm_filter" in j["roofline"]["kernel"]
 
 
 def test_bench_rccl_bring_up_hangs_on_one_rank():

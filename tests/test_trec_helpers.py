@@ -90,3 +90,24 @@ def test_rcap_cli(tmp_path):
                          cwd=ROOT, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip() == str({'R_cap@2': 0.75})
+
+
+def test_effectiveness_hand_worked(tmp_path):
+    """nDCG@10 / MRR@10 / R@1000 (trec.effectiveness: the evaluator behind bench.py --qrels) against values worked out by hand from
+    trec_eval's definitions."""
+    qrels_path = tmp_path / 'qrels.tsv'
+    qrels_path.write_text('q1 0 a 1\nq1 0 b 0\nq1 0 c 2\nq2\t0\tx\t1\nq3 0 z 0\n')
+    qrels = trec.read_qrels_any(str(qrels_path))
+    assert qrels == {'q1': {'a': 1, 'b': 0, 'c': 2}, 'q2': {'x': 1}, 'q3': {'z': 0}}
+    run = {'q1': (['b', 'c', 'u', 'a'], [4.0, 3.0, 2.0, 1.0]),       # gains 0, 2, 0, 1
+           'q2': (['y', 'w'], [2.0, 1.0]),                           # the relevant doc is not retrieved
+           'q3': (['z'], [1.0]),                                     # no relevant judgment: skipped, as trec_eval does
+           'q4': (['z'], [1.0])}                                     # not judged at all: skipped
+    e = trec.effectiveness(qrels, run)
+    dcg = 2 / np.log2(3) + 1 / np.log2(5)
+    idcg = 2 / np.log2(2) + 1 / np.log2(3)
+    assert e['queries_evaluated'] == 2
+    assert e['nDCG@10'] == round((dcg / idcg + 0.0) / 2, 5)
+    assert e['MRR@10'] == round((1 / 2 + 0.0) / 2, 5)
+    assert e['R@1000'] == round((2 / 2 + 0 / 1) / 2, 5)
+    assert trec.effectiveness(qrels, {'q9': (['a'], [1.0])}) == {'queries_evaluated': 0}
