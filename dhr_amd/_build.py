@@ -14,9 +14,14 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdhr_hip.so")
 OBJDIR = os.path.join(CSRC, "build")
-SOURCES = ["abi.cpp", "kernels.hip", "gemm_w4.hip", "gemm_g8.hip", "gemm_g8p.hip", "api.hip", "sharded.hip", "pq_adc.hip", "select_global.hip", "host_io.hip"]
+SOURCES = ["abi.cpp", "kernels.hip", "gemm_w4.hip", "gemm_g8.hip", "api.hip", "sharded.hip", "pq_adc.hip", "select_global.hip", "host_io.hip"]
 HEADERS = ["dhr_internal.h", "abi_guard.h", "libdhr.map", "gemm_common.h", "gemm_g8.h", os.path.join("..", "..", "include", "dhr_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
+# A/B builds only (DHR_AB_VARIANTS=1 in the environment of the build, tools/ab_build.sh): the retired persistent-workgroup form of the integer
+# bound GEMM (tools/ab/gemm_g8p.hip, DHR_PARAM_GEMM_VARIANT = 6) -- the measurement behind DESIGN.md section 4b, not part of the shipped library
+if os.environ.get("DHR_AB_VARIANTS") == "1":
+    SOURCES = SOURCES + [os.path.join("..", "..", "tools", "ab", "gemm_g8p.hip")]
+    FLAGS = FLAGS + ["-DDHR_AB_VARIANTS", "-I" + CSRC]
 
 
 def _mtime(path: str) -> float:
@@ -29,7 +34,7 @@ def _stale() -> bool:
 
 
 def _compile(hipcc: str, src: str, newest_header: float, force: bool, verbose: bool) -> str:
-    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+    obj = os.path.join(OBJDIR, os.path.splitext(os.path.basename(src))[0] + ".o")
     if not force and _mtime(obj) > max(_mtime(os.path.join(CSRC, src)), newest_header):
         return obj
     tmp = obj + ".tmp.%d" % os.getpid()

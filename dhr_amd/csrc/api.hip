@@ -177,6 +177,8 @@ struct dhr_index {
   struct { bool valid = false, done = false, gate = false, mid = false, pre = false; int Q = 0, k = 0; double rate = 0.0, rate_r = 0.0; int64_t dev_bound = 0, dev_exact = 0;
            int64_t pre_pos = 0, pre_seen = 0, pre_last_rows = 0; } pend;   // mid: dhr_search_mid ran the first slice of the main pass; pre: dhr_search_pre ran the first part of the sampled run (sample positions [0, pre_pos), pre_seen rows)
   Workspace ws, ws_fb[2];              // ws_fb[d]: workspace of fallback depth d+1 (16x candidate capacity)
+  void* sh_arena = nullptr;            // grow-only scratch of dhr_search_sharded_local (sharded.hip): the gathered blocks of a step, kept between steps
+  size_t sh_arena_bytes = 0;
   dhr_search_stats stats{};
 };
 
@@ -200,6 +202,7 @@ extern "C" void dhr_index_destroy(dhr_index* ix) try {
   free_ws(ix->ws_fb[1]);
   if (ix->s_aux) hipStreamDestroy(ix->s_aux);
   if (ix->s_gemm) hipStreamDestroy(ix->s_gemm);
+  hipFree(ix->sh_arena);
   hipFree(ix->resid8); hipFree(ix->i8_col_scale); hipFree(ix->g8_inv_cs); hipFree(ix->g8_w); hipFree(ix->g8_rsum); hipFree(ix->tiles); hipFree(ix->c_idx); hipFree(ix->vals_rm); hipFree(ix->bucket_map); hipFree(ix->heavy_key);      // (heavy_val points into the heavy_key records)
   delete ix;
 } DHR_CATCH_VOID
@@ -230,8 +233,7 @@ extern "C" int dhr_index_get_info(const dhr_index* ix, int32_t what, double* out
     case DHR_INFO_ROW_NORM_MAX: *out = ix->dmax; return DHR_OK;
     case DHR_INFO_GATED_I8: *out = ix->gated_i8 ? 1.0 : 0.0; return DHR_OK;
     case DHR_INFO_GEMM_KERNEL: *out = (double)ix->last_gemm_kernel; return DHR_OK;
-    case DHR_INFO_TILE_BYTES: *out = (double)(ix->ts + ix->td > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * (ix->gated_i8 ? S8_STAGE_A : SP_STAGE_A) + (size_t)ix->td * SP_DENSE)
-                                                                      : (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2); return DHR_OK;
+    case DHR_INFO_TILE_BYTES: *out = (double)((size_t)ix->n_tiles * ((size_t)ix->ts * (ix->gated_i8 ? S8_STAGE_A : SP_STAGE_A) + (size_t)ix->td * SP_DENSE)); return DHR_OK;
   }
   return set_error(DHR_ERR_INVALID, "unknown info id");
 } DHR_CATCH_STATUS
@@ -266,7 +268,10 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
     case DHR_PARAM_GEMM_EXCLUSIVE: ix->gemm_exclusive = value != 0; return DHR_OK;
     case DHR_PARAM_OVERLAP_AUX: ix->overlap_aux = value < 0 ? -1 : value != 0; return DHR_OK;
     case DHR_PARAM_GEMM_VARIANT:
-      if (value < 3 || value > 6) return set_error(DHR_ERR_INVALID, "gemm_variant: 3 (12-wave producer / consumer kernel), 4 (4 waves, 128 x 128 wave tiles), 5 (8 waves, 128 x 64 wave tiles) or 6 (5 with persistent workgroups on gated_i8 indexes)");
+#ifdef DHR_AB_VARIANTS
+      if (value == 6) { ix->gemm_variant = 6; return DHR_OK; }      // A/B builds: persistent workgroups on gated_i8 indexes (tools/ab/gemm_g8p.hip)
+#endif
+      if (value != 4 && value != 5) return set_error(DHR_ERR_INVALID, "gemm_variant: 4 (4 waves, 128 x 128 wave tiles) or 5 (8 waves, 128 x 64 wave tiles; default) -- the fp16-gated kernel; integer (gated_i8) indexes have one kernel");
       ix->gemm_variant = (int)value; return DHR_OK;
     case DHR_PARAM_MAX_GROWTH:
       if (value < 1 || value > 1024) return set_error(DHR_ERR_INVALID, "max_growth must be in [1,1024] sixteenths");
@@ -276,7 +281,8 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
 } DHR_CATCH_STATUS
 
 extern "C" int dhr_index_device(const dhr_index* ix) try { return ix ? ix->device : -1; } DHR_CATCH_VALUE(-1)
-extern "C" int64_t dhr_index_device_bytes(const dhr_index* ix) try { return ix ? ix->index_bytes + ix->ws.bytes + ix->ws_fb[0].bytes + ix->ws_fb[1].bytes : 0; } DHR_CATCH_VALUE(0)
+extern "C" void dhr_internal_index_arena(dhr_index* ix, void*** base, size_t** bytes) try { *base = &ix->sh_arena; *bytes = &ix->sh_arena_bytes; } DHR_CATCH_VOID
+extern "C" int64_t dhr_index_device_bytes(const dhr_index* ix) try { return ix ? ix->index_bytes + ix->ws.bytes + ix->ws_fb[0].bytes + ix->ws_fb[1].bytes + (int64_t)ix->sh_arena_bytes : 0; } DHR_CATCH_VALUE(0)
 extern "C" int dhr_get_stats(const dhr_index* ix, dhr_search_stats* out) try {
   if (!ix || !out) return set_error(DHR_ERR_INVALID, "null argument");
   *out = ix->stats;
@@ -321,13 +327,10 @@ static int ingest(dhr_index* ix, const dhr_index_desc* d, uint32_t* d_flags /* {
 // Pass 2: the bound-GEMM operand tiles from the device copy (needs the bucket map and abs_mode).
 static int build_tiles(dhr_index* ix, hipStream_t s) {
   const int64_t n = ix->n_rows, fill = ix->n_tiles * TILE_ROWS;
-  if (ix->ts + ix->td > 0)       // stage layout (2:4 sparse stages and / or 32-column dense stages)
-    HIP_TRY(launch_tile_rows_sparse(ix->vals_rm, ix->k_rm, 0, n, fill, ix->d_dlr, ix->d_cls, ix->ts, ix->td, ix->c_idx, ix->idx_dtype,
-                                    ix->bucket_map, ix->abs_mode, (char*)ix->tiles, ix->dense_i8 ? 1.f / ix->i8_scale : 0.f, ix->i8_col_scale,
-                                    ix->gated_i8 ? ix->g8_inv_cs : nullptr, s));
-  else
-    HIP_TRY(launch_tile_rows(ix->vals_rm, ix->k_rm, 0, n, fill, ix->d_dlr, ix->d_cls, ix->n_buckets, ix->kt, ix->c_idx, ix->idx_dtype,
-                             ix->bucket_map, ix->abs_mode, ix->tiles, s));
+  // stage images: 2:4 sparse stages of 32 gated slices, then stages of 32 (fp16) / 64 (int8) ungated columns
+  HIP_TRY(launch_tile_rows_sparse(ix->vals_rm, ix->k_rm, 0, n, fill, ix->d_dlr, ix->d_cls, ix->ts, ix->td, ix->c_idx, ix->idx_dtype,
+                                  ix->bucket_map, ix->abs_mode, (char*)ix->tiles, ix->dense_i8 ? 1.f / ix->i8_scale : 0.f, ix->i8_col_scale,
+                                  ix->gated_i8 ? ix->g8_inv_cs : nullptr, s));
   return DHR_OK;
 }
 
@@ -376,7 +379,8 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) t
   if (has_idx && (d->index_dtype < DHR_IDX_U8 || d->index_dtype > DHR_IDX_I16)) return set_error(DHR_ERR_INVALID, "bad index_dtype");
   if (has_idx && d->ld_index < d->d_dlr) return set_error(DHR_ERR_INVALID, "bad ld_index");
   if (d->d_dlr + d->d_cls > 8192) return set_error(DHR_ERR_UNSUPPORTED, "more than 8192 columns");
-  if (d->idx_buckets < 0 || d->idx_buckets > 16) return set_error(DHR_ERR_INVALID, "idx_buckets must be in [0,16] (0 = default)");
+  if (d->idx_buckets < 0 || d->idx_buckets > 2)
+    return set_error(d->idx_buckets > 2 ? DHR_ERR_UNSUPPORTED : DHR_ERR_INVALID, "idx_buckets must be 0 (default: 2), 1 (ungated bound) or 2: the bucket-split operands of more than two buckets went with the K-step tile layout (round 6)");
   if (d->mem_kind != DHR_MEM_HOST && d->mem_kind != DHR_MEM_DEVICE) return set_error(DHR_ERR_INVALID, "bad mem_kind");
   dhr::alloc_checkpoint();
   HIP_TRY(hipSetDevice(d->device));
@@ -397,40 +401,39 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) t
   ix->dlr_pad = dlr_pad;
   ix->k = d->d_dlr + d->d_cls;
   ix->k_rm = (int)round_up(ix->k, TILE_K);
-  // default for gated indexes: two buckets on the sparse matrix cores (needs 32-slice stages);
-  // idx_buckets = 1,3,4,... selects the dense bucket-split operands instead
-  const bool sparse_ok = has_idx && (d->d_dlr % 32 == 0);
+  // ONE layout (round 6): stage images -- 2:4 sparse stages of 32 gated slices (two index buckets per slice; idx_buckets = 1: every index
+  // value in bucket 0, the ungated bound) and stages of 32 (fp16) / 64 (int8) ungated columns, an EVEN number of either kind: gated widths that
+  // are no multiple of 64 and odd ungated stage counts are rounded up with all-zero stages (the tile builder and query_prep_kernel write zeros
+  // behind d_dlr / d_cls), so that every index runs on the two 8-wave kernels.  The K-step tile layout (bucket counts above two, their own
+  // kernel) and the 12-wave kernel of odd stage counts were retired.
+  auto even_up = [](int v) { return v + (v & 1); };
   // int8 image of the ungated columns (process-wide option / DHR_DENSE_I8; default: gated indexes only, where the gated part
   // dominates the spread of the scores and the int8 margin costs few extra candidates -- DESIGN.md section 6b)
   int want_i8 = g_opt_dense_i8;
   if (const char* e = getenv("DHR_DENSE_I8")) want_i8 = atoi(e);
   bool dense_only_trial = false;
-  if (sparse_ok && (d->idx_buckets == 0 || d->idx_buckets == 2)) {
-    ix->n_buckets = 2;
-    ix->ts = d->d_dlr / 32;
-    ix->dense_i8 = d->d_cls > 0 && !(ix->ts & 1) && (want_i8 < 0 || want_i8 > 0);   // stage pairs: the int8 stages run on the 8 / 4-wave kernels only
-    ix->td = ix->dense_i8 ? 2 * ((d->d_cls + 127) / 128) : (d->d_cls + 31) / 32;     // ungated columns in 32-column fp16 stages or PAIRS of 64-column int8 stages
+  if (has_idx) {
+    ix->n_buckets = d->idx_buckets == 1 ? 1 : 2;
+    ix->ts = even_up((d->d_dlr + 31) / 32);
+    ix->dense_i8 = d->d_cls > 0 && (want_i8 < 0 || want_i8 > 0);
+    ix->td = ix->dense_i8 ? 2 * ((d->d_cls + 127) / 128) : even_up((d->d_cls + 31) / 32);     // ungated columns in 32-column fp16 stages or PAIRS of 64-column int8 stages
     ix->kt = ix->ts * TILE_K + ix->td * 32;            // operand bytes / 2 per row (fp16: logical columns, two bucket columns per gated slice)
-    // gated half as int8 on the 2:4 int8 instruction (gemm_g8.hip): default wherever the stages pair up and the
-    // ungated half (if any) is the int8 image too; DHR_GATED_I8=0 / dhr_set_option(DHR_OPT_GATED_I8, 0) keeps the fp16 image
+    // gated half as int8 on the 2:4 int8 instruction (gemm_g8.hip): default for large shards whose ungated half (if any)
+    // is the int8 image too; DHR_GATED_I8=0 / dhr_set_option(DHR_OPT_GATED_I8, 0) keeps the fp16 image
     int want_g8 = g_opt_gated_i8;
     if (const char* e = getenv("DHR_GATED_I8")) want_g8 = atoi(e);
     if (want_g8 < 0) want_g8 = d->n_rows >= (2 * d->d_cls >= d->d_dlr ? GATED_I8_MIN_ROWS : GATED_I8_MIN_ROWS_NARROW) ? 1 : 0;
-    ix->gated_i8 = want_g8 != 0 && !(ix->ts & 1) && (d->d_cls == 0 || ix->dense_i8) && d->d_dlr <= 4096;
-  } else if (!has_idx && d->idx_buckets == 0) {
-    // dense-only index: the same 32-column stage images (ts = 0), so that it runs on the 8-wave kernel of the 2:4 layout
-    // (idx_buckets = 1 keeps the K-step tile layout and gemm_filter_v3_kernel)
+    ix->gated_i8 = want_g8 != 0 && ix->n_buckets == 2 && (d->d_cls == 0 || ix->dense_i8) && d->d_dlr <= 4096;
+  } else {
+    // dense-only index: the same stage images with no gated stage (ts = 0)
     ix->n_buckets = 1;
     ix->ts = 0;
     // int8 image for a dense-only index: explicitly (option = 1), or -- default, large shards -- on trial: the margin it needs is measured
     // below (i8_row_err pass) and the fp16 image is kept where it would be too large a share of the spread of the scores
     dense_only_trial = want_i8 < 0 && d->n_rows >= DENSE_ONLY_I8_MIN_ROWS && d->d_cls >= 128;
     ix->dense_i8 = want_i8 > 0 || dense_only_trial;
-    ix->td = ix->dense_i8 ? 2 * ((d->d_cls + 127) / 128) : (d->d_cls + 31) / 32;
+    ix->td = ix->dense_i8 ? 2 * ((d->d_cls + 127) / 128) : even_up((d->d_cls + 31) / 32);
     ix->kt = ix->td * 32;
-  } else {
-    ix->n_buckets = has_idx ? (d->idx_buckets > 0 ? d->idx_buckets : 3) : 1;
-    ix->kt = (int)round_up((int64_t)ix->n_buckets * ix->d_dlr + ix->d_cls, TILE_K);
   }
   ix->ksteps = (ix->kt + TILE_K - 1) / TILE_K;
   ix->idx_dtype = has_idx ? d->index_dtype : DHR_IDX_NONE;
@@ -526,20 +529,19 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) t
         ix->dense_i8 = false;
         hipFree(ix->i8_col_scale); ix->i8_col_scale = nullptr;
         ix->i8_scale = ix->i8_ec = ix->i8_nc = 0.f;
-        ix->td = (d->d_cls + 31) / 32;
+        ix->td = ((d->d_cls + 31) / 32 + 1) & ~1;
         ix->kt = ix->td * 32;
         ix->ksteps = (ix->kt + TILE_K - 1) / TILE_K;
       }
     }
   }
-  // dense-only int8 index: residual image = the refine level between the filter and the exact rescoring (DHR_DENSE_RESID=0 switches it off).
+  // dense-only int8 index: residual image = the refine level between the filter and the exact rescoring.
   // The int8 margin is  ||q'|| ec (corpus rounding) + ||q' - q8'|| nc (query rounding); with the residuals the first term is MEASURED per
   // candidate from 384 bytes (four bits per value) instead of bounded, and the candidates that only the corpus half of the margin let through
   // never reach the 1.5 KB rows of the exact rescoring.
   {
-    static const int env_resid = getenv("DHR_DENSE_RESID") ? atoi(getenv("DHR_DENSE_RESID")) : 1;
     const int ld = (int)round_up(ix->d_cls, 256) / 2;           // four bits per value
-    if (env_resid != 0 && ix->dense_i8 && ix->d_dlr == 0 && ld <= 512 && ix->i8_ec > 0.f) {
+    if (ix->dense_i8 && ix->d_dlr == 0 && ld <= 512 && ix->i8_ec > 0.f) {
       const size_t rb = (size_t)ix->n_rows * ld;
       if (hipMalloc((void**)&ix->resid8, rb) != hipSuccess) return fail(set_error(DHR_ERR_HIP, "hipMalloc of the residual image failed"));
       ix->index_bytes += (int64_t)rb;
@@ -549,8 +551,7 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) t
       ix->resid_ec2 = std::sqrt((float)ix->d_cls) * ix->i8_scale / 28.f;       // every residual is within half of 1/14 of its column's step: scale / 28 in the weighted space
     }
   }
-  const size_t tile_bytes = ix->ts + ix->td > 0 ? (size_t)ix->n_tiles * ((size_t)ix->ts * (ix->gated_i8 ? S8_STAGE_A : SP_STAGE_A) + (size_t)ix->td * SP_DENSE)
-                                       : (size_t)ix->n_tiles * ix->ksteps * TILE_HALVES * 2;
+  const size_t tile_bytes = (size_t)ix->n_tiles * ((size_t)ix->ts * (ix->gated_i8 ? S8_STAGE_A : SP_STAGE_A) + (size_t)ix->td * SP_DENSE);
   if (hipMalloc((void**)&ix->tiles, tile_bytes) != hipSuccess)
     return fail(set_error(DHR_ERR_HIP, "hipMalloc of " + std::to_string(tile_bytes) + " bytes for the corpus tiles failed"));
   ix->index_bytes += (int64_t)tile_bytes;
@@ -593,6 +594,12 @@ extern "C" int dhr_index_create(const dhr_index_desc* d_user, dhr_index** out) t
       return fail(set_error(DHR_ERR_HIP, "g8_row_sum launch failed"));
   }
   // bucket maps from the value mass per (slice, index value)
+  if (has_idx && ix->n_buckets == 1) {
+    // idx_buckets = 1: every index value in bucket 0 (an all-zero map serves 8- and 16-bit index dtypes alike: bucket_of reads map[j][value & 255])
+    const size_t mb = (size_t)d->d_dlr * 256;
+    if (hipMalloc((void**)&ix->bucket_map, mb) != hipSuccess || hipMemsetAsync(ix->bucket_map, 0, mb, s) != hipSuccess)
+      return fail(set_error(DHR_ERR_HIP, "bucket map allocation failed"));
+  }
   if (has_idx && ix->n_buckets > 1 && idx_esize(d->index_dtype) == 1) {
     const size_t hb = (size_t)d->d_dlr * 256 * 4;
     if (hipMalloc((void**)&d_hist, hb) != hipSuccess || hipMemsetAsync(d_hist, 0, hb, s) != hipSuccess)
@@ -1055,8 +1062,7 @@ static int gemm_phase(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi
 // statistics are accumulated there (w.d_stats), a list that overflowed flags its query (fail_flags: redone by the fallback), and the
 // per-candidate kernels are launched with a fixed grid that walks the block list by grid stride.
 static uint32_t async_grid() {
-  static const uint32_t g = getenv("DHR_FLAT_GRID") ? (uint32_t)atoi(getenv("DHR_FLAT_GRID")) : FLAT_GRID_ASYNC;
-  return g ? g : FLAT_GRID_ASYNC;
+  return FLAT_GRID_ASYNC;
 }
 static int gemm_phase_async(dhr_index* ix, Workspace& w, int Q, int64_t lo, int64_t hi, int map_mode, int period, int64_t head,
                             Timer& tm, dhr_search_stats& st, hipStream_t s) {
@@ -1175,8 +1181,7 @@ static int rescore_select(dhr_index* ix, Workspace& w, int Q, bool gate, SelectA
 // bound's amplification through: 1 400 of the 4 340 exact rescorings per query of a config-3 step were spent finding the 64 best of
 // the 1/32 sample.
 static int adaptive_rank(int r, double phi) {
-  static const int on = getenv("DHR_ADAPTIVE_RANK") ? atoi(getenv("DHR_ADAPTIVE_RANK")) : 1;
-  if (!on || !(phi < 1.0)) return r;
+  if (!(phi < 1.0)) return r;
   if (phi < 0.0) phi = 0.0;
   const double m = (double)r * phi;
   return std::max(1, std::min(r, (int)std::ceil(m + 6.0 * std::sqrt(m * (1.0 - phi)) + 4.0)));
@@ -1297,10 +1302,14 @@ static int mid_share16() {
 }
 // Rows scored exhaustively in phase 0 (>= the rank that defines tau, so that tau exists afterwards), whole tiles -- 512 rows until round 3, 256
 // since; 0 = none: a sampled search (S >= 2) bootstraps its first thresholds from the bound GEMM instead (search_core), unless the caller
-// fixed the head (DHR_PARAM_FIRST_ROWS) or DHR_BOOTSTRAP=0.
+// fixed the head (DHR_PARAM_FIRST_ROWS).
 static int64_t head_rows(const dhr_index* ix, int S, int r_eff) {
-  static const int boot = getenv("DHR_BOOTSTRAP") ? atoi(getenv("DHR_BOOTSTRAP")) : 1;
-  if (boot && S >= 2 && ix->first_rows <= 0 && ix->n_tiles >= 8) return 0;
+  if (S >= 2 && ix->first_rows <= 0 && ix->n_tiles >= 8) {
+    // the bootstrap takes the r0-th best of at most BOOT_M rows of tile 0: a sampling rule under which r0 outgrows that (today r0 <= 44) must not
+    // publish the threshold of a lower rank -- it falls back to the exhaustive head instead (search_core computes r0 from the same expression)
+    const int64_t sample_rows = ((ix->n_tiles + S - 1) / S) * TILE_ROWS;
+    if (adaptive_rank(r_eff, (double)TILE_ROWS / (double)sample_rows) <= BOOT_M) return 0;
+  }
   return ix->first_rows > 0 ? std::max<int64_t>(ix->first_rows, 2 * (int64_t)r_eff) : std::max<int64_t>(S >= 2 ? 256 : 512, 2 * (int64_t)r_eff);
 }
 static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, int k, int depth, Timer& tm,
@@ -1336,11 +1345,10 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
   const int64_t first_valid = std::min(first, n);
   if ((rc = ensure_ws(ix, w, Q, k, first_valid, depth == 0 ? 1 : 16, gate || ix->gated_i8 || ix->resid8 != nullptr)) != DHR_OK) return rc;
 
-  // first attempt of a sampled search: the controller only enqueues (no host read-backs); DHR_ASYNC=0 / DHR_PARAM_ASYNC_CONTROLLER 0 keep the
+  // first attempt of a sampled search: the controller only enqueues (no host read-backs); DHR_PARAM_ASYNC_CONTROLLER 0 keeps the
   // host-driven controller (and the fallback depths always use it: it is the one that is exact for any input)
-  static const int env_async = getenv("DHR_ASYNC") ? atoi(getenv("DHR_ASYNC")) : -1;
-  const bool async_ctl = depth == 0 && S >= 2 && (env_async < 0 ? ix->async_ctl != 0 : env_async != 0) && !getenv("DHR_DEBUG_PLAN");
-  const bool plan_read = (env_async < 0 ? ix->async_ctl : env_async) >= 2;      // 2: the chunk plan of the main pass reads the sampled run's list lengths back
+  const bool async_ctl = depth == 0 && S >= 2 && ix->async_ctl != 0 && !getenv("DHR_DEBUG_PLAN");
+  const bool plan_read = ix->async_ctl >= 2;      // 2: the chunk plan of the main pass reads the sampled run's list lengths back
   if (fresh) {
     tm.begin(T_PREP);
     if ((rc = prep_queries(ix, w, qb, s)) != DHR_OK) return rc;
@@ -1415,20 +1423,21 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     if (stage == 4) {
       n_hi = pre_positions(n_sample);
       if (n_hi <= 0) return set_error(DHR_ERR_INVALID, "the sample of this index is too small for a pre step");
+      static const int pre_one = getenv("DHR_PRE_ONE") ? atoi(getenv("DHR_PRE_ONE")) : 0;      // A/B: the first part of the sample as ONE phase behind the bootstrap
+      if (pre_one) chunk0 = round_up(n_hi, DOC_GROUP);
     }
     if (stage == 5) {
       // the threshold the shards agreed on after the first part (never below this shard's own: thresholds only rise), and on with the growth rule
       pos0 = ix->pend.pre_pos; seen0 = ix->pend.pre_seen;
       HIP_TRY(launch_raise_thr(w.tau, tau_ext, Q, s));
       HIP_TRY(launch_make_thr(w.tau, w.margin, Q, w.q_pad, w.thr, s));
-      // ONE phase for the rest (DHR_PRE_REST_ONE=0: the growth rule): the agreed threshold is the union's (r phi + 6 sigma + 4)-th best of 1/8 of
+      // ONE phase for the rest: the agreed threshold is the union's (r phi + 6 sigma + 4)-th best of 1/8 of
       // the union sample -- 8 x the rows this shard has seen -- and a phase of a shard's sampled run is bound by its launches, not by its rows
-      static const int rest_one = getenv("DHR_PRE_REST_ONE") ? atoi(getenv("DHR_PRE_REST_ONE")) : 1;
-      chunk0 = rest_one ? round_up(n_sample - pos0, DOC_GROUP) : std::max<int64_t>(DOC_GROUP, round_up(seen0 * ix->max_growth16 / 16 / TILE_ROWS, DOC_GROUP));
+      chunk0 = round_up(n_sample - pos0, DOC_GROUP);
     }
     // (the first part of a shard's sample is 17 tiles of a 1/8 shard of the benchmark: phases of 4 + 13 tiles instead of 4 + 8 + 5 -- a phase there
-    // is bound by its ~8 dependent launches, 0.4-0.5 ms, not by its rows; DHR_PRE_GROWTH16 in 1/16ths)
-    static const int pre_growth = getenv("DHR_PRE_GROWTH16") ? std::max(16, atoi(getenv("DHR_PRE_GROWTH16"))) : 64;
+    // is bound by its ~8 dependent launches, 0.4-0.5 ms, not by its rows: growth 4 x there)
+    constexpr int pre_growth = 64;
     if ((rc = stream_phases(ix, w, Q, gate, sel, n_hi, 1, S, head, chunk0, seen0, tm, st, s, &rate, &rate_r, async_ctl, &last_rows,
                             r_eff, first_valid + n_sample * TILE_ROWS, pos0, stage == 4 ? std::max(ix->max_growth16, pre_growth) : 0,
                             stage == 5 ? ix->pend.pre_last_rows : 0)) != DHR_OK) return rc;      // (stage 5: w.cnt still holds the lists of the pre call's last phase)
@@ -1441,7 +1450,7 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
     if (async_ctl && w.arena > 0) {          // the main pass plans its second list tier from these (possibly in a later call: staged search)
       HIP_TRY(hipMemcpyAsync(w.cnt_plan, w.cnt, (size_t)w.q_pad * 4, hipMemcpyDeviceToDevice, s));
       w.plan_rows = last_rows;
-    }
+    } else w.plan_rows = 0;                  // nothing to plan from: a main pass that finds the arena in use (a controller switched between the calls) plans no segments
     if (async_ctl && plan_read && stage == 0 && last_rows > 0) {
       // the ONE read-back besides the final one: 32 bytes, the fullest bound / survivor list of the last sampled phase -> how many chunks
       // the main pass needs for the hottest query's lists to fit (a list that overflows costs its query tile an extra pass over the corpus:
@@ -1527,13 +1536,8 @@ static int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, i
         }
       }
       if (!ix->s_aux) {
-        // DHR_AUX_PRIO=1: the refine / rescoring stream at the LOWEST queue priority, so that a CU that a bound-GEMM workgroup has just left
-        // takes the next GEMM workgroup first and the gathers fill what is left (co-residence instead of time slices)
-        static const int aux_prio = getenv("DHR_AUX_PRIO") ? atoi(getenv("DHR_AUX_PRIO")) : 0;
-        int least = 0, greatest = 0;
-        if (aux_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
-          HIP_TRY(hipStreamCreateWithPriority(&ix->s_aux, hipStreamNonBlocking, least));
-        else HIP_TRY(hipStreamCreateWithFlags(&ix->s_aux, hipStreamNonBlocking));
+        // (round 5 measured the aux stream at the lowest queue priority: no gain -- a CU between two GEMM workgroups fills with gather waves whatever the priority)
+        HIP_TRY(hipStreamCreateWithFlags(&ix->s_aux, hipStreamNonBlocking));
       }
       ix->aux_cus_made = aux_cus; ix->gemm_excl_made = ix->gemm_exclusive;
     }
@@ -1982,8 +1986,6 @@ extern "C" int32_t dhr_search_pre_ranks(const dhr_index* ix, int32_t k, int32_t*
   if (out_local) *out_local = 0;
   if (out_union) *out_union = 0;
   if (!ix || k <= 0) return 0;
-  static const bool on = !(getenv("DHR_SHARD_PRE") && atoi(getenv("DHR_SHARD_PRE")) == 0);
-  if (!on) return 0;
   int S = 0, r = k;
   plan_sampling(ix, k, S, r);
   if (S < 2) return 0;
@@ -2483,25 +2485,7 @@ extern "C" int dhr_debug_gemm_time(dhr_index* ix, const dhr_query_batch* qb, int
     std::vector<float> inf((size_t)w.q_pad, INFINITY);
     HIP_TRY(hipMemcpyAsync(w.thr, inf.data(), (size_t)w.q_pad * 4, hipMemcpyHostToDevice, s));
   }
-  // DHR_GEMM_THR_SAVE / DHR_GEMM_THR_LOAD (tuning): the thresholds of an open-filter timing written to / read from a file, so that an
-  // ablation build of the library (whose own searches are meaningless) can be timed at the thresholds of a correct one
-  bool opened = open;
-  if (const char* f = getenv("DHR_GEMM_THR_SAVE")) {
-    if (open) {
-      std::vector<float> t((size_t)w.q_pad);
-      HIP_TRY(hipMemcpyAsync(t.data(), w.thr, t.size() * 4, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      if (FILE* fp = fopen(f, "wb")) { fwrite(t.data(), 4, t.size(), fp); fclose(fp); }
-    }
-  } else if (const char* f = getenv("DHR_GEMM_THR_LOAD")) {
-    std::vector<float> t((size_t)w.q_pad);
-    FILE* fp = fopen(f, "rb");
-    if (!fp || fread(t.data(), 4, t.size(), fp) != t.size()) { if (fp) fclose(fp); return set_error(DHR_ERR_INVALID, "DHR_GEMM_THR_LOAD: cannot read the threshold file"); }
-    fclose(fp);
-    HIP_TRY(hipMemcpyAsync(w.thr, t.data(), t.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    opened = true;
-  }
+  const bool opened = open;
   HIP_TRY(hipMemsetAsync(w.cnt, 0, (size_t)w.q_pad * 4, s));
   GemmArgs g{};
   g.a_tiles = ix->tiles; g.b_tiles = w.q_tiles; g.ksteps = ix->ksteps; g.ts = ix->ts; g.td = ix->td; g.ts_q = w.ts_q; g.variant = ix->gemm_variant; g.i8_mul = (ix->dense_i8 || ix->gated_i8) ? w.i8_mul : nullptr; g.g8_shift = ix->gated_i8 ? w.g8_shift : nullptr; g.g8_rsum = ix->g8_rsum; g.seq_lo = 0; g.seq_hi = ix->n_tiles; g.map_mode = 0;

@@ -11,6 +11,7 @@
 // library-internal helpers with C linkage (api.hip), used by the other translation units
 extern "C" int dhr_set_error_message(int code, const char* msg);   // records the calling thread's last error, returns code
 extern "C" int dhr_index_device(const dhr_index* ix);
+extern "C" void dhr_internal_index_arena(dhr_index* ix, void*** base, size_t** bytes);   // the handle's grow-only scratch for dhr_search_sharded_local
 // dhr_search_begin / dhr_search_finish without their final stream synchronisation (sharded.hip: the shards of a one-process search work
 // concurrently until the collective layer synchronises; over RCCL the whole call enqueues up to its one host read)
 extern "C" int dhr_internal_search_begin_async(dhr_index* ix, const dhr_query_batch* qb, int32_t k, float* out_sample_scores_dev, void* stream);
@@ -137,7 +138,7 @@ struct GemmArgs {
   int64_t dump_ld;
   int64_t dump_row0;
   int n_queries;
-  int variant;                // 2:4 layout kernel (3 / 4 / 5), 0 = the library default (g_gemm_variant)
+  int variant;                // fp16-gated kernel: 4 (4 waves) / 5 (8 waves), 0 = the library default (g_gemm_variant); 6: A/B builds, persistent workgroups
   const int32_t* g8_shift;    // [Q_pad] or null.  Non-null: gated_i8 index (gemm_g8.hip) -- the ts gated stages are int8 2:4 images and run FIRST into int32
                               // accumulators, which are then shifted left by this per-query amount (gated unit = 2^shift x ungated unit) before the td
                               // int8 stages of the ungated columns accumulate on top; i8_mul is the final unit (score = sum * i8_mul)
@@ -247,9 +248,6 @@ hipError_t launch_scan_rows(const __half* src, int64_t ld, int64_t n_rows, int d
 hipError_t launch_i8_row_err(const __half* vals_rm, int k_rm, int64_t n_rows, int d_dlr, int d_cls, float scale, const float* col_scale,
                              uint32_t* out_bits, hipStream_t s);
 hipError_t launch_col_absmax(const __half* vals_rm, int k_rm, int64_t n_rows, int col0, int n_cols, uint32_t* colmax_bits, hipStream_t s);   // columns [col0, col0 + n_cols)
-hipError_t launch_tile_rows(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
-                            int d_dlr, int d_cls, int n_buckets, int kt, const void* idx, int idx_dtype,
-                            const uint8_t* map, bool abs_dlr, __half* tiles, hipStream_t s);
 hipError_t launch_tile_rows_sparse(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
                                    int d_dlr, int d_cls, int ts, int td, const void* idx, int idx_dtype, const uint8_t* map,
                                    bool abs_dlr, char* tiles, float i8_inv_scale /* 0: fp16 dense stages */, const float* col_scale,
@@ -283,13 +281,28 @@ hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const 
 // are dispatched x-fastest and dealt round-robin to the 8 XCDs, so blockIdx.x is the XCD, and each XCD sweeps DOC_GROUP corpus tiles
 // against all query tiles before it moves on (its L2 holds those corpus tiles; the query tile set streams from the Infinity Cache) --
 // the linear order of the former 1-D grid, without its division by DOC_GROUP * n_qtiles.
+constexpr int MAP_SPREAD_Q = 0x100;        // GemmArgs::map_mode flag (set by launch_gemm_filter): the launch has fewer than 8 tile groups -- see gemm_wg_tile
 __device__ __forceinline__ bool gemm_wg_tile(const GemmArgs& p, int64_t& dt, int& qt) {
   const int r = (int)blockIdx.y;
-  qt = r / DOC_GROUP;
-  const int dl = r - qt * DOC_GROUP;
-  const int64_t seq = p.seq_lo + ((int64_t)blockIdx.z * 8 + (int64_t)blockIdx.x) * DOC_GROUP + dl;
+  const int mode = p.map_mode;
+  int64_t seq;
+  if (mode & MAP_SPREAD_Q) {
+    // Small launches (threshold bootstrap: 1 tile; first phases of a sampled run: 4, 13 tiles): with fewer than 8 tile groups the XCD-major
+    // map above leaves XCDs idle -- the 112 workgroups of a 4-tile launch all landed on ONE XCD's 32 CUs, 3.5 rounds, 214 us for a launch whose
+    // tiles take ~55 us each (found in round 6 on a shard's kernel timeline: the begin of a 1/8 shard is made of such launches).  Here the
+    // XCD (blockIdx.x) takes every 8th QUERY tile of every corpus tile instead: grid = (8, DOC_GROUP x ceil(n_qtiles / 8), tile groups).
+    const int qg = r / DOC_GROUP;
+    const int dl = r - qg * DOC_GROUP;
+    qt = qg * 8 + (int)blockIdx.x;
+    if (qt >= p.n_qtiles) return false;
+    seq = p.seq_lo + (int64_t)blockIdx.z * DOC_GROUP + dl;
+  } else {
+    qt = r / DOC_GROUP;
+    const int dl = r - qt * DOC_GROUP;
+    seq = p.seq_lo + ((int64_t)blockIdx.z * 8 + (int64_t)blockIdx.x) * DOC_GROUP + dl;
+  }
   if (seq >= p.seq_hi) return false;
-  dt = seq_to_tile_fast(seq, p.map_mode, p.period, p.head, p.perm_mul, p.perm_n, p.inv_perm_n, p.inv_pm1);
+  dt = seq_to_tile_fast(seq, mode & 0xff, p.period, p.head, p.perm_mul, p.perm_n, p.inv_perm_n, p.inv_pm1);
   return dt < p.n_tiles;
 }
 #endif

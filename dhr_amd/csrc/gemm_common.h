@@ -35,7 +35,9 @@ __device__ __forceinline__ void expand_bucket_columns(const uint32_t (&r)[4], ui
 
 hipError_t launch_gemm_wx(const GemmArgs& a, dim3 grid, int variant, hipStream_t s);   // variant 4 (4 waves) or 5 (8 waves)
 hipError_t launch_gemm_g8(const GemmArgs& a, dim3 grid, hipStream_t s);                 // gated_i8 indexes (gemm_g8.hip)
-hipError_t launch_gemm_g8p(const GemmArgs& a, hipStream_t s);                           // ... with persistent workgroups (gemm_g8p.hip)
+#ifdef DHR_AB_VARIANTS
+hipError_t launch_gemm_g8p(const GemmArgs& a, hipStream_t s);                           // ... with persistent workgroups (tools/ab/gemm_g8p.hip, A/B builds)
 bool gemm_g8p_ok(const GemmArgs& a);
+#endif
 
 }  // namespace dhr

@@ -503,7 +503,7 @@ hipError_t launch_gemm_g8(const GemmArgs& a, dim3 grid, hipStream_t s) {
   }
   if (a.dump) { hipLaunchKernelGGL(gemm_filter_g8_kernel<true>, grid, dim3(G8_NT), G8_RING_LDS, s, a); return hipGetLastError(); }
   GemmArgs b = a;
-  static const int partial_on = getenv("DHR_G8_PARTIAL") ? atoi(getenv("DHR_G8_PARTIAL")) : 1;
+  constexpr int partial_on = 1;
   const int valid_last = a.n_queries - (a.n_qtiles - 1) * TILE_ROWS;          // real queries of the batch's last query tile
   b.partial_wn = (partial_on && valid_last > 0 && valid_last <= 128) ? (valid_last + 63) / 64 : 0;
   hipLaunchKernelGGL(gemm_filter_g8_kernel<false>, grid, dim3(G8_NT), G8_RING_LDS, s, b);

@@ -177,66 +177,6 @@ __device__ __forceinline__ int load_idx(const void* __restrict__ idx, int dtype,
   return ((const uint8_t*)idx)[off];
 }
 
-// Thread per 16-byte chunk of the OPERAND-TILE image, rows [row_lo, row_lo+n_rows_fill).  Tile columns:
-//   [ bucket 0 : d_dlr ][ bucket 1 : d_dlr ] ... [ bucket B-1 : d_dlr ][ dense : d_cls ][ zero pad ]
-// the gated value of slice j sits in segment bucket(idx[j]) and is 0 in the other segments, so the
-// plain inner product of two such rows is  sum_j q_j d_j [bucket(qi_j)==bucket(di_j)]  >=  the gated sum
-// (values made non-negative with |.| when abs_dlr) -- an upper bound B-times tighter than the ungated one.
-// Rows beyond n_rows_src and columns beyond the data are zero.
-__global__ void __launch_bounds__(256) tile_rows_kernel(const __half* __restrict__ src, int64_t ld, int64_t row_lo,
-                                                        int64_t n_rows_src, int64_t n_rows_fill, int d_dlr, int d_cls,
-                                                        int n_buckets, int kt, const void* __restrict__ idx, int idx_dtype,
-                                                        const uint8_t* __restrict__ map, int abs_dlr,
-                                                        __half* __restrict__ tiles) {
-  const int cpr = kt >> 3;
-  const int ksteps = kt >> 6;
-  const int k = d_dlr + d_cls;
-  const int dlr_cols = n_buckets * d_dlr;
-  const int64_t total = n_rows_fill * cpr;
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t rl = g / cpr;
-    const int c = (int)(g - rl * cpr);
-    const int64_t row = row_lo + rl;
-    half8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
-    if (rl < n_rows_src) {
-      const int col0 = c * 8;
-      if (col0 < dlr_cols) {
-        const int b = col0 / d_dlr, j0 = col0 - b * d_dlr;          // d_dlr % 8 == 0: a chunk never straddles
-        const __half* r = src + rl * ld + j0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          _Float16 x = (_Float16)__half2float(r[e]);
-          if (n_buckets > 1 && bucket_of(load_idx(idx, idx_dtype, row * d_dlr + j0 + e), j0 + e, map, n_buckets) != b)
-            x = (_Float16)0.f;
-          if (abs_dlr && x < (_Float16)0.f) x = -x;
-          v[e] = x;
-        }
-      } else {
-        const int j0 = d_dlr + (col0 - dlr_cols);
-        const __half* r = src + rl * ld + j0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (j0 + e < k) v[e] = (_Float16)__half2float(r[e]);
-      }
-    }
-    *(half8*)(tiles + tiled_chunk_offset(row, c, ksteps)) = v;
-  }
-}
-
-hipError_t launch_tile_rows(const __half* src, int64_t ld, int64_t row_lo, int64_t n_rows_src, int64_t n_rows_fill,
-                            int d_dlr, int d_cls, int n_buckets, int kt, const void* idx, int idx_dtype,
-                            const uint8_t* map, bool abs_dlr, __half* tiles, hipStream_t s) {
-  if (n_rows_fill <= 0) return hipSuccess;
-  const int64_t total = n_rows_fill * (kt >> 3);
-  const int64_t blocks = (total + 255) / 256;
-  hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, src, ld,
-                     row_lo, n_rows_src, n_rows_fill, d_dlr, d_cls, n_buckets, kt, idx, idx_dtype, map,
-                     abs_dlr ? 1 : 0, tiles);
-  return hipGetLastError();
-}
-
 // ---- 2:4 layout (two index buckets, sparse matrix cores).  Logical gated columns are (slice, bucket)
 // pairs, k = 2*slice + bucket: every group of four logical columns = two slices holds exactly two
 // values, which is the structured sparsity v_smfmac_f32_32x32x32_f16 wants on its A operand.  So the
@@ -647,26 +587,6 @@ __global__ void __launch_bounds__(256) query_prep_kernel(const void* __restrict_
         *(half8*)(tile + (int64_t)ts_q * SP_STAGE_B + (int64_t)st * SP_DENSE + r * 64 + ((cc ^ ((r >> 2) & 3)) * 16)) = h8;
       }
     }
-  } else
-  // operand tile image: gated value in the segment of its bucket (all segments when the batch is
-  // ungated: then every bucket pair "matches" and the product is the plain inner product)
-  for (int c = lane; c * 8 < kt; c += 64) {
-    half8 h;
-    const int col0 = c * 8;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = 0.f;
-      if (col0 < dlr_cols) {
-        const int b = col0 / d_dlr, j = col0 - b * d_dlr + e;
-        v = qval(j);
-        if (n_buckets > 1 && idx && bucket_of(qidx(j), j, map, n_buckets) != b) v = 0.f;
-        v = abs_dlr ? fabsf(v) : fmaxf(v, 0.f);          // corpus values are >= 0 here: q+ d bounds the gated product
-      } else {
-        v = qval(d_dlr + (col0 - dlr_cols) + e);
-      }
-      h[e] = (_Float16)v;                                  // round to nearest even
-    }
-    *(half8*)(q_tiles + tiled_chunk_offset(q, c, ksteps)) = h;
   }
   s16 = wave_sum(s16);
   sr = wave_sum(sr);
@@ -722,463 +642,30 @@ hipError_t launch_query_prep(const void* src, int src_is_f32, int64_t ld, const 
 }
 
 // ------------------------------------------------------------------------------------------ gemm_filter
-// Output tile: 256 corpus rows x 256 queries, K-step 64, 8 waves (2 along rows x 4 along queries),
-// each wave 128 rows x 64 queries = 4x2 blocks of v_mfma_f32_32x32x16_f16 (128 fp32 accumulators).
-// A (corpus) and B (queries) K-step tiles are contiguous 32 KiB LDS images in HBM; each wave DMAs
-// 4+4 KiB per K-step with global_load_lds_dwordx4 into a double-buffered 2 x 64 KiB LDS ring.
-// MFMA D layout: column (lane&31) = query, rows over registers = corpus rows, so one threshold
-// register per 32-query block covers all 16 accumulators of a block.
+// The bound GEMM U = Q x D^T fused with the per-query threshold filter: 256 corpus rows x 256 queries per workgroup over the STAGE images
+// (32 gated slices on the 2:4 sparse matrix instructions / 32 or 64 ungated columns on the dense ones per stage, every stage one contiguous
+// LDS image: tile_rows_sparse_kernel, query_prep_kernel).  The kernels live in their own translation units:
+//   gemm_g8.hip   gemm_filter_g8_kernel      integer operands (gated_i8 indexes; dense-only int8 indexes with no gated stage): the default
+//                                            of every index of a million rows or more
+//   gemm_w4.hip   gemm_filter_wx_kernel<NI>  fp16 gated stages (optionally int8 ungated stages), 8 waves (NI = 2) or 4 waves (NI = 4)
+// Both take any even number of gated and of ungated stages (dhr_index_create rounds the stage counts up with all-zero stages), so there is
+// no other layout any more: the K-step tile layout with its kernel (gemm_filter_v3_kernel: bucket counts other than two, gated widths that
+// are no multiple of 32) and the 12-wave producer / consumer kernel (gemm_filter_sparse_kernel: odd stage counts) were retired in round 6
+// together with the persistent-workgroup form of the integer kernel (tools/ab/gemm_g8p.hip, built only with DHR_AB_VARIANTS=1).
 //
-// Workgroup -> tile map (XCD aware): workgroup b runs on XCD b%8 (observed placement, speed only).
-// Each XCD sweeps DOC_GROUP corpus tiles against every query tile, consecutive workgroups sharing
-// operands, so a K-step slice of the group is fetched once into that XCD's L2 and reused.
-constexpr int GEMM_THREADS = 512;
-constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_HALVES * 2;   // 2 stages x (A + B) x 32 KiB = 128 KiB
+// Workgroup -> tile map (XCD aware): grid = (8 XCDs, DOC_GROUP corpus tiles x query tiles, tile groups): dhr_internal.h gemm_wg_tile.
 
-// Epilogue of the 8-wave kernels.  Filter: accumulators that reach the query's threshold are first queued
-// in LDS (the staging ring is dead by now), then the whole workgroup flushes the queue -- one global
-// atomic + one 8-byte store per survivor, all in flight at once.  (Appending straight from the
-// accumulator loop costs one dependent L2 round trip per hit, ~20 % of the kernel at 0.2 % hit rate.)
-__device__ __forceinline__ void gemm_dump_tile(const GemmArgs& p, floatx16 (&acc)[4][2], int64_t dt, int qt, int wm, int wn, int lane) {
-  const int fhalf = lane >> 5;
-  const int64_t row_base = dt * TILE_ROWS + wm * 128;
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
-    if (q < p.n_queries) {
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int64_t row = row_base + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
-          if (row < p.n_rows && row >= p.dump_row0 && row - p.dump_row0 < p.dump_ld)
-            p.dump[(int64_t)q * p.dump_ld + (row - p.dump_row0)] = acc[mi][ni][e];
-        }
-    }
-  }
-}
-// Filter epilogue of the bound GEMM: every accumulator that reaches its query's threshold becomes a (row, bound)
-// candidate of that query.  Hit rates are tiny on average (0.2 %) but extremely skewed (the fullest query of the bench
-// passes 37 % of the rows), so neither "one global atomic per hit" nor "LDS queue with one LDS atomic per hit" works:
-// the first pays a dependent L2 round trip inside a divergent branch per hit, the second a dependent LDS round trip
-// (measured +9 % on the kernel at the mean rate, far more in waves that hold a hot query).  Here a hit costs ONE
-// fire-and-forget LDS store: each consumer thread has a private stack of EPI_STACK slots in the (now idle) staging ring,
-// laid out [slot][thread] so that stores never conflict, indexed by a register counter.  After the scan the thread
-// reserves room in the global list with ONE atomic per (thread, query) -- a hot query's 24 hits per tile cost one
-// atomic -- and copies its own stack out.  Only hits beyond the stack (a thread with more than 32 of its 128
-// accumulators passing) fall back to one-by-one appends.
-template <bool DUMP, int NTHREADS = 512>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, floatx16 (&acc)[4][2], int64_t dt, int qt, int wm, int wn,
-                                              int lane, char* smem, bool has_acc = true) {
-  if (DUMP) {
-    if (has_acc) gemm_dump_tile(p, acc, dt, qt, wm, wn, lane);
-    return;
-  }
-  __syncthreads();                       // every wave is done with the staging ring
-  if (!has_acc) return;
-  const int fhalf = lane >> 5;
-  const int64_t row0 = dt * TILE_ROWS;
-  const int rows_valid = (int)(p.n_rows - row0 < TILE_ROWS ? p.n_rows - row0 : TILE_ROWS);
-  const int tid = (wm * 4 + wn) * 64 + lane;               // consumer thread 0..511
-  uint2* stack = (uint2*)smem + tid;                       // slot j at stack[j * 512]
-  uint32_t j = 0, j0 = 0;
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int ql = wn * 64 + ni * 32 + (lane & 31);
-    const int q = qt * TILE_ROWS + ql;
-    const float t = p.thr[q];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      // one compare per 32 x 32 block first (v_max3 tree over the lane's 16 values): 97 % of the blocks hold no hit
-      const floatx16& a = acc[mi][ni];
-      const float m0 = __builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), a[2]), m1 = __builtin_fmaxf(__builtin_fmaxf(a[3], a[4]), a[5]);
-      const float m2 = __builtin_fmaxf(__builtin_fmaxf(a[6], a[7]), a[8]), m3 = __builtin_fmaxf(__builtin_fmaxf(a[9], a[10]), a[11]);
-      const float m4 = __builtin_fmaxf(__builtin_fmaxf(a[12], a[13]), a[14]);
-      const float mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(m2, m3)), __builtin_fmaxf(m4, a[15]));
-      if (mx >= t) {
-        asm volatile("");                  // keep this a (rarely taken) branch: as a select chain the predicates spill
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = a[e];
-          if (v >= t) {
-            asm volatile("");
-            const int rl = wm * 128 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fhalf;
-            if (rl < rows_valid) {         // (zero padding behind the last row of the shard)
-              if (j < EPI_STACK) stack[j * 512] = make_uint2((uint32_t)rl, __float_as_uint(v));
-              else {
-                const uint32_t slot = atomicAdd(p.cnt + q, 1u);
-                cand_store(p, q, slot, make_uint2((uint32_t)(row0 + rl), __float_as_uint(v)));
-              }
-              ++j;
-            }
-          }
-        }
-      }
-    }
-    if (ni == 0) j0 = j;
-  }
-  if (j == 0) return;
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const uint32_t lo = ni ? (j0 < EPI_STACK ? j0 : EPI_STACK) : 0u;
-    const uint32_t hi = ni ? (j < EPI_STACK ? j : EPI_STACK) : (j0 < EPI_STACK ? j0 : EPI_STACK);
-    if (hi > lo) {
-      const int q = qt * TILE_ROWS + wn * 64 + ni * 32 + (lane & 31);
-      const uint32_t base = atomicAdd(p.cnt + q, hi - lo);
-      for (uint32_t i = lo; i < hi; ++i) {
-        const uint2 en = stack[i * 512];
-        const uint32_t slot = base + (i - lo);
-        cand_store(p, q, slot, make_uint2((uint32_t)row0 + en.x, en.y));
-      }
-    }
-  }
-}
+int g_gemm_variant = 5;   // DHR_PARAM_GEMM_VARIANT of the fp16-gated kernel: 4 (4 waves, 128 x 128 wave tiles) or 5 (8 waves, 128 x 64; default: 2 % faster in the bench)
 
-// Bound GEMM for the K-step tile layout (dense-only indexes, bucket counts other than two): 256 x 256 tile, 8 waves
-// (128 x 64 per wave), each wave DMAs 4 + 4 KiB per K-step with global_load_lds_dwordx4 into a double-buffered
-// 2 x 64 KiB LDS ring, with three refinements aimed at
-// the matrix pipe's idle time: (1) the two wave groups (one wave of each per SIMD) issue their LDS-DMA
-// at DIFFERENT points of the K-step (group 0 at the start, group 1 in the middle), so one wave of every
-// SIMD is always in its MFMA stream while the other pays the DMA issue cost; (2) fragments are
-// software-pipelined one 16-deep k-slice ahead (two register sets); (3) the single hand-over barrier of a
-// K-step sits BEFORE the last k-slice's MFMAs, and the first fragments of the next K-step are read under them.
-template <bool DUMP>
-__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_filter_v3_kernel(GemmArgs p) {
-  constexpr int ABL = 0;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int64_t dt;
-  int qt;
-  if (!gemm_wg_tile(p, dt, qt)) return;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2;            // wave group / 128-row half
-  const int wn = wave & 3;
-  const int ksteps = p.ksteps;
-  const char* a_src = (const char*)(p.a_tiles + dt * (int64_t)ksteps * TILE_HALVES);
-  const char* b_src = (const char*)(p.b_tiles + (int64_t)qt * ksteps * TILE_HALVES);
-  const int piece0 = wave * 4;
-
-  auto stage = [&](int buf, int ks) {
-    char* la = smem + buf * (2 * TILE_HALVES * 2);
-    char* lb = la + TILE_HALVES * 2;
-    const char* ga = a_src + (int64_t)ks * (TILE_HALVES * 2);
-    const char* gb = b_src + (int64_t)ks * (TILE_HALVES * 2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int off = (piece0 + j) * 1024;
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga + off + lane * 16), LDS_PTR(la + off), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gb + off + lane * 16), LDS_PTR(lb + off), 16, 0, 0);
-    }
-  };
-
-  floatx16 acc[4][2];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-
-  const int frow = lane & 31;
-  const int fhalf = lane >> 5;
-  const int swz = (frow >> 1) & 7;
-  int a_off[4], b_off[2];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) a_off[mi] = (wm * 128 + mi * 32 + frow) * 128;
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) b_off[ni] = (wn * 64 + ni * 32 + frow) * 128;
-
-  half8 a0[4], b0[2], a1[4], b1[2];
-#define V3_READ(AF, BF, BUF, KK)                                                               \
-  {                                                                                            \
-    const char* la_ = smem + (BUF) * (2 * TILE_HALVES * 2);                                    \
-    const char* lb_ = la_ + TILE_HALVES * 2;                                                   \
-    const int coff_ = ((((KK) * 2) + fhalf) ^ swz) * 16;                                       \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) AF[mi] = *(const half8*)(la_ + a_off[mi] + coff_); \
-    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) BF[ni] = *(const half8*)(lb_ + b_off[ni] + coff_); \
-  }
-#define V3_MFMA8(AF, BF)                                                                       \
-  {                                                                                            \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                           \
-    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                           \
-      acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[mi], BF[ni], acc[mi][ni], 0, 0, 0); \
-  }
-
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  V3_READ(a0, b0, 0, 0);
-  V3_READ(a1, b1, 0, 1);
-  const int last = ksteps - 1;
-  for (int t = 0; t < ksteps; ++t) {
-    const int buf = t & 1;
-    const int ks1 = t + 1 < last ? t + 1 : last;     // past the end: re-stage the last K-step into the dead buffer
-    if (wm == 0 && ABL < 5) stage(buf ^ 1, ks1);
-    if (ABL != 6) V3_READ(a1, b1, buf, 1);
-    V3_MFMA8(a0, b0);
-    if (ABL != 6) V3_READ(a0, b0, buf, 2);
-    V3_MFMA8(a1, b1);
-    if (wm == 1 && ABL < 5) stage(buf ^ 1, ks1);
-    if (ABL != 6) V3_READ(a1, b1, buf, 3);
-    V3_MFMA8(a0, b0);
-    if (ABL == 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (ABL != 4) __builtin_amdgcn_s_barrier();
-    if (ABL != 6) V3_READ(a0, b0, buf ^ 1, 0);
-    V3_MFMA8(a1, b1);
-  }
-#undef V3_READ
-#undef V3_MFMA8
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  gemm_epilogue<DUMP>(p, acc, dt, qt, wm, wn, lane, smem);
-}
-
-// Sparse-core bound GEMM (two index buckets), producer / consumer wave specialisation.
-//   ts_q stages of 32 gated slices on v_smfmac_f32_32x32x32_f16 (corpus = 2:4 sparse A operand: stored slice
-//   values + position bits; queries = B operand, held compressed -- one fp16 per slice, bucket in the sign
-//   bit -- and expanded to the two bucket columns per slice with one v_pk_max_f16 per register), then td
-//   stages of 32 ungated columns on v_mfma_f32_32x32x16_f16.  Every stage is 16 matrix instructions per
-//   consumer wave and 32-34 KiB of operand bytes per 256 x 256 tile (the expanded query image would be 50 KiB:
-//   measured, the LDS-DMA stream alone then takes as long as the matrix work).
-// 12 waves: waves 0-7 are CONSUMERS (256 x 256 tile, 128 x 64 per wave, LDS fragment reads + matrix
-// instructions only), waves 8-11 are PRODUCERS (one per SIMD) that do nothing but issue the LDS-DMA of the
-// stage three ahead into a 4-slot ring of 34 KiB slots.  One barrier per stage hands a slot over: producers
-// pass it once the NEXT stage has landed (counted vmcnt, the two stages after that stay in flight),
-// consumers once they are done reading the current slot.
-constexpr int GEMM_PC_THREADS = 768;
-constexpr int GEMM_PC_SLOTS = 4;
-constexpr int GEMM_PC_LDS = GEMM_PC_SLOTS * SP_SLOT + 64;      // 136 KiB ring (the filter epilogue's hit queue reuses it, + its counter word)
-
-// ABL (timing experiments only, wrong results unless noted): 1 no in-loop DMA, 2 no fragment reads, 3 no matrix instructions, 4 no epilogue,
-// 5 = 1 + 2, 7 no query-side DMA, 8 = 7 + no query fragment reads, 9 no corpus-side DMA, 11 both operands always from L2-hot tiles,
-// 12 producers never wait for the DMA, 13 register-staged producers (global_load -> VGPR -> ds_write; CORRECT results, slower),
-// 21 / 22 / 23 nothing sinks below the stage barrier in the waves with wm = 1 / the odd waves / all waves (CORRECT results, slower)
-template <bool DUMP, int ABL = 0>
-__global__ void __launch_bounds__(GEMM_PC_THREADS, 3) gemm_filter_sparse_kernel(GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int64_t dt;
-  int qt;
-  if (!gemm_wg_tile(p, dt, qt)) return;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ts = p.ts, tsq = p.ts_q, td = p.td, nst = tsq + td;
-  const char* a_src = (const char*)p.a_tiles + (ABL == 11 ? (dt & 3) : dt) * ((int64_t)ts * SP_STAGE_A + (int64_t)td * SP_DENSE);
-  const char* b_src = (const char*)p.b_tiles + (int64_t)(ABL == 11 ? (qt & 1) : qt) * ((int64_t)tsq * SP_STAGE_B + (int64_t)td * SP_DENSE);
-
-  floatx16 acc[4][2];
-  const int wm = (wave >> 2) & 1;
-  const int wn = wave & 3;
-
-  if (wave >= 8) {
-    // ------------------------------------------------------------------ producers
-    // Fixed roles keep the issue loop to a few scalar instructions per piece (measured: a generic piece loop of
-    // ~20 instructions per piece made the DMA stream itself the bottleneck): producers 0,1 stream the corpus
-    // half-stages (9 + 9 KiB of a sparse stage, 8 + 8 of a dense one), producers 2,3 the query half-stages (8 + 8).
-    const int pw = wave - 8;
-    __builtin_amdgcn_s_setprio(3);     // a producer has a dozen instructions per stage: never let them queue behind the consumers'
-    const bool is_a = pw < 2;
-    const int hf = pw & 1;
-    const uint32_t lane_off = (uint32_t)lane * 16u;
-    const char* a_dense = a_src + (int64_t)ts * SP_STAGE_A;
-    const char* b_dense = b_src + (int64_t)tsq * SP_STAGE_B;
-    auto issue = [&](int u) {
-      const bool sp = u < tsq;
-      const char* g;
-      int l;
-      if (is_a) {
-        g = sp ? a_src + (int64_t)(u < ts ? u : u - ts) * SP_STAGE_A + hf * 9216 : a_dense + (int64_t)(u - tsq) * SP_DENSE + hf * 8192;
-        l = sp ? hf * 9216 : hf * 8192;
-      } else {
-        g = (sp ? b_src + (int64_t)u * SP_STAGE_B : b_dense + (int64_t)(u - tsq) * SP_DENSE) + hf * 8192;
-        l = SP_STAGE_A + hf * 8192;
-      }
-      char* lds = smem + (u & (GEMM_PC_SLOTS - 1)) * SP_SLOT + l;
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g + j * 1024 + lane_off), LDS_PTR(lds + j * 1024), 16, 0, 0);
-      if (is_a && sp) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g + 8192 + lane_off), LDS_PTR(lds + 8192), 16, 0, 0);
-    };
-    if (ABL == 13) {
-      // Register-staged producers (correct results): global_load_dwordx4 -> VGPRs (three stages in flight in the
-      // producer's otherwise idle registers) -> ds_write_b128 into the slot one stage ahead of the consumers.
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      u32x4 rb0[9], rb1[9], rb2[9];
-      auto src_of = [&](int u, int& l) __attribute__((always_inline)) -> const char* {
-        const bool sp = u < tsq;
-        if (is_a) { l = sp ? hf * 9216 : hf * 8192;
-                    return sp ? a_src + (int64_t)(u < ts ? u : u - ts) * SP_STAGE_A + hf * 9216 : a_dense + (int64_t)(u - tsq) * SP_DENSE + hf * 8192; }
-        l = SP_STAGE_A + hf * 8192;
-        return (sp ? b_src + (int64_t)u * SP_STAGE_B : b_dense + (int64_t)(u - tsq) * SP_DENSE) + hf * 8192;
-      };
-      auto ld = [&](int u, u32x4 (&rb)[9]) __attribute__((always_inline)) {
-        int l; const char* g = src_of(u, l) + lane_off;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rb[j] = *(const u32x4*)(g + j * 1024);
-        if (is_a && u < tsq) rb[8] = *(const u32x4*)(g + 8192);
-      };
-      auto st = [&](int u, const u32x4 (&rb)[9]) __attribute__((always_inline)) {
-        int l; (void)src_of(u, l);
-        char* lds = smem + (u & (GEMM_PC_SLOTS - 1)) * SP_SLOT + l + lane_off;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) *(u32x4*)(lds + j * 1024) = rb[j];
-        if (is_a && u < tsq) *(u32x4*)(lds + 8192) = rb[8];
-      };
-      ld(0, rb0);
-      if (nst > 1) ld(1, rb1);
-      if (nst > 2) ld(2, rb2);
-      st(0, rb0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                   // stage 0 is in its slot
-      // iteration u: fetch stage u+3 into the buffer stage u left, put stage u+1 into its slot, end stage u
-      auto step = [&](int u, u32x4 (&rb_new)[9], const u32x4 (&rb_next)[9]) __attribute__((always_inline)) {
-        if (u >= nst) return;
-        if (u + 3 < nst) ld(u + 3, rb_new);
-        if (u + 1 < nst) st(u + 1, rb_next);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      };
-#pragma unroll 1
-      for (int u = 0; u < nst; u += 3) {
-        step(u, rb0, rb1);
-        step(u + 1, rb1, rb2);
-        step(u + 2, rb2, rb0);
-      }
-    } else {
-    issue(0);
-    if (nst > 1) issue(1);
-    if (nst > 2) issue(2);
-    // every stage is >= 8 pieces per producer: waiting for "<= 8 per stage that may stay in flight" is safe
-    if (nst > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (nst > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                     // stage 0 landed
-#pragma unroll 1
-    for (int u = 0; u < nst; ++u) {
-      // slot (u+3)&3 was read during stage u-1; every consumer passed the barrier that ended it
-      if (u + 3 < nst && ABL != 1 && ABL != 5 && !((ABL == 7 || ABL == 8) && !is_a) && !(ABL == 9 && is_a)) issue(u + 3);
-      // stage u+1 must have landed before the barrier; the stages after it stay in flight
-      const int after = (nst - 1 < u + 3 ? nst - 1 : u + 3) - (u + 1);
-      if (ABL == 12) { /* timing only: never wait for the DMA inside the loop */ }
-      else if (ABL == 1 || ABL == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    }
-  } else {
-    // ------------------------------------------------------------------ consumers
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-    const int frow = lane & 31;
-    const int fhalf = lane >> 5;
-    // Per-lane LDS offsets inside a ring slot, kept in a handful of registers (everything else is an
-    // immediate offset of the ds_read): the wave has 168 registers at 3 waves per SIMD, 128 are accumulators.
-    // All three images (corpus values, query values, dense columns of either side) have 64-byte rows with the
-    // 16-byte chunk c stored at c ^ ((row>>2)&3); 16-slice / 16-column block kb is chunk kb*2 + fhalf.
-    const int swz4 = (frow >> 2) & 3;
-    const int a_row = (wm * 128 + frow) * 64;                         // + mi*2048
-    const int a_c0 = a_row + ((fhalf ^ swz4) << 4);
-    const int a_c1 = a_row + (((2 + fhalf) ^ swz4) << 4);
-    const int q_row = SP_STAGE_A + (wn * 64 + frow) * 64;             // + ni*2048
-    const int q_c0 = q_row + ((fhalf ^ swz4) << 4), q_c1 = q_row + (((2 + fhalf) ^ swz4) << 4);
-    const int p_off = SP_A_BYTES + ((wm * 8 + fhalf) * 32 + frow) * 4; // position words, + mi*256
-    half8 abl_f;
-    if (ABL == 2 || ABL == 5 || ABL == 8) { for (int e = 0; e < 8; ++e) abl_f[e] = (_Float16)(0.001f * (float)(lane + e)); asm volatile("" : "+v"(abl_f)); }
-    __builtin_amdgcn_s_barrier();
-    // The compiler sinks the last block's matrix instructions of a stage below the s_barrier (they only need registers), so a
-    // wave arrives at the next stage with 8 of them queued and issues its first fragment reads after them.  Two waves share a
-    // SIMD; in the LATE copy of the loops nothing may sink, so that one wave of the pair waits for its reads while the other
-    // one still has matrix work (ABL 21 / 22 / 23 choose which waves run the LATE copy -- the waves with wm = 1, the odd waves, all; results are unchanged;
-    // measured 38.3 / 38.6 / 39.6 against 37.4 ms: the more waves arrive with work queued, the better).
-    auto consumer_loops = [&](auto late_c) __attribute__((always_inline)) {
-    constexpr bool LATE = decltype(late_c)::value;
-    // ---- gated columns: sparse matrix cores
-#pragma unroll 1
-    for (int u = 0; u < tsq; ++u) {
-      const char* sl = smem + (u & (GEMM_PC_SLOTS - 1)) * SP_SLOT;
-      uint32_t pwd[4];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) pwd[mi] = (ABL == 2 || ABL == 5) ? 0x44444444u : *(const uint32_t*)(sl + p_off + mi * 256);
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        // all six fragment reads of the 16-slice block go out first (4 corpus, 2 compressed query), so that the
-        // LDS latency is paid once per 8 matrix instructions
-        half8 af[4];
-        union { half8 h; uint32_t w[4]; } raw[2];
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) raw[ni].h = (ABL == 2 || ABL == 5 || ABL == 8) ? abl_f : *(const half8*)(sl + (kb ? q_c1 : q_c0) + ni * 2048);
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) af[mi] = (ABL == 2 || ABL == 5) ? abl_f : *(const half8*)(sl + (kb ? a_c1 : a_c0) + mi * 2048);
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          // compressed query fragment -> the lane's 16 B-operand elements: slice value v becomes (max(v,0), max(-v,0))
-          union { half16 h; uint32_t w[8]; } bf;
-          expand_bucket_columns(raw[ni].w, bf.w);
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi) {
-            if (ABL == 3) { asm volatile("" :: "v"(af[mi]), "v"(bf.w[0]), "v"(bf.w[7]), "v"(pwd[mi])); continue; }
-            if (kb == 0) acc[mi][ni] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(af[mi], bf.h, acc[mi][ni], (int)pwd[mi], 0, 0);
-            else acc[mi][ni] = __builtin_amdgcn_smfmac_f32_32x32x32_f16(af[mi], bf.h, acc[mi][ni], (int)pwd[mi], 0, 1);
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of the slot are complete
-      if constexpr (LATE) __builtin_amdgcn_sched_barrier(0);   // nothing sinks below the barrier in this copy
-      __builtin_amdgcn_s_barrier();
-    }
-    // ---- ungated columns: 32 per stage
-#pragma unroll 1
-    for (int u = tsq; u < nst; ++u) {
-      const char* sl = smem + (u & (GEMM_PC_SLOTS - 1)) * SP_SLOT;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        half8 bf[2];
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) bf[ni] = (ABL == 2 || ABL == 5 || ABL == 8) ? abl_f : *(const half8*)(sl + (kk ? q_c1 : q_c0) + ni * 2048);
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-          const half8 af = (ABL == 2 || ABL == 5) ? abl_f : *(const half8*)(sl + (kk ? a_c1 : a_c0) + mi * 2048);
-          if (ABL == 3) { asm volatile("" :: "v"(af), "v"(bf[0]), "v"(bf[1])); continue; }
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[ni], acc[mi][ni], 0, 0, 0);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if constexpr (LATE) __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-    }
-    };
-    const bool late = ABL == 21 ? wm == 1 : ABL == 22 ? (wave & 1) != 0 : ABL == 23;
-    if (late) consumer_loops(std::true_type{}); else consumer_loops(std::false_type{});
-  }
-  if (ABL == 4) { if (wave < 8) asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1])); return; }
-  gemm_epilogue<DUMP, GEMM_PC_THREADS>(p, acc, dt, qt, wm, wn, lane, smem, wave < 8);
-}
-
-
-int g_gemm_ablate = 0;    // tuning only (DHR_GEMM_ABLATE environment variable): timing ablations of the 2:4 kernel, wrong results
-int g_gemm_variant = 5;   // DHR_PARAM_GEMM_VARIANT: 2:4 layout kernels 3 (12 waves, producer / consumer), 4 (4 waves), 5 (8 waves; default: 2 % faster in the bench)
-
-// The bound GEMM + filter over the tiles [seq_lo, seq_hi) of the sequence: gemm_filter_sparse_kernel for the 2:4 layout
-// (a.ts > 0), gemm_filter_v3_kernel for the K-step tile layout (dense-only indexes, other bucket counts).
 // which bound-GEMM kernel the calling thread's latest launch_gemm_filter ran (dhr_index_get_info(DHR_INFO_GEMM_KERNEL): a report names the
-// kernel that really ran instead of re-deriving the dispatch below): 1 gemm_filter_v3_kernel, 2 gemm_filter_sparse_kernel, 3 / 4
-// gemm_filter_wx_kernel<2> / <4>, 5 gemm_filter_g8_kernel, 6 gemm_filter_g8p_kernel
+// kernel that really ran instead of re-deriving the dispatch below): 3 / 4 gemm_filter_wx_kernel<2> / <4>, 5 gemm_filter_g8_kernel,
+// 6 gemm_filter_g8p_kernel (A/B builds only); 1 and 2 were the kernels retired in round 6
 thread_local int g_last_gemm_kernel = 0;
 static hipError_t launch_gemm_filter_grid(const GemmArgs& a, dim3 grid, hipStream_t s);
 hipError_t launch_gemm_filter(const GemmArgs& a_in, hipStream_t s) {
   static bool env_read = false;
   if (!env_read) {
-    if (const char* e = getenv("DHR_GEMM_ABLATE")) g_gemm_ablate = atoi(e);
-    if (const char* e = getenv("DHR_GEMM_VARIANT")) g_gemm_variant = atoi(e);     // tuning only (the torch-free PMC driver)
+    if (const char* e = getenv("DHR_GEMM_VARIANT")) g_gemm_variant = atoi(e) == 4 ? 4 : 5;     // tuning only (the torch-free PMC driver)
     env_read = true;
   }
   const int64_t n_tiles = a_in.seq_hi - a_in.seq_lo;
@@ -1189,16 +676,22 @@ hipError_t launch_gemm_filter(const GemmArgs& a_in, hipStream_t s) {
   // proper message, the others cannot be reached through the C ABI (n_rows < 2^32, sample period <= 256)
   if ((int64_t)DOC_GROUP * a_in.n_qtiles > 65535 || a_in.perm_n >= (1 << 24) || a_in.period > (1 << 20)) return hipErrorInvalidValue;
   if (a_in.map_mode >= 2 && a_in.period < 2) return hipErrorInvalidValue;      // "everything but the sample" needs a sample: divmod24 by period - 1
-  // gated_i8 indexes: persistent workgroups over the whole launch (gemm_g8p.hip) for DHR_PARAM_GEMM_VARIANT = 6 (or DHR_G8_PERSIST=1, tuning).
-  // Not the default: the kernel runs at the package power cap, where the ~10 % of cycles the persistent form saves come back as a lower
-  // clock, not as time, and a workgroup that never leaves its CU keeps refine / rescoring of the previous chunk from interleaving
+#ifdef DHR_AB_VARIANTS
+  // A/B builds (tools/ab_build.sh): the integer kernel with persistent workgroups over the whole launch (tools/ab/gemm_g8p.hip) for
+  // DHR_PARAM_GEMM_VARIANT = 6 / DHR_G8_PERSIST=1 -- the measurement that shows the kernel is held by the package power cap
   static const int g8_persist = getenv("DHR_G8_PERSIST") ? atoi(getenv("DHR_G8_PERSIST")) : 0;
   if (a_in.g8_shift && (g8_persist || a_in.variant == 6) && gemm_g8p_ok(a_in)) { g_last_gemm_kernel = 6; return launch_gemm_g8p(a_in, s); }
+#endif
   GemmArgs a = a_in;
   a.inv_perm_n = 1.0 / (double)(a.perm_n > 0 ? a.perm_n : 1);
   a.inv_pm1 = 1.0 / (double)(a.period > 1 ? a.period - 1 : 1);
   // grid = (XCD, corpus tile of the group x query tile, tile group of the XCD): gemm_wg_tile (dhr_internal.h); gridDim.z <= 65535, so a
   // launch over more than 65535 x 32 corpus tiles (537 M rows) is cut into several
+  if (groups < 8) {      // fewer tile groups than XCDs: the query tiles are dealt over the XCDs instead (gemm_wg_tile, MAP_SPREAD_Q)
+    a.map_mode |= MAP_SPREAD_Q;
+    const dim3 grid(8u, (unsigned)(DOC_GROUP * ((a.n_qtiles + 7) / 8)), (unsigned)groups);
+    return launch_gemm_filter_grid(a, grid, s);
+  }
   for (int64_t z0 = 0; z0 < groups_per_xcd; z0 += 65535) {
     GemmArgs c = a;
     c.seq_lo = a.seq_lo + z0 * 8 * DOC_GROUP;
@@ -1209,54 +702,16 @@ hipError_t launch_gemm_filter(const GemmArgs& a_in, hipStream_t s) {
   return hipSuccess;
 }
 static hipError_t launch_gemm_filter_grid(const GemmArgs& a, dim3 grid, hipStream_t s) {
-  // per-device, under a lock: handles on different devices may be used from different host threads (dhr_hip.h)
-  static std::mutex attr_mu;
-  static bool attr_set_dev[64] = {};
-  int dev_ = 0;
-  (void)hipGetDevice(&dev_);
-  std::lock_guard<std::mutex> attr_lock(attr_mu);
-  bool& attr_set = attr_set_dev[dev_ & 63];
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)gemm_filter_v3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_PC_LDS);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_PC_LDS);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  const int variant = a.variant == 6 ? 5 : a.variant ? a.variant : g_gemm_variant;        // per handle (dhr_index_set_param), else the library default
-  if (a.g8_shift) { g_last_gemm_kernel = 5; return (a.ts > 0 && !(a.ts & 1) && !(a.td & 1) && a.ts_q == a.ts) ? launch_gemm_g8(a, grid, s) : hipErrorInvalidValue; }
+  const int variant = a.variant == 4 ? 4 : a.variant ? 5 : g_gemm_variant;        // per handle (dhr_index_set_param), else the library default
+  // every index is a stage image with an even number of stages of either kind (dhr_index_create pads with all-zero stages)
+  if (a.ts + a.td <= 0 || (a.ts & 1) || (a.td & 1) || (a.ts_q & 1)) return hipErrorInvalidValue;
+  if (a.g8_shift) { g_last_gemm_kernel = 5; return (a.ts > 0 && a.ts_q == a.ts) ? launch_gemm_g8(a, grid, s) : hipErrorInvalidValue; }
   // a dense-only int8 index (no gated stage on either side): the integer kernel of the gated_i8 indexes with ts = 0 -- the same operand
   // images, integer filter epilogue; config 2: 2.78 -> 2.70 ms per launch alone, 76.4 -> 75.1 ms per step (DHR_DENSE_G8=0: gemm_filter_wx_kernel)
   static const int dense_g8 = getenv("DHR_DENSE_G8") ? atoi(getenv("DHR_DENSE_G8")) : 1;
-  if (a.i8_mul && dense_g8 && a.ts == 0 && a.ts_q == 0 && a.td > 0 && !(a.td & 1)) { g_last_gemm_kernel = 5; return launch_gemm_g8(a, grid, s); }
-  if (a.i8_mul) {    // int8 dense stages exist in the every-wave-computes kernels only (dhr_index_create enables them only where those run)
-    g_last_gemm_kernel = variant == 4 ? 4 : 3;
-    return (a.ts + a.td > 0 && !(a.ts_q & 1) && !(a.td & 1)) ? launch_gemm_wx(a, grid, variant == 4 ? 4 : 5, s) : hipErrorInvalidValue;
-  }
-  if (a.ts + a.td > 0 && (variant == 4 || variant == 5) && g_gemm_ablate == 0 && !(a.ts_q & 1) && !(a.td & 1)) { g_last_gemm_kernel = variant == 4 ? 4 : 3; return launch_gemm_wx(a, grid, variant, s); }   // pairs of stages
-  g_last_gemm_kernel = a.ts + a.td > 0 ? 2 : 1;
-  if (a.ts + a.td > 0) {
-    if (a.dump)
-      hipLaunchKernelGGL(gemm_filter_sparse_kernel<true>, grid, dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a);
-    else if (g_gemm_ablate >= 1) {
-#define SP_ABL(N) { (void)hipFuncSetAttribute((const void*)gemm_filter_sparse_kernel<false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_PC_LDS); \
-      hipLaunchKernelGGL((gemm_filter_sparse_kernel<false, N>), grid, dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a); }
-      if (g_gemm_ablate == 1) SP_ABL(1) else if (g_gemm_ablate == 2) SP_ABL(2) else if (g_gemm_ablate == 3) SP_ABL(3) else if (g_gemm_ablate == 4) SP_ABL(4)
-      else if (g_gemm_ablate == 7) SP_ABL(7) else if (g_gemm_ablate == 8) SP_ABL(8) else if (g_gemm_ablate == 9) SP_ABL(9) else if (g_gemm_ablate == 11) SP_ABL(11)
-      else if (g_gemm_ablate == 12) SP_ABL(12) else if (g_gemm_ablate == 13) SP_ABL(13) else if (g_gemm_ablate == 21) SP_ABL(21)
-      else if (g_gemm_ablate == 22) SP_ABL(22) else if (g_gemm_ablate == 23) SP_ABL(23) else SP_ABL(5)
-#undef SP_ABL
-    } else
-      hipLaunchKernelGGL(gemm_filter_sparse_kernel<false>, grid, dim3(GEMM_PC_THREADS), GEMM_PC_LDS, s, a);
-  } else if (a.dump)
-    hipLaunchKernelGGL(gemm_filter_v3_kernel<true>, grid, dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
-  else
-    hipLaunchKernelGGL(gemm_filter_v3_kernel<false>, grid, dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, a);
-  return hipGetLastError();
+  if (a.i8_mul && dense_g8 && a.ts == 0 && a.ts_q == 0 && a.td > 0) { g_last_gemm_kernel = 5; return launch_gemm_g8(a, grid, s); }
+  g_last_gemm_kernel = variant == 4 ? 4 : 3;
+  return launch_gemm_wx(a, grid, variant, s);      // fp16 gated stages; ungated stages fp16 or (i8_mul) int8
 }
 
 // Flat launches of the per-candidate kernels.  Their natural grid is (blocks of the LONGEST list) x (queries), which
@@ -1853,6 +1308,15 @@ __device__ __forceinline__ uint32_t pair_mask(uint32_t x, uint32_t sel) {
   t.v = t.v - one.v;
   return t.u;
 }
+// the same for 16-bit index values: x = two corpus ^ query index values, one per fp16 of the pair
+__device__ __forceinline__ uint32_t pair_mask16(uint32_t x) {
+  union { uint32_t u; ushort2v v; } t, one;
+  t.u = x;
+  one.u = 0x00010001u;
+  t.v = __builtin_elementwise_min(t.v, one.v);
+  t.v = t.v - one.v;
+  return t.u;
+}
 // PATH 0: every path (72 registers with 60 bytes of scratch: the allocation is the maximum over the paths).  PATH 1 / 2: the instantiations of
 // rescore_fast_kernel / rescore_narrow_kernel -- every query fp16-representable with no all-zero chunk, rows of more than / at most 128 chunks:
 // the general loop's fast branch alone (52 registers) / the 16-lanes-per-pair path alone.
@@ -1882,64 +1346,92 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
     const float4 qb = *(const float4*)(q32 + c * 8 + 4);
     if (qa.x != 0.f || qa.y != 0.f || qa.z != 0.f || qa.w != 0.f || qb.x != 0.f || qb.y != 0.f || qb.z != 0.f || qb.w != 0.f) nz_mask |= 1u << t;
   }
-  // Sparse queries (at most 8 non-zero chunks in the whole query: stage 1 of --theta 0.3 --rerank keeps 4-12 columns): a wave per
-  // pair would run 1-8 of its 64 lanes and still pay a full memory round trip per pair.  Instead 8 lanes per pair, 8 pairs per wave:
-  // lane (pair slot ci, s) owns the s-th non-zero chunk.  Same products, fp64 sums over at most 64 terms (the zero chunks the dense
-  // path adds are exact zeros).
-  if constexpr (PATH == 0)
-  if (fast && some_zero) {
-    int nzc[8];
-    int m = 0;
-    for (int c0 = 0, t = 0; c0 < nchunks && m <= 8; c0 += 64, ++t) {
-      uint64_t b = __ballot((nz_mask >> t) & 1u);
-      while (b && m <= 8) { if (m < 8) nzc[m] = c0 + (__ffsll((unsigned long long)b) - 1); ++m; b &= b - 1; }
+  // Sparse queries (at most 16 non-zero chunks in the whole query: stage 1 of --theta 0.3 --rerank keeps 4-12 columns, a BM25 query 4-12
+  // terms): a wave per pair would run 1-16 of its 64 lanes and still pay a full memory round trip per pair.  Instead 8 (up to 8 non-zero
+  // chunks) or 16 lanes per pair, 8 / 4 pairs per wave: lane (pair slot ci, s) owns the s-th non-zero chunk.  Same products, fp64 sums
+  // over at most 128 terms (the zero chunks the dense path adds are exact zeros).  Round 6: also over int16 slice indices (the whole-word
+  // BM25 index of BASELINE config 1, whose 2 k exact rescorings per query took the general one-wave-per-pair loop: 8.4 of its 15.7 ms per
+  // step) -- the 16-bit lanes of corpus ^ query index words are compared directly -- and up to 16 chunks (8 until then).
+  // (its own kernel, rescore_sparse_kernel = PATH 3: the 16 chunk ids cost the general kernel, which sits at its register budget, another
+  // 72 bytes of scratch per lane; the general kernel only counts the chunks and leaves these queries to it)
+  if constexpr (PATH == 0) {
+    if (p.split && p.q16 && *p.q_inexact == 0u && some_zero) {
+      int m = 0;
+      for (int t = 0; t * 64 < nchunks; ++t) m += __popcll(__ballot((nz_mask >> t) & 1u));
+      if (m <= 16) return;
     }
-    if (m <= 8) {
-      const int ci = lane >> 3, sl = lane & 7;
-      int myc = -1;
+  }
+  if constexpr (PATH == 3) {
+    if (!(p.q16 && *p.q_inexact == 0u && some_zero)) return;
+    const bool idx16 = p.c_idx_dtype == DHR_IDX_I16;
+    int nzc[16];
+    int m = 0;
+    for (int c0 = 0, t = 0; c0 < nchunks && m <= 16; c0 += 64, ++t) {
+      uint64_t b = __ballot((nz_mask >> t) & 1u);
+      while (b && m <= 16) { if (m < 16) nzc[m] = c0 + (__ffsll((unsigned long long)b) - 1); ++m; b &= b - 1; }
+    }
+    if (m > 16) return;
+    {
+      auto run = [&](auto lanes_c) __attribute__((always_inline)) {
+        constexpr int L = decltype(lanes_c)::value, P = 64 / L;
+        const int ci = lane / L, sl = lane % L;
+        int myc = -1;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) if (e < m && sl == e) myc = nzc[e];
-      uint4 qv = make_uint4(0u, 0u, 0u, 0u);
-      uint2 qi8 = make_uint2(0u, 0u);
-      const bool gated_chunk = myc >= 0 && myc < dlr_chunks && p.gate;
-      if (myc >= 0) qv = *(const uint4*)(p.q16 + (int64_t)q * p.k_rm + myc * 8);
-      if (gated_chunk) qi8 = *(const uint2*)(p.q_idx8 + (int64_t)q * p.d_dlr + myc * 8);
-      const uint32_t i = base + wave * 8 + ci;
-      static_assert(RESCORE_CANDS_PER_WG == 32, "4 waves x 8 pairs");
-      const bool live = i < count;
-      uint32_t row = 0u;
-      if (live) {
-        if (p.cand) row = p.cand[(int64_t)q * p.cap + i].x;
-        else if (p.rows32) row = p.rows32[(int64_t)q * p.ld_rows + i];
-        else row = (uint32_t)(p.row0 + i);
-      }
-      const bool valid = live && (int64_t)row < p.n_rows;
-      double acc = 0.0;
-      if (valid && myc >= 0) {
-        const uint4 dv = *(const uint4*)(p.vals_rm + (int64_t)row * p.k_rm + myc * 8);
-        uint32_t d[4] = {dv.x, dv.y, dv.z, dv.w};
-        const uint32_t qq[4] = {qv.x, qv.y, qv.z, qv.w};
+        for (int e = 0; e < L; ++e) if (e < m && sl == e) myc = nzc[e];
+        uint4 qv = make_uint4(0u, 0u, 0u, 0u);
+        uint4 qix = make_uint4(0u, 0u, 0u, 0u);          // the chunk's 8 query index values: 8 bytes (x, y) or 8 int16
+        const bool gated_chunk = myc >= 0 && myc < dlr_chunks && p.gate;
+        if (myc >= 0) qv = *(const uint4*)(p.q16 + (int64_t)q * p.k_rm + myc * 8);
         if (gated_chunk) {
-          const uint2 cix = *(const uint2*)((const uint8_t*)p.c_idx + (int64_t)row * p.d_dlr + myc * 8);
-          const uint32_t x0 = cix.x ^ qi8.x, x1 = cix.y ^ qi8.y;
-          d[0] &= pair_mask(x0, 0x0c010c00u); d[1] &= pair_mask(x0, 0x0c030c02u);
-          d[2] &= pair_mask(x1, 0x0c010c00u); d[3] &= pair_mask(x1, 0x0c030c02u);
+          if (idx16) qix = *(const uint4*)(p.q_idx + (int64_t)q * p.d_dlr + myc * 8);
+          else { const uint2 t8 = *(const uint2*)(p.q_idx8 + (int64_t)q * p.d_dlr + myc * 8); qix.x = t8.x; qix.y = t8.y; }
         }
+        static_assert(RESCORE_CANDS_PER_WG % (4 * P) == 0, "4 waves x P pairs per round");
+        for (uint32_t i0 = base + wave * P; i0 < base + RESCORE_CANDS_PER_WG && i0 < count; i0 += 4 * P) {
+          const uint32_t i = i0 + ci;
+          const bool live = i < count;
+          uint32_t row = 0u;
+          if (live) {
+            if (p.cand) row = p.cand[(int64_t)q * p.cap + i].x;
+            else if (p.rows32) row = p.rows32[(int64_t)q * p.ld_rows + i];
+            else row = (uint32_t)(p.row0 + i);
+          }
+          const bool valid = live && (int64_t)row < p.n_rows;
+          double acc = 0.0;
+          if (valid && myc >= 0) {
+            const uint4 dv = *(const uint4*)(p.vals_rm + (int64_t)row * p.k_rm + myc * 8);
+            uint32_t d[4] = {dv.x, dv.y, dv.z, dv.w};
+            const uint32_t qq[4] = {qv.x, qv.y, qv.z, qv.w};
+            if (gated_chunk && idx16) {
+              const uint4 cix = *(const uint4*)((const int16_t*)p.c_idx + (int64_t)row * p.d_dlr + myc * 8);
+              d[0] &= pair_mask16(cix.x ^ qix.x); d[1] &= pair_mask16(cix.y ^ qix.y);
+              d[2] &= pair_mask16(cix.z ^ qix.z); d[3] &= pair_mask16(cix.w ^ qix.w);
+            } else if (gated_chunk) {
+              const uint2 cix = *(const uint2*)((const uint8_t*)p.c_idx + (int64_t)row * p.d_dlr + myc * 8);
+              const uint32_t x0 = cix.x ^ qix.x, x1 = cix.y ^ qix.y;
+              d[0] &= pair_mask(x0, 0x0c010c00u); d[1] &= pair_mask(x0, 0x0c030c02u);
+              d[2] &= pair_mask(x1, 0x0c010c00u); d[3] &= pair_mask(x1, 0x0c030c02u);
+            }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc += (double)fmix_lo(d[e], qq[e]);
-          acc += (double)fmix_hi(d[e], qq[e]);
+            for (int e = 0; e < 4; ++e) {
+              acc += (double)fmix_lo(d[e], qq[e]);
+              acc += (double)fmix_hi(d[e], qq[e]);
+            }
+          }
+#pragma unroll
+          for (int o = 1; o < L; o <<= 1) acc += __shfl_xor(acc, o, 64);
+          if (sl == 0 && live) {
+            const float sc = valid ? (float)acc : -INFINITY;
+            if (p.out_keys) p.out_keys[(int64_t)q * p.ld_keys + i] = valid ? make_key(sc, row) : 0ull;
+            if (p.out_scores && q < p.n_queries) p.out_scores[(int64_t)q * p.ld_scores + i] = sc;
+          }
         }
-      }
-      acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
-      if (sl == 0 && live) {
-        const float sc = valid ? (float)acc : -INFINITY;
-        if (p.out_keys) p.out_keys[(int64_t)q * p.ld_keys + i] = valid ? make_key(sc, row) : 0ull;
-        if (p.out_scores && q < p.n_queries) p.out_scores[(int64_t)q * p.ld_scores + i] = sc;
-      }
+      };
+      if (m <= 8) run(std::integral_constant<int, 8>{}); else run(std::integral_constant<int, 16>{});
       return;
     }
   }
+  if constexpr (PATH != 3) {
   // Narrow rows (at most 128 chunks: dense-only indexes, 768 columns = 1.5 KB per row; the 768 + 128 BEIR layout): a wave per pair leaves half
   // of the lanes idle in its second pass and pays one 64-lane fp64 reduction per 1.5 KB -- measured 2.0 TB/s of row bytes against 5.4 TB/s on
   // 3.8 KB hybrid rows.  Instead 16 lanes per pair, four pairs per wave: lane s of a pair owns chunks s, s + 16, ... (ascending: six
@@ -2066,6 +1558,7 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
       if (p.out_scores && q < p.n_queries) p.out_scores[(int64_t)q * p.ld_scores + i] = sc;
     }
   }
+  }      // PATH != 3
 }
 // Flat launches walk the block list with a grid stride: the grid is the exact block count when the host knows it, and a fixed one when the
 // controller runs without host read-backs (the list lengths then exist in device memory only).
@@ -2097,6 +1590,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) r
   if (!rescore_fast_batch(p) || (p.k_rm >> 3) <= 128) return;
   rescore_run<1>(p);
 }
+// ... the queries with at most 16 non-zero chunks of a batch that has any (stage 1 of the theta modes, BM25 queries; any index dtype)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) rescore_sparse_kernel(RescoreArgs p) {
+  if (!p.q16 || p.q_inexact[0] != 0u || p.q_inexact[1] == 0u) return;
+  rescore_run<3>(p);
+}
 // ... and the narrow-row batch (dense-only 768, BM25, the 768 + 128 BEIR layout).
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) rescore_narrow_kernel(RescoreArgs p) {
   if (!rescore_fast_batch(p) || (p.k_rm >> 3) > 128) return;
@@ -2106,8 +1604,7 @@ hipError_t launch_rescore(const RescoreArgs& a_in, hipStream_t s) {
   if (a_in.max_count == 0 || a_in.n_queries <= 0) return hipSuccess;
   RescoreArgs a = a_in;
   // with an fp16 copy of the queries: the specialised kernel of the row width beside the general kernel (rescore_fast_batch decides on the device)
-  static const int split_on = getenv("DHR_RESCORE_SPLIT") ? atoi(getenv("DHR_RESCORE_SPLIT")) : 1;
-  a.split = (split_on && a.q16 && a.q_inexact) ? 1 : 0;
+  a.split = (a.q16 && a.q_inexact) ? 1 : 0;
   const bool wide = (a.k_rm >> 3) > 128;
   dim3 grid;
   if (a.blk_off) {
@@ -2116,6 +1613,7 @@ hipError_t launch_rescore(const RescoreArgs& a_in, hipStream_t s) {
   } else grid = dim3((a.max_count + RESCORE_CANDS_PER_WG - 1) / RESCORE_CANDS_PER_WG, (unsigned)a.n_queries);
   if (a.split && wide) hipLaunchKernelGGL(rescore_fast_kernel, grid, dim3(256), 0, s, a);
   if (a.split && !wide) hipLaunchKernelGGL(rescore_narrow_kernel, grid, dim3(256), 0, s, a);
+  if (a.split) hipLaunchKernelGGL(rescore_sparse_kernel, grid, dim3(256), 0, s, a);
   hipLaunchKernelGGL(rescore_kernel, grid, dim3(256), 0, s, a);
   return hipGetLastError();
 }
@@ -2934,8 +2432,7 @@ hipError_t launch_merge_lists(int n_queries, int n_lists, int list_len, const fl
   if (stride_r <= 0) stride_r = (int64_t)n_queries * list_len;
   const size_t bytes = ((size_t)n_lists * list_len + (size_t)k_out) * (in_rows ? 12 : 4);
   if (bytes > 160 * 1024 || n_lists > 64) return hipErrorInvalidValue;
-  static const int env_threads = getenv("DHR_MERGE_THREADS") ? atoi(getenv("DHR_MERGE_THREADS")) : 0;
-  const int threads = env_threads ? env_threads : 512;     // measured best of 256 / 512 / 1024 on every shard-reduce shape
+  const int threads = 512;     // measured best of 256 / 512 / 1024 on every shard-reduce shape
   auto go = [&](auto kernel, size_t& attr_bytes) -> hipError_t {
     if (bytes > attr_bytes) {
       hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);

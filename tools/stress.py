@@ -28,7 +28,7 @@ def main():
         neg = bool(rng.random() < 0.3)
         q32 = bool(rng.random() < 0.4)
         sparse_vals = bool(rng.random() < 0.5)
-        nb = int(rng.choice([0, 0, 0, 1, 2, 3, 4]))
+        nb = int(rng.choice([0, 0, 0, 1, 2]))
         ungated = bool(d_dlr and rng.random() < 0.15)
         g8 = int(rng.integers(0, 2))                   # image of the gated half: fp16 2:4 (the library's choice at these sizes) or int8 2:4
         os.environ["DHR_GATED_I8"] = str(g8)

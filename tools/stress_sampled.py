@@ -31,7 +31,7 @@ def main():
         first = int(rng.choice([0, 0, 256, 2048]))
         order = str(rng.choice(["random", "random", "sorted_desc", "sorted_asc", "sample_tiles", "one_residue"]))
         shards = int(rng.choice([1, 1, 2, 3]))
-        nb = int(rng.choice([0, 0, 1, 2, 3]))
+        nb = int(rng.choice([0, 0, 1, 2]))
         g8 = int(rng.integers(0, 2))                   # image of the gated half: fp16 2:4 (the library's choice at these sizes) or int8 2:4
         os.environ["DHR_GATED_I8"] = str(g8)
         cfg = dict(case=case, n=n, q=q, d_dlr=d_dlr, d_cls=d_cls, k=k, period=period, cap=cap, chunks=chunks, first=first,
