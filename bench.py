@@ -614,7 +614,7 @@ def run_workload(args, spec, ctx):
                          "peak_instruction_mix": round(peak_mix, 1), "frac_of_instruction_mix_peak": round(ach_tf / peak_mix, 4),
                          "frac_of_instruction_mix_peak_kernel_alone": round(ach_k / peak_mix, 4) if serial else None,
                          "traffic": None if traffic_per_row is None else round(traffic_per_row * rows_per_launch, 0),
-                         "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE, gfx950-corrected; profiles/r05_gemm_pmc.txt; fp16-gated hybrid images: r02_gemm_pmc.txt)",
+                         "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE, gfx950-corrected; profiles/r06_gemm_pmc.txt; fp16-gated hybrid images: r02_gemm_pmc.txt)",
                          "algorithmic_bytes_per_launch": round(alg_bytes_per_row * rows_per_launch, 0),
                          "launches": launches, "avg_launch_ms": round(gemm_ms / max(launches, 1), 3),
                          "avg_launch_ms_kernel_alone": round(serial["gemm_ms_per_step"] * 3 / max(serial["launches"], 1), 3) if serial else None,
@@ -700,7 +700,7 @@ def run_workload(args, spec, ctx):
 # (key: d_dlr, d_cls, queries, DHR_INFO_GEMM_KERNEL id, dense_i8, gated_i8)
 TRAFFIC_BYTES_PER_ROW = {(768, 768, 6980, 3, 0, 0): 34.6e3,     # gemm_filter_wx_kernel, fp16 image of the ungated columns: 17.31 GB per 500 000-row launch (r02)
                          (768, 768, 6980, 3, 1, 0): 26.2e3,     # ... int8 image of the ungated columns, fp16 gated: 13.10 GB (r02)
-                         (768, 768, 6980, 5, 1, 1): 22.5e3,     # gemm_filter_g8_kernel, gated_i8 (default since round 3): 11.23 GB (profiles/r05_gemm_pmc.txt; r04: 11.23, r03: 11.27)
+                         (768, 768, 6980, 5, 1, 1): 22.5e3,     # gemm_filter_g8_kernel, gated_i8 (default since round 3): 11.23 GB (profiles/r06_gemm_pmc.txt: 11.24; r05 / r04: 11.23, r03: 11.27)
                          (0, 768, 6980, 3, 0, 0): 14.6e3,       # dense-only index, fp16 stage images: 7.30 GB (r04)
                          (0, 768, 6980, 3, 1, 0): 6.06e3,       # dense-only index, int8 stage images on gemm_filter_wx_kernel (DHR_DENSE_G8=0): 3.03 GB (r04)
                          (0, 768, 6980, 5, 1, 0): 6.06e3}       # ... on gemm_filter_g8_kernel with no gated stage (default since round 5): the same operand images and tile order

@@ -14,8 +14,8 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdhr_hip.so")
 OBJDIR = os.path.join(CSRC, "build")
-SOURCES = ["abi.cpp", "kernels.hip", "gemm_w4.hip", "gemm_g8.hip", "api.hip", "sharded.hip", "pq_adc.hip", "select_global.hip", "host_io.hip"]
-HEADERS = ["dhr_internal.h", "abi_guard.h", "libdhr.map", "gemm_common.h", "gemm_g8.h", os.path.join("..", "..", "include", "dhr_hip.h")]
+SOURCES = ["abi.cpp", "kernels.hip", "gemm_w4.hip", "gemm_g8.hip", "index_build.hip", "search_core.hip", "api.hip", "sharded.hip", "pq_adc.hip", "select_global.hip", "host_io.hip"]
+HEADERS = ["dhr_internal.h", "dhr_state.h", "abi_guard.h", "libdhr.map", "gemm_common.h", "gemm_g8.h", os.path.join("..", "..", "include", "dhr_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 # A/B builds only (DHR_AB_VARIANTS=1 in the environment of the build, tools/ab_build.sh): the retired persistent-workgroup form of the integer
 # bound GEMM (tools/ab/gemm_g8p.hip, DHR_PARAM_GEMM_VARIANT = 6) -- the measurement behind DESIGN.md section 4b, not part of the shipped library

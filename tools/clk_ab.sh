@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage (GPU box): bash tools/clk_ab.sh  -> package power / sclk while the bound GEMM runs alone (closed and open filter), one workgroup per tile
-# against persistent workgroups; the power cap of the board first
+# usage (GPU box): bash tools/clk_ab.sh  -> package power / sclk while the bound GEMM runs alone (closed and open filter); the power cap of the board first.
+# PERSIST="0 1" (with DHR_HIP_LIB pointing at a DHR_AB_VARIANTS=1 build, tools/ab): one workgroup per tile against persistent workgroups, as in rounds 4-5
 export DHR_GATED_I8=1
 rocm-smi --showmaxpower --showpowercap 2>/dev/null | grep -i -E "power|cap" | head -6
-for pz in 0 1; do for o in "" "--open"; do
+for pz in ${PERSIST:-0}; do for o in "" "--open"; do
   ( while true; do rocm-smi --showpower --showclocks 2>/dev/null | grep -E 'sclk|Package Power' | tr '\n' ' ' | sed 's/GPU\[0\]//g; s/\t//g'; echo; sleep 0.2; done ) > /tmp/smi_$pz$o.log 2>&1 &
   SMI=$!
   r=$(DHR_G8_PERSIST=$pz timeout 300 python tools/gemm_bench.py --synth --dlr 768 --rows 2000000 --iters 200 $o 2>&1 | grep -a variant | sed 's/.*: \([0-9.]*\) ms.*/\1/')

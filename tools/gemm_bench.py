@@ -43,7 +43,7 @@ def main():
         os.environ["DHR_GEMM_TIME_OPEN"] = "1"
         ix.search(qv, qi, 1000, out_device=True)
     del cv
-    if a.variant != 3:
+    if a.variant in (4, 5):          # (6: A/B builds only, tools/ab)
         ix.set_param(_lib.PARAM_GEMM_VARIANT, a.variant)
     qb, keep = _lib.make_query_batch(qv, qi)
     ms, fl = C.c_double(), C.c_double()

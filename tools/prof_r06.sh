@@ -50,13 +50,13 @@ if [ $PART = pmc ] || [ $PART = all ]; then
   SQ2="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_MFMA"
   for cfg in "g8 768 1 -1 0" "dense 0 1 0 0" "densei8 0 1 1 0"; do
     set -- $cfg
-    export DHR_GATED_I8=$3 DHR_DENSE_I8=$4 DHR_G8_PERSIST=$5
+    export DHR_GATED_I8=$3 DHR_DENSE_I8=$4
     timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_$1_f -- $R/tools/probe/_bin/gemm_pmc 500000 6980 $2 > $O/pmc_$1_f.log 2>&1
     timeout 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d $O/pmc_$1_t -- $R/tools/probe/_bin/gemm_pmc 500000 6980 $2 > $O/pmc_$1_t.log 2>&1
     timeout 200 rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d $O/pmc_$1_s -- $R/tools/probe/_bin/gemm_pmc 500000 6980 $2 > $O/pmc_$1_s.log 2>&1
     timeout 200 rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d $O/pmc_$1_l -- $R/tools/probe/_bin/gemm_pmc 500000 6980 $2 > $O/pmc_$1_l.log 2>&1
   done
-  unset DHR_GATED_I8 DHR_DENSE_I8 DHR_G8_PERSIST
+  unset DHR_GATED_I8 DHR_DENSE_I8
   cd $R
   python3 tools/pmc_summary.py $O > $O/${TAG}_gemm_pmc_raw.txt
   cat $O/${TAG}_gemm_pmc_raw.txt
