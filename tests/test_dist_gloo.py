@@ -75,7 +75,7 @@ class _FakeShard:
     def union_rank(self, k):
         return self.r
 
-    def sample_rank(self, k, share):               # this shard's share of the union's rank (api.hip local_sample_rank)
+    def sample_rank(self, k, share):               # this shard's share of the union's rank (search_core.hip local_sample_rank)
         m = self.r / share
         return self.r if share <= 1 else min(self.r, int(np.ceil(m + 5.0 * np.sqrt(m) + 4.0)))
 

@@ -1984,7 +1984,7 @@ def test_extrapolated_threshold_failure_is_redone(G, gated_image):
     fraction of the corpus seen so far.  Adversarial placement: 56 outstanding rows (fewer than k = 64), ALL inside the tiles the
     scattered order visits in the first chunk -- the extrapolation (rank 53 of the seen rows) lands on their score, every later row
     is filtered, fewer than k rows reach the threshold: the verification must fail and the query be redone exactly.  The visiting
-    order is restated from api.hip (search_core): non-sample position i -> (i * perm_mul) % n_main."""
+    order is restated from search_core.hip (search_core): non-sample position i -> (i * perm_mul) % n_main."""
     import math
     from dhr_amd import _lib
     n, S, k, M = 720_000, 4, 64, 8                      # 2 108 non-sample tiles: the planner allows 8 chunks from 2 048 on
