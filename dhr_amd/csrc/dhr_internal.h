@@ -1,4 +1,4 @@
-// Internal declarations shared by the kernels (kernels.hip) and the host controller (api.hip).
+// Internal declarations shared by the kernels (kernels.hip, gemm_*.hip) and the host side (dhr_state.h: index_build.hip, search_core.hip, api.hip; sharded.hip).
 // gfx950 only: 64-wide wavefronts, v_mfma_f32_32x32x16_f16, global_load_lds (16 B), 160 KiB LDS.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -8,7 +8,7 @@
 #include "../../include/dhr_hip.h"
 #include "abi_guard.h"
 
-// library-internal helpers with C linkage (api.hip), used by the other translation units
+// library-internal helpers with C linkage (abi.cpp, index_build.hip, api.hip), used by the other translation units
 extern "C" int dhr_set_error_message(int code, const char* msg);   // records the calling thread's last error, returns code
 extern "C" int dhr_index_device(const dhr_index* ix);
 extern "C" void dhr_internal_index_arena(dhr_index* ix, void*** base, size_t** bytes);   // the handle's grow-only scratch for dhr_search_sharded_local

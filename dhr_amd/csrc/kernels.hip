@@ -672,7 +672,7 @@ hipError_t launch_gemm_filter(const GemmArgs& a_in, hipStream_t s) {
   if (n_tiles <= 0) return hipSuccess;
   const int64_t groups = (n_tiles + DOC_GROUP - 1) / DOC_GROUP;
   const int64_t groups_per_xcd = (groups + 7) / 8;
-  // limits of the 3-D grid and of the division-free tile map; check_queries (api.hip) rejects the batches that would hit the first with a
+  // limits of the 3-D grid and of the division-free tile map; check_queries (search_core.hip) rejects the batches that would hit the first with a
   // proper message, the others cannot be reached through the C ABI (n_rows < 2^32, sample period <= 256)
   if ((int64_t)DOC_GROUP * a_in.n_qtiles > 65535 || a_in.perm_n >= (1 << 24) || a_in.period > (1 << 20)) return hipErrorInvalidValue;
   if (a_in.map_mode >= 2 && a_in.period < 2) return hipErrorInvalidValue;      // "everything but the sample" needs a sample: divmod24 by period - 1
