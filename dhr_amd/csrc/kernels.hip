@@ -1163,14 +1163,19 @@ hipError_t launch_resid_build(const __half* vals_rm, int k_rm, int64_t n_rows, i
 #else
 #define DENSE_REFINE_ATTR
 #endif
+#ifndef DENSE_REFINE_LPC
+#define DENSE_REFINE_LPC 16      // lanes per candidate: 16 (8-byte pieces, 4 candidates per wave per round) or 8 (16-byte pieces, 8 candidates per wave per round)
+#endif
 template <int CH>
 __global__ void __launch_bounds__(256) DENSE_REFINE_ATTR dense_refine_kernel(RefineArgs p) {
+  constexpr int LPC = DENSE_REFINE_LPC, PB = 128 / LPC, WPP = PB / 4;      // lanes per candidate; bytes / 32-bit words of a lane's piece of a 128-byte line
+  static_assert(LPC == 16 || LPC == 8, "one load instruction of a candidate's lanes = one 128-byte line");
   __shared__ float a_s[1024];
   __shared__ uint32_t f_s[2 * 128];        // packed int8 factors: [0, 128) even columns of every group of eight, [128, 256) odd columns
   __shared__ float red[3 * 4];             // per wave: max |a|, then sum a8 and sum |da| (as floats: both are below 2^24 in magnitude / harmlessly rounded UP below)
   int q = blockIdx.y;
   uint32_t blk = blockIdx.x;
-  const int sub = threadIdx.x & 15, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = threadIdx.x & (LPC - 1), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int NCOL = CH * 16;
   for (uint32_t fb = blockIdx.x;; fb += gridDim.x) {       // flat launches: grid stride over the block list (see rescore_kernel); else one pass
   if (p.blk_off && !flat_block(p.blk_off, p.n_queries, fb, q, blk)) return;
@@ -1213,45 +1218,52 @@ __global__ void __launch_bounds__(256) DENSE_REFINE_ATTR dense_refine_kernel(Ref
   __syncthreads();
   s8 = red[4] + red[5] + red[6] + red[7];
   sd = (red[8] + red[9] + red[10] + red[11]) * 1.0001f;
-  // lane `sub` owns the 8-byte pieces sub, 16 + sub, ... of a row = columns 256 u + 16 sub ..: groups of eight 32 u + 2 sub, 32 u + 2 sub + 1
+  // lane `sub` owns the PB-byte pieces sub, LPC + sub, ... of a row = columns 256 u + 2 PB sub ..: groups of eight 32 u + WPP sub + h, h < WPP
   constexpr int U = CH / 16;
-  uint32_t fe[2 * U], fo[2 * U];
+  uint32_t fe[WPP * U], fo[WPP * U];
 #pragma unroll
   for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) { fe[2 * u + h] = f_s[32 * u + 2 * sub + h]; fo[2 * u + h] = f_s[128 + 32 * u + 2 * sub + h]; }
+    for (int h = 0; h < WPP; ++h) { fe[WPP * u + h] = f_s[32 * u + WPP * sub + h]; fo[WPP * u + h] = f_s[128 + 32 * u + WPP * sub + h]; }
   const int off = 8 * (int)s8;                               // the residuals are stored with an offset of 8 (s8 is an integer below 2^17: exact)
   const float t = p.thr[q] + p.thr_raise[q] - 7.f * sd;      // 7 sum |da|: what the int8 factors can be off by over a row's residuals
   // the loads of the NEXT 16 candidates go out before the current ones are summed (the kernel waits for round trips, not for bytes)
-  auto fetch = [&](uint32_t i, uint2& c, uint2 (&v)[U]) __attribute__((always_inline)) {
+  struct Piece { uint32_t w[WPP]; };
+  constexpr int CPR = 256 / LPC;               // candidates of the workgroup per round
+  auto fetch = [&](uint32_t i, uint2& c, Piece (&v)[U]) __attribute__((always_inline)) {
     c = make_uint2(0u, 0u);
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = make_uint2(0x88888888u, 0x88888888u);
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int h = 0; h < WPP; ++h) v[u].w[h] = 0x88888888u;
     if (i < count) {
       c = i < p.cap ? p.cand[(int64_t)q * p.cap + i] : p.ovf[(size_t)p.ovf_off[q] + (i - p.cap)];
-      const uint8_t* r = p.resid8 + (int64_t)c.x * p.resid_ld + sub * 8;
+      const uint8_t* r = p.resid8 + (int64_t)c.x * p.resid_ld + sub * PB;
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = gather8(r + u * 128);
+      for (int u = 0; u < U; ++u) {
+        if constexpr (PB == 8) { const uint2 t = gather8(r + u * 128); v[u].w[0] = t.x; v[u].w[1] = t.y; }
+        else { const uint4 t = gather16(r + u * 128); v[u].w[0] = t.x; v[u].w[1] = t.y; v[u].w[WPP - 2] = t.z; v[u].w[WPP - 1] = t.w; }
+      }
     }
   };
   uint2 c;
-  uint2 v[U];
-  fetch(base + (threadIdx.x >> 4), c, v);
-  for (uint32_t i = base + (threadIdx.x >> 4); i < base + REFINE_PER_WG; i += 16) {
+  Piece v[U];
+  fetch(base + (threadIdx.x / LPC), c, v);
+  for (uint32_t i = base + (threadIdx.x / LPC); i < base + REFINE_PER_WG; i += CPR) {
     uint2 cn;
-    uint2 vn[U];
-    fetch(i + 16 < base + REFINE_PER_WG ? i + 16 : 0xffffffffu, cn, vn);
+    Piece vn[U];
+    fetch(i + CPR < base + REFINE_PER_WG ? i + CPR : 0xffffffffu, cn, vn);
     int isum = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t w[2] = {v[u].x, v[u].y};
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        isum = __builtin_amdgcn_sdot4((int)fe[2 * u + h], (int)(w[h] & 0x0f0f0f0fu), isum, false);
-        isum = __builtin_amdgcn_sdot4((int)fo[2 * u + h], (int)((w[h] >> 4) & 0x0f0f0f0fu), isum, false);
+      for (int h = 0; h < WPP; ++h) {
+        isum = __builtin_amdgcn_sdot4((int)fe[WPP * u + h], (int)(v[u].w[h] & 0x0f0f0f0fu), isum, false);
+        isum = __builtin_amdgcn_sdot4((int)fo[WPP * u + h], (int)((v[u].w[h] >> 4) & 0x0f0f0f0fu), isum, false);
       }
     }
-    isum += __shfl_xor(isum, 1, 64); isum += __shfl_xor(isum, 2, 64); isum += __shfl_xor(isum, 4, 64); isum += __shfl_xor(isum, 8, 64);
+#pragma unroll
+    for (int o = 1; o < LPC; o <<= 1) isum += __shfl_xor(isum, o, 64);
     if (sub == 0 && i < count) {
       float u2 = __uint_as_float(c.y) + sa * (float)(isum - off);
       u2 += fabsf(u2) * 4.8e-7f;                             // the product and the sum rounded up
@@ -1439,7 +1451,10 @@ __device__ __forceinline__ void rescore_block(const RescoreArgs& p, const int q,
   // width alone, so scores stay reproducible between searches, shards and entry points.  (32 lanes per pair: 2.9-3.1 TB/s.)
   if constexpr (PATH == 0 || PATH == 2)
   if (fast && !some_zero && nchunks <= 128) {
-    constexpr int L = 16, P = 64 / L;
+#ifndef RESCORE_NARROW_L
+#define RESCORE_NARROW_L 16      // lanes per pair on narrow rows (32: 2.9-3.1 TB/s, 16: 3.4; 8: A/B builds)
+#endif
+    constexpr int L = RESCORE_NARROW_L, P = 64 / L;
     const int g = lane / L, sl = lane % L;
     static_assert(RESCORE_CANDS_PER_WG % (4 * P) == 0, "4 waves x P pairs per round");
     for (uint32_t i0 = base + wave * P; i0 < base + RESCORE_CANDS_PER_WG && i0 < count; i0 += 4 * P) {

@@ -1573,6 +1573,17 @@ def test_random_controller_configurations(G, monkeypatch):
     stress_sampled.main()
 
 
+def test_random_mode_configurations(G, monkeypatch):
+    """A slice of tools/stress_modes.py: the entry points beside the plain search (two-stage modes on the device, dhr_score_rows, the
+    index file round trip, the one-process sharded search over ragged shards, the shard reduces on the device and on the host) on
+    random shapes / dtypes / signs / bucket counts / k1 / k, each against the oracle's float64 scores and parity rules."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import stress_modes
+    monkeypatch.setattr(sys, "argv", ["stress_modes.py", "60", "3"])
+    stress_modes.main()
+
+
 def test_bench_two_ranks_share_one_gpu():
     """bench.py's N>1 path end to end (torch.distributed.run, staged sharded search, collectives, JSON line) with two
     ranks on ONE GPU over gloo (DHR_BENCH_SINGLE_DEVICE=1, testing mode); the line must carry the contract's fields

@@ -1,0 +1,148 @@
+#!/usr/bin/env python
+"""Randomised differential test of the entry points BESIDE the plain search: the two-stage modes on the device
+(dhr_search_rerank: theta > 0 and --IP first stages, gip_retrieval.py:128-156), dhr_score_rows, the index file round trip
+(dhr_index_save / dhr_index_load), the sharded search in one process (dhr_search_sharded_local over 1 ... 5 row shards of ragged
+sizes) and the shard reduces (dhr_merge_topk, dhr_merge_topk_lists, device and host twins) -- random shapes, dtypes, value signs,
+bucket counts, k1 / k, both images of the gated half -- against the oracle's float64 scores and its parity rules.  Prints the
+failing configuration and exits non-zero on the first mismatch.  usage: python tools/stress_modes.py [n_cases] [seed]"""
+import os, sys, tempfile, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    import torch
+    from dhr_amd import _lib, dist as D
+    from dhr_amd.retrieval import gip_retrieval as G
+    from oracle import gip_oracle as O
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    tmp = tempfile.mkdtemp(prefix="dhr_stress_")
+    for case in range(n_cases):
+        n = int(rng.choice([300, 1000, 2500, 5000, 20000, 60000]))
+        q = int(rng.integers(1, 14))
+        d_dlr = int(rng.choice([8, 32, 64, 128, 256, 768]))
+        d_cls = int(rng.choice([0, 8, 64, 128, 768]))
+        k1 = int(min(n, rng.choice([10, 100, 1000, 3000, 10000, 20000])))
+        k = int(min(k1, rng.choice([1, 10, 100, 1000])))
+        idx_dtype = rng.choice([np.uint8, np.int8, np.int16])
+        n_idx = int(rng.choice([2, 5, 39, 120]))
+        neg = bool(rng.random() < 0.25)
+        q32 = bool(rng.random() < 0.4)
+        nb = int(rng.choice([0, 0, 1, 2]))
+        g8 = int(rng.integers(0, 2))
+        theta = float(rng.choice([0.05, 0.1, 0.3, 0.6]))
+        what = str(rng.choice(["theta", "ip", "score_rows", "file", "local_shards", "merge"]))
+        os.environ["DHR_GATED_I8"] = str(g8)
+        cfg = dict(case=case, what=what, n=n, q=q, d_dlr=d_dlr, d_cls=d_cls, k1=k1, k=k, idx=np.dtype(idx_dtype).name, n_idx=n_idx,
+                   neg=neg, q32=q32, nb=nb, gated_i8=g8, theta=theta)
+        K = d_dlr + d_cls
+
+        def vals(m):
+            v = np.abs(rng.standard_normal((m, K))) * 0.5
+            v[:, :d_dlr] *= (rng.random((m, d_dlr)) < 0.3)
+            if neg:
+                v[:, :d_dlr] *= np.where(rng.random((m, d_dlr)) < 0.2, -1.0, 1.0)
+            v[:, d_dlr:] = rng.standard_normal((m, d_cls)) * 0.2
+            return v
+        cv = vals(n).astype(np.float16)
+        qv = vals(q)
+        qv = (qv * 0.9).astype(np.float32) if q32 else qv.astype(np.float16).astype(np.float32)
+        lo = -n_idx // 2 if np.dtype(idx_dtype).kind == "i" else 0
+        ci = rng.integers(lo, lo + n_idx, (n, d_dlr)).astype(idx_dtype)
+        qi = rng.integers(lo, lo + n_idx, (q, d_dlr)).astype(idx_dtype)
+        c32 = cv.astype(np.float32)
+        exact = lambda i: O.gip_scores_f64(qv[i], qi[i], c32, ci)       # noqa: E731
+        try:
+            if what == "merge":
+                n_lists, ll = int(rng.integers(1, 10)), int(rng.choice([1, 7, 100, 448, 1000]))
+                kk = int(rng.choice([1, 10, 100, 1000]))
+                # sorted lists with duplicate scores across lists and ragged padded tails
+                sc = np.round(rng.standard_normal((n_lists, q, ll)), int(rng.choice([1, 3, 6]))).astype(np.float32)
+                rows = np.stack([rng.permutation(ll * n_lists)[:ll] + 0 for _ in range(n_lists * q)]).reshape(n_lists, q, ll).astype(np.int64)
+                for l in range(n_lists):
+                    rows[l] += l * 10_000_000           # lists of different shards hold different rows
+                    fill = rng.integers(0, ll + 1, q)
+                    for i in range(q):
+                        o = np.lexsort((rows[l, i], -sc[l, i].astype(np.float64)))
+                        sc[l, i], rows[l, i] = sc[l, i][o], rows[l, i][o]
+                        sc[l, i, fill[i]:], rows[l, i, fill[i]:] = -np.inf, -1
+                es, er = O.merge_topk([sc[l] for l in range(n_lists)], [rows[l] for l in range(n_lists)], kk)
+                for dev in ("cuda", "cpu"):
+                    ts, tr = torch.from_numpy(sc).to(dev), torch.from_numpy(rows).to(dev)
+                    ms, mr = D.merge_sorted_lists(ts, tr, kk)
+                    np.testing.assert_array_equal(mr.cpu().numpy(), er)
+                    np.testing.assert_array_equal(ms.cpu().numpy(), es)
+                    cs, cr = ts.permute(1, 0, 2).reshape(q, -1), tr.permute(1, 0, 2).reshape(q, -1)
+                    perm = torch.from_numpy(rng.permutation(cs.shape[1])).to(dev)
+                    ms, mr = D.merge_topk(cs[:, perm].contiguous(), cr[:, perm].contiguous(), kk)
+                    np.testing.assert_array_equal(mr.cpu().numpy(), er)
+                    np.testing.assert_array_equal(ms.cpu().numpy(), es)
+                    ms, _ = D.merge_sorted_lists(ts, None, kk)
+                    np.testing.assert_array_equal(ms.cpu().numpy(), es)
+            elif what == "local_shards":
+                n_sh = int(rng.integers(1, 6))
+                cuts = np.sort(rng.choice(np.arange(1, n), n_sh - 1, replace=False)) if n_sh > 1 else np.zeros(0, np.int64)
+                bounds = [0] + [int(c) for c in cuts] + [n]
+                shards = [G.GipIndex(cv[a:b], ci[a:b], row_offset=a, idx_buckets=nb) for a, b in zip(bounds[:-1], bounds[1:])]
+                try:
+                    kk = k1
+                    s, r = D.search_sharded_local(shards, qv, qi, kk)
+                    s, r = np.asarray(s.cpu() if hasattr(s, "cpu") else s), np.asarray(r.cpu() if hasattr(r, "cpu") else r)
+                    for i in range(q):
+                        ex = exact(i)
+                        O.check_topk(r[i], s[i], ex, kk)
+                        np.testing.assert_allclose(s[i], ex[r[i]].astype(np.float32), rtol=0, atol=1e-6 * max(1.0, np.abs(ex).max()))
+                finally:
+                    for sh in shards:
+                        sh.close()
+                cfg["bounds"] = bounds
+            else:
+                ix = G.GipIndex(cv, ci, idx_buckets=nb)
+                try:
+                    if what in ("theta", "ip"):
+                        if what == "theta":
+                            q1, qi1 = np.where(qv > theta, qv, np.float32(0)), qi
+                        else:
+                            q1, qi1 = qv, None
+                        s, r = ix.search_rerank(q1, qi1, qv, qi, k1, k)
+                        for i in range(q):
+                            s1 = O.stage1_scores_f64(qv[i], qi[i], c32, ci, theta, what == "ip")
+                            O.check_two_stage(r[i], s[i], s1, exact(i), k1, k)
+                    elif what == "score_rows":
+                        m = int(rng.choice([1, 3, 100, 1000, 5000]))
+                        rows = rng.integers(0, n, (q, m)).astype(np.int64)          # duplicates allowed
+                        got = ix.score_rows(qv, qi, rows)
+                        for i in range(q):
+                            ex = exact(i)
+                            np.testing.assert_allclose(got[i], ex[rows[i]].astype(np.float32), rtol=0, atol=1e-6 * max(1.0, np.abs(ex).max()))
+                    else:
+                        kk = k1
+                        s0, r0 = ix.search(qv, qi, kk)
+                        path = os.path.join(tmp, "ix.dhr")
+                        ix.save(path, docids=["d%d" % j for j in range(min(n, 50))])
+                        ix2, ids = G.GipIndex.load(path)
+                        try:
+                            s1, r1 = ix2.search(qv, qi, kk)
+                        finally:
+                            ix2.close()
+                        os.unlink(path)
+                        assert ids == ["d%d" % j for j in range(min(n, 50))]
+                        np.testing.assert_array_equal(r1, r0)
+                        np.testing.assert_array_equal(s1, s0)
+                        for i in range(q):
+                            O.check_topk(r0[i], s0[i], exact(i), kk)
+                finally:
+                    ix.close()
+        except Exception as e:  # noqa: BLE001
+            print("FAILED", cfg, "->", repr(e)[:600])
+            sys.exit(1)
+        if case % 10 == 0:
+            print("case %d ok (%.0f s) %s" % (case, time.time() - t0, cfg), flush=True)
+    print("all %d cases ok in %.0f s" % (n_cases, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
