@@ -156,7 +156,7 @@ def main():
     ap.add_argument("--overlap-aux", type=int, default=-1)
     ap.add_argument("--progressive-thr", type=int, default=-1, help="tuning: 1 = running exact thresholds only, 2 (library default) = + extrapolated from the scattered fraction seen")
     ap.add_argument("--dense-i8", type=int, default=-1, help="int8 image of the ungated columns in the bound GEMM (dhr_set_option DHR_OPT_DENSE_I8): -1 library default (gated indexes), 0 off, 1 on for dense-only indexes too")
-    ap.add_argument("--gemm-variant", type=int, default=-1, help="tuning: bound-GEMM kernel of the 2:4 layout (3 = 12-wave producer / consumer, 4 = 4 waves, 5 = 8 waves)")
+    ap.add_argument("--gemm-variant", type=int, default=-1, help="tuning: bound-GEMM kernel of the fp16 2:4 image (4 = 4 waves of 128 x 128, 5 = 8 waves of 128 x 64: the default)")
     ap.add_argument("--no-progressive-thr", action="store_true", help="A/B: keep the sampled thresholds frozen over the main pass")
     ap.add_argument("--first-rows", type=int, default=0)
     ap.add_argument("--list-stride", type=int, default=0, help="tuning: DHR_PARAM_LIST_STRIDE (uniform slots per query of the bound lists; 262144 = the uniform lists of rounds 3-4)")
@@ -558,9 +558,7 @@ def run_workload(args, spec, ctx):
         kid = int(index.info(_lib.INFO_GEMM_KERNEL))
         g8_ops = ("gated half on v_smfmac_i32_32x32x64_i8, ungated half on v_mfma_i32_32x32x32_i8" if d_dlr and d_cls else
                   "v_smfmac_i32_32x32x64_i8 (2:4 int8)" if d_dlr else "v_mfma_i32_32x32x32_i8 on the int8 stage images, no gated stage")
-        kernel = {1: "gemm_filter_v3_kernel (bound GEMM on the K-step tile layout + fused threshold filter)",
-                  2: "gemm_filter_sparse_kernel (bound GEMM on the 2:4 sparse matrix cores + fused threshold filter, 12 waves)",
-                  3: "gemm_filter_wx_kernel<NI=2> (bound GEMM on the %s + fused threshold filter, 8 waves)" % ("2:4 sparse matrix cores" if sparse_layout else "matrix cores, 32-column stage images"),
+        kernel = {3: "gemm_filter_wx_kernel<NI=2> (bound GEMM on the %s + fused threshold filter, 8 waves)" % ("2:4 sparse matrix cores" if sparse_layout else "matrix cores, 32-column stage images"),
                   4: "gemm_filter_wx_kernel<NI=4> (bound GEMM on the %s + fused threshold filter, 4 waves)" % ("2:4 sparse matrix cores" if sparse_layout else "matrix cores, 32-column stage images"),
                   5: "gemm_filter_g8_kernel (integer bound GEMM: %s, fused threshold filter, 8 waves)" % g8_ops,
                   6: "gemm_filter_g8p_kernel (integer bound GEMM with persistent workgroups: %s)" % g8_ops}.get(kid, "unknown (DHR_INFO_GEMM_KERNEL = %d)" % kid)

@@ -7,8 +7,8 @@
 namespace dhr {
 
 // ------------------------------------------------------------------------------------------ bound GEMM, every wave computes
-// Same operand images and the same 256 x 256 tile as the 12-wave producer / consumer kernel (kernels.hip), but no parked
-// producer registers: EVERY wave holds accumulators and issues its share of the LDS-DMA.
+// Stage images of the operands, 256 x 256 tiles; no producer waves with parked registers (the 12-wave producer / consumer kernel these
+// replaced was retired in round 6): EVERY wave holds accumulators and issues its share of the LDS-DMA.
 //   NI = 4: four waves, one per SIMD with the SIMD's whole 512-entry register file, 128 x 128 wave tiles (256 accumulators):
 //           a third less LDS fragment traffic per multiply-add.  The wave is its SIMD's only instruction stream.
 //   NI = 2: eight waves, two per SIMD at 256 registers, 128 x 64 wave tiles: while one wave of a SIMD sits in a DMA issue

@@ -151,9 +151,9 @@ typedef enum dhr_info {
   DHR_INFO_ROW_NORM_MAX = 5,  /* max over rows of || row || */
   DHR_INFO_TILE_BYTES = 6,    /* bytes of the bound-GEMM operand images */
   DHR_INFO_GATED_I8 = 7,      /* 1 if the gated stages are int8 2:4 images */
-  DHR_INFO_GEMM_KERNEL = 8    /* the bound-GEMM kernel the handle's latest search launched (0: none yet): 1 gemm_filter_v3_kernel (K-step layout), 2
-                                 gemm_filter_sparse_kernel (12 waves), 3 / 4 gemm_filter_wx_kernel<2> / <4> (8 / 4 waves), 5 gemm_filter_g8_kernel (integer
-                                 operands, 8 waves), 6 the same with persistent workgroups */
+  DHR_INFO_GEMM_KERNEL = 8    /* the bound-GEMM kernel the handle's latest search launched (0: none yet): 3 / 4 gemm_filter_wx_kernel<2> / <4>
+                                 (fp16 2:4 image, 8 / 4 waves), 5 gemm_filter_g8_kernel (integer operands, 8 waves), 6 the same with persistent workgroups (A/B
+                                 builds only); 1 and 2 named the two kernels retired in version 105 and are never reported */
 } dhr_info;
 int dhr_index_get_info(const dhr_index* index, int32_t what, double* out);
 

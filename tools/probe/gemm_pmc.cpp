@@ -13,7 +13,7 @@ static inline uint32_t next() { rng = rng * 1664525u + 1013904223u; return rng >
 int main(int argc, char** argv) {
   const int64_t n = argc > 1 ? atoll(argv[1]) : 500000;
   const int q = argc > 2 ? atoi(argv[2]) : 6980;
-  const int d_dlr = argc > 3 ? atoi(argv[3]) : 768, d_cls = 768, k = d_dlr + d_cls;      // d_dlr = 0: dense-only index (gemm_filter_v3_kernel)
+  const int d_dlr = argc > 3 ? atoi(argv[3]) : 768, d_cls = 768, k = d_dlr + d_cls;      // d_dlr = 0: dense-only index
   std::vector<__half> cv((size_t)n * k), qv((size_t)q * k);
   std::vector<uint8_t> ci((size_t)n * d_dlr + 1), qi((size_t)q * d_dlr + 1);
   auto fill = [&](std::vector<__half>& v, std::vector<uint8_t>& idx, int64_t rows) {
