@@ -69,9 +69,12 @@ __host__ __device__ inline int64_t tiled_chunk_offset(int64_t row, int chunk, in
 }
 
 // Candidate keys: (order-preserving bits of the fp32 score) << 32 | (0xFFFFFFFF - local row), so a
-// plain descending u64 sort is "score desc, row asc".  0 = empty slot.
+// plain descending u64 sort is "score desc, row asc".  0 = empty slot.  -0.0 takes +0.0's pattern: the two compare equal as floats
+// (torch.topk, Python's sorted), so they must tie here too and fall to "row asc" (the shard reduces take any caller's scores; found by
+// tools/stress_modes.py in round 6 -- until then +0.0 sorted before -0.0); a key decodes to +0.0.
 __host__ __device__ inline uint32_t f32_ordered(float f) {
   union { float f; uint32_t u; } v; v.f = f;
+  if ((v.u << 1) == 0u) return 0x80000000u;
   return (v.u & 0x80000000u) ? ~v.u : (v.u | 0x80000000u);
 }
 __host__ __device__ inline float ordered_f32(uint32_t o) {

@@ -482,7 +482,7 @@ def sharded_search_host(shard, q_value, q_index, k: int, group=None):
 def _ordered_u32(scores):
     """fp32 tensor -> int64 tensor of order-preserving 32-bit patterns (dhr_internal.h f32_ordered)."""
     import torch
-    b = scores.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    b = (scores.contiguous() + 0.0).view(torch.int32).to(torch.int64) & 0xFFFFFFFF       # (+ 0.0: -0.0 ties with +0.0, as in the library)
     return torch.where((b >> 31) != 0, (~b) & 0xFFFFFFFF, b | 0x80000000)
 
 

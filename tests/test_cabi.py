@@ -87,6 +87,32 @@ def test_host_merge_matches_oracle():
         assert np.all(hr2[i, valid[i]:] == -1) and np.all(np.isneginf(hs2[i, valid[i]:]))
 
 
+def test_host_merge_signed_zero_ties():
+    """-0.0 and +0.0 are ONE score (they compare equal in torch.topk and in Python's sorted, merge.result.py:36): the reduces must tie them
+    and fall to "row asc" -- until round 6 the order-preserving key put every +0.0 before every -0.0 (found by tools/stress_modes.py)."""
+    from dhr_amd import _lib
+    from oracle import gip_oracle as O
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    q, n_in, k = 5, 64, 48
+    s = np.where(rng.random((q, n_in)) < 0.5, np.float32(0.0), np.float32(-0.0)).astype(np.float32)
+    s[:, :8] = np.float32(1.5)
+    s[:, 8:12] = np.float32(-2.0)
+    r = np.stack([rng.permutation(1000)[:n_in] for _ in range(q)]).astype(np.int64)
+    es, er = O.merge_topk([s], [r], k)
+    hs, hr = np.empty((q, k), np.float32), np.empty((q, k), np.int64)
+    assert lib.dhr_merge_topk_host(q, n_in, s.ctypes.data, r.ctypes.data, k, hs.ctypes.data, hr.ctypes.data) == 0
+    np.testing.assert_array_equal(hr, er)
+    np.testing.assert_array_equal(hs, es)
+    # the same entries as 4 sorted lists of 16
+    order = np.stack([np.concatenate([c * 16 + np.lexsort((r[i, c * 16:(c + 1) * 16], -s[i, c * 16:(c + 1) * 16].astype(np.float64))) for c in range(4)]) for i in range(q)])
+    sl = np.ascontiguousarray(np.take_along_axis(s, order, 1).reshape(q, 4, 16).transpose(1, 0, 2))
+    rl = np.ascontiguousarray(np.take_along_axis(r, order, 1).reshape(q, 4, 16).transpose(1, 0, 2))
+    assert lib.dhr_merge_topk_lists_host(q, 4, 16, sl.ctypes.data, rl.ctypes.data, k, hs.ctypes.data, hr.ctypes.data) == 0
+    np.testing.assert_array_equal(hr, er)
+    np.testing.assert_array_equal(hs, es)
+
+
 def test_host_merge_lists_matches_oracle():
     from dhr_amd import _lib
     from oracle import gip_oracle as O

@@ -1573,6 +1573,35 @@ def test_random_controller_configurations(G, monkeypatch):
     stress_sampled.main()
 
 
+@pytest.mark.parametrize("n_lists,ll", [(4, 16), (8, 448), (3, 7000)])
+def test_device_merge_signed_zero_ties(G, n_lists, ll):
+    """-0.0 ties with +0.0 in the shard reduces on the device (LDS merge of sorted lists, LDS bitonic reduce, the global-memory reduce beyond
+    16 384 entries): "score desc, row asc" as floats compare, equal to the oracle and to the host twins."""
+    import torch
+    from dhr_amd import dist as D
+    rng = np.random.default_rng(n_lists * 1000 + ll)
+    q, k = 6, min(1000, n_lists * ll)
+    sc = np.where(rng.random((n_lists, q, ll)) < 0.5, np.float32(0.0), np.float32(-0.0)).astype(np.float32)
+    sc[:, :, : ll // 4] = np.round(rng.standard_normal((n_lists, q, ll // 4)), 1).astype(np.float32) + np.float32(3.0)
+    rows = np.stack([rng.permutation(n_lists * ll)[:ll] for _ in range(n_lists * q)]).reshape(n_lists, q, ll).astype(np.int64)
+    for l in range(n_lists):
+        rows[l] += l * 10_000_000
+        for i in range(q):
+            o = np.lexsort((rows[l, i], -sc[l, i].astype(np.float64)))
+            sc[l, i], rows[l, i] = sc[l, i][o], rows[l, i][o]
+    es, er = O.merge_topk(list(sc), list(rows), k)
+    for dev in ("cuda", "cpu"):
+        ts, tr = torch.from_numpy(sc).to(dev), torch.from_numpy(rows).to(dev)
+        ms, mr = D.merge_sorted_lists(ts, tr, k)
+        np.testing.assert_array_equal(mr.cpu().numpy(), er)
+        np.testing.assert_array_equal(ms.cpu().numpy(), es)
+        perm = torch.from_numpy(rng.permutation(n_lists * ll)).to(dev)
+        cs, cr = ts.permute(1, 0, 2).reshape(q, -1)[:, perm].contiguous(), tr.permute(1, 0, 2).reshape(q, -1)[:, perm].contiguous()
+        ms, mr = D.merge_topk(cs, cr, k)
+        np.testing.assert_array_equal(mr.cpu().numpy(), er)
+        np.testing.assert_array_equal(ms.cpu().numpy(), es)
+
+
 def test_random_mode_configurations(G, monkeypatch):
     """A slice of tools/stress_modes.py: the entry points beside the plain search (two-stage modes on the device, dhr_score_rows, the
     index file round trip, the one-process sharded search over ragged shards, the shard reduces on the device and on the host) on

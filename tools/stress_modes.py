@@ -4,7 +4,8 @@
 (dhr_index_save / dhr_index_load), the sharded search in one process (dhr_search_sharded_local over 1 ... 5 row shards of ragged
 sizes) and the shard reduces (dhr_merge_topk, dhr_merge_topk_lists, device and host twins) -- random shapes, dtypes, value signs,
 bucket counts, k1 / k, both images of the gated half -- against the oracle's float64 scores and its parity rules.  Prints the
-failing configuration and exits non-zero on the first mismatch.  usage: python tools/stress_modes.py [n_cases] [seed]"""
+failing configuration and exits non-zero on the first mismatch.  usage: python tools/stress_modes.py [n_cases] [seed] [only_case]
+(only_case: replay -- every other case only draws its random numbers; without a GPU a replayed `merge` case runs the host twins alone)"""
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -13,6 +14,7 @@ import numpy as np
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
     import torch
     from dhr_amd import _lib, dist as D
     from dhr_amd.retrieval import gip_retrieval as G
@@ -39,6 +41,7 @@ def main():
         cfg = dict(case=case, what=what, n=n, q=q, d_dlr=d_dlr, d_cls=d_cls, k1=k1, k=k, idx=np.dtype(idx_dtype).name, n_idx=n_idx,
                    neg=neg, q32=q32, nb=nb, gated_i8=g8, theta=theta)
         K = d_dlr + d_cls
+        live = only < 0 or case == only
 
         def vals(m):
             v = np.abs(rng.standard_normal((m, K))) * 0.5
@@ -69,14 +72,19 @@ def main():
                         o = np.lexsort((rows[l, i], -sc[l, i].astype(np.float64)))
                         sc[l, i], rows[l, i] = sc[l, i][o], rows[l, i][o]
                         sc[l, i, fill[i]:], rows[l, i, fill[i]:] = -np.inf, -1
+                cfg.update(n_lists=n_lists, list_len=ll, k_out=kk)
                 es, er = O.merge_topk([sc[l] for l in range(n_lists)], [rows[l] for l in range(n_lists)], kk)
                 for dev in ("cuda", "cpu"):
+                    perm_np = rng.permutation(n_lists * ll)
+                    if not live or (dev == "cuda" and not torch.cuda.is_available()):
+                        continue
+                    cfg["device"] = dev
                     ts, tr = torch.from_numpy(sc).to(dev), torch.from_numpy(rows).to(dev)
                     ms, mr = D.merge_sorted_lists(ts, tr, kk)
                     np.testing.assert_array_equal(mr.cpu().numpy(), er)
                     np.testing.assert_array_equal(ms.cpu().numpy(), es)
                     cs, cr = ts.permute(1, 0, 2).reshape(q, -1), tr.permute(1, 0, 2).reshape(q, -1)
-                    perm = torch.from_numpy(rng.permutation(cs.shape[1])).to(dev)
+                    perm = torch.from_numpy(perm_np).to(dev)
                     ms, mr = D.merge_topk(cs[:, perm].contiguous(), cr[:, perm].contiguous(), kk)
                     np.testing.assert_array_equal(mr.cpu().numpy(), er)
                     np.testing.assert_array_equal(ms.cpu().numpy(), es)
@@ -86,6 +94,8 @@ def main():
                 n_sh = int(rng.integers(1, 6))
                 cuts = np.sort(rng.choice(np.arange(1, n), n_sh - 1, replace=False)) if n_sh > 1 else np.zeros(0, np.int64)
                 bounds = [0] + [int(c) for c in cuts] + [n]
+                if not live:
+                    continue
                 shards = [G.GipIndex(cv[a:b], ci[a:b], row_offset=a, idx_buckets=nb) for a, b in zip(bounds[:-1], bounds[1:])]
                 try:
                     kk = k1
@@ -100,6 +110,11 @@ def main():
                         sh.close()
                 cfg["bounds"] = bounds
             else:
+                if what == "score_rows":
+                    m = int(rng.choice([1, 3, 100, 1000, 5000]))
+                    rows = rng.integers(0, n, (q, m)).astype(np.int64)          # duplicates allowed
+                if not live:
+                    continue
                 ix = G.GipIndex(cv, ci, idx_buckets=nb)
                 try:
                     if what in ("theta", "ip"):
@@ -112,8 +127,6 @@ def main():
                             s1 = O.stage1_scores_f64(qv[i], qi[i], c32, ci, theta, what == "ip")
                             O.check_two_stage(r[i], s[i], s1, exact(i), k1, k)
                     elif what == "score_rows":
-                        m = int(rng.choice([1, 3, 100, 1000, 5000]))
-                        rows = rng.integers(0, n, (q, m)).astype(np.int64)          # duplicates allowed
                         got = ix.score_rows(qv, qi, rows)
                         for i in range(q):
                             ex = exact(i)
@@ -139,7 +152,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             print("FAILED", cfg, "->", repr(e)[:600])
             sys.exit(1)
-        if case % 10 == 0:
+        if live and (case % 10 == 0 or only >= 0):
             print("case %d ok (%.0f s) %s" % (case, time.time() - t0, cfg), flush=True)
     print("all %d cases ok in %.0f s" % (n_cases, time.time() - t0))
 
