@@ -24,6 +24,15 @@ from .. import _lib
 PQ_FORMAT = "dhr-pq"
 
 
+def _f16_values(values):
+    """The library reads PQ training / encoding input as fp16 rows (the index record's dtype; the C entry points take no dtype argument): anything
+    else is converted here -- fp32 that was widened from a record converts back exactly -- instead of being reinterpreted."""
+    if isinstance(values, np.ndarray):
+        return values if values.dtype == np.float16 else values.astype(np.float16)
+    import torch
+    return values if values.dtype == torch.float16 else values.half()
+
+
 def train_and_encode(values, M: int = 64, n_bits: int = 8, iters: int = 25, max_points: int = 65536, device: int = 0):
     """values: fp16 [N, d] numpy array (or a torch CUDA tensor).  -> (codebooks float32 [M, 2^n_bits, d/M], codes uint8 [N,M], mse).
     `--n_bits` as in quantize_index.py:22,29 (faiss.IndexPQ(d, M, nbits)): 1..8; codes are one byte per sub-quantiser here, the
@@ -31,6 +40,7 @@ def train_and_encode(values, M: int = 64, n_bits: int = 8, iters: int = 25, max_
     if not 1 <= int(n_bits) <= 8:
         raise ValueError("--n_bits must be in [1, 8] (faiss' IndexPQ takes up to 24 bits; codes wider than a byte are not built)")
     lib = _lib.load()
+    values = _f16_values(values)
     n, d = int(values.shape[0]), int(values.shape[1])
     ksub = 1 << int(n_bits)
     if d % M:
@@ -55,6 +65,7 @@ def encode(values, codebooks, n_bits: int = 8, device: int = 0):
     """Codes of `values` under GIVEN codebooks (dhr_pq_encode: nearest centroid per sub-quantiser): what a shard of a row-sharded
     PQ index does with the corpus-wide codebooks.  values and codebooks live in the same memory kind.  -> codes uint8 [N, M]."""
     lib = _lib.load()
+    values = _f16_values(values)
     n, d = int(values.shape[0]), int(values.shape[1])
     M = int(codebooks.shape[0])
     p, ld, kind = _lib._ptr_ld(values)
@@ -79,12 +90,14 @@ def decode(codebooks, codes, device: int = 0):
     n, d = int(codes.shape[0]), M * dsub
     if isinstance(codes, np.ndarray):
         out = np.empty((n, d), np.float16)
-        _lib.check(lib.dhr_pq_decode_nbits(device, _lib.MEM_HOST, codes.ctypes.data, n, d, M, nbits, np.ascontiguousarray(codebooks, np.float32).ctypes.data,
-                                           out.ctypes.data, d, None), "dhr_pq_decode")
+        codes = np.ascontiguousarray(codes, np.uint8)                     # (locals: the converted copies must outlive the call)
+        cb = np.ascontiguousarray(np.asarray(codebooks), np.float32)
+        _lib.check(lib.dhr_pq_decode_nbits(device, _lib.MEM_HOST, codes.ctypes.data, n, d, M, nbits, cb.ctypes.data, out.ctypes.data, d, None), "dhr_pq_decode")
         return out
     import torch
     out = torch.empty((n, d), dtype=torch.float16, device=codes.device)
-    _lib.check(lib.dhr_pq_decode_nbits(device, _lib.MEM_DEVICE, codes.data_ptr(), n, d, M, nbits, codebooks.data_ptr(), out.data_ptr(), d, None), "dhr_pq_decode")
+    codes, cb = codes.to(torch.uint8).contiguous(), codebooks.to(torch.float32).contiguous()
+    _lib.check(lib.dhr_pq_decode_nbits(device, _lib.MEM_DEVICE, codes.data_ptr(), n, d, M, nbits, cb.data_ptr(), out.data_ptr(), d, None), "dhr_pq_decode")
     return out
 
 

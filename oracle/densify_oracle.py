@@ -21,7 +21,10 @@ def densify(lexical_reps: np.ndarray, dims: int = 768, strategy: str = "stride",
         raise ValueError('Input lexical representation cannot be densified, please fix dims or remove_dims')
     batch = lexical_reps.shape[0]
     view = lexical_reps[:, remove_dims:].reshape(batch, -1, dims)                           # :20
-    return view.max(1), view.argmax(1).astype(np.int64)                                     # :21 (argmax = first maximum)
+    idx = view.argmax(1)                                                                    # :21 (argmax = first maximum)
+    # the value is the element AT that index, as torch.max(1) returns it: numpy's own max(1) picks either zero of a (-0.0, +0.0) tie,
+    # torch the first (checked against torch in the build container; found by tools/stress_modes.py in round 6)
+    return np.take_along_axis(view, idx[:, None, :], 1)[:, 0, :], idx.astype(np.int64)
 
 
 def densify_encoded(lexical_reps: np.ndarray, dims: int = 768, remove_dims: int = 570):

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Randomised differential test of the entry points BESIDE the plain search: the two-stage modes on the device
 (dhr_search_rerank: theta > 0 and --IP first stages, gip_retrieval.py:128-156), dhr_score_rows, the index file round trip
-(dhr_index_save / dhr_index_load), the sharded search in one process (dhr_search_sharded_local over 1 ... 5 row shards of ragged
+(dhr_index_save / dhr_index_load), the fused densify (dhr_densify: ties, all-zero rows, more than 256 groups), the product-quantised first stage (dhr_pq_*: ADC scores and
+search, encode / decode, the faiss IndexPQ file; random codebooks, M, sub-vector widths and code widths against oracle/pq_oracle.py), the sharded search in one process (dhr_search_sharded_local over 1 ... 5 row shards of ragged
 sizes) and the shard reduces (dhr_merge_topk, dhr_merge_topk_lists, device and host twins) -- random shapes, dtypes, value signs,
 bucket counts, k1 / k, both images of the gated half -- against the oracle's float64 scores and its parity rules.  Prints the
 failing configuration and exits non-zero on the first mismatch.  usage: python tools/stress_modes.py [n_cases] [seed] [only_case]
@@ -36,7 +37,7 @@ def main():
         nb = int(rng.choice([0, 0, 1, 2]))
         g8 = int(rng.integers(0, 2))
         theta = float(rng.choice([0.05, 0.1, 0.3, 0.6]))
-        what = str(rng.choice(["theta", "ip", "score_rows", "file", "local_shards", "merge"]))
+        what = str(rng.choice(["theta", "ip", "score_rows", "file", "local_shards", "merge", "densify", "pq"]))
         os.environ["DHR_GATED_I8"] = str(g8)
         cfg = dict(case=case, what=what, n=n, q=q, d_dlr=d_dlr, d_cls=d_cls, k1=k1, k=k, idx=np.dtype(idx_dtype).name, n_idx=n_idx,
                    neg=neg, q32=q32, nb=nb, gated_i8=g8, theta=theta)
@@ -90,6 +91,75 @@ def main():
                     np.testing.assert_array_equal(ms.cpu().numpy(), es)
                     ms, _ = D.merge_sorted_lists(ts, None, kk)
                     np.testing.assert_array_equal(ms.cpu().numpy(), es)
+            elif what == "densify":
+                from dhr_amd import densify as DZ
+                from oracle import densify_oracle as DO
+                dims = int(rng.choice([8, 64, 256, 768]))
+                groups = int(rng.choice([1, 2, 39, 257, 300]))
+                rem = int(rng.choice([0, 5, 570]))
+                batch = int(rng.integers(1, 70))
+                dt = np.float16 if rng.random() < 0.5 else np.float32
+                x = rng.standard_normal((batch, rem + groups * dims)).astype(np.float32)
+                mode = int(rng.integers(0, 4))
+                if mode == 1:
+                    x = np.round(x, 0)                     # many ties: the first maximum wins
+                elif mode == 2:
+                    x = np.maximum(x, 0) * (rng.random(x.shape) < 0.05)          # sparse, mostly exact zeros (a lexical representation)
+                elif mode == 3:
+                    x[rng.integers(0, batch)] = 0.0        # an all-zero row
+                    x = -np.abs(x)                         # ... and nothing positive elsewhere
+                x = x.astype(dt)
+                cfg.update(dims=dims, groups=groups, remove_dims=rem, batch=batch, dtype=np.dtype(dt).name, mode=mode)
+                if not live:
+                    continue
+                ev, ei = DO.densify(x, dims, "stride", rem)
+                v, i = DZ.densify(x, dims, "stride", rem)
+                assert v.dtype == x.dtype and i.dtype == np.int64
+                np.testing.assert_array_equal(i, ei)
+                np.testing.assert_array_equal(v.view(np.uint16 if dt == np.float16 else np.uint32), ev.view(np.uint16 if dt == np.float16 else np.uint32))
+                tv, ti = DZ.densify(torch.from_numpy(x).cuda(), dims, "stride", rem)
+                np.testing.assert_array_equal(ti.cpu().numpy(), ei)
+                np.testing.assert_array_equal(tv.cpu().numpy(), ev)
+            elif what == "pq":
+                from dhr_amd.retrieval import quantize_index as QI
+                from oracle import pq_oracle as PO
+                M = int(rng.choice([1, 4, 8, 16, 64]))
+                dsub = int(rng.choice([1, 2, 7, 14, 24]))
+                nbits = int(rng.choice([4, 6, 8]))
+                kp = int(min(n, rng.choice([1, 10, 500, 5000, 20000])))
+                cb = (rng.standard_normal((M, 1 << nbits, dsub)) * rng.choice([0.1, 1.0, 30.0])).astype(np.float32)
+                codes = rng.integers(0, 1 << nbits, (n, M)).astype(np.uint8)
+                if rng.random() < 0.3:
+                    codes[:, :] = codes[0]                 # every row the same score: ties down to "row asc"
+                qp = rng.standard_normal((q, M * dsub)).astype(np.float32)
+                xs = rng.standard_normal((min(n, 400), M * dsub)).astype(np.float16).astype(np.float32)      # (fp32 in: the wrapper converts back to the records' fp16)
+                cfg.update(M=M, dsub=dsub, nbits=nbits, k_pq=kp)
+                if not live:
+                    continue
+                pix = QI.PqIndex(cb, codes, nbits=nbits)
+                try:
+                    adc = PO.adc_scores(qp, codes, cb)
+                    tol = 1e-5 * max(1.0, float(np.abs(adc).max()))
+                    np.testing.assert_allclose(pix.adc_scores(qp).cpu().numpy(), adc, rtol=0, atol=tol)
+                    sp, rp = pix.search(qp, kp)
+                    for i in range(q):
+                        O.check_topk(rp[i], sp[i], adc[i], kp, atol=10 * tol)
+                finally:
+                    pix.close()
+                np.testing.assert_array_equal(QI.decode(cb, codes[:400]), PO.decode(codes[:400], cb).astype(np.float16))
+                enc, ref = QI.encode(xs, cb, nbits), PO.encode(xs, cb)
+                if (enc != ref).any():                     # a different code is admissible only where its centroid is as near (float ties)
+                    sub = xs.reshape(len(xs), M, dsub)
+                    for a, m in zip(*np.nonzero(enc != ref)):
+                        d0 = float(((sub[a, m] - cb[m, enc[a, m]]) ** 2).sum()); d1 = float(((sub[a, m] - cb[m, ref[a, m]]) ** 2).sum())
+                        assert abs(d0 - d1) <= 1e-4 * max(1.0, d1), (a, m, d0, d1)
+                path = os.path.join(tmp, "pq.idx")
+                QI.save_pq(path, cb, codes, nbits)
+                back = QI.load_pq(path)
+                os.unlink(path)
+                assert back["nbits"] == nbits
+                np.testing.assert_array_equal(back["codes"], codes)
+                np.testing.assert_array_equal(np.asarray(back["codebooks"], np.float32).reshape(cb.shape), cb)
             elif what == "local_shards":
                 n_sh = int(rng.integers(1, 6))
                 cuts = np.sort(rng.choice(np.arange(1, n), n_sh - 1, replace=False)) if n_sh > 1 else np.zeros(0, np.int64)
