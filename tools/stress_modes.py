@@ -4,7 +4,9 @@
 (dhr_index_save / dhr_index_load), the fused densify (dhr_densify: ties, all-zero rows, more than 256 groups), the product-quantised first stage (dhr_pq_*: ADC scores and
 search, encode / decode, the faiss IndexPQ file; random codebooks, M, sub-vector widths and code widths against oracle/pq_oracle.py), the sharded search in one process (dhr_search_sharded_local over 1 ... 5 row shards of ragged
 sizes) and the shard reduces (dhr_merge_topk, dhr_merge_topk_lists, device and host twins) -- random shapes, dtypes, value signs,
-bucket counts, k1 / k, both images of the gated half -- against the oracle's float64 scores and its parity rules.  Prints the
+bucket counts, k1 / k, both images of the gated half -- against the oracle's float64 scores and its parity rules; and the command line
+itself (gip_retrieval.main on random pickles: --lamda, --total_shrad / --shrad, --theta / --IP / --rerank / --brute_force, a query whose own
+document is in the corpus, dense-only files) with every line of the run file checked.  Prints the
 failing configuration and exits non-zero on the first mismatch.  usage: python tools/stress_modes.py [n_cases] [seed] [only_case]
 (only_case: replay -- every other case only draws its random numbers; without a GPU a replayed `merge` case runs the host twins alone)"""
 import os, sys, tempfile, time
@@ -37,7 +39,7 @@ def main():
         nb = int(rng.choice([0, 0, 1, 2]))
         g8 = int(rng.integers(0, 2))
         theta = float(rng.choice([0.05, 0.1, 0.3, 0.6]))
-        what = str(rng.choice(["theta", "ip", "score_rows", "file", "local_shards", "merge", "densify", "pq"]))
+        what = str(rng.choice(["theta", "ip", "score_rows", "file", "local_shards", "merge", "densify", "pq", "cli"]))
         os.environ["DHR_GATED_I8"] = str(g8)
         cfg = dict(case=case, what=what, n=n, q=q, d_dlr=d_dlr, d_cls=d_cls, k1=k1, k=k, idx=np.dtype(idx_dtype).name, n_idx=n_idx,
                    neg=neg, q32=q32, nb=nb, gated_i8=g8, theta=theta)
@@ -120,6 +122,78 @@ def main():
                 tv, ti = DZ.densify(torch.from_numpy(x).cuda(), dims, "stride", rem)
                 np.testing.assert_array_equal(ti.cpu().numpy(), ei)
                 np.testing.assert_array_equal(tv.cpu().numpy(), ev)
+            elif what == "cli":
+                import pickle
+                dense_only = bool(rng.random() < 0.25)
+                lamda = float(rng.choice([1.0, 0.3, 2.5]))
+                total = int(rng.choice([1, 1, 2, 3]))
+                shrad = int(rng.integers(0, total))
+                mode = str(rng.choice(["brute", "theta", "theta_rerank", "ip", "ip_rerank"]))
+                lo_r, hi_r = O.shard_rows(n, total, shrad)
+                n_sh = hi_r - lo_r
+                topk = int(min(n_sh, rng.choice([1, 10, 100, 1000])))
+                agip = int(min(n_sh, max(topk, rng.choice([10, 100, 1000, 5000]))))
+                self_row = int(rng.integers(0, n))
+                cfg.update(dense_only=dense_only, lamda=lamda, total_shrad=total, shrad=shrad, mode=mode, topk=topk, agip_topk=agip, self_row=self_row)
+                if not live:
+                    continue
+                docids = ["d%d" % j for j in range(n)]
+                qids = ["q%d" % j for j in range(q)]
+                qids[0] = docids[self_row]                 # a query whose own document is in the corpus: its line is skipped, the rank numbers keep the gap
+                qpath, cpath, opath = (os.path.join(tmp, f) for f in ("q.pt", "c.pt", "out.trec"))
+                qv16 = qv.astype(np.float16)
+                if dense_only:
+                    if d_cls == 0:
+                        continue
+                    with open(qpath, "wb") as f:
+                        pickle.dump([qv16[:, d_dlr:], None, qids], f, protocol=4)
+                    with open(cpath, "wb") as f:
+                        pickle.dump([cv[:, d_dlr:], 0, docids], f, protocol=4)     # a merged dense index stores the int 0 as its index array (index.py:40-43)
+                else:
+                    with open(qpath, "wb") as f:
+                        pickle.dump([qv16, qi, qids], f, protocol=4)
+                    with open(cpath, "wb") as f:
+                        pickle.dump([cv, ci, docids], f, protocol=4)
+                argv = ["--query_emb_path", qpath, "--index_path", cpath, "--emb_dim", str(0 if dense_only else d_dlr), "--topk", str(topk), "--agip_topk", str(agip),
+                        "--lamda", str(lamda), "--total_shrad", str(total), "--shrad", str(shrad), "--output", opath, "--theta", str(theta)]
+                argv += {"brute": ["--brute_force"], "theta": [], "theta_rerank": ["--rerank"], "ip": ["--IP"], "ip_rerank": ["--IP", "--rerank"]}[mode]
+                G.main(argv)
+                got = {}
+                for line in open(opath).read().splitlines():
+                    qid, q0, did, rank, sc_txt, run = line.split(" ")
+                    assert q0 == "Q0" and run == "h2oloo"
+                    got.setdefault(qid, []).append((int(did[1:]) - lo_r, int(rank), float(sc_txt)))
+                qf, qif = O.prepare_queries(qv16[:, d_dlr:] if dense_only else qv16, None if dense_only else qi, 0 if dense_only else d_dlr, lamda)
+                cs = cv[lo_r:hi_r, d_dlr:].astype(np.float32) if dense_only else c32[lo_r:hi_r]
+                cis = None if dense_only else ci[lo_r:hi_r]
+                for i, qid in enumerate(qids):
+                    ex = O.gip_scores_f64(qf[i], None if dense_only else qif[i], cs, cis)
+                    two_stage = (not dense_only) and mode != "brute"
+                    s1 = O.stage1_scores_f64(qf[i], qif[i], cs, cis, theta, mode.startswith("ip")) if two_stage else ex
+                    rerank = two_stage and mode.endswith("rerank")
+                    k_out = min(topk, agip) if rerank else topk          # (no --rerank: the stage-1 list itself, topk long)
+                    lst = got.get(qid, [])
+                    rows_l = [-1] * k_out
+                    sc_l = [0.0] * k_out
+                    for row, rank, scv in lst:
+                        assert 1 <= rank <= k_out and rows_l[rank - 1] == -1, ("rank", rank)
+                        rows_l[rank - 1], sc_l[rank - 1] = row, scv
+                    holes = [j for j in range(k_out) if rows_l[j] == -1]
+                    if holes:                              # only the query's own document may be missing, at one rank
+                        assert i == 0 and len(holes) == 1 and lo_r <= self_row < hi_r, ("holes", holes)
+                        rows_l[holes[0]] = self_row - lo_r
+                        sc_l[holes[0]] = float(np.float32((ex if (rerank or not two_stage) else s1)[self_row - lo_r]))
+                    elif i == 0 and lo_r <= self_row < hi_r:
+                        assert (self_row - lo_r) not in rows_l
+                    assert all(0 <= r_ < n_sh for r_ in rows_l)
+                    sc_a = np.asarray(sc_l, np.float32)
+                    assert np.array_equal(sc_a.astype(np.float64), np.asarray(sc_l)), "a score in the file is not an fp32 value"
+                    if rerank:
+                        O.check_two_stage(rows_l, sc_a, s1, ex, agip, topk)
+                    else:
+                        O.check_topk(rows_l, sc_a, s1, k_out)
+                for f_ in (qpath, cpath, opath):
+                    os.unlink(f_)
             elif what == "pq":
                 from dhr_amd.retrieval import quantize_index as QI
                 from oracle import pq_oracle as PO
