@@ -1602,6 +1602,67 @@ def test_device_merge_signed_zero_ties(G, n_lists, ll):
         np.testing.assert_array_equal(ms.cpu().numpy(), es)
 
 
+def test_distinct_handles_from_concurrent_host_threads(G):
+    """dhr_hip.h: "one handle is used by one host thread at a time; distinct handles may be used concurrently".  Four host threads, each with
+    its own index (different shapes: gated int8 / fp16 images, dense-only, BM25-like int16), its own stream and 12 searches + a two-stage search
+    + a shard reduce in flight at the same time (ctypes drops the GIL over every call): every result equals the same thread's serial result bit
+    for bit, the per-thread error record stays the thread's own."""
+    import threading
+    import torch
+    from dhr_amd import _lib, synth, dist as D
+    specs = [(31, 30000, 24, 768, 128, "hybrid"), (32, 9000, 9, 0, 768, "dense"), (33, 12000, 17, 768, 0, "bm25"), (34, 5000, 33, 128, 64, "hybrid")]
+    data = [synth.make_pair(seed, n, q, dd, dc, kind=kind) if kind != "hybrid" else synth.make_pair(seed, n, q, dd, dc) for seed, n, q, dd, dc, kind in specs]
+
+    def work(t, out, streams):
+        cv, ci, qv, qi = data[t]
+        q32 = qv.astype(np.float32)
+        ix = G.GipIndex(cv, ci)
+        try:
+            res = []
+            st = streams[t].cuda_stream if streams else 0
+            for it in range(12):
+                k = [1, 10, 100, 1000][it % 4]
+                res.append(ix.search(q32, qi, k, stream=st))
+            if ci is not None:
+                res.append(ix.search_rerank(np.where(q32 > 0.3, q32, np.float32(0)), qi, q32, qi, 2000, 100, stream=st))
+            s, r = res[3]
+            res.append(tuple(x.numpy() for x in D.merge_topk(torch.from_numpy(s), torch.from_numpy(r), 50)))
+            # an error on this thread: the record is this thread's own
+            with pytest.raises(_lib.DhrError) as ei:
+                ix.search(q32[:, :-1].copy() if q32.shape[1] > 1 else q32, qi, 10, stream=st)
+            res.append(str(ei.value))
+            out[t] = res
+        finally:
+            ix.close()
+
+    serial, conc = [None] * 4, [None] * 4
+    for t in range(4):
+        work(t, serial, None)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    errs = []
+
+    def guarded(t):
+        try:
+            work(t, conc, streams)
+        except BaseException as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+    for rep in range(3):
+        th = [threading.Thread(target=guarded, args=(t,)) for t in range(4)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errs, errs
+        for t in range(4):
+            assert len(conc[t]) == len(serial[t])
+            for a_, b_ in zip(conc[t], serial[t]):
+                if isinstance(a_, str):
+                    assert a_ == b_
+                else:
+                    np.testing.assert_array_equal(a_[0], b_[0])
+                    np.testing.assert_array_equal(a_[1], b_[1])
+
+
 def test_random_mode_configurations(G, monkeypatch):
     """A slice of tools/stress_modes.py: the entry points beside the plain search (two-stage modes on the device, dhr_score_rows, the
     index file round trip, the one-process sharded search over ragged shards, the shard reduces on the device and on the host) on
