@@ -1663,6 +1663,69 @@ def test_distinct_handles_from_concurrent_host_threads(G):
                     np.testing.assert_array_equal(a_[1], b_[1])
 
 
+def test_no_device_memory_left_behind(G, tmp_path):
+    """Every handle returns its device memory: cycles of index build / searches of growing batches / two-stage / score_rows / file round trip /
+    one-process sharded search / PQ scan / failing calls (bad arguments, an injected host allocation failure half-way through a search), then
+    destroy -- the free device memory after five more cycles is what it was after the first."""
+    import torch
+    from dhr_amd import _lib, synth, dist as D
+    from dhr_amd.retrieval import quantize_index as QI
+    lib = _lib.load()
+    cv, ci, qv, qi = synth.make_pair(77, 40000, 40, 768, 128)
+    q32 = qv.astype(np.float32)
+    rng = np.random.default_rng(0)
+    cb = rng.standard_normal((64, 256, 14)).astype(np.float32)
+    codes = rng.integers(0, 256, (40000, 64)).astype(np.uint8)
+
+    def cycle():
+        ix = G.GipIndex(cv, ci)
+        try:
+            for nq, k in ((3, 10), (40, 1000), (17, 20000)):
+                ix.search(q32[:nq], qi[:nq], k)
+            s, r = ix.search_rerank(np.where(q32 > 0.3, q32, np.float32(0)), qi, q32, qi, 5000, 100)
+            ix.score_rows(q32, qi, r)
+            ix.save(str(tmp_path / "ix.dhr"))
+            with pytest.raises(_lib.DhrError):
+                ix.search(q32[:, :-8].copy(), qi, 10)
+            a0 = lib.dhr_debug_fail_alloc(0)
+            ix.search(q32, qi, 100)
+            n_alloc = lib.dhr_debug_fail_alloc(0) - a0             # host allocations of one search on the warm handle
+            assert n_alloc >= 1
+            lib.dhr_debug_fail_alloc(n_alloc // 2 + 1)         # ... one of them fails half-way through the next search
+            try:
+                with pytest.raises(_lib.DhrError):
+                    ix.search(q32, qi, 100)
+            finally:
+                lib.dhr_debug_fail_alloc(0)
+            ix.search(q32, qi, 100)
+        finally:
+            ix.close()
+        ix2, _ = G.GipIndex.load(str(tmp_path / "ix.dhr"))
+        ix2.search(q32, qi, 10)
+        ix2.close()
+        shards = [G.GipIndex(cv[a:b], ci[a:b], row_offset=a) for a, b in ((0, 9000), (9000, 30000), (30000, 40000))]
+        try:
+            D.search_sharded_local(shards, q32, qi, 1000)
+        finally:
+            for sh in shards:
+                sh.close()
+        pix = QI.PqIndex(cb, codes)
+        try:
+            pix.search(q32, 3000)
+        finally:
+            pix.close()
+        torch.cuda.synchronize()
+
+    cycle()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(5):
+        cycle()
+    torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free1 >= free0 - (32 << 20), "device memory left behind: %.1f MB over five cycles" % ((free0 - free1) / 1e6)
+
+
 def test_random_mode_configurations(G, monkeypatch):
     """A slice of tools/stress_modes.py: the entry points beside the plain search (two-stage modes on the device, dhr_score_rows, the
     index file round trip, the one-process sharded search over ragged shards, the shard reduces on the device and on the host) on
