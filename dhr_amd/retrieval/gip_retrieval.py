@@ -58,7 +58,13 @@ class GipIndex:
         self.n_rows, self.k, self.d_dlr, self.device, self.row_offset = n, k, d_dlr, device, row_offset
 
     def _qb(self, q_value, q_index):
-        """Query batch for the library (the caller's own record width; the library pads where --emb_dim is not a multiple of 8)."""
+        """Query batch for the library (the caller's own record width; the library pads where --emb_dim is not a multiple of 8).
+        The C struct carries leading dimensions, not widths: a batch of another width than the index is refused here (the reference's einsum
+        raises on it, gip_retrieval.py:121), instead of being read as the first K columns of wider rows."""
+        if len(q_value.shape) != 2 or int(q_value.shape[1]) != self.k:
+            raise ValueError(f"query batch of shape {tuple(q_value.shape)} against an index of width {self.k}")
+        if q_index is not None and (len(q_index.shape) != 2 or int(q_index.shape[1]) != self.d_dlr or int(q_index.shape[0]) != int(q_value.shape[0])):
+            raise ValueError(f"query index array of shape {tuple(q_index.shape)} against {int(q_value.shape[0])} queries and an index array of width {self.d_dlr}")
         return _lib.make_query_batch(q_value, q_index)
 
     # ---- device-ready index file (dhr_index_save / dhr_index_load; SURVEY section 8f row 2)

@@ -1629,7 +1629,7 @@ def test_distinct_handles_from_concurrent_host_threads(G):
             res.append(tuple(x.numpy() for x in D.merge_topk(torch.from_numpy(s), torch.from_numpy(r), 50)))
             # an error on this thread: the record is this thread's own
             with pytest.raises(_lib.DhrError) as ei:
-                ix.search(q32[:, :-1].copy() if q32.shape[1] > 1 else q32, qi, 10, stream=st)
+                ix.search(q32, qi, 0, stream=st)               # k = 0: refused by the library
             res.append(str(ei.value))
             out[t] = res
         finally:
@@ -1686,7 +1686,9 @@ def test_no_device_memory_left_behind(G, tmp_path):
             ix.score_rows(q32, qi, r)
             ix.save(str(tmp_path / "ix.dhr"))
             with pytest.raises(_lib.DhrError):
-                ix.search(q32[:, :-8].copy(), qi, 10)
+                ix.search(q32, qi, 0)                               # refused by the library
+            with pytest.raises(ValueError):
+                ix.search(q32[:, :-8].copy(), qi, 10)              # refused by the mirror: a batch of another width
             a0 = lib.dhr_debug_fail_alloc(0)
             ix.search(q32, qi, 100)
             n_alloc = lib.dhr_debug_fail_alloc(0) - a0             # host allocations of one search on the warm handle

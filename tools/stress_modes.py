@@ -39,7 +39,7 @@ def main():
         nb = int(rng.choice([0, 0, 1, 2]))
         g8 = int(rng.integers(0, 2))
         theta = float(rng.choice([0.05, 0.1, 0.3, 0.6]))
-        what = str(rng.choice(["theta", "ip", "score_rows", "file", "local_shards", "merge", "densify", "pq", "cli"]))
+        what = str(rng.choice(["theta", "ip", "score_rows", "file", "local_shards", "merge", "densify", "pq", "cli", "strided"]))
         os.environ["DHR_GATED_I8"] = str(g8)
         cfg = dict(case=case, what=what, n=n, q=q, d_dlr=d_dlr, d_cls=d_cls, k1=k1, k=k, idx=np.dtype(idx_dtype).name, n_idx=n_idx,
                    neg=neg, q32=q32, nb=nb, gated_i8=g8, theta=theta)
@@ -194,6 +194,39 @@ def main():
                         O.check_topk(rows_l, sc_a, s1, k_out)
                 for f_ in (qpath, cpath, opath):
                     os.unlink(f_)
+            elif what == "strided":
+                # the C structs carry leading dimensions: rows of wider host arrays / device tensors (column slices), fp16 and fp32 query batches,
+                # against the same search on contiguous copies -- bit-equal
+                padc, padq, padi = int(rng.choice([0, 8, 13])), int(rng.choice([0, 3, 64])), int(rng.choice([0, 1, 5]))
+                kk = int(min(n, rng.choice([1, 10, 100, 1000])))
+                on_dev = bool(rng.random() < 0.5)
+                cfg.update(pad_corpus=padc, pad_query=padq, pad_index=padi, on_device=on_dev, k_search=kk)
+                if not live:
+                    continue
+                def wide(a, pad, fill):
+                    big = np.full((a.shape[0], a.shape[1] + pad), fill, a.dtype)
+                    big[:, :a.shape[1]] = a
+                    return big
+                qsrc = qv if q32 else qv.astype(np.float16)
+                bc, bci, bq, bqi = wide(cv, padc, 7), wide(ci, padi, 1), wide(qsrc, padq, 9), wide(qi, padi, 1)
+                if on_dev:
+                    bc, bci, bq, bqi = (torch.from_numpy(x).cuda() for x in (bc, bci, bq, bqi))
+                vc, vci, vq, vqi = bc[:, :K], bci[:, :d_dlr], bq[:, :K], bqi[:, :d_dlr]
+                ix = G.GipIndex(cv, ci, idx_buckets=nb)
+                try:
+                    s0, r0 = ix.search(qsrc, qi, kk)
+                finally:
+                    ix.close()
+                ix = G.GipIndex(vc, vci, idx_buckets=nb)
+                try:
+                    s1, r1 = ix.search(vq, vqi, kk)
+                    s2, r2 = ix.search_rerank(vq, vqi, vq, vqi, kk, kk)      # stage 1 = the full batch: the same lists again
+                finally:
+                    ix.close()
+                for a_, b_ in ((r1, r0), (s1, s0), (r2, r0), (s2, s0)):
+                    np.testing.assert_array_equal(np.asarray(a_), b_)
+                for i in range(q):
+                    O.check_topk(r0[i], s0[i], O.gip_scores_f64(qsrc[i].astype(np.float32), qi[i], c32, ci), kk)
             elif what == "pq":
                 from dhr_amd.retrieval import quantize_index as QI
                 from oracle import pq_oracle as PO
