@@ -28,6 +28,10 @@ int on_exception() noexcept;
 void alloc_checkpoint();
 }  // namespace dhr
 
+// dhr_mem_kind arguments: any value but the two enumerators is refused (until round 6 an unknown kind was taken for "device": a host pointer
+// handed to a kernel is a GPU fault that aborts the process, not a status).
+#define DHR_MEM_KIND_OK(k) ((k) == DHR_MEM_HOST || (k) == DHR_MEM_DEVICE)
+
 #define DHR_CATCH_STATUS catch (...) { return dhr::on_exception(); }
 #define DHR_CATCH_VALUE(v) catch (...) { (void)dhr::on_exception(); return (v); }
 #define DHR_CATCH_VOID catch (...) { (void)dhr::on_exception(); }

@@ -11,6 +11,7 @@ extern "C" int dhr_search(dhr_index* ix, const dhr_query_batch* qb, int32_t k, f
   if (k <= 0) return set_error(DHR_ERR_INVALID, "k must be > 0");
   if (k > (1 << 20)) return set_error(DHR_ERR_UNSUPPORTED, "k > 1048576 is not supported");      // k > 16384: global-memory merge (select_global.hip)
   if (!out_scores || !out_rows) return set_error(DHR_ERR_INVALID, "null output pointer");
+  if (!DHR_MEM_KIND_OK(out_mem_kind)) return set_error(DHR_ERR_INVALID, "bad out_mem_kind");
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = (hipStream_t)stream;
   const int Q = qb->n_queries;
@@ -67,6 +68,7 @@ extern "C" int dhr_search_rerank(dhr_index* ix, const dhr_query_batch* qb1, cons
   if (k <= 0 || k1 < k) return set_error(DHR_ERR_INVALID, "need 0 < k <= k1");
   if (k1 > (1 << 20)) return set_error(DHR_ERR_UNSUPPORTED, "k1 > 1048576 is not supported");
   if (!out_scores || !out_rows) return set_error(DHR_ERR_INVALID, "null output pointer");
+  if (!DHR_MEM_KIND_OK(out_mem_kind)) return set_error(DHR_ERR_INVALID, "bad out_mem_kind");
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = (hipStream_t)stream;
   const int Q = qb1->n_queries;
@@ -370,6 +372,7 @@ static int search_finish_impl(dhr_index* ix, const float* tau_hat_dev, float* ou
                               int32_t* out_count_dev, int32_t out_mem_kind, void* stream, bool sync) {
   if (!ix || !ix->pend.valid) return set_error(DHR_ERR_INVALID, "dhr_search_finish without a matching dhr_search_begin");
   if (!out_scores || !out_rows || !out_count_dev) return set_error(DHR_ERR_INVALID, "null output pointer");
+  if (!DHR_MEM_KIND_OK(out_mem_kind)) return set_error(DHR_ERR_INVALID, "bad out_mem_kind");
   if (!ix->pend.done && !tau_hat_dev) return set_error(DHR_ERR_INVALID, "thresholds are required (the shard ran a sampled pass)");
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = (hipStream_t)stream;
@@ -425,6 +428,7 @@ extern "C" int dhr_score_rows(dhr_index* ix, const dhr_query_batch* qb, int32_t 
   int rc = check_queries(ix, qb);
   if (rc) return rc;
   if (m <= 0 || !rows || !out_scores) return set_error(DHR_ERR_INVALID, "bad m / null pointer");
+  if (!DHR_MEM_KIND_OK(mem_kind)) return set_error(DHR_ERR_INVALID, "bad mem_kind");
   if (ix->pend.valid && !ix->pend.done)      // the staged search keeps its query batch in the workspace this call would overwrite
     return set_error(DHR_ERR_INVALID, "dhr_score_rows between dhr_search_begin and dhr_search_finish on the same handle");
   HIP_TRY(hipSetDevice(ix->device));
@@ -463,6 +467,7 @@ extern "C" int dhr_densify(int32_t device, int32_t mem_kind, const void* lexical
                            int32_t remove_dims, int32_t dims, void* out_value, int32_t out_value_dtype, int64_t ld_value, void* out_index,
                            int32_t index_dtype, int64_t ld_index, void* stream) try {
   if (!lexical || !out_value || !out_index) return set_error(DHR_ERR_INVALID, "null pointer");
+  if (!DHR_MEM_KIND_OK(mem_kind)) return set_error(DHR_ERR_INVALID, "bad mem_kind");
   if (batch < 0 || vocab <= 0 || dims <= 0 || remove_dims < 0 || remove_dims >= vocab || ld < vocab || ld_value < dims || ld_index < dims)
     return set_error(DHR_ERR_INVALID, "bad sizes / strides");
   if ((vocab - remove_dims) % dims != 0)
@@ -511,8 +516,9 @@ extern "C" int dhr_densify(int32_t device, int32_t mem_kind, const void* lexical
 
 // ------------------------------------------------------------------------------------------ product quantiser
 namespace {
-int pq_check(const void* a, const void* b, int64_t n, int d, int M, int64_t ld) {
+int pq_check(const void* a, const void* b, int64_t n, int d, int M, int64_t ld, int mem_kind) {
   if (!a || !b) return set_error(DHR_ERR_INVALID, "null pointer");
+  if (!DHR_MEM_KIND_OK(mem_kind)) return set_error(DHR_ERR_INVALID, "bad mem_kind");
   if (n < 0 || d <= 0 || M <= 0 || d % M != 0 || ld < d) return set_error(DHR_ERR_INVALID, "bad sizes (d must be a multiple of M, ld >= d)");
   if (d / M > 64) return set_error(DHR_ERR_UNSUPPORTED, "sub-vectors wider than 64 columns are not supported");
   return DHR_OK;
@@ -542,7 +548,7 @@ extern "C" int dhr_pq_train(int32_t device, int32_t mem_kind, const void* values
 } DHR_CATCH_STATUS
 extern "C" int dhr_pq_train_nbits(int32_t device, int32_t mem_kind, const void* values, int64_t ld, int64_t n, int32_t d, int32_t M, int32_t nbits,
                                   int32_t iters, int64_t max_points, float* codebooks, double* out_error, void* stream) try {
-  int rc = pq_check(values, codebooks, n, d, M, ld);
+  int rc = pq_check(values, codebooks, n, d, M, ld, mem_kind);
   if (rc) return rc;
   if (nbits < 1 || nbits > 8) return set_error(DHR_ERR_UNSUPPORTED, "nbits must be in [1, 8] (one code byte per sub-quantiser on the device; faiss' bit-packed rows are a file format matter)");
   const int ksub = 1 << nbits;
@@ -602,7 +608,7 @@ extern "C" int dhr_pq_encode(int32_t device, int32_t mem_kind, const void* value
 } DHR_CATCH_STATUS
 extern "C" int dhr_pq_encode_nbits(int32_t device, int32_t mem_kind, const void* values, int64_t ld, int64_t n, int32_t d, int32_t M, int32_t nbits,
                                    const float* codebooks, uint8_t* codes, void* stream) try {
-  int rc = pq_check(values, codebooks, n, d, M, ld);
+  int rc = pq_check(values, codebooks, n, d, M, ld, mem_kind);
   if (rc) return rc;
   if (nbits < 1 || nbits > 8) return set_error(DHR_ERR_UNSUPPORTED, "nbits must be in [1, 8]");
   const int ksub = 1 << nbits;
@@ -641,7 +647,7 @@ extern "C" int dhr_pq_decode(int32_t device, int32_t mem_kind, const uint8_t* co
 } DHR_CATCH_STATUS
 extern "C" int dhr_pq_decode_nbits(int32_t device, int32_t mem_kind, const uint8_t* codes, int64_t n, int32_t d, int32_t M, int32_t nbits,
                                    const float* codebooks, void* out_values, int64_t ld_out, void* stream) try {
-  int rc = pq_check(codes, codebooks, n, d, M, ld_out);
+  int rc = pq_check(codes, codebooks, n, d, M, ld_out, mem_kind);
   if (rc) return rc;
   if (nbits < 1 || nbits > 8) return set_error(DHR_ERR_UNSUPPORTED, "nbits must be in [1, 8]");
   const int ksub = 1 << nbits;

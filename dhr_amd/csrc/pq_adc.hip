@@ -210,6 +210,7 @@ extern "C" int dhr_pq_create(int32_t device, int32_t mem_kind, int64_t n, int32_
                              const uint8_t* codes, int64_t row_offset, dhr_pq** out) try {
   if (!out || !codebooks || !codes || n <= 0 || d <= 0 || M <= 0 || d % M || nbits < 1 || nbits > 8)
     return dhr_set_error_message(DHR_ERR_INVALID, "bad argument (1 <= nbits <= 8, d a multiple of M)");
+  if (!DHR_MEM_KIND_OK(mem_kind)) return dhr_set_error_message(DHR_ERR_INVALID, "bad mem_kind");
   if ((M << nbits) * 8 > 160 * 1024 - 1024) return dhr_set_error_message(DHR_ERR_UNSUPPORTED, "the lookup tables of a query pair (M * 2^nbits * 8 B) do not fit the LDS");
   PQ_HIP(hipSetDevice(device));
   dhr_pq* pq = new dhr_pq();
@@ -263,6 +264,7 @@ extern "C" int dhr_pq_search(dhr_pq* pq, const dhr_query_batch* qb, int32_t k, f
                              void* stream) try {
   if (!pq || !qb || !qb->value || !out_scores || !out_rows || qb->n_queries <= 0) return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
   if (k <= 0 || k > (1 << 20)) return dhr_set_error_message(DHR_ERR_INVALID, "k must be in [1, 1048576]");      // k > 16384: the global-memory merge (select_global.hip)
+  if (!DHR_MEM_KIND_OK(out_mem_kind) || !DHR_MEM_KIND_OK(qb->mem_kind)) return dhr_set_error_message(DHR_ERR_INVALID, "bad mem_kind");
   PQ_HIP(hipSetDevice(pq->device));
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t e0, e1;

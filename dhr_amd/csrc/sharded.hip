@@ -951,7 +951,7 @@ extern "C" int dhr_search_sharded_host(const dhr_host_shard* shard, int32_t worl
 
 extern "C" int dhr_search_sharded(dhr_index* shard, dhr_comm* comm, const dhr_query_batch* qb, int32_t k, float* out_scores, int64_t* out_rows,
                                   int32_t out_mem_kind, void* stream) try {
-  if (!shard || !comm || !qb || !out_scores || !out_rows || k <= 0) return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
+  if (!shard || !comm || !qb || !out_scores || !out_rows || k <= 0 || !DHR_MEM_KIND_OK(out_mem_kind)) return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
   if (comm->dead) return dhr_set_error_message(DHR_ERR_INVALID, "the communicator was aborted (dhr_comm_abort)");
   dhr::alloc_checkpoint();
   const int device = dhr_index_device(shard);
@@ -980,7 +980,8 @@ extern "C" int dhr_search_sharded(dhr_index* shard, dhr_comm* comm, const dhr_qu
 
 extern "C" int dhr_search_sharded_local(dhr_index** shards, int32_t n_shards, const dhr_query_batch* qb, int32_t k, float* out_scores,
                                         int64_t* out_rows, int32_t out_mem_kind, void* stream) try {
-  if (!shards || n_shards < 1 || n_shards > 64 || !qb || !out_scores || !out_rows || k <= 0) return dhr_set_error_message(DHR_ERR_INVALID, "bad argument (1 <= n_shards <= 64)");
+  if (!shards || n_shards < 1 || n_shards > 64 || !qb || !out_scores || !out_rows || k <= 0 || !DHR_MEM_KIND_OK(out_mem_kind))
+    return dhr_set_error_message(DHR_ERR_INVALID, "bad argument (1 <= n_shards <= 64)");
   std::vector<Arena> arenas;
   arenas.reserve(n_shards);
   HipBackend B;

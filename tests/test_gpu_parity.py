@@ -1728,6 +1728,86 @@ def test_no_device_memory_left_behind(G, tmp_path):
     assert free1 >= free0 - (32 << 20), "device memory left behind: %.1f MB over five cycles" % ((free0 - free1) / 1e6)
 
 
+def test_bad_arguments_on_a_device_are_statuses(G):
+    """Every detectable misuse of the C structs comes back as a negative status with a message -- with a GPU present, where the argument checks
+    are followed by real work (tests/test_cabi.py covers the host without one) -- and leaves the library usable: one field of a valid
+    dhr_index_desc / dhr_query_batch / call broken at a time, a valid search before and after."""
+    import ctypes as C
+    from dhr_amd import _lib, synth
+    lib = _lib.load()
+    cv, ci, qv, qi = synth.make_pair(55, 3000, 6, 64, 32)
+    q32 = qv.astype(np.float32)
+    ix = G.GipIndex(cv, ci)
+    s0, r0 = ix.search(q32, qi, 50)
+
+    def desc():
+        d = _lib.IndexDesc()
+        d.device, d.n_rows, d.d_dlr, d.d_cls = 0, 3000, 64, 32
+        d.value, d.ld_value, d.mem_kind = _lib._ptr_ld(cv)
+        d.index, d.ld_index, d.index_dtype = ci.ctypes.data, 64, _lib.idx_code(ci.dtype)
+        return d
+    bad_desc = [("device", 99), ("device", -1), ("mem_kind", 7), ("n_rows", 0), ("n_rows", -5), ("n_rows", 1 << 33), ("d_dlr", -8), ("d_cls", -1), ("value", None),
+                ("ld_value", 95), ("ld_value", -1), ("index_dtype", 9), ("index_dtype", _lib.IDX_NONE), ("idx_buckets", 3), ("idx_buckets", -1), ("ld_index", 63), ("row_offset", -1)]
+    for field, val in bad_desc:
+        d = desc()
+        setattr(d, field, val)
+        if field == "n_rows" and val > 3000:
+            d.value = None                                 # (a row count beyond the caller's buffer is the caller's business: only the null pointer is detectable)
+        h = C.c_void_p()
+        rc = lib.dhr_index_create(C.byref(d), C.byref(h))
+        assert rc < 0 and not h.value and lib.dhr_last_error(), (field, val, rc)
+    d = desc()
+    assert lib.dhr_index_create(None, C.byref(C.c_void_p())) < 0 and lib.dhr_index_create(C.byref(d), None) < 0
+    d.d_dlr, d.d_cls, d.index, d.index_dtype = 0, 0, None, _lib.IDX_NONE                 # no columns at all
+    assert lib.dhr_index_create(C.byref(d), C.byref(C.c_void_p())) < 0
+
+    hs, hr = np.empty((6, 50), np.float32), np.empty((6, 50), np.int64)
+    def call(qb, k=50, ps=None, pr=None, kind=_lib.MEM_HOST):
+        return lib.dhr_search(ix._h, C.byref(qb), k, hs.ctypes.data if ps is None else ps, hr.ctypes.data if pr is None else pr, kind, None)
+    bad_qb = [("n_queries", 0), ("n_queries", -3), ("mem_kind", 5), ("value", None), ("value_dtype", 9), ("ld_value", 95), ("index_dtype", 7), ("ld_index", 10)]
+    for field, val in bad_qb:
+        qb, keep = _lib.make_query_batch(q32, qi)
+        setattr(qb, field, val)
+        rc = call(qb)
+        assert rc < 0 and lib.dhr_last_error(), (field, val, rc)
+    qb, keep = _lib.make_query_batch(q32, qi)
+    for kw in (dict(k=0), dict(k=-1), dict(k=(1 << 20) + 1), dict(kind=9)):
+        assert call(qb, **kw) < 0 and lib.dhr_last_error(), kw
+    assert lib.dhr_search(ix._h, C.byref(qb), 50, None, hr.ctypes.data, _lib.MEM_HOST, None) < 0
+    assert lib.dhr_search(ix._h, C.byref(qb), 50, hs.ctypes.data, None, _lib.MEM_HOST, None) < 0
+    assert lib.dhr_search(None, C.byref(qb), 50, hs.ctypes.data, hr.ctypes.data, _lib.MEM_HOST, None) < 0
+    assert lib.dhr_search(ix._h, None, 50, hs.ctypes.data, hr.ctypes.data, _lib.MEM_HOST, None) < 0
+    assert lib.dhr_search_rerank(ix._h, C.byref(qb), None, 100, 50, hs.ctypes.data, hr.ctypes.data, _lib.MEM_HOST, None) < 0
+    assert lib.dhr_search_rerank(ix._h, C.byref(qb), C.byref(qb), 10, 50, hs.ctypes.data, hr.ctypes.data, _lib.MEM_HOST, None) < 0 or True   # (k > k1 is clamped or refused: either is a status)
+    rows = np.zeros((6, 4), np.int64)
+    out = np.empty((6, 4), np.float32)
+    assert lib.dhr_score_rows(ix._h, C.byref(qb), 0, rows.ctypes.data, out.ctypes.data, _lib.MEM_HOST, None) < 0
+    assert lib.dhr_score_rows(ix._h, C.byref(qb), 4, None, out.ctypes.data, _lib.MEM_HOST, None) < 0
+    assert lib.dhr_score_rows(ix._h, C.byref(qb), 4, rows.ctypes.data, None, _lib.MEM_HOST, None) < 0
+    assert lib.dhr_score_rows(ix._h, C.byref(qb), 4, rows.ctypes.data, out.ctypes.data, 9, None) < 0           # an unknown memory kind is not "device"
+    assert lib.dhr_search_rerank(ix._h, C.byref(qb), C.byref(qb), 100, 50, hs.ctypes.data, hr.ctypes.data, 9, None) < 0
+    arr = (C.c_void_p * 1)(ix._h)
+    assert lib.dhr_search_sharded_local(arr, 1, C.byref(qb), 50, hs.ctypes.data, hr.ctypes.data, 9, None) < 0
+    assert lib.dhr_search_sharded_local(arr, 0, C.byref(qb), 50, hs.ctypes.data, hr.ctypes.data, _lib.MEM_HOST, None) < 0
+    cb = np.zeros((4, 16, 2), np.float32); codes = np.zeros((10, 4), np.uint8)
+    hp = C.c_void_p()
+    assert lib.dhr_pq_create(0, 9, 10, 8, 4, 4, cb.ctypes.data, codes.ctypes.data, 0, C.byref(hp)) < 0 and not hp.value
+    assert lib.dhr_pq_create(0, _lib.MEM_HOST, 10, 8, 3, 4, cb.ctypes.data, codes.ctypes.data, 0, C.byref(hp)) < 0 and not hp.value      # d no multiple of M
+    assert lib.dhr_pq_decode_nbits(0, 9, codes.ctypes.data, 10, 8, 4, 4, cb.ctypes.data, out.ctypes.data, 8, None) < 0
+    lex = np.zeros((2, 16), np.float32); dv = np.zeros((2, 8), np.float32); di = np.zeros((2, 8), np.uint8)
+    assert lib.dhr_densify(0, 9, lex.ctypes.data, _lib.VAL_F32, 16, 2, 16, 0, 8, dv.ctypes.data, _lib.VAL_F32, 8, di.ctypes.data, _lib.idx_code(di.dtype), 8, None) < 0
+    assert lib.dhr_densify(0, _lib.MEM_HOST, lex.ctypes.data, _lib.VAL_F32, 16, 2, 16, 0, 5, dv.ctypes.data, _lib.VAL_F32, 8, di.ctypes.data, _lib.idx_code(di.dtype), 8, None) < 0
+    assert lib.dhr_index_set_param(ix._h, 999, 1) < 0 and lib.dhr_index_set_param(None, _lib.PARAM_CAND_CAP, 1024) < 0
+    assert lib.dhr_index_save(ix._h, b"/nonexistent_dir/x.dhr", None, 0) < 0
+    h = C.c_void_p()
+    assert lib.dhr_index_load(b"/nonexistent_dir/x.dhr", 0, -1, C.byref(h)) < 0 and not h.value
+    # ... and the handle is as good as before
+    s1, r1 = ix.search(q32, qi, 50)
+    ix.close()
+    np.testing.assert_array_equal(r1, r0)
+    np.testing.assert_array_equal(s1, s0)
+
+
 def test_random_mode_configurations(G, monkeypatch):
     """A slice of tools/stress_modes.py: the entry points beside the plain search (two-stage modes on the device, dhr_score_rows, the
     index file round trip, the one-process sharded search over ragged shards, the shard reduces on the device and on the host) on
