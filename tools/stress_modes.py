@@ -39,7 +39,7 @@ def main():
         nb = int(rng.choice([0, 0, 1, 2]))
         g8 = int(rng.integers(0, 2))
         theta = float(rng.choice([0.05, 0.1, 0.3, 0.6]))
-        what = str(rng.choice(["theta", "ip", "score_rows", "file", "local_shards", "merge", "densify", "pq", "cli", "strided"]))
+        what = str(rng.choice(["theta", "ip", "score_rows", "file", "local_shards", "merge", "densify", "pq", "cli", "strided", "params"]))
         os.environ["DHR_GATED_I8"] = str(g8)
         cfg = dict(case=case, what=what, n=n, q=q, d_dlr=d_dlr, d_cls=d_cls, k1=k1, k=k, idx=np.dtype(idx_dtype).name, n_idx=n_idx,
                    neg=neg, q32=q32, nb=nb, gated_i8=g8, theta=theta)
@@ -227,6 +227,47 @@ def main():
                     np.testing.assert_array_equal(np.asarray(a_), b_)
                 for i in range(q):
                     O.check_topk(r0[i], s0[i], O.gip_scores_f64(qsrc[i].astype(np.float32), qi[i], c32, ci), kk)
+            elif what == "params":
+                # every tuning parameter of a handle at random values of its WHOLE admitted range (extremes included), on a corpus large enough for the
+                # sampled controller: whatever the plan, the result is the exact top-k (values outside the range are refused: test_bad_arguments...)
+                nn = int(rng.choice([20000, 70000, 150000]))
+                dd, dc = int(rng.choice([32, 64, 128])), int(rng.choice([0, 32, 64]))
+                kk = int(rng.choice([10, 100, 1000, 3000]))
+                def pick(lo, hi, step=1):
+                    r_ = rng.random()
+                    return int(lo if r_ < 0.2 else hi if r_ < 0.4 else lo + step * rng.integers(0, (hi - lo) // step + 1))
+                prm = {_lib.PARAM_CAND_CAP: pick(1024, 1 << 20), _lib.PARAM_FIRST_ROWS: pick(0, nn + 1000), _lib.PARAM_MAX_GROWTH: pick(1, 1024),
+                       _lib.PARAM_SAMPLE_PERIOD: pick(0, 256), _lib.PARAM_MAIN_CHUNKS: pick(1, 64), _lib.PARAM_PROGRESSIVE_THR: pick(0, 2),
+                       _lib.PARAM_AUX_CUS: pick(0, 192, 8), _lib.PARAM_GEMM_EXCLUSIVE: pick(0, 1), _lib.PARAM_OVERLAP_AUX: pick(-1, 1),
+                       _lib.PARAM_SAMPLE_SHARE: pick(1, 4096), _lib.PARAM_ASYNC_CONTROLLER: pick(0, 2), _lib.PARAM_LIST_STRIDE: 0 if rng.random() < 0.4 else pick(256, 1 << 20, 256),
+                       _lib.PARAM_PROFILE: pick(0, 1)}
+                keys = [k_ for k_ in prm if rng.random() < 0.6]
+                cvp = np.abs(rng.standard_normal((nn, dd + dc), dtype=np.float32)) * 0.3
+                cvp[:, dd:] = rng.standard_normal((nn, dc), dtype=np.float32) * 0.1
+                cvp = cvp.astype(np.float16)
+                qvp = np.abs(rng.standard_normal((q, dd + dc), dtype=np.float32)) * 0.3
+                qvp[:, dd:] = rng.standard_normal((q, dc), dtype=np.float32) * 0.1
+                qvp = qvp.astype(np.float16).astype(np.float32)
+                cip = rng.integers(0, 7, (nn, dd)).astype(np.uint8)
+                qip = rng.integers(0, 7, (q, dd)).astype(np.uint8)
+                cfg.update(n=nn, d_dlr=dd, d_cls=dc, k_search=kk, params={int(k_): prm[k_] for k_ in keys})
+                if not live:
+                    continue
+                ix = G.GipIndex(cvp, cip, idx_buckets=nb)
+                try:
+                    for k_ in keys:
+                        ix.set_param(k_, prm[k_])
+                    sp, rp = ix.search(qvp, qip, kk)
+                    sp2, rp2 = ix.search(qvp, qip, kk)             # ... twice: the second call starts from the first one's workspace
+                finally:
+                    ix.close()
+                np.testing.assert_array_equal(rp2, rp)
+                np.testing.assert_array_equal(sp2, sp)
+                cp32 = cvp.astype(np.float32)
+                for i in range(q):
+                    ex = O.gip_scores_f64(qvp[i], qip[i], cp32, cip)
+                    O.check_topk(rp[i], sp[i], ex, kk)
+                    np.testing.assert_allclose(sp[i], ex[rp[i]].astype(np.float32), rtol=0, atol=1e-6 * max(1.0, np.abs(ex).max()))
             elif what == "pq":
                 from dhr_amd.retrieval import quantize_index as QI
                 from oracle import pq_oracle as PO
