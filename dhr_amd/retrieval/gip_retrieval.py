@@ -55,6 +55,7 @@ class GipIndex:
         h = C.c_void_p()
         _lib.check(lib.dhr_index_create(C.byref(desc), C.byref(h)), "dhr_index_create")
         self._h, self._lib = h, lib
+        self._pending = None
         self.n_rows, self.k, self.d_dlr, self.device, self.row_offset = n, k, d_dlr, device, row_offset
 
     def _qb(self, q_value, q_index):
@@ -92,6 +93,7 @@ class GipIndex:
         _lib.check(lib.dhr_index_load(os.fsencode(path), device, row_offset, C.byref(h)), "dhr_index_load")
         self = cls.__new__(cls)
         self._h, self._lib = h, lib
+        self._pending = None
         self.n_rows, self.k, self.d_dlr, self.device = int(info.n_rows), int(info.d_dlr + info.d_cls), int(info.d_dlr), device
         self.row_offset = int(info.row_offset) if row_offset < 0 else row_offset
         docids = None
@@ -180,6 +182,12 @@ class GipIndex:
         del keep
         return out
 
+    def _staged(self, what: str):
+        """(n_queries, k) of the staged search this handle has open (search_begin / search_pre); the later stages size their outputs by it."""
+        if getattr(self, "_pending", None) is None:
+            raise _lib.DhrError(f"{what} without a matching search_begin / search_pre on this handle", _lib.ERR_INVALID)
+        return self._pending
+
     def pre_ranks(self, k: int):
         """(local, union) ranks of the first agreement's first round (dhr_search_pre_ranks); (0, 0): this index has no pre step."""
         lo, un = C.c_int32(), C.c_int32()
@@ -201,7 +209,7 @@ class GipIndex:
     def search_begin_rest(self, tau, stream: int = 0):
         """The rest of the sampled run, filtered at the agreed thresholds tau [Q]; -> what search_begin returns (dhr_search_begin_rest)."""
         import torch
-        nq, k = self._pending
+        nq, k = self._staged("search_begin_rest")
         dev = torch.device("cuda", self.device)
         out = torch.empty((nq, self.sample_rank(k)), dtype=torch.float32, device=dev)
         tau = tau.to(device=dev, dtype=torch.float32).contiguous()
@@ -218,7 +226,7 @@ class GipIndex:
         """First slice of the main pass with the common thresholds tau_hat [Q]; -> torch cuda tensor [Q, r_local]: this shard's best
         scores seen so far (dhr_search_mid).  search_finish then takes the thresholds of the second agreement."""
         import torch
-        nq, k = self._pending
+        nq, k = self._staged("search_mid")
         dev = torch.device("cuda", self.device)
         rl = int(r_local) or self.mid_ranks(k)[0]
         out = torch.empty((nq, rl), dtype=torch.float32, device=dev)
@@ -230,7 +238,7 @@ class GipIndex:
         """tau_hat: torch cuda tensor [Q] (or None after a non-sampled begin).  -> (scores [Q,k], rows [Q,k],
         count [Q] int32 rows reaching tau_hat, -1 = list overflow), all torch cuda tensors."""
         import torch
-        nq, k = self._pending
+        nq, k = self._staged("search_finish")
         dev = torch.device("cuda", self.device)
         scores = torch.empty((nq, k), dtype=torch.float32, device=dev)
         rows = torch.empty((nq, k), dtype=torch.int64, device=dev)

@@ -117,7 +117,10 @@ typedef enum dhr_param {
                                      lengths back after every phase).  DHR_ASYNC overrides. */
   DHR_PARAM_SAMPLE_SHARE = 12, /* staged search only (dhr_search_begin / finish): the number of shards the sampled threshold is agreed between; a shard then
                                  reports its r / shards + 5 sqrt(r / shards) + 4 best sample scores (dhr_search_sample_rank) instead of all r
-                                 (dhr_search_union_rank).  dhr_search_sharded[_local] set it themselves.  Default 1. */
+                                 (dhr_search_union_rank), and plans its lists for its SHARE of k: a shard that turns out to hold far more of the top-k
+                                 than k / shards reports count = -1 for those queries in dhr_search_finish (the caller's repair step, which
+                                 dhr_search_sharded* run themselves, redoes them with local thresholds).  dhr_search_sharded[_local] set the
+                                 parameter themselves.  Default 1. */
   DHR_PARAM_LIST_STRIDE = 14, /* entries every query owns in the uniform part of the bound-candidate lists (default 0 = 32 768); what a hot query needs
                                  beyond that comes from a shared arena planned on the device (two-tier lists: the workspace of an 8.8 M-row index is
                                  ~7 GB instead of 34).  Takes effect for indexes with a refine level whose planned list depth exceeds it; tests

@@ -1808,6 +1808,17 @@ def test_bad_arguments_on_a_device_are_statuses(G):
     np.testing.assert_array_equal(s1, s0)
 
 
+def test_staged_search_call_sequences(G, monkeypatch):
+    """A slice of tools/fuzz_staged.py: the staged search calls (pre / begin / begin_rest / mid / finish) in ANY order, mixed with the calls that share
+    the handle's workspace, with plausible and implausible thresholds -- statuses, never a crash; a protocol-conforming staged search returns the exact
+    top-k, a plain search afterwards equals the reference."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import fuzz_staged
+    monkeypatch.setattr(sys, "argv", ["fuzz_staged.py", "150", "9"])
+    fuzz_staged.main()
+
+
 def test_random_mode_configurations(G, monkeypatch):
     """A slice of tools/stress_modes.py: the entry points beside the plain search (two-stage modes on the device, dhr_score_rows, the
     index file round trip, the one-process sharded search over ragged shards, the shard reduces on the device and on the host) on
