@@ -1556,6 +1556,7 @@ def test_random_configurations(G, monkeypatch):
     """A slice of tools/stress.py (randomised shapes / dtypes / signs / fp32-or-fp16 queries / bucket counts / mixed query and
     corpus index dtypes, each checked against the oracle's float64 scores)."""
     import os, sys
+    monkeypatch.setenv("DHR_GATED_I8", "0")      # (the tool sets the variable per case: restored when the test ends)
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     import stress
     monkeypatch.setattr(sys, "argv", ["stress.py", "80", "11"])
@@ -1567,6 +1568,7 @@ def test_random_controller_configurations(G, monkeypatch):
     chunk count / head size, benign and adversarial row orders, single index and the staged sharded search -- each checked
     against the oracle's float64 scores."""
     import os, sys
+    monkeypatch.setenv("DHR_GATED_I8", "0")      # (the tool sets the variable per case: restored when the test ends)
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     import stress_sampled
     monkeypatch.setattr(sys, "argv", ["stress_sampled.py", "14", "5"])
@@ -1808,6 +1810,16 @@ def test_bad_arguments_on_a_device_are_statuses(G):
     np.testing.assert_array_equal(s1, s0)
 
 
+def test_degenerate_inputs(G, monkeypatch):
+    """tools/degenerate.py: all-zero corpus / queries, identical rows (all ties -> row ascending), k == n, one row, fp16 maxima and subnormals,
+    all-negative values, one non-zero column -- both images of the gated half, against the oracle."""
+    import os, sys
+    monkeypatch.setenv("DHR_GATED_I8", "0")      # (the tool sets the variable per case: restored when the test ends)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import degenerate
+    degenerate.main()
+
+
 def test_staged_search_call_sequences(G, monkeypatch):
     """A slice of tools/fuzz_staged.py: the staged search calls (pre / begin / begin_rest / mid / finish) in ANY order, mixed with the calls that share
     the handle's workspace, with plausible and implausible thresholds -- statuses, never a crash; a protocol-conforming staged search returns the exact
@@ -1824,6 +1836,7 @@ def test_random_mode_configurations(G, monkeypatch):
     index file round trip, the one-process sharded search over ragged shards, the shard reduces on the device and on the host) on
     random shapes / dtypes / signs / bucket counts / k1 / k, each against the oracle's float64 scores and parity rules."""
     import os, sys
+    monkeypatch.setenv("DHR_GATED_I8", "0")      # (the tool sets the variable per case: restored when the test ends)
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     import stress_modes
     monkeypatch.setattr(sys, "argv", ["stress_modes.py", "60", "3"])
