@@ -1810,6 +1810,57 @@ def test_bad_arguments_on_a_device_are_statuses(G):
     np.testing.assert_array_equal(s1, s0)
 
 
+def test_host_corpus_beyond_2_32_elements(G):
+    """The reference hands over HOST arrays (the unpickled index): 2.9 M rows x (768 + 768) fp16 = 4.45e9 elements (8.9 GB; 2.2e9 index bytes) cross
+    every 32-bit offset of the host ingest (staged blocks, the 2-D copy of the index array).  The index built from the host arrays answers bit for bit
+    like the one built from the same data on the device, the last rows of the corpus are where the best scores are, and the returned scores are the float64
+    scores of their rows recomputed here."""
+    import torch
+    n, d, q, k = 2_900_000, 768, 8, 100
+    rng = np.random.default_rng(5)
+    blk = 100_000
+    base_v = (np.abs(rng.standard_normal((blk, 2 * d), dtype=np.float32)) * 0.2).astype(np.float16)
+    base_v[:, d:] = (rng.standard_normal((blk, d), dtype=np.float32) * 0.1).astype(np.float16)
+    base_i = rng.integers(0, 6, (blk, d)).astype(np.uint8)
+    cv = np.empty((n, 2 * d), np.float16)
+    ci = np.empty((n, d), np.uint8)
+    for lo in range(0, n, blk):
+        cv[lo:lo + blk] = base_v
+        ci[lo:lo + blk] = base_i
+    # every row its own: a ramp in one ungated column that the queries weigh positively -- the LAST rows (beyond 2^32 elements) score highest
+    ramp = (np.arange(n, dtype=np.float32) / n * 60.0).astype(np.float16)
+    cv[:, d] = ramp
+    qv = (np.abs(rng.standard_normal((q, 2 * d), dtype=np.float32)) * 0.2).astype(np.float32)
+    qv[:, d:] = rng.standard_normal((q, d), dtype=np.float32) * 0.1
+    qv[:, d] = 3.0
+    qi = rng.integers(0, 6, (q, d)).astype(np.uint8)
+    ix_h = G.GipIndex(cv, ci)
+    try:
+        s_h, r_h = ix_h.search(qv, qi, k)
+    finally:
+        ix_h.close()
+    dv, di = torch.empty((n, 2 * d), dtype=torch.float16, device="cuda"), torch.empty((n, d), dtype=torch.uint8, device="cuda")
+    for lo in range(0, n, 500_000):
+        dv[lo:lo + 500_000] = torch.from_numpy(cv[lo:lo + 500_000]).cuda()
+        di[lo:lo + 500_000] = torch.from_numpy(ci[lo:lo + 500_000]).cuda()
+    ix_d = G.GipIndex(dv, di)
+    try:
+        s_d, r_d = ix_d.search(qv, qi, k)
+    finally:
+        ix_d.close()
+    np.testing.assert_array_equal(r_h, r_d)
+    np.testing.assert_array_equal(s_h, s_d)
+    assert (r_h >= (1 << 32) // (2 * d)).all(), "the best rows are the last ones"
+    for i in range(q):
+        rows = r_h[i]
+        ex = O.gip_scores_f64(qv[i], qi[i], cv[rows].astype(np.float32), ci[rows])
+        np.testing.assert_allclose(s_h[i], ex.astype(np.float32), rtol=0, atol=1e-6 * float(np.abs(ex).max()))
+        # ... and no row of the last 300 000 outside the list beats its k-th score
+        tail = slice(n - 300_000, n)
+        ext = O.gip_scores_f64(qv[i], qi[i], cv[tail].astype(np.float32), ci[tail])
+        O.check_topk(rows - (n - 300_000), s_h[i], ext, k)
+
+
 def test_degenerate_inputs(G, monkeypatch):
     """tools/degenerate.py: all-zero corpus / queries, identical rows (all ties -> row ascending), k == n, one row, fp16 maxima and subnormals,
     all-negative values, one non-zero column -- both images of the gated half, against the oracle."""
