@@ -432,16 +432,11 @@ __device__ __forceinline__ void g8_tile(const GemmArgs& p, char* smem, const int
   g8_epilogue(p, acc, dt, qt, wm, wn, (int)threadIdx.x, lane, smem, thr_r, mul_r);
 }
 
-// G8_VGPR_CAP (build flag, architectural registers = HALF the cap on the unified file): 116 = 232 registers per wave -- two waves leave 48
-// of a SIMD's 512 registers to a co-resident refine / rescoring wave; 0 = no cap (243)
-#ifndef G8_VGPR_CAP
-#define G8_VGPR_CAP 0
-#endif
-#if G8_VGPR_CAP > 0
-#define G8_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(2, 2), amdgpu_num_vgpr(G8_VGPR_CAP)))
-#else
+// (Until round 6 a build flag G8_VGPR_CAP capped the kernel at 2 x 224 registers per SIMD for the "gathers resident beside the GEMM" experiment of
+// DESIGN.md section 4c.  Round 6 re-ran it with the gather launches cut to one workgroup per CU: a capped build of today's kernel no longer returns
+// the right candidates (scratch inside the asm-pinned stage loops), and the gathers reach 1.0 TB/s from one wave per SIMD where the step needs 5 --
+// docs/experiments.md; the flag is gone.)
 #define G8_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
-#endif
 template <bool DUMP>
 __global__ void __launch_bounds__(G8_NT) G8_KERNEL_ATTR gemm_filter_g8_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
