@@ -178,6 +178,7 @@ def main():
     ap.add_argument("--two-stage", type=int, default=-1, help="1: after the timed steps also time 3 steps each of the two-stage modes of the reference's docs on the resident index (--theta 0.3 --rerank and --IP --rerank, agip_topk 10000) and attach them as two_stage (default: on for the plain N=1 hybrid invocation)")
     ap.add_argument("--other-configs", type=int, default=-1, help="1: after the headline workload also time 5 steps each of config 2 (dense) and config 1 (bm25) and attach them as other_configs (default: on for the plain N=1 hybrid invocation)")
     ap.add_argument("--data", default="iid", choices=["iid", "clustered"], help="dense columns: iid Gaussian (SURVEY 8d) or the structured variant (2 000 clusters, decaying spectrum, 1 %% near-duplicate rows, 5 %% hot queries)")
+    ap.add_argument("--per-step", action="store_true", help="diagnostics: attach the library's own total_ms of every timed step (per_step_total_ms) -- a slow step among fast ones is a host-side stall, not kernel time")
     ap.add_argument("--dist-backend", default="nccl", help="testing only: 'gloo' lets several ranks share ONE GPU (with DHR_BENCH_SINGLE_DEVICE=1)")
     args = ap.parse_args()
     if args.quick:
@@ -440,6 +441,7 @@ def run_workload(args, spec, ctx):
             stats_acc["adc_scan_ms"] = stats_acc.get("adc_scan_ms", 0) + ms_scan
             stats_acc["adc_code_bytes"] = stats_acc.get("adc_code_bytes", 0) + by_scan
         acc["gemm_ms"] += st["gemm_ms"]
+        acc.setdefault("total_by_step", []).append(round(st["total_ms"], 3))
         acc["launches"] += st["phases"]
         acc["gemm_flops_alg"] += st["gemm_flops_alg"]           # algorithmic: real Q and K of every launch
         for key in ("refine_ms", "rescore_ms", "select_ms", "prep_ms", "total_ms", "candidates_bound", "candidates_exact",
@@ -625,6 +627,7 @@ def run_workload(args, spec, ctx):
                                  | {"gemm_ms": round(gemm_ms / args.steps, 3)},
             "candidates_per_query": {"bound": round(stats_acc["candidates_bound"] / args.steps / nq, 1),
                                      "exact": round(stats_acc["candidates_exact"] / args.steps / nq, 1)},
+            **({"per_step_total_ms": acc.get("total_by_step", [])} if args.per_step else {}),
             "sample_fallback_queries_per_step": stats_acc["sample_fallback_queries"] / args.steps,
             "overflow_retries_per_step": stats_acc["overflow_retries"] / args.steps,
             "setup_s": {"generate": round(t_gen, 2), "index_build": round(t_build, 2)},

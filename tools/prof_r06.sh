@@ -64,7 +64,7 @@ if [ $PART = pmc ] || [ $PART = all ]; then
   tail -1 $O/pmc_g8_f.log; tail -1 $O/pmc_dense_f.log; tail -1 $O/pmc_densei8_f.log
 fi
 if [ $PART = beir ] || [ $PART = all ]; then
-  timeout 1500 python bench.py --workload beir --no-cpu-baseline --steps 10 --warmup 3 > $O/bench_${TAG}_beir_exact.jsonl 2> $O/bench_beir_exact.err
+  timeout 1500 python bench.py --workload beir --no-cpu-baseline --steps 10 --warmup 3 --per-step > $O/bench_${TAG}_beir_exact.jsonl 2> $O/bench_beir_exact.err
   [ "${BEIR_PQ:-0}" = 1 ] && timeout 2400 python bench.py --workload beir --pq --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_${TAG}_beir_pq.jsonl 2> $O/bench_beir_pq.err
   python3 - <<P
 import json
