@@ -54,7 +54,7 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
   if (!ix) return set_error(DHR_ERR_INVALID, "null index");
   switch (param) {
     case DHR_PARAM_CAND_CAP:
-      if (value < 1024 || value > (1 << 22)) return set_error(DHR_ERR_INVALID, "cand_cap must be in [1024, 4194304]");
+      if (value < DOC_GROUP * TILE_ROWS || value > (1 << 22)) return set_error(DHR_ERR_INVALID, "cand_cap must be in [1024, 4194304]");      // (>= the rows of a minimum chunk, as list_stride below)
       ix->cand_cap = value; return DHR_OK;
     case DHR_PARAM_FIRST_ROWS:
       if (value < 0) return set_error(DHR_ERR_INVALID, "first_rows must be >= 0");
@@ -65,7 +65,11 @@ extern "C" int dhr_index_set_param(dhr_index* ix, int32_t param, int64_t value) 
       ix->sample_period = (int)value; return DHR_OK;
     case DHR_PARAM_ASYNC_CONTROLLER: ix->async_ctl = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return DHR_OK;
     case DHR_PARAM_LIST_STRIDE:
-      if (value != 0 && (value < 256 || value > (1 << 22) || value % 256)) return set_error(DHR_ERR_INVALID, "list_stride must be 0 (default) or a multiple of 256 in [256, 4194304]");
+      // (>= the rows of the smallest chunk the host-driven controller can fall back to, DOC_GROUP tiles: a list that cannot hold every row of it could
+      // overflow with nothing left to halve -- until round 6 the range began at 256, and such a chunk lost its entries beyond the stride SILENTLY
+      // on corpora too small for the sampled controller; found by tools/stress_modes.py)
+      if (value != 0 && (value < DOC_GROUP * TILE_ROWS || value > (1 << 22) || value % 256))
+        return set_error(DHR_ERR_INVALID, "list_stride must be 0 (default) or a multiple of 256 in [1024, 4194304]");
       ix->list_stride = value; return DHR_OK;
     case DHR_PARAM_SAMPLE_SHARE:
       if (value < 1 || value > 4096) return set_error(DHR_ERR_INVALID, "sample_share must be in [1,4096]");

@@ -436,6 +436,8 @@ static int stream_phases(dhr_index* ix, Workspace& w, int Q, bool gate, SelectAr
       chunk = std::max<int64_t>(DOC_GROUP, round_up(chunk / 2, DOC_GROUP));
       continue;
     }
+    // (cannot happen: every list depth the workspace plans holds the rows of a minimum chunk -- ensure_ws, DHR_PARAM_CAND_CAP / _LIST_STRIDE >= 1024)
+    if (maxc > w.cap) return set_error(DHR_ERR_INTERNAL, "bound list overflow at the minimum chunk size");
     st.candidates_bound += (int64_t)sumc;
     if (last_rate) *last_rate = (double)maxc / (double)chunk_rows;      // fullest list per corpus row, at the latest thresholds
     rc = rescore_select(ix, w, Q, gate, sel, w.cand, w.cnt, w.thr, maxc, tm, st, s, (int64_t)sumc, nullptr);

@@ -124,7 +124,7 @@ typedef enum dhr_param {
   DHR_PARAM_LIST_STRIDE = 14, /* entries every query owns in the uniform part of the bound-candidate lists (default 0 = 32 768); what a hot query needs
                                  beyond that comes from a shared arena planned on the device (two-tier lists: the workspace of an 8.8 M-row index is
                                  ~7 GB instead of 34).  Takes effect for indexes with a refine level whose planned list depth exceeds it; tests
-                                 force a small stride to exercise the second tier on small inputs */
+                                 force a small stride to exercise the second tier on small inputs.  0 or a multiple of 256 in [1024, 4194304] */
   DHR_PARAM_SAMPLE_PERIOD = 5 /* every S-th corpus tile seeds the thresholds (default 32; 0 = plain streaming) */
 } dhr_param;
 

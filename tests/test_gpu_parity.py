@@ -741,10 +741,10 @@ def test_smaller_batch_reuses_the_workspace(G):
         ix.close()
 
 
-@pytest.mark.parametrize("stride", [256, 4096])
+@pytest.mark.parametrize("stride", [1024, 4096])
 def test_two_tier_candidate_lists(G, gated_image, stride):
     """Two-tier bound lists (round 5: every query owns DHR_PARAM_LIST_STRIDE uniform slots, a hot query the rest of its depth from an arena
-    planned on the device).  With a stride far below what the lists of this batch hold (256: below even the first sampled phase's; 4 096), the second tier carries most entries of the hot
+    planned on the device).  With a stride far below what the lists of this batch hold (1 024, the smallest admitted: below even the first sampled phase's; 4 096), the second tier carries most entries of the hot
     queries -- and a query whose plan came out too small overflows, is flagged and redone: either way the result must be the result of the
     default stride, which is checked against the oracle.  The footprint shrinks with the stride."""
     from dhr_amd import synth, _lib
@@ -792,7 +792,7 @@ def test_two_tier_lists_with_cu_masked_streams(G, aux_cus, exclusive):
     ix = G.GipIndex(cv, ci)
     try:
         s0, r0 = ix.search(q, qi, k)
-        ix.set_param(_lib.PARAM_LIST_STRIDE, 256)
+        ix.set_param(_lib.PARAM_LIST_STRIDE, 1024)
         ix.set_param(_lib.PARAM_AUX_CUS, aux_cus)
         ix.set_param(_lib.PARAM_GEMM_EXCLUSIVE, exclusive)
         for _ in range(3):                                 # (the plan of a step reads what the previous one left in the workspace)
@@ -1800,6 +1800,9 @@ def test_bad_arguments_on_a_device_are_statuses(G):
     assert lib.dhr_densify(0, 9, lex.ctypes.data, _lib.VAL_F32, 16, 2, 16, 0, 8, dv.ctypes.data, _lib.VAL_F32, 8, di.ctypes.data, _lib.idx_code(di.dtype), 8, None) < 0
     assert lib.dhr_densify(0, _lib.MEM_HOST, lex.ctypes.data, _lib.VAL_F32, 16, 2, 16, 0, 5, dv.ctypes.data, _lib.VAL_F32, 8, di.ctypes.data, _lib.idx_code(di.dtype), 8, None) < 0
     assert lib.dhr_index_set_param(ix._h, 999, 1) < 0 and lib.dhr_index_set_param(None, _lib.PARAM_CAND_CAP, 1024) < 0
+    for prm, val in ((_lib.PARAM_LIST_STRIDE, 256), (_lib.PARAM_LIST_STRIDE, 1025), (_lib.PARAM_CAND_CAP, 1023), (_lib.PARAM_SAMPLE_PERIOD, 257), (_lib.PARAM_MAIN_CHUNKS, 0),
+                     (_lib.PARAM_AUX_CUS, 12), (_lib.PARAM_SAMPLE_SHARE, 0), (_lib.PARAM_MAX_GROWTH, 0), (_lib.PARAM_FIRST_ROWS, -1), (_lib.PARAM_GEMM_VARIANT, 3)):
+        assert lib.dhr_index_set_param(ix._h, prm, val) < 0, (prm, val)
     assert lib.dhr_index_save(ix._h, b"/nonexistent_dir/x.dhr", None, 0) < 0
     h = C.c_void_p()
     assert lib.dhr_index_load(b"/nonexistent_dir/x.dhr", 0, -1, C.byref(h)) < 0 and not h.value

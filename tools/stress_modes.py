@@ -239,7 +239,7 @@ def main():
                 prm = {_lib.PARAM_CAND_CAP: pick(1024, 1 << 20), _lib.PARAM_FIRST_ROWS: pick(0, nn + 1000), _lib.PARAM_MAX_GROWTH: pick(1, 1024),
                        _lib.PARAM_SAMPLE_PERIOD: pick(0, 256), _lib.PARAM_MAIN_CHUNKS: pick(1, 64), _lib.PARAM_PROGRESSIVE_THR: pick(0, 2),
                        _lib.PARAM_AUX_CUS: pick(0, 192, 8), _lib.PARAM_GEMM_EXCLUSIVE: pick(0, 1), _lib.PARAM_OVERLAP_AUX: pick(-1, 1),
-                       _lib.PARAM_SAMPLE_SHARE: pick(1, 4096), _lib.PARAM_ASYNC_CONTROLLER: pick(0, 2), _lib.PARAM_LIST_STRIDE: 0 if rng.random() < 0.4 else pick(256, 1 << 20, 256),
+                       _lib.PARAM_SAMPLE_SHARE: pick(1, 4096), _lib.PARAM_ASYNC_CONTROLLER: pick(0, 2), _lib.PARAM_LIST_STRIDE: 0 if rng.random() < 0.4 else pick(1024, 1 << 20, 256),
                        _lib.PARAM_PROFILE: pick(0, 1)}
                 keys = [k_ for k_ in prm if rng.random() < 0.6]
                 cvp = np.abs(rng.standard_normal((nn, dd + dc), dtype=np.float32)) * 0.3
@@ -253,6 +253,8 @@ def main():
                 cfg.update(n=nn, d_dlr=dd, d_cls=dc, k_search=kk, params={int(k_): prm[k_] for k_ in keys})
                 if not live:
                     continue
+                if os.environ.get("DHR_STRESS_DUMP"):          # replay aid: the inputs of this case for a stand-alone script
+                    np.savez(os.environ["DHR_STRESS_DUMP"], cv=cvp, ci=cip, qv=qvp, qi=qip, k=kk, nb=nb, g8=g8, keys=np.array(keys), vals=np.array([prm[k_] for k_ in keys]))
                 ix = G.GipIndex(cvp, cip, idx_buckets=nb)
                 try:
                     for k_ in keys:
