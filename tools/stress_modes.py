@@ -40,6 +40,8 @@ def main():
         g8 = int(rng.integers(0, 2))
         theta = float(rng.choice([0.05, 0.1, 0.3, 0.6]))
         what = str(rng.choice(["theta", "ip", "score_rows", "file", "local_shards", "merge", "densify", "pq", "cli", "strided", "params"]))
+        if os.environ.get("DHR_STRESS_KINDS"):             # e.g. DHR_STRESS_KINDS=params,strided : only these kinds (another random sequence than the full mix)
+            what = str(rng.choice(os.environ["DHR_STRESS_KINDS"].split(",")))
         os.environ["DHR_GATED_I8"] = str(g8)
         cfg = dict(case=case, what=what, n=n, q=q, d_dlr=d_dlr, d_cls=d_cls, k1=k1, k=k, idx=np.dtype(idx_dtype).name, n_idx=n_idx,
                    neg=neg, q32=q32, nb=nb, gated_i8=g8, theta=theta)
