@@ -397,6 +397,20 @@ def sharded_search_host(shard, q_value, q_index, k: int, group=None):
         n = int(np.prod(shape))
         return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,)).view(dt).reshape(shape)
 
+    def fit(a, cols, fill, dt):
+        """The callback contract is a full [n, cols] array (scores padded with -inf, rows with -1): a shard object that returns SHORTER lists (k beyond
+        its rows, fewer sample scores than the agreed rank) is padded here, a longer one cut -- written as it came, a short block would be read with the
+        wrong row stride (queries mixed, a stale tail merged as if it were a result)."""
+        a = np.asarray(a, dt)
+        if a.ndim == 1:
+            a = a.reshape(-1, 1) if cols == 1 else a.reshape(1, -1)
+        if a.shape[1] == cols:
+            return a
+        o = np.full((a.shape[0], cols), fill, dt)
+        m = min(cols, a.shape[1])
+        o[:, :m] = a[:, :m]
+        return o
+
     def guard(f):
         def g(*a):
             try:
@@ -410,23 +424,23 @@ def sharded_search_host(shard, q_value, q_index, k: int, group=None):
     def cb_begin(_u, qb, kk, share, sample):
         v, x = batch_arrays(qb)
         state["n"] = v.shape[0]
-        s = np.asarray(shard.search_begin(v, x, int(kk), int(share)), np.float32)
+        s = fit(shard.search_begin(v, x, int(kk), int(share)), int(shard.sample_rank(int(kk), int(share))), -np.inf, np.float32)
         out(sample, s.shape, np.float32)[...] = s
         return 0
 
     def cb_finish(_u, tau, ps, pr, pc):
         n = state["n"]
         s, r, c = shard.search_finish(out(tau, (n,), np.float32).copy())
-        out(ps, (n, k), np.float32)[...] = s
-        out(pr, (n, k), np.int64)[...] = r
+        out(ps, (n, k), np.float32)[...] = fit(s, k, -np.inf, np.float32)
+        out(pr, (n, k), np.int64)[...] = fit(r, k, -1, np.int64)
         out(pc, (n,), np.int32)[...] = c
         return 0
 
     def cb_search(_u, qb, kk, ps, pr):
         v, x = batch_arrays(qb)
         s, r = shard.search(v, x, int(kk))
-        out(ps, s.shape, np.float32)[...] = s
-        out(pr, r.shape, np.int64)[...] = r
+        out(ps, (v.shape[0], int(kk)), np.float32)[...] = fit(s, int(kk), -np.inf, np.float32)
+        out(pr, (v.shape[0], int(kk)), np.int64)[...] = fit(r, int(kk), -1, np.int64)
         return 0
 
     def cb_mid_ranks(_u, kk, share, p_local, p_union):
@@ -436,7 +450,7 @@ def sharded_search_host(shard, q_value, q_index, k: int, group=None):
 
     def cb_mid(_u, tau, r_local, ps):
         n = state["n"]
-        s = np.asarray(shard.search_mid(out(tau, (n,), np.float32).copy(), int(r_local)), np.float32)
+        s = fit(shard.search_mid(out(tau, (n,), np.float32).copy(), int(r_local)), int(r_local), -np.inf, np.float32)
         out(ps, (n, int(r_local)), np.float32)[...] = s
         return 0
 
@@ -447,14 +461,14 @@ def sharded_search_host(shard, q_value, q_index, k: int, group=None):
 
     def cb_pre(_u, qb, kk, share, r_local, ps):
         v, x = batch_arrays(qb)
-        state["n"] = v.shape[0]
-        s = np.asarray(shard.search_pre(v, x, int(kk), int(share), int(r_local)), np.float32)
+        state["n"], state["share"] = v.shape[0], int(share)
+        s = fit(shard.search_pre(v, x, int(kk), int(share), int(r_local)), int(r_local), -np.inf, np.float32)
         out(ps, (v.shape[0], int(r_local)), np.float32)[...] = s
         return 0
 
     def cb_begin_rest(_u, tau, sample):
         n = state["n"]
-        s = np.asarray(shard.search_begin_rest(out(tau, (n,), np.float32).copy()), np.float32)
+        s = fit(shard.search_begin_rest(out(tau, (n,), np.float32).copy()), int(shard.sample_rank(k, state.get("share", 1))), -np.inf, np.float32)
         out(sample, s.shape, np.float32)[...] = s
         return 0
 
