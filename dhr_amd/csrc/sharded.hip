@@ -186,7 +186,50 @@ struct Step {
   std::vector<int> st;             // first failure of local shard i (DHR_OK: none); its later local work is skipped
   std::vector<int32_t*> rec;       // per local shard: {failed queries, first failing rank's status, that rank, -} in the shard's memory
   char msg[1024];                  // dhr_last_error() of the first local failure (later calls overwrite the thread's record)
+  // What this rank still OWES the other ranks (round 6, second half: a failure OUTSIDE the local work -- a std::bad_alloc in the control flow itself, a block
+  // that cannot be allocated -- used to return at once and leave the others in their next collective until the transport's timeout): the rank agreement
+  // is one exchange of a fixed size; once the ranks are agreed the blocks of the step's all-gathers follow from them (owe(), fixed storage: planning
+  // must not allocate).  leave() pays the debt with this rank's status in every block.
+  Block plan[8];
+  int n_plan = 0, done = 0;        // planned all-gathers; how many of them have been issued
+  bool agreed = false;             // the rank agreement has been issued (successfully or not: it is never issued twice)
+  bool over = false;               // the step is over on EVERY rank at this point of the sequence (a failure all of them have just read in the same
+                                   // exchange) or the transport itself failed: no further collective may be issued
   explicit Step(Backend& b) : B(b), spmd(b.world > b.n_local), st(b.n_local, DHR_OK), rec(b.n_local, nullptr) { msg[0] = 0; }
+  void owe(const Block& b) { if (n_plan < 8) plan[n_plan++] = b; }
+  // The way out of a step that failed with `status` somewhere the sequence above does not cover: the agreement with the status in v[10] if it is still
+  // owed, else every planned all-gather not yet issued, with the status in its record (host transports end the step on every rank at the first such
+  // gather; with device-side records the others run the plan to its end and read the status there).  Never throws; keeps the thread's error message.
+  void leave(int status) noexcept {
+    if (!spmd || status == DHR_OK || over) return;
+    char keep[1024];
+    snprintf(keep, sizeof(keep), "%s", dhr_last_error());
+    try {
+      if (!agreed) {
+        agreed = true;
+        int32_t v[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, status, 0};
+        (void)B.min_over_ranks(v);
+      } else {
+        std::vector<const void*> send(B.n_local);
+        std::vector<void*> recv(B.n_local);
+        while (done < n_plan) {
+          const Block& b = plan[done];
+          bool ok = true;
+          for (int i = 0; i < B.n_local && ok; ++i) {
+            void* blk = B.alloc(i, b.stride);
+            recv[i] = B.alloc(i, (size_t)B.world * b.stride);
+            ok = blk && recv[i] && B.zero(i, blk, b.stride) == DHR_OK && B.put_status(i, blk, b, st[i] != DHR_OK ? st[i] : status) == DHR_OK;
+            send[i] = blk;
+          }
+          if (!ok) break;
+          ++done;
+          if (B.gather(send, recv, b) != DHR_OK) { over = true; break; }
+        }
+      }
+    } catch (...) {
+    }
+    (void)dhr_set_error_message(status, keep);
+  }
   int own() const { for (int v : st) if (v != DHR_OK) return v; return DHR_OK; }
   int own_error() const { return dhr_set_error_message(own(), msg); }
   // local work of shard i.  A failure is recorded; in a one-process search (nobody else is waiting) it ends the step at once.
@@ -210,8 +253,12 @@ struct Step {
   }
   // the all-gather of one block per shard, status records included
   int gather(const std::vector<const void*>& send, const std::vector<void*>& recv, const Block& b) {
+    if (done < n_plan && (plan[done].stride != b.stride || plan[done].payload != b.payload))
+      return dhr_set_error_message(DHR_ERR_INTERNAL, "sharded step: an all-gather does not match the step's plan");
     for (int i = 0; i < B.n_local; ++i) SH_TRY(B.put_status(i, const_cast<void*>(send[i]), b, st[i]));
+    ++done;
     const int rc = B.gather(send, recv, b);
+    if (rc != DHR_OK) over = true;                                      // a failure every rank has read in this gather, or a broken transport
     if (rc == DHR_ERR_PEER && own() != DHR_OK) return own_error();      // this rank is the one that failed
     SH_TRY(rc);
     for (int i = 0; i < B.n_local; ++i) SH_TRY(B.fold_status(i, recv[i], b, rec[i]));
@@ -228,11 +275,16 @@ struct Step {
 
 // local thresholds for a (sub-)batch: every shard searches with k, full lists gathered (ONE all-gather: scores and rows in one block) and
 // merged.  out_* [n_q, k] per local shard.
+// the block of the step's last all-gather: [Q] counts | [Q, kk] scores | [Q, kk] rows
+inline size_t final_off_s(int Q) { return ((size_t)Q * 4 + 15) & ~(size_t)15; }
+inline size_t final_off_r(int Q, int kk) { return (final_off_s(Q) + (size_t)Q * kk * 4 + 15) & ~(size_t)15; }
+inline Block final_block(int Q, int kk) { return block_of(final_off_r(Q, kk) + (size_t)Q * kk * 8); }
+inline Block local_block(int Q, int k) { return block_of((((size_t)Q * k * 4 + 15) & ~(size_t)15) + (size_t)Q * k * 8); }
 int local_path(Step& S, const std::vector<dhr_query_batch>& qb, int k, const std::vector<float*>& out_s, const std::vector<int64_t*>& out_r) {
   Backend& B = S.B;
   const int nl = B.n_local, world = B.world, Q = qb[0].n_queries;
   const size_t off_r = ((size_t)Q * k * 4 + 15) & ~(size_t)15;
-  const Block b = block_of(off_r + (size_t)Q * k * 8);
+  const Block b = local_block(Q, k);
   std::vector<const void*> send(nl);
   std::vector<void*> recv(nl);
   for (int i = 0; i < nl; ++i) {
@@ -274,7 +326,9 @@ int agree_rank(Step& S, int k, int* r_out, int* ru_out, int* rl_mid_out, int* ru
     pl_min = std::min(pl_min, pl); pl_max = std::max(pl_max, pl); pu_max = std::max(pu_max, pu);
   }
   int32_t v[12] = {r, -r, ru, -ru, ml_min, -ml_max, -mu_max, pl_min, -pl_max, -pu_max, S.own(), 0};
-  SH_TRY(B.min_over_ranks(v));
+  S.agreed = true;
+  { const int rc_x = B.min_over_ranks(v); if (rc_x != DHR_OK) { S.over = true; return rc_x; } }
+  if (v[10] != DHR_OK) S.over = true;                 // every rank reads the same v[10] and leaves here
   if (v[10] != DHR_OK) return S.own() != DHR_OK ? S.own_error() : dhr_set_error_message(DHR_ERR_PEER, "another rank failed while setting up this sharded step; the step was abandoned on every rank");
   *r_out = (v[0] == r && -v[1] == r && v[2] == ru && -v[3] == ru) ? r : 0;
   *ru_out = ru;
@@ -295,15 +349,57 @@ struct ShareGuard {
 
 thread_local int g_last_repairs = 0;      // queries the calling thread's last sharded search redid with local thresholds (dhr_debug_sharded_repairs)
 
-int sharded_core(Backend& B, const dhr_query_batch* qb_in, int k, const std::vector<float*>& out_s, const std::vector<int64_t*>& out_r) {
-  const int nl = B.n_local, world = B.world, Q = qb_in->n_queries;
+static int sharded_body(Step& S, const dhr_query_batch* qb_in, int k, float* const* out_s_in, int64_t* const* out_r_in);
+// The step and its way out: whatever the body returns or throws, a rank that fails does not leave the others waiting (Step::leave).  out_s / out_r: one
+// [Q, k] device (host shards: host) array per LOCAL shard.
+int sharded_core(Backend& B, const dhr_query_batch* qb_in, int k, float* const* out_s, int64_t* const* out_r) {
   g_last_repairs = 0;
-  std::vector<dhr_query_batch> qb(nl, *qb_in);
+  const bool spmd = B.world > B.n_local;
+  int rc;
+  try {
+    Step S(B);
+    try {
+      dhr::alloc_checkpoint();
+      rc = sharded_body(S, qb_in, k, out_s, out_r);
+    } catch (...) {
+      rc = dhr::on_exception();
+    }
+    S.leave(rc);
+    return rc;
+  } catch (...) {          // the step's own state could not be built: nothing has been exchanged yet
+    rc = dhr::on_exception();
+  }
+  if (spmd) {
+    char keep[1024];
+    snprintf(keep, sizeof(keep), "%s", dhr_last_error());
+    try {
+      int32_t v[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, rc, 0};
+      (void)B.min_over_ranks(v);
+    } catch (...) {
+    }
+    (void)dhr_set_error_message(rc, keep);
+  }
+  return rc;
+}
+static int sharded_body(Step& S, const dhr_query_batch* qb_in, int k, float* const* out_s_in, int64_t* const* out_r_in) {
+  Backend& B = S.B;
+  const int nl = B.n_local, world = B.world, Q = qb_in->n_queries;
   ShareGuard share_guard{B};
-  Step S(B);
+  const std::vector<float*> out_s(out_s_in, out_s_in + nl);
+  const std::vector<int64_t*> out_r(out_r_in, out_r_in + nl);
+  std::vector<dhr_query_batch> qb(nl, *qb_in);
   for (int i = 0; i < nl; ++i) SH_LOCAL(i, B.set_share(i, world));      // a shard chases only its share of the union's rank
   int r = 0, ru_all = 0, rl_mid = 0, ru_mid = 0, rl_pre = 0, ru_pre = 0;
   SH_TRY(agree_rank(S, k, &r, &ru_all, &rl_mid, &ru_mid, &rl_pre, &ru_pre));
+  // the all-gathers this step owes from here on (Step::leave): nothing below may fail before they are on record
+  const int kk_plan = prefix_len(k, world);
+  if (r <= 0) S.owe(local_block(Q, k));
+  else {
+    if (rl_pre > 0 && ru_pre > 0) S.owe(block_of((size_t)Q * rl_pre * 4));
+    S.owe(block_of((size_t)Q * r * 4));
+    if (rl_mid > 0 && ru_mid > 0) S.owe(block_of((size_t)Q * rl_mid * 4));
+    S.owe(final_block(Q, kk_plan));
+  }
   SH_TRY(S.init());
   std::vector<int32_t*> fail_ids(nl, nullptr);
   std::vector<int32_t> ids;
@@ -380,8 +476,8 @@ int sharded_core(Backend& B, const dhr_query_batch* qb_in, int k, const std::vec
   // 3-5: main passes; ONE all-gather of [counts | list prefixes: scores | rows] per shard (round 6; until then the counts travelled in a
   // collective of their own, and scores and rows in one each), failure flags, reduce
   const int kk = prefix_len(k, world);
-  const size_t off_s = ((size_t)Q * 4 + 15) & ~(size_t)15, off_r = (off_s + (size_t)Q * kk * 4 + 15) & ~(size_t)15;
-  const Block bl = block_of(off_r + (size_t)Q * kk * 8);
+  const size_t off_s = final_off_s(Q), off_r = final_off_r(Q, kk);
+  const Block bl = final_block(Q, kk);
   std::vector<const void*> send_l(nl);
   std::vector<void*> recv_l(nl);
   for (int i = 0; i < nl; ++i) {
@@ -416,6 +512,7 @@ int sharded_core(Backend& B, const dhr_query_batch* qb_in, int k, const std::vec
   // (a failure of THIS rank behind the last gather -- its reduce -- is unknown to the others: without a repair step there is no collective left
   // and it just reports it; with one it keeps to the sequence below and its status travels in that gather)
   if (F == 0) return S.verdict(0, 0);
+  S.owe(local_block(F, k));                              // the repair step's all-gather (every rank read the same F)
   std::sort(ids.begin(), ids.end());
   // failed queries (unrepresentative sample, skewed shards): sub-batch with local thresholds, gathered at full length, scattered into the result
   std::vector<dhr_query_batch> sub(nl, *qb_in);
@@ -624,16 +721,19 @@ struct HipBackend : Backend {
   int min_over_ranks(int32_t v[12]) override {
     if (!comm || world <= 1) return DHR_OK;
     if (comm->dead) return dhr_set_error_message(DHR_ERR_INVALID, "the communicator was aborted (dhr_comm_abort)");
-    std::vector<int32_t> all((size_t)world * 12);
+    int32_t few[64 * 12];                            // (no allocation in front of the exchange for up to 64 ranks: Step::leave)
+    std::vector<int32_t> many;
+    if (world > 64) many.resize((size_t)world * 12);
+    int32_t* all = world > 64 ? many.data() : few;
     if (comm->cb) {                                  // host transport: the values are host memory already
-      if (comm->cb(comm->cb_user, v, all.data(), 48) != 0) return dhr_set_error_message(DHR_ERR_INTERNAL, "the caller's all-gather callback failed");
+      if (comm->cb(comm->cb_user, v, all, 48) != 0) return dhr_set_error_message(DHR_ERR_INTERNAL, "the caller's all-gather callback failed");
     } else {                                         // (no status record on this exchange: v[10] is the status)
       SH_HIP(hipSetDevice(sh[0].device));
       int32_t* d = (int32_t*)sh[0].arena->get(64 + (size_t)world * 48);
       if (!d) return dhr_set_error_message(DHR_ERR_HIP, "out of device memory");
       SH_HIP(hipMemcpyAsync(d, v, 48, hipMemcpyHostToDevice, sh[0].stream));
       SH_NCCL(ncclAllGather(d, d + 16, 48, ncclInt8, comm->comm, sh[0].stream));
-      SH_HIP(hipMemcpyAsync(all.data(), d + 16, (size_t)world * 48, hipMemcpyDeviceToHost, sh[0].stream));
+      SH_HIP(hipMemcpyAsync(all, d + 16, (size_t)world * 48, hipMemcpyDeviceToHost, sh[0].stream));
       SH_HIP(hipStreamSynchronize(sh[0].stream));
     }
     for (int w = 0; w < world; ++w)
@@ -791,8 +891,11 @@ struct HostBackend : Backend {
   }
   int min_over_ranks(int32_t v[12]) override {
     if (world <= 1) return DHR_OK;
-    std::vector<int32_t> all((size_t)world * 12);
-    if (cb(cb_user, v, all.data(), 48) != 0) return dhr_set_error_message(DHR_ERR_INTERNAL, "the caller's all-gather callback failed");
+    int32_t few[64 * 12];                            // (no allocation in front of the exchange for up to 64 ranks: Step::leave)
+    std::vector<int32_t> many;
+    if (world > 64) many.resize((size_t)world * 12);
+    int32_t* all = world > 64 ? many.data() : few;
+    if (cb(cb_user, v, all, 48) != 0) return dhr_set_error_message(DHR_ERR_INTERNAL, "the caller's all-gather callback failed");
     for (int w = 0; w < world; ++w)
       for (int j = 0; j < 12; ++j) v[j] = std::min(v[j], all[(size_t)w * 12 + j]);
     return DHR_OK;
@@ -942,36 +1045,55 @@ extern "C" int dhr_search_sharded_host(const dhr_host_shard* shard, int32_t worl
       k <= 0 || world < 1 || rank < 0 || rank >= world || (world > 1 && !allgather))
     return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
   if (qb->mem_kind != DHR_MEM_HOST) return dhr_set_error_message(DHR_ERR_INVALID, "host shards take host query batches");
-  dhr::alloc_checkpoint();
   HostBackend B;
   B.world = world; B.n_local = 1;
   B.shard = shard; B.cb = allgather; B.cb_user = user;
-  return sharded_core(B, qb, k, {out_scores}, {out_rows});
+  return sharded_core(B, qb, k, &out_scores, &out_rows);
 } DHR_CATCH_STATUS
 
 extern "C" int dhr_search_sharded(dhr_index* shard, dhr_comm* comm, const dhr_query_batch* qb, int32_t k, float* out_scores, int64_t* out_rows,
                                   int32_t out_mem_kind, void* stream) try {
   if (!shard || !comm || !qb || !out_scores || !out_rows || k <= 0 || !DHR_MEM_KIND_OK(out_mem_kind)) return dhr_set_error_message(DHR_ERR_INVALID, "bad argument");
   if (comm->dead) return dhr_set_error_message(DHR_ERR_INVALID, "the communicator was aborted (dhr_comm_abort)");
-  dhr::alloc_checkpoint();
   const int device = dhr_index_device(shard);
   if (device != comm->device) return dhr_set_error_message(DHR_ERR_INVALID, "the shard and the communicator live on different devices");
   SH_HIP(hipSetDevice(device));
   Arena arena{&comm->arena, &comm->arena_bytes, 0, device};
   HipBackend B;
-  B.sh = {{shard, device, (hipStream_t)stream, &arena}};
   B.world = comm->world; B.n_local = 1;
   B.comm = comm->world > 1 ? comm : nullptr;       // a single rank gathers by copy (n_local == world == 1)
   std::vector<ShardCtx>& sh = B.sh;
   const int Q = qb->n_queries;
   float* ds = out_scores;
   int64_t* dr = out_rows;
-  if (out_mem_kind == DHR_MEM_HOST) {
-    ds = (float*)arena.get((size_t)Q * k * 4);
-    dr = (int64_t*)arena.get((size_t)Q * k * 8);
-    if (!ds || !dr) { arena.finish(); return dhr_set_error_message(DHR_ERR_HIP, "out of device memory"); }
+  // this rank's set-up: a failure here is answered in the rank agreement the others are about to enter (the step's own failures: Step::leave)
+  int rc = DHR_OK;
+  try {
+    sh.push_back({shard, device, (hipStream_t)stream, &arena});
+    if (out_mem_kind == DHR_MEM_HOST) {
+      ds = (float*)arena.get((size_t)Q * k * 4);
+      dr = (int64_t*)arena.get((size_t)Q * k * 8);
+      if (!ds || !dr) rc = dhr_set_error_message(DHR_ERR_HIP, "out of device memory");
+    }
+  } catch (...) {
+    rc = dhr::on_exception();
   }
-  int rc = sharded_core(B, qb, k, {ds}, {dr});
+  if (rc != DHR_OK) {
+    if (sh.size() == 1 && B.comm) {
+      char keep[1024];
+      snprintf(keep, sizeof(keep), "%s", dhr_last_error());
+      try {
+        int32_t v[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, rc, 0};
+        (void)B.min_over_ranks(v);
+      } catch (...) {
+      }
+      (void)hipStreamSynchronize((hipStream_t)stream);
+      (void)dhr_set_error_message(rc, keep);
+    }
+    arena.finish();
+    return rc;
+  }
+  rc = sharded_core(B, qb, k, &ds, &dr);
   if (rc == DHR_OK) rc = deliver(sh[0], Q, k, ds, dr, out_scores, out_rows, out_mem_kind);
   else (void)hipStreamSynchronize((hipStream_t)stream);
   arena.finish();
@@ -1012,7 +1134,7 @@ extern "C" int dhr_search_sharded_local(dhr_index** shards, int32_t n_shards, co
     orow[i] = (int64_t*)arenas[i].get((size_t)Q * k * 8);
     if (!os[i] || !orow[i]) rc = dhr_set_error_message(DHR_ERR_HIP, "out of device memory");
   }
-  if (rc == DHR_OK) rc = sharded_core(B, qb, k, os, orow);
+  if (rc == DHR_OK) rc = sharded_core(B, qb, k, os.data(), orow.data());
   if (rc == DHR_OK) { (void)hipSetDevice(sh[0].device); rc = deliver(sh[0], Q, k, os[0], orow[0], out_scores, out_rows, out_mem_kind); }
   for (int i = 0; i < n_shards; ++i) {
     (void)hipSetDevice(sh[i].device);

@@ -244,6 +244,79 @@ def test_sharded_core_over_gloo(tmp_path, mode, world):
         assert (len(calls[0]) == (4 if mode.startswith("mid") else 3)) == (mode in ("adversarial", "mid_adversarial"))
 
 
+def _alloc_fail_worker(rank, world, port, tmp, kind):
+    sys.path.insert(0, ROOT)
+    import datetime
+    import time
+    import torch.distributed as dist
+    from dhr_amd import _lib, dist as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=30))
+    try:
+        lib = _lib.load()
+        rng = np.random.default_rng(11)
+        n, k, nq = 3000, 40, 4
+        cv = rng.standard_normal((n, 16)).astype(np.float32)
+        q = rng.standard_normal((nq, 16)).astype(np.float32)
+        lo, hi = D.shard_bounds(n, world, rank)
+        cls = _FakeShardMid if kind == "mid" else _FakeShardPre if kind == "pre" else _FakeShard
+        full = q.astype(np.float64) @ cv.astype(np.float64).T
+        want = np.argsort(-full, axis=1, kind="stable")[:, :k]
+        a0 = lib.dhr_debug_fail_alloc(0)
+        ms, mr = D.sharded_search_host(cls(cv[lo:hi], lo), q, None, k)
+        n_alloc = int(lib.dhr_debug_fail_alloc(0) - a0)             # host allocations of one step of the library on this rank
+        np.testing.assert_array_equal(mr, want)
+        victim = world - 1
+        outcomes = []
+        for fail_at in range(1, n_alloc + 2):
+            dist.barrier()
+            t0 = time.time()
+            if rank == victim:
+                lib.dhr_debug_fail_alloc(fail_at)
+            status = 0
+            try:
+                ms, mr = D.sharded_search_host(cls(cv[lo:hi], lo), q, None, k)
+            except _lib.DhrError as e:
+                status = e.status
+            finally:
+                lib.dhr_debug_fail_alloc(0)
+            dt = time.time() - t0
+            assert dt < 5.0, (fail_at, rank, status, dt)              # nobody waits for a transport timeout
+            if status == 0:
+                np.testing.assert_array_equal(mr, want)               # (a rank that was not told of a failure holds the right result)
+            outcomes.append(status)
+        # ... and the group still works
+        dist.barrier()
+        ms, mr = D.sharded_search_host(cls(cv[lo:hi], lo), q, None, k)
+        np.testing.assert_array_equal(mr, want)
+        np.save(os.path.join(tmp, f"out{rank}.npy"), np.array(outcomes))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("kind", ["plain", "mid", "pre"])
+def test_allocation_failure_on_one_rank_is_collective(tmp_path, kind, world):
+    """EVERY host allocation the library makes during a sharded step fails once, on ONE rank that stays alive (dhr_debug_fail_alloc), in a 2- and a
+    3-rank group over gloo: every rank returns within seconds each time -- the victim with DHR_ERR_NOMEM, the others with DHR_ERR_PEER -- and the group
+    runs the next step.  (Round 6, second half: a std::bad_alloc in the control flow itself -- outside the shards' local work, which was covered --
+    returned at once and left the other ranks in their next collective until the transport's timeout; Step::leave now answers the rank agreement or
+    the step's remaining all-gathers with the status.)  Failures BEHIND the last all-gather stay the victim's own: the others hold a complete result."""
+    import torch.multiprocessing as mp
+    from dhr_amd import _lib
+    port = 27300 + (os.getpid() % 1500) + 7 * world + ["plain", "mid", "pre"].index(kind)
+    mp.spawn(_alloc_fail_worker, args=(world, port, str(tmp_path), kind), nprocs=world, join=True)
+    outs = [np.load(tmp_path / f"out{r}.npy") for r in range(world)]
+    victim = outs[world - 1]
+    assert (victim[:-1] == _lib.ERR_NOMEM).all() and victim[-1] == 0, victim        # every armed allocation failed the victim's step; one past the last: none
+    for r in range(world - 1):
+        o = outs[r]
+        assert set(o.tolist()) <= {0, _lib.ERR_PEER}, o
+        told = np.nonzero(o == _lib.ERR_PEER)[0]
+        assert len(told) >= len(o) // 2 and (o[: told[-1] + 1] == _lib.ERR_PEER).all(), o      # told of every failure up to the last all-gather, of none behind it
+        np.testing.assert_array_equal(o, outs[0])
+
+
 def _fuzz_worker(rank, world, port, tmp, seed, n_cfg):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
