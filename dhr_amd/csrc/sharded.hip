@@ -403,6 +403,8 @@ static int sharded_body(Step& S, const dhr_query_batch* qb_in, int k, float* con
   SH_TRY(S.init());
   std::vector<int32_t*> fail_ids(nl, nullptr);
   std::vector<int32_t> ids;
+  ids.reserve((size_t)Q);          // (the read behind the last planned all-gather must not allocate: a rank that failed THERE would not know whether the
+                                   // others go on to a repair step -- until then it was the one gap a random failure could hit: tests/test_dist_gloo.py)
   int peer_status = 0, peer_rank = 0;
   if (r <= 0) {
     // shards that cannot be sampled alike: local thresholds for the whole batch
