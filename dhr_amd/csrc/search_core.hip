@@ -528,7 +528,6 @@ int search_core(dhr_index* ix, Workspace& w, const dhr_query_batch* qb, int k, i
   const bool gate = !fresh ? ix->pend.gate
                            : (ix->d_dlr > 0 && qb->index != nullptr && qb->index_dtype != DHR_IDX_NONE);   // else plain IP
   const int64_t n = ix->n_rows;
-  const int64_t group_rows = (int64_t)DOC_GROUP * TILE_ROWS;
   // depth 0: sampled thresholds; depth 1 (queries that failed at depth 0): the same with 16x list capacity;
   // depth 2: plain streaming, exact for any input
   const bool allow_sampling = depth < 2;
