@@ -1864,6 +1864,16 @@ def test_host_corpus_beyond_2_32_elements(G):
         O.check_topk(rows - (n - 300_000), s_h[i], ext, k)
 
 
+def test_corrupted_index_files_are_statuses(G, monkeypatch):
+    """A slice of tools/fuzz_index_file.py: byte flips / extreme values in the header region, truncations, garbage behind a valid magic -- dhr_index_file_info
+    and dhr_index_load answer with a status, a file whose damage the header cannot see loads and searches without a crash."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import fuzz_index_file
+    monkeypatch.setattr(sys, "argv", ["fuzz_index_file.py", "400", "5"])
+    fuzz_index_file.main()
+
+
 def test_degenerate_inputs(G, monkeypatch):
     """tools/degenerate.py: all-zero corpus / queries, identical rows (all ties -> row ascending), k == n, one row, fp16 maxima and subnormals,
     all-negative values, one non-zero column -- both images of the gated half, against the oracle."""
