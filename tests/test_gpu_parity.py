@@ -1864,6 +1864,28 @@ def test_host_corpus_beyond_2_32_elements(G):
         O.check_topk(rows - (n - 300_000), s_h[i], ext, k)
 
 
+def test_integration_md_stub_runs_as_printed(G):
+    """The ctypes stub INTEGRATION.md section 2 shows a dhr maintainer is executed AS PRINTED (the first ```python block of the file, the library path
+    aside) against the oracle: a stub that cannot run is worse than none (round 6: it passed 64-bit addresses without argtypes)."""
+    import re
+    from types import SimpleNamespace
+    from dhr_amd import _lib, synth
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    _lib.load()
+    code = code.replace('C.CDLL("libdhr_hip.so")', 'C.CDLL(%r)' % os.environ.get("DHR_HIP_LIB", os.path.join(root, "dhr_amd", "csrc", "libdhr_hip.so")))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    cv, ci, qv, qi = synth.make_pair(61, 5000, 7, 64, 32)
+    q32 = qv.astype(np.float32)
+    qids = ["q%d" % i for i in range(7)]
+    res, sc = ns["GIP_retrieval"](qids, q32, qi, cv, ci, SimpleNamespace(emb_dim=64, topk=30))
+    c32 = cv.astype(np.float32)
+    for i, qid in enumerate(qids):
+        O.check_topk(np.array(res[qid]), np.array(sc[qid], np.float32), O.gip_scores_f64(q32[i], qi[i], c32, ci), 30)
+
+
 def test_corrupted_index_files_are_statuses(G, monkeypatch):
     """A slice of tools/fuzz_index_file.py: byte flips / extreme values in the header region, truncations, garbage behind a valid magic -- dhr_index_file_info
     and dhr_index_load answer with a status, a file whose damage the header cannot see loads and searches without a crash."""
