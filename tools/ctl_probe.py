@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Controller A/B at config 3 (or --rows / --cls): one index, several parameter settings, wall time + phase times + candidate counts
-of each, all results compared bit for bit with the first.  Environment knobs read once by the library (DHR_ADAPTIVE_RANK ...) need a
+of each, all results compared bit for bit with the first.  A/B builds of the library (tools/ab_build.sh, DHR_HIP_LIB) need a
 process of their own: run this script once per setting."""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -38,7 +38,7 @@ def main():
                 % (st["phases"], st["gemm_ms"], st["refine_ms"], st["rescore_ms"], st["select_ms"], st["total_ms"], st["candidates_bound"] / nq,
                    st["candidates_exact"] / nq, st["sample_fallback_queries"]))
     ref = None
-    print("env: DHR_ADAPTIVE_RANK=%s DHR_HIP_LIB=%s" % (os.environ.get("DHR_ADAPTIVE_RANK"), os.environ.get("DHR_HIP_LIB")), flush=True)
+    print("env: DHR_HIP_LIB=%s" % os.environ.get("DHR_HIP_LIB"), flush=True)
     for setting in ([""] + [x for x in args.sets.split(";") if x]):
         cur = dict(defaults)
         for kv in [x for x in setting.split(",") if x]:
